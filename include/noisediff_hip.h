@@ -1,0 +1,241 @@
+/*
+ * noisediff_hip.h -- C ABI of libnoisediff_hip.so (gfx950 / MI355X).
+ *
+ * The reference (IVRL/NoiseDiff) has no native layer: its "kernels" are ATen ops
+ * dispatched from Python.  This library is the native layer under
+ * the two Python plug-in interfaces of the sampling hot path -- the arch class
+ * (models/modules.py:32-41 -> models/archs/Diffusion_arch.py:447-646) and
+ * GaussianDiffusion (models/denoising_diffusion_pytorch.py:167-451).  Each entry
+ * point below names the reference code it replaces.  The Python side that binds
+ * them with ctypes is noisediff_amd/_lib.py; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated; activations are
+ *     NHWC ("pixel-major": [B][H][W][C], `ld` = floats between consecutive pixels);
+ *   - `stream` is a hipStream_t passed as void*; nothing here allocates, frees,
+ *     synchronises or touches the default stream, so every call is legal inside
+ *     hipStreamBeginCapture/EndCapture;
+ *   - return value: 0 = ok, >0 = hipError_t of the launch, <0 = ND_E_* argument error.
+ *     No exceptions cross the boundary; nd_last_error() gives a message.
+ */
+#ifndef NOISEDIFF_HIP_H
+#define NOISEDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ND_E_BADARG   (-1)   /* null pointer / non-positive size            */
+#define ND_E_SHAPE    (-2)   /* shape not supported by the kernel's tiling   */
+#define ND_E_ALIGN    (-3)   /* pointer or stride not 16-byte aligned        */
+#define ND_E_STATE    (-4)   /* graph/plan handle misuse                     */
+
+/* ------------------------------------------------------------------ library */
+int         nd_version(void);                 /* 1000*major + minor                     */
+const char* nd_last_error(void);              /* thread-local, never NULL               */
+int         nd_device_arch(char* buf, int n); /* gcnArchName of the current device      */
+
+/* ------------------------------------------------------------------ operand descriptors */
+
+/* How a GEMM-like kernel reads its activation operand (the "A" side).              */
+enum nd_prologue {
+    ND_PRO_NONE        = 0,  /* raw values                                              */
+    ND_PRO_AFFINE_SILU = 1,  /* silu((x - M[b,c]) * A[b,c] + D[b,c]): GroupNorm + time
+                                scale/shift + SiLU of Block.forward, Diffusion_arch.py:137-143 */
+    ND_PRO_AFFINE_MAP_SILU = 2, /* same, then *(S[p,c]+1)+Sh[p,c] before SiLU: ResnetBlock2's
+                                per-pixel scale/shift, Diffusion_arch.py:188-192           */
+    ND_PRO_LAYERNORM   = 3,  /* LayerNorm over C of (x + vec[b,c]): AttnBlock.norm2 on
+                                x + CrossAttention(...), Diffusion_arch.py:438-439          */
+    ND_PRO_SILU        = 4   /* silu(x): ResnetBlock2.mlp[0], Diffusion_arch.py:177         */
+};
+
+typedef struct nd_src {
+    const float* p0;      /* first source                                               */
+    const float* p1;      /* second source of a virtual concat (torch.cat dim=1,
+                             Diffusion_arch.py:598,628,631,640) or NULL                 */
+    int32_t c0, c1;       /* channels taken from p0 / p1 (multiples of 4)               */
+    int32_t ld0, ld1;     /* pixel strides in floats                                    */
+    int32_t mode;         /* enum nd_prologue                                           */
+    int32_t upsample;     /* 1: p0 is (H/2, W/2), read through nearest x2 (nn.Upsample,
+                             Diffusion_arch.py:74); conv3x3 only                        */
+    int32_t unshuffle;    /* 1: p0 is (2H, 2W, c0/4) read as 'b c (h p1)(w p2) -> b (c p1 p2) h w'
+                             (Diffusion_arch.py:80) with K order (p1 p2 c); pointwise only */
+    int32_t _pad;
+    const float* mad;     /* [B][3][C] M, A, D for the AFFINE modes (from nd_groupnorm_finalize_f32) */
+    const float* map;     /* [B][H][W][2C] scale|shift map (AFFINE_MAP)                 */
+    const float* vec;     /* [B][C] per-sample vector added before LayerNorm            */
+    const float* gamma;   /* [C] LayerNorm weight                                       */
+    const float* beta;    /* [C] LayerNorm bias                                         */
+} nd_src;
+
+enum nd_act { ND_ACT_NONE = 0, ND_ACT_GELU = 1, ND_ACT_SILU = 2 };
+
+/* ------------------------------------------------------------------ conv 3x3 */
+
+/* nn.Conv2d(cin, cout, 3, padding=1) on NHWC fp32 with exact-fp32 MFMA accumulation
+ * (v_mfma_f32_32x32x2_f32 == an fmaf chain).  Replaces Block.proj (Diffusion_arch.py:131,136),
+ * the last-stage down/up convs (:533,:547) and Upsample's conv (:75).
+ * Weights are pre-packed by nd_pack_conv3x3_weight.  When `stats` != NULL the epilogue
+ * also emits per-(sample, slot, channel) partial sums {sum, M2} of the output for the
+ * following GroupNorm (Block.norm :132); `slot_count[slot]` receives the number of pixels
+ * behind each slot.  Query the slot count with nd_conv3x3_stat_slots. */
+typedef struct nd_conv3x3 {
+    nd_src   src;
+    const float* weight;   /* packed, see nd_pack_conv3x3_weight                         */
+    const float* bias;     /* [cout] or NULL                                             */
+    float*   out;          /* [B][H][W] x ldo                                            */
+    float*   stats;        /* [B][slots][cout][2] or NULL                                */
+    float*   slot_count;   /* [slots] or NULL                                            */
+    int32_t  B, H, W;      /* OUTPUT spatial size                                        */
+    int32_t  cin, cout, ldo;
+} nd_conv3x3;
+
+int nd_conv3x3_nhwc_f32(const nd_conv3x3* d, void* stream);
+int nd_conv3x3_stat_slots(int H, int W, int cout, int B);
+/* OIHW (cout,cin,3,3) -> [tap][cin/4][coutP][4], coutP = cout rounded up to 64; zero padded. */
+int64_t nd_pack_conv3x3_weight_floats(int cin, int cout);
+int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
+
+/* ------------------------------------------------------------------ pointwise GEMM */
+
+/* out[p, n] = epi( sum_k pro(in[p, k]) * W[k, n] + bias[n] ) per pixel: nn.Conv2d(k=1) and
+ * nn.Linear on tokens are the same op in NHWC.  Replaces res_conv (:156), Downsample's conv
+ * (:81), Mlp.fc1/fc2 (:345-347), ResnetBlock2.mlp (:178), FeedForward (:410-419),
+ * AttnBlock.proj_out (:432), final_conv (:554).
+ * Epilogue, in order: +bias, act, +res0, +res1, +vec[b,n], +silu((t - M)*A + D) where t is a
+ * raw conv output (ResnetBlock tail `h + res_conv(x)`, :170). */
+typedef struct nd_pointwise {
+    nd_src   src;
+    const float* weight;   /* packed [cinP/4][coutP][4], see nd_pack_pointwise_weight     */
+    const float* bias;     /* [cout] or NULL                                             */
+    float*   out;
+    const float* res0; const float* res1;   /* [B][HW] x ldr0/ldr1 or NULL               */
+    const float* vec;      /* [B][cout] or NULL                                          */
+    const float* gn_t;     /* tensor t for the fused GroupNorm+SiLU add, or NULL          */
+    const float* gn_mad;   /* [B][3][cout]                                               */
+    int32_t  B, HW, W;     /* HW = output pixels per sample; W = output width (unshuffle) */
+    int32_t  cin, cout, ldo, ldr0, ldr1, ldt;
+    int32_t  act;          /* enum nd_act                                                */
+} nd_pointwise;
+
+int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream);
+/* (cout, cin) row-major (Linear / 1x1 conv weight) -> [cinP/4][coutP][4]; `unshuffle_c` > 0
+ * permutes K from (c p1 p2) to (p1 p2 c) for a pixel-unshuffled input with c = unshuffle_c. */
+int64_t nd_pack_pointwise_weight_floats(int cin, int cout);
+int nd_pack_pointwise_weight(const float* w, float* packed, int cin, int cout, int unshuffle_c, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm plumbing */
+
+/* Combine conv partials (Chan's parallel variance, fp64) into per-(b, group) mean / rstd
+ * (nn.GroupNorm eps, biased variance) and fold gamma/beta and the optional time
+ * scale/shift into M, A, D so that Block.forward's  GN -> x*(scale+1)+shift  (:137-141)
+ * becomes (x - M) * A + D.  scale/shift: [B] rows of stride ld_ss, scale at +0, shift at +cout. */
+int nd_groupnorm_finalize_f32(const float* stats, const float* slot_count, int slots,
+                              const float* gamma, const float* beta,
+                              const float* scale_shift, int ld_ss,
+                              float* mad, int B, int C, int groups, float eps, void* stream);
+
+/* out = silu((t - M)*A + D) [+ res0] [+ res1]: the tail of ResnetBlock.forward (:168-170)
+ * when res_conv is the identity, plus `shot_emb + r` (:603). */
+int nd_affine_silu_add_f32(const float* t, int ldt, const float* mad,
+                           const float* res0, int ldr0, const float* res1, int ldr1,
+                           float* out, int ldo, int B, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ small dense ops on rows */
+
+/* out[b, n] = act_out( sum_k act_in(in[b, k]) * W[n, k] + bias[n] ), W in torch (N, K) layout.
+ * time_mlp (:502-507), every ResnetBlock.mlp (:149-152, batched as one tall matrix),
+ * CrossAttention.to_v / to_out on the 1-token context (:385,:402). */
+int nd_linear_rows_f32(const float* in, int ld_in, const float* W, const float* bias,
+                       float* out, int ld_out, int B, int K, int N,
+                       int act_in, int act_out, void* stream);
+/* SinusoidalPosEmb.forward (:100-107): emb[b] = cat(sin(t*f), cos(t*f)), t int64 -> fp32 multiply.
+ * freqs[half] = exp(arange(half) * -(ln(theta)/(half-1))) is a constant of the model, computed
+ * once on the host so that the angle t*f is bit-identical to the reference's. */
+int nd_sinusoidal_time_emb_f32(const int64_t* time, const float* freqs, float* emb, int B, int half, void* stream);
+/* nn.Embedding lookup (:591): out[b] = table[idx[b]], idx int64. */
+int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, int B, int rows, int dim, void* stream);
+
+/* ------------------------------------------------------------------ full-resolution special layers */
+
+/* init_conv: nn.Conv2d(4, cout, 7, padding=3) (:478,:606).  x NHWC with 4 channels;
+ * weight packed [7*7*4][cout] by nd_pack_conv7x7_weight. */
+int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo,
+                      int B, int H, int W, int cout, void* stream);
+int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout, void* stream);
+/* LearnedSinusoidalPosEmb (:331-337): position NCHW (B,2,H,W) -> NHWC (B,H,W,3*hid):
+ * w = conv1x1(position); cat(w, sin(2 pi w), cos(2 pi w)). */
+int nd_pos_enc_f32(const float* position_nchw, const float* w /*[hid][2]*/, const float* bias,
+                   float* out, int B, int H, int W, int hid, void* stream);
+/* layout plumbing for the 4-channel API tensors (reference tensors are NCHW) */
+int nd_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, void* stream);
+int nd_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ sampler */
+
+/* Device-resident loop state so that one captured step graph can be replayed T times:
+ * step counter, current/next timestep table and the per-timestep coefficient table. */
+typedef struct nd_sampler_state {
+    int32_t* step;          /* [1] device counter, incremented by nd_sampler_advance       */
+    const int32_t* t_cur;   /* [n_steps] timestep fed to the network at each step          */
+    const int32_t* t_next;  /* [n_steps] DDIM: next timestep (-1 at the end); DDPM unused  */
+    const float* coef;      /* [n_steps][8] per-step scalars, see sampler.hip              */
+    int64_t* time_out;      /* [B] int64 buffer the network's time embedding reads         */
+    int32_t n_steps, B;
+} nd_sampler_state;
+
+/* time_out[b] = t_cur[*step]  (p_sample's batched_times, denoising_diffusion_pytorch.py:369,419) */
+int nd_sampler_begin_step(const nd_sampler_state* s, void* stream);
+int nd_sampler_advance(const nd_sampler_state* s, void* stream);
+
+/* One reverse-diffusion update on NHWC (B,H,W,C) tensors, in place on x:
+ *  DDPM (p_sample :366-373 + p_mean_variance :356-364 + q_posterior :322-329),
+ *  DDIM (ddim_sample :418-439, model_predictions :331-354 with clip + rederived eps).
+ * objective: 0 pred_noise, 1 pred_x0, 2 pred_v.  noise: explicit draws (parity mode; the draw of
+ * step i is at noise + i * noise_step_stride floats, the i-th torch.randn_like of the reference)
+ * or NULL => Philox4x32-10 keyed (seed, first_sample + b, step) (throughput mode). */
+int nd_sampler_step_ddpm_f32(float* x, const float* model_out, const float* noise, int64_t noise_step_stride,
+                             const nd_sampler_state* s, int objective,
+                             uint64_t seed, int64_t first_sample,
+                             int B, int HW, int C, void* stream);
+int nd_sampler_step_ddim_f32(float* x, const float* model_out, const float* noise, int64_t noise_step_stride,
+                             const nd_sampler_state* s, int objective,
+                             uint64_t seed, int64_t first_sample,
+                             int B, int HW, int C, void* stream);
+/* x_T ~ N(0,1): torch.randn(shape) (:381,:413) from the same Philox stream (step = -1). */
+int nd_philox_normal_f32(float* out, uint64_t seed, int64_t first_sample, int32_t step,
+                         int B, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ full attention (config 4) */
+
+/* Attention.forward (:255-266) core on MFMA: out = softmax(q k^T / sqrt(dh)) v per (b, head).
+ * qkv NHWC [B][N][3*heads*dh] as produced by the to_qkv 1x1 conv ('b (h c) x y' channel order,
+ * q | k | v thirds); out [B][N][heads*dh].  dh must be 32. */
+int nd_attention_mfma_f32(const float* qkv, int ld_qkv, float* out, int ld_out,
+                          int B, int N, int heads, int dh, void* stream);
+/* RMSNorm.forward (:89-90) over channels: out = x / max(||x||, 1e-12) * g * sqrt(C). */
+int nd_rmsnorm_nhwc_f32(const float* x, int ldx, const float* g, float* out, int ldo,
+                        int B, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ HIP graph helpers */
+int nd_stream_create(void** stream);
+int nd_stream_destroy(void* stream);
+int nd_stream_sync(void* stream);
+int nd_graph_begin(void* stream);                 /* hipStreamBeginCapture (thread-local mode) */
+int nd_graph_end(void* stream, void** graph_exec);
+int nd_graph_launch(void* graph_exec, void* stream);
+int nd_graph_destroy(void* graph_exec);
+/* timing on the library's own stream: HIP events are only meaningful on the stream they are
+ * recorded on (torch.cuda.Event sees torch's current stream only). */
+int nd_event_create(void** ev);
+int nd_event_record(void* ev, void* stream);
+int nd_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises `stop` */
+int nd_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOISEDIFF_HIP_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of libnoisediff_hip.so (the C ABI in include/noisediff_hip.h).
+
+No fallback: ``load()`` raises if the library is missing (build it with
+``python -m noisediff_amd.build`` / ``__graft_entry__.build()``), and every call is
+checked -- a non-zero return raises ``HipError`` with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnoisediff_hip.so")
+
+# enum nd_prologue / nd_act
+PRO_NONE, PRO_AFFINE_SILU, PRO_AFFINE_MAP_SILU, PRO_LAYERNORM, PRO_SILU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+OBJECTIVES = {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}
+
+fptr = C.c_void_p   # device pointers travel as integers
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class Src(C.Structure):
+    _fields_ = [("p0", fptr), ("p1", fptr), ("c0", C.c_int32), ("c1", C.c_int32), ("ld0", C.c_int32), ("ld1", C.c_int32),
+                ("mode", C.c_int32), ("upsample", C.c_int32), ("unshuffle", C.c_int32), ("_pad", C.c_int32),
+                ("mad", fptr), ("map", fptr), ("vec", fptr), ("gamma", fptr), ("beta", fptr)]
+
+
+class Conv3x3(C.Structure):
+    _fields_ = [("src", Src), ("weight", fptr), ("bias", fptr), ("out", fptr), ("stats", fptr), ("slot_count", fptr),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("ldo", C.c_int32)]
+
+
+class Pointwise(C.Structure):
+    _fields_ = [("src", Src), ("weight", fptr), ("bias", fptr), ("out", fptr), ("res0", fptr), ("res1", fptr), ("vec", fptr),
+                ("gn_t", fptr), ("gn_mad", fptr), ("B", C.c_int32), ("HW", C.c_int32), ("W", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("ldo", C.c_int32), ("ldr0", C.c_int32), ("ldr1", C.c_int32), ("ldt", C.c_int32), ("act", C.c_int32)]
+
+
+class SamplerState(C.Structure):
+    _fields_ = [("step", fptr), ("t_cur", fptr), ("t_next", fptr), ("coef", fptr), ("time_out", fptr),
+                ("n_steps", C.c_int32), ("B", C.c_int32)]
+
+
+i32, i64, u64, vp, f32 = C.c_int, C.c_int64, C.c_uint64, C.c_void_p, C.c_float
+
+# name -> (restype, argtypes); everything include/noisediff_hip.h declares
+SIGNATURES = {
+    "nd_version": (i32, []),
+    "nd_last_error": (C.c_char_p, []),
+    "nd_device_arch": (i32, [C.c_char_p, i32]),
+    "nd_conv3x3_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
+    "nd_conv3x3_stat_slots": (i32, [i32, i32, i32, i32]),
+    "nd_pack_conv3x3_weight_floats": (i64, [i32, i32]),
+    "nd_pack_conv3x3_weight": (i32, [vp, vp, i32, i32, vp]),
+    "nd_pointwise_gemm_nhwc_f32": (i32, [C.POINTER(Pointwise), vp]),
+    "nd_pack_pointwise_weight_floats": (i64, [i32, i32]),
+    "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
+    "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
+    "nd_affine_silu_add_f32": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "nd_linear_rows_f32": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "nd_sinusoidal_time_emb_f32": (i32, [vp, vp, vp, i32, i32, vp]),
+    "nd_embedding_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nd_pack_conv7x7_weight": (i32, [vp, vp, i32, vp]),
+    "nd_pos_enc_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "nd_nchw_to_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "nd_nhwc_to_nchw_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "nd_sampler_begin_step": (i32, [C.POINTER(SamplerState), vp]),
+    "nd_sampler_advance": (i32, [C.POINTER(SamplerState), vp]),
+    "nd_sampler_step_ddpm_f32": (i32, [vp, vp, vp, i64, C.POINTER(SamplerState), i32, u64, i64, i32, i32, i32, vp]),
+    "nd_sampler_step_ddim_f32": (i32, [vp, vp, vp, i64, C.POINTER(SamplerState), i32, u64, i64, i32, i32, i32, vp]),
+    "nd_philox_normal_f32": (i32, [vp, u64, i64, i32, i32, i32, i32, vp]),
+    "nd_attention_mfma_f32": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "nd_rmsnorm_nhwc_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "nd_stream_create": (i32, [C.POINTER(vp)]),
+    "nd_stream_destroy": (i32, [vp]),
+    "nd_stream_sync": (i32, [vp]),
+    "nd_graph_begin": (i32, [vp]),
+    "nd_graph_end": (i32, [vp, C.POINTER(vp)]),
+    "nd_graph_launch": (i32, [vp, vp]),
+    "nd_graph_destroy": (i32, [vp]),
+    "nd_event_create": (i32, [C.POINTER(vp)]),
+    "nd_event_record": (i32, [vp, vp]),
+    "nd_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
+    "nd_event_destroy": (i32, [vp]),
+}
+
+_UNCHECKED = {"nd_version", "nd_last_error", "nd_conv3x3_stat_slots", "nd_pack_conv3x3_weight_floats",
+              "nd_pack_pointwise_weight_floats"}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the library and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise HipError(f"{path} is missing: the HIP library is the product and there is no fallback. "
+                       "Build it with `python -m noisediff_amd.build`.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().nd_last_error().decode(errors="replace")
+        raise HipError(f"{what or 'libnoisediff_hip'} failed with code {code}: {msg}")
+
+
+def call(name: str, *args):
+    """Checked call: raises HipError on a non-zero status."""
+    r = getattr(load(), name)(*args)
+    if name not in _UNCHECKED:
+        check(r, name)
+    return r
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

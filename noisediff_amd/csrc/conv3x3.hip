@@ -1,0 +1,310 @@
+// conv3x3.hip -- NHWC fp32 3x3 convolution (pad 1, stride 1) as an implicit GEMM on the
+// exact-fp32 matrix pipe of gfx950 (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain).
+//
+// Replaces every nn.Conv2d(.., 3, padding=1) of NoiseDiffNet: Block.proj
+// (models/archs/Diffusion_arch.py:131,136), the last-stage down/up convs (:533,:547) and the
+// conv behind nn.Upsample (:74-75).  One workgroup = 4 waves = one (TH x TW pixels) x (BN couts)
+// output tile of one sample:
+//   * A operand (activations): the tile plus its 1-pixel halo, KC=32 channels at a time, is
+//     staged global -> registers -> LDS.  The staging pass is where the *previous* layer's
+//     GroupNorm + scale/shift + SiLU is applied (ND_PRO_AFFINE_*), where torch.cat is resolved
+//     (two base pointers) and where nearest-x2 upsampling is resolved (index >> 1); zero padding
+//     is applied after the transform, exactly like padding the activated tensor.  Each staged
+//     value is reused by 9 taps x BN output channels.
+//   * B operand (weights): pre-packed [tap][cin/4][coutP][4] so that the fragment a lane needs
+//     for four consecutive k-steps is ONE coalesced 16-byte global load (32 lanes x 16 B = 512 B
+//     contiguous); weights are shared by every workgroup, so these hit L2/MALL.  Fragments for
+//     tap t+1 are fetched while tap t is multiplied (two register sets).
+//   * Epilogue: +bias, store, and per-(wave, channel) {sum, M2} partials of the output for the
+//     following GroupNorm (two-pass inside registers, so no E[x^2]-E[x]^2 cancellation).
+// K order inside a group of 8 channels: lane half h supplies channel 4h+s at k-step s.
+#include "nd_common.h"
+
+namespace {
+
+constexpr int KC = 32;        // channels per staged chunk
+constexpr int LDA = KC + 4;   // LDS floats per staged pixel (16-byte pad keeps b128 reads spread over banks)
+
+struct ConvArgs {
+    nd_conv3x3 d;
+    int tiles_x, tiles_y, n_tiles, coutP, slots, total_wg;
+};
+
+template <int TW, int MB, int NB>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int RB = 32 / TW;            // image rows covered by one 32-pixel M-block
+    constexpr int TH = WM * MB * RB;
+    constexpr int TWH = TW + 2, THH = TH + 2;
+    constexpr int NPIX = TWH * THH;
+    constexpr int BN = WN * NB * 32;
+    constexpr int STAGE_IT = (NPIX + 31) / 32;
+    __shared__ __attribute__((aligned(16))) float As[NPIX * LDA];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, col = lane & 31;
+
+    int lid = nd_xcd_remap(blockIdx.x, a.total_wg);
+    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
+    const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
+    const int ty = lid % a.tiles_y;
+    const int b = lid / a.tiles_y;
+
+    const nd_src& s = a.d.src;
+    const int H = a.d.H, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
+    const int sH = s.upsample ? (H >> 1) : H, sW = s.upsample ? (W >> 1) : W;
+    const int Ctot = s.c0 + s.c1;
+    const int n0 = nt * BN;
+
+    // staging role: 8 channel-quads x 32 pixel slots
+    const int quad = tid & 7, prow = tid >> 3;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+
+    // A-fragment LDS offsets (floats) of this lane for tap (0,0), group 0
+    int a_off[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int ly = (wm * MB + mb) * RB + col / TW, lx = col % TW;
+        a_off[mb] = (ly * TWH + lx) * LDA + 4 * half;
+    }
+    // B-fragment base: Wp[((tap*Q + q) * coutP + n) * 4]
+    const int Q = Cin >> 2;
+    const float* wbase = a.d.weight + ((size_t)half * a.coutP + n0 + wn * NB * 32 + col) * 4;
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+    f32x4 bq[2][NB][4];
+
+    for (int cb = 0; cb < Cin; cb += KC) {
+        const int ng = min(4, (Cin - cb) >> 3);   // groups of 8 channels in this chunk
+
+        auto load_b = [&](int buf, int tap) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g < ng)
+                        bq[buf][nb][g] = nd_ld4(wbase + ((size_t)(tap * Q + (cb >> 2) + 2 * g) * a.coutP + nb * 32) * 4);
+        };
+        load_b(0, 0);   // overlaps with the staging pass below
+
+        __syncthreads();   // everyone is done reading the previous chunk
+        {
+            const int c = cb + quad * 4;
+            const bool cvalid = c < Cin;
+            const float* base = s.p0;
+            int ld = s.ld0, cc = c;
+            if (c >= s.c0) { base = s.p1; ld = s.ld1; cc = c - s.c0; }
+            f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
+            if (s.mode != ND_PRO_NONE && cvalid) {
+                const float* m = s.mad + (size_t)b * 3 * Ctot + c;
+                tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
+            }
+#pragma unroll
+            for (int it = 0; it < STAGE_IT; ++it) {
+                const int p = prow + it * 32;
+                if (p < NPIX) {
+                    const int hy = p / TWH, hx = p - hy * TWH;
+                    const int y = y0 + hy, x = x0 + hx;
+                    f32x4 v = {0, 0, 0, 0};
+                    if (cvalid && y >= 0 && y < H && x >= 0 && x < W) {
+                        const int sy = s.upsample ? (y >> 1) : y, sx = s.upsample ? (x >> 1) : x;
+                        v = nd_ld4(base + ((size_t)(b * sH + sy) * sW + sx) * ld + cc);
+                        if (s.mode != ND_PRO_NONE) {
+                            v = (v - tM) * tA + tD;
+                            if (s.mode == ND_PRO_AFFINE_MAP_SILU) {
+                                const float* mp = s.map + ((size_t)(b * H + y) * W + x) * (2 * Ctot) + c;
+                                const f32x4 sc = nd_ld4(mp), sh = nd_ld4(mp + Ctot);
+                                v = v * (sc + 1.0f) + sh;
+                            }
+                            v = nd_silu4(v);
+                        }
+                    }
+                    nd_st4(&As[p * LDA + quad * 4], v);
+                }
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_b((tap + 1) & 1, tap + 1);
+            const int toff = ((tap / 3) * TWH + (tap % 3)) * LDA;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < ng) {
+                    f32x4 av[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) av[mb] = nd_ld4(&As[a_off[mb] + toff + g * 8]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = nd_mfma(av[mb][k], bq[tap & 1][nb][g][k], acc[mb][nb]);
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------ epilogue
+    const int wrow0 = ty * TH + wm * MB * RB;                       // first image row of this wave
+    const int rows_valid = max(0, min(MB * RB, H - wrow0));
+    const int cols_valid = max(0, min(TW, W - tx * TW));
+    const int cnt = rows_valid * cols_valid;
+    const int slot = (ty * a.tiles_x + tx) * WM + wm;
+    float* out = a.d.out;
+
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + (wn * NB + nb) * 32 + col;
+        const bool nvalid = n < Cout;
+        const float bias = (nvalid && a.d.bias) ? a.d.bias[n] : 0.0f;
+        float s1 = 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = nd_acc_row(r, lane);
+                const int y = wrow0 + mb * RB + rr / TW, x = tx * TW + rr % TW;
+                const float v = acc[mb][nb][r] + bias;
+                acc[mb][nb][r] = v;
+                if (y < H && x < W) {
+                    s1 += v;
+                    if (nvalid) out[((size_t)(b * H + y) * W + x) * a.d.ldo + n] = v;
+                }
+            }
+        if (a.d.stats) {
+            s1 += __shfl_xor(s1, 32);
+            const float mean = s1 / (float)max(cnt, 1);
+            float m2 = 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = nd_acc_row(r, lane);
+                    const int y = wrow0 + mb * RB + rr / TW, x = tx * TW + rr % TW;
+                    const float dv = acc[mb][nb][r] - mean;
+                    if (y < H && x < W) m2 += dv * dv;
+                }
+            m2 += __shfl_xor(m2, 32);
+            if (half == 0 && nvalid) {
+                float* st = a.d.stats + (((size_t)b * a.slots + slot) * Cout + n) * 2;
+                st[0] = s1;
+                st[1] = m2;
+            }
+        }
+    }
+    if (a.d.slot_count && b == 0 && nt == 0 && wn == 0 && lane == 0) a.d.slot_count[slot] = (float)cnt;
+}
+
+// ---------------------------------------------------------------- tiling choice (host)
+struct Tiling { int tw, mb, nb, th, bn; };
+
+Tiling choose_tiling(int B, int H, int W, int cout) {
+    // candidates in order of preference (bigger tiles = more operand reuse); take the first that
+    // still yields >= 2 workgroups per CU, otherwise the one with the most workgroups.
+    const Tiling cand[4] = {{16, 2, 2, 8, 128}, {16, 2, 1, 8, 64}, {8, 1, 2, 8, 128}, {8, 1, 1, 8, 64}};
+    int best = -1;
+    long best_wg = -1;
+    for (int i = 0; i < 4; ++i) {
+        const Tiling& t = cand[i];
+        if (t.tw == 16 && W < 16) continue;
+        if (t.bn == 128 && cout % 128 != 0) continue;   // packed weights are padded to 64 columns
+        const long wg = (long)B * nd_cdiv(H, t.th) * nd_cdiv(W, t.tw) * nd_cdiv(cout, t.bn);
+        if (wg >= 512) return t;
+        if (wg > best_wg) { best_wg = wg; best = i; }
+    }
+    return cand[best];
+}
+
+template <int TW, int MB, int NB>
+void launch(const ConvArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB>), dim3(a.total_wg), dim3(256), 0, st, a);
+}
+
+// OIHW -> [tap][cin/4][coutP][4], coutP = cout rounded up to 64
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int coutP) {
+    const size_t total = (size_t)9 * cin * coutP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3;
+        size_t r = i >> 2;
+        const int n = r % coutP; r /= coutP;
+        const int q = r % (cin >> 2);
+        const int tap = r / (cin >> 2);
+        const int ci = q * 4 + e;
+        out[i] = n < cout ? w[((size_t)n * cin + ci) * 9 + tap] : 0.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" int nd_conv3x3_stat_slots(int H, int W, int cout, int B) {
+    if (H <= 0 || W <= 0 || cout <= 0 || B <= 0) return ND_E_BADARG;
+    const Tiling t = choose_tiling(B, H, W, cout);
+    return nd_cdiv(H, t.th) * nd_cdiv(W, t.tw) * 2;
+}
+
+extern "C" int64_t nd_pack_conv3x3_weight_floats(int cin, int cout) {
+    return (int64_t)9 * cin * nd_round_up(cout, 64);
+}
+
+extern "C" int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
+    ND_REQUIRE(oihw && packed, ND_E_BADARG, "nd_pack_conv3x3_weight: null pointer");
+    ND_REQUIRE(cin > 0 && cout > 0 && cin % 8 == 0, ND_E_SHAPE, "nd_pack_conv3x3_weight: cin=%d must be a positive multiple of 8", cin);
+    const int coutP = nd_round_up(cout, 64);
+    const size_t total = (size_t)9 * cin * coutP;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cout, coutP);
+    return nd_launch_status("nd_pack_conv3x3_weight");
+}
+
+extern "C" int nd_conv3x3_nhwc_f32(const nd_conv3x3* d, void* stream) {
+    ND_REQUIRE(d, ND_E_BADARG, "nd_conv3x3: null descriptor");
+    const nd_src& s = d->src;
+    ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3: null tensor pointer");
+    ND_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->cin > 0 && d->cout > 0, ND_E_BADARG, "nd_conv3x3: non-positive size");
+    ND_REQUIRE(d->cin % 8 == 0, ND_E_SHAPE, "nd_conv3x3: cin=%d must be a multiple of 8", d->cin);
+    ND_REQUIRE(s.c0 + s.c1 == d->cin && s.c0 % 4 == 0 && s.c1 % 4 == 0 && s.c0 > 0, ND_E_SHAPE,
+               "nd_conv3x3: source channels %d+%d do not match cin=%d (multiples of 4)", s.c0, s.c1, d->cin);
+    ND_REQUIRE((s.c1 == 0) == (s.p1 == nullptr), ND_E_BADARG, "nd_conv3x3: p1/c1 mismatch");
+    ND_REQUIRE(s.ld0 >= s.c0 && s.ld0 % 4 == 0 && (s.c1 == 0 || (s.ld1 >= s.c1 && s.ld1 % 4 == 0)), ND_E_ALIGN,
+               "nd_conv3x3: pixel strides must be >= channels and multiples of 4");
+    ND_REQUIRE(nd_aligned16(s.p0) && nd_aligned16(s.p1) && nd_aligned16(d->weight) && nd_aligned16(s.mad) && nd_aligned16(s.map),
+               ND_E_ALIGN, "nd_conv3x3: pointers must be 16-byte aligned");
+    ND_REQUIRE(d->ldo >= d->cout, ND_E_SHAPE, "nd_conv3x3: ldo < cout");
+    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_AFFINE_SILU || s.mode == ND_PRO_AFFINE_MAP_SILU, ND_E_BADARG,
+               "nd_conv3x3: unsupported prologue %d", s.mode);
+    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mad, ND_E_BADARG, "nd_conv3x3: affine prologue needs mad");
+    ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || s.map, ND_E_BADARG, "nd_conv3x3: map prologue needs map");
+    ND_REQUIRE(!s.upsample || (d->H % 2 == 0 && d->W % 2 == 0 && s.c1 == 0), ND_E_SHAPE, "nd_conv3x3: upsample needs even H, W and one source");
+    ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3: unshuffle is a pointwise-only addressing mode");
+    ND_REQUIRE((d->stats == nullptr) == (d->slot_count == nullptr), ND_E_BADARG, "nd_conv3x3: stats and slot_count go together");
+
+    const Tiling t = choose_tiling(d->B, d->H, d->W, d->cout);
+    ConvArgs a;
+    a.d = *d;
+    a.tiles_x = nd_cdiv(d->W, t.tw);
+    a.tiles_y = nd_cdiv(d->H, t.th);
+    a.n_tiles = nd_cdiv(d->cout, t.bn);
+    a.coutP = nd_round_up(d->cout, 64);
+    a.slots = a.tiles_x * a.tiles_y * 2;
+    const long wg = (long)d->B * a.tiles_x * a.tiles_y * a.n_tiles;
+    ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_conv3x3: grid too large");
+    a.total_wg = (int)wg;
+    ND_REQUIRE(a.n_tiles * t.bn <= a.coutP, ND_E_SHAPE, "nd_conv3x3: internal tiling error");   // weight columns read
+    hipStream_t st = (hipStream_t)stream;
+    if (t.tw == 16 && t.nb == 2) launch<16, 2, 2>(a, st);
+    else if (t.tw == 16) launch<16, 2, 1>(a, st);
+    else if (t.nb == 2) launch<8, 1, 2>(a, st);
+    else launch<8, 1, 1>(a, st);
+    return nd_launch_status("nd_conv3x3_nhwc_f32");
+}

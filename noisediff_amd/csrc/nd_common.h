@@ -1,0 +1,77 @@
+// Shared host/device helpers for libnoisediff_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/noisediff_hip.h"
+
+#define ND_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- host side
+void nd_set_error(const char* fmt, ...);
+
+#define ND_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            nd_set_error(__VA_ARGS__);         \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+static inline int nd_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        nd_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+static inline bool nd_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int nd_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int nd_round_up(int a, int b) { return nd_cdiv(a, b) * b; }
+
+// ---------------------------------------------------------------- device side
+#ifdef __HIPCC__
+
+// XCD-aware block remap (bijective for any grid size): hardware deals consecutive
+// workgroup ids round-robin over the 8 XCDs, so ids {k, k+8, ...} share an L2.  Give
+// each XCD one contiguous range of logical tiles so neighbouring tiles (shared conv
+// halos, shared activation rows across N-tiles) hit the same L2.  Speed only.
+__device__ __forceinline__ int nd_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+__device__ __forceinline__ float nd_silu(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float nd_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float nd_act(float v, int act) {
+    if (act == ND_ACT_GELU) return nd_gelu(v);
+    if (act == ND_ACT_SILU) return nd_silu(v);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 nd_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void nd_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ f32x4 nd_silu4(f32x4 v) {
+    f32x4 r;
+    r.x = nd_silu(v.x); r.y = nd_silu(v.y); r.z = nd_silu(v.z); r.w = nd_silu(v.w);
+    return r;
+}
+
+// exact-fp32 matrix FMA: D(32x32) += A(32x2) * B(2x32); lane l gives A[l&31][l>>5], B[l>>5][l&31]
+__device__ __forceinline__ f32x16 nd_mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// accumulator register r of lane l holds D[row][col]: col = l & 31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+__device__ __forceinline__ int nd_acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+#endif  // __HIPCC__

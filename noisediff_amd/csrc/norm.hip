@@ -1,0 +1,132 @@
+// norm.hip -- GroupNorm statistics plumbing, the fused ResnetBlock tail, RMSNorm.
+#include "nd_common.h"
+
+namespace {
+
+// One wave per (sample, group): Chan/Welford merge of the conv epilogue's per-(slot, channel)
+// {sum, M2} partials in fp64, fixed order => bitwise reproducible.  Then fold gamma/beta and the
+// time-embedding scale/shift so that  GN(x)*(scale+1)+shift == (x - M)*A + D
+// (Block.forward, models/archs/Diffusion_arch.py:137-141; nn.GroupNorm: biased variance, eps inside sqrt).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ slot_count,
+                                                         int slots, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ ss, int ld_ss, float* __restrict__ mad,
+                                                         int C, int G, float eps) {
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int cpg = C / G, lane = threadIdx.x;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    const int items = slots * cpg;
+    for (int i = lane; i < items; i += 64) {
+        const int slot = i / cpg, ch = g * cpg + (i - slot * cpg);
+        const double ni = (double)slot_count[slot];
+        if (ni > 0.0) {
+            const float* st = stats + (((size_t)b * slots + slot) * C + ch) * 2;
+            const double mi = (double)st[0] / ni, m2i = (double)st[1];
+            const double nt = n + ni, dl = mi - mean;
+            mean += dl * ni / nt;
+            m2 += m2i + dl * dl * n * ni / nt;
+            n = nt;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double n2 = __shfl_xor(n, o), mean2 = __shfl_xor(mean, o), m22 = __shfl_xor(m2, o);
+        const double nt = n + n2;
+        if (nt > 0.0) {
+            const double dl = mean2 - mean;
+            // symmetric form so that both partners compute the same value
+            const double nm = (mean * n + mean2 * n2) / nt;
+            m2 = m2 + m22 + dl * dl * n * n2 / nt;
+            mean = nm;
+            n = nt;
+        }
+    }
+    const double var = n > 0.0 ? m2 / n : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    for (int i = lane; i < cpg; i += 64) {
+        const int ch = g * cpg + i;
+        const float sc = ss ? ss[(size_t)b * ld_ss + ch] : 0.0f;
+        const float sh = ss ? ss[(size_t)b * ld_ss + C + ch] : 0.0f;
+        float* m = mad + (size_t)b * 3 * C + ch;
+        m[0] = fmean;
+        m[C] = rstd * gamma[ch] * (sc + 1.0f);
+        m[2 * C] = beta[ch] * (sc + 1.0f) + sh;
+    }
+}
+
+// out = silu((t - M)*A + D) + res0 + res1   (ResnetBlock.forward tail, Diffusion_arch.py:168-170,
+// when res_conv is nn.Identity; res1 carries `shot_emb + r`, :603).  Pure HBM streaming.
+__global__ __launch_bounds__(256) void affine_silu_add_kernel(const float* __restrict__ t, int ldt, const float* __restrict__ mad,
+                                                              const float* __restrict__ r0, int ld0, const float* __restrict__ r1, int ld1,
+                                                              float* __restrict__ out, int ldo, int B, int HW, int C) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)B * HW * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        const size_t pix = i / cq;
+        const int b = (int)(pix / HW);
+        const float* m = mad + (size_t)b * 3 * C + c;
+        f32x4 v = nd_silu4((nd_ld4(t + pix * ldt + c) - nd_ld4(m)) * nd_ld4(m + C) + nd_ld4(m + 2 * C));
+        if (r0) v += nd_ld4(r0 + pix * ld0 + c);
+        if (r1) v += nd_ld4(r1 + pix * ld1 + c);
+        nd_st4(out + pix * ldo + c, v);
+    }
+}
+
+// RMSNorm.forward (Diffusion_arch.py:89-90): F.normalize(x, dim=channel) * g * sqrt(C); one wave per pixel.
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                      float* __restrict__ out, int ldo, size_t npix, int C) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const float rootc = sqrtf((float)C);
+    for (size_t p = wave; p < npix; p += nwaves) {
+        const float* row = x + p * ldx;
+        float ssq = 0.0f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = nd_ld4(row + c);
+            ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o);
+        const float inv = rootc / fmaxf(sqrtf(ssq), 1e-12f);
+        for (int c = lane * 4; c < C; c += 256) nd_st4(out + p * ldo + c, nd_ld4(row + c) * inv * nd_ld4(g + c));
+    }
+}
+
+}  // namespace
+
+extern "C" int nd_groupnorm_finalize_f32(const float* stats, const float* slot_count, int slots, const float* gamma,
+                                         const float* beta, const float* scale_shift, int ld_ss, float* mad, int B, int C,
+                                         int groups, float eps, void* stream) {
+    ND_REQUIRE(stats && slot_count && gamma && beta && mad, ND_E_BADARG, "nd_groupnorm_finalize: null pointer");
+    ND_REQUIRE(B > 0 && C > 0 && groups > 0 && slots > 0 && C % groups == 0, ND_E_SHAPE, "nd_groupnorm_finalize: C=%d groups=%d", C, groups);
+    ND_REQUIRE(!scale_shift || ld_ss >= 2 * C, ND_E_SHAPE, "nd_groupnorm_finalize: ld_ss < 2C");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
+                       beta, scale_shift, ld_ss, mad, C, groups, eps);
+    return nd_launch_status("nd_groupnorm_finalize_f32");
+}
+
+extern "C" int nd_affine_silu_add_f32(const float* t, int ldt, const float* mad, const float* res0, int ldr0, const float* res1,
+                                      int ldr1, float* out, int ldo, int B, int HW, int C, void* stream) {
+    ND_REQUIRE(t && mad && out, ND_E_BADARG, "nd_affine_silu_add: null pointer");
+    ND_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, ND_E_SHAPE, "nd_affine_silu_add: C=%d must be a multiple of 4", C);
+    ND_REQUIRE(ldt % 4 == 0 && ldo % 4 == 0 && (!res0 || ldr0 % 4 == 0) && (!res1 || ldr1 % 4 == 0), ND_E_ALIGN, "nd_affine_silu_add: strides");
+    ND_REQUIRE(nd_aligned16(t) && nd_aligned16(mad) && nd_aligned16(res0) && nd_aligned16(res1) && nd_aligned16(out), ND_E_ALIGN,
+               "nd_affine_silu_add: pointers must be 16-byte aligned");
+    const size_t total = (size_t)B * HW * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(affine_silu_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, ldt, mad, res0, ldr0, res1, ldr1,
+                       out, ldo, B, HW, C);
+    return nd_launch_status("nd_affine_silu_add_f32");
+}
+
+extern "C" int nd_rmsnorm_nhwc_f32(const float* x, int ldx, const float* g, float* out, int ldo, int B, int HW, int C, void* stream) {
+    ND_REQUIRE(x && g && out, ND_E_BADARG, "nd_rmsnorm: null pointer");
+    ND_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, ND_E_SHAPE, "nd_rmsnorm: C and strides must be multiples of 4");
+    ND_REQUIRE(nd_aligned16(x) && nd_aligned16(g) && nd_aligned16(out), ND_E_ALIGN, "nd_rmsnorm: alignment");
+    const size_t npix = (size_t)B * HW;
+    const int blocks = (int)((npix + 3) / 4 < 4096 ? (npix + 3) / 4 : 4096);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, g, out, ldo, npix, C);
+    return nd_launch_status("nd_rmsnorm_nhwc_f32");
+}

@@ -1,0 +1,297 @@
+// pointwise.hip -- per-pixel GEMM on NHWC fp32 (1x1 conv == Linear on tokens), exact-fp32 MFMA.
+//
+// Replaces res_conv (models/archs/Diffusion_arch.py:156), Downsample's conv1x1 behind the
+// pixel-unshuffle (:80-81), Mlp.fc1/fc2 (:345-347), ResnetBlock2.mlp (:176-179),
+// FeedForward's two Linears (:410-419), AttnBlock.proj_out (:432), final_conv (:554) and the
+// Attention to_qkv/to_out convs (:252-253).  CrossAttention itself (:379-402) needs no kernel:
+// with the 1-token ISO context its output is the per-sample vector to_out(to_v(ctx)), which
+// enters here as `src.vec` (added before LayerNorm) and `vec` (residual in the epilogue).
+//
+// One workgroup = 4 waves = BM consecutive pixels of one sample x BN output channels.  The A
+// tile (BM x 64 channels per chunk) is staged through LDS with the prologue applied on the way
+// (LayerNorm / SiLU / pixel-unshuffle addressing / virtual concat); B fragments come straight
+// from the packed weight [k/4][coutP][4] as coalesced 16-byte loads (see conv3x3.hip).
+#include "nd_common.h"
+
+namespace {
+
+constexpr int KC = 64;
+constexpr int LDA = KC + 4;
+
+struct PwArgs {
+    nd_pointwise d;
+    int m_tiles, n_tiles, coutP, cinP, total_wg;
+};
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int BM = WM * MB * 32, BN = WN * NB * 32;
+    constexpr int STAGE_IT = BM / 16;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
+    __shared__ float rowMean[BM], rowRstd[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, col = lane & 31;
+
+    int lid = nd_xcd_remap(blockIdx.x, a.total_wg);
+    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
+    const int mt = lid % a.m_tiles;
+    const int b = lid / a.m_tiles;
+
+    const nd_src& s = a.d.src;
+    const int HW = a.d.HW, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
+    const int p0 = mt * BM, n0 = nt * BN;
+
+    // ---- LayerNorm row statistics (two-pass in registers), rows split over the 4 waves
+    if (s.mode == ND_PRO_LAYERNORM) {
+        for (int r = wave; r < BM; r += 4) {
+            const int p = p0 + r;
+            float mean = 0.0f, rstd = 0.0f;
+            if (p < HW) {
+                const float* row = s.p0 + ((size_t)b * HW + p) * s.ld0;
+                f32x4 v[4];
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = lane * 4 + j * 256;
+                    v[j] = (f32x4){0, 0, 0, 0};
+                    if (c < Cin) {
+                        v[j] = nd_ld4(row + c);
+                        if (s.vec) v[j] += nd_ld4(s.vec + (size_t)b * Cin + c);
+                        sum += v[j].x + v[j].y + v[j].z + v[j].w;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                mean = sum / (float)Cin;
+                float m2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = lane * 4 + j * 256;
+                    if (c < Cin) {
+                        const f32x4 dv = v[j] - mean;
+                        m2 += dv.x * dv.x + dv.y * dv.y + dv.z * dv.z + dv.w * dv.w;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+                rstd = rsqrtf(m2 / (float)Cin + 1e-5f);
+            }
+            if (lane == 0) { rowMean[r] = mean; rowRstd[r] = rstd; }
+        }
+    }
+
+    int a_off[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_off[mb] = ((wm * MB + mb) * 32 + col) * LDA + 4 * half;
+    const float* wbase = a.d.weight + ((size_t)half * a.coutP + n0 + wn * NB * 32 + col) * 4;
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+    const int quad = tid & 15, prow = tid >> 4;
+    const int Cs = s.unshuffle ? (s.c0 >> 2) : 0;
+
+    for (int cb = 0; cb < a.cinP; cb += KC) {
+        const int ng = min(8, (a.cinP - cb) >> 3);
+        __syncthreads();   // previous chunk consumed (and LN statistics visible)
+        {
+            const int c = cb + quad * 4;
+            const bool cvalid = c < Cin;
+            const float* base = s.p0;
+            int ld = s.ld0, cc = c, py = 0, px = 0;
+            if (s.unshuffle) {
+                const int sub = c / Cs;
+                cc = c - sub * Cs; py = sub >> 1; px = sub & 1;
+            } else if (c >= s.c0) {
+                base = s.p1; ld = s.ld1; cc = c - s.c0;
+            }
+            f32x4 g4 = {1, 1, 1, 1}, b4 = {0, 0, 0, 0}, vec4 = {0, 0, 0, 0};
+            f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
+            if (cvalid && s.mode == ND_PRO_LAYERNORM) {
+                g4 = nd_ld4(s.gamma + c); b4 = nd_ld4(s.beta + c);
+                if (s.vec) vec4 = nd_ld4(s.vec + (size_t)b * Cin + c);
+            }
+            if (cvalid && s.mode == ND_PRO_AFFINE_SILU) {
+                const float* m = s.mad + (size_t)b * 3 * Cin + c;
+                tM = nd_ld4(m); tA = nd_ld4(m + Cin); tD = nd_ld4(m + 2 * Cin);
+            }
+#pragma unroll
+            for (int it = 0; it < STAGE_IT; ++it) {
+                const int r = prow + it * 16;
+                const int p = p0 + r;
+                f32x4 v = {0, 0, 0, 0};
+                if (cvalid && p < HW) {
+                    size_t pix;
+                    if (s.unshuffle) {
+                        const int y = p / W, x = p - y * W;
+                        pix = ((size_t)b * (2 * (HW / W)) + 2 * y + py) * (2 * W) + 2 * x + px;
+                    } else {
+                        pix = (size_t)b * HW + p;
+                    }
+                    v = nd_ld4(base + pix * ld + cc);
+                    if (s.mode == ND_PRO_LAYERNORM) v = ((v + vec4) - rowMean[r]) * rowRstd[r] * g4 + b4;
+                    else if (s.mode == ND_PRO_SILU) v = nd_silu4(v);
+                    else if (s.mode == ND_PRO_AFFINE_SILU) v = nd_silu4((v - tM) * tA + tD);
+                }
+                nd_st4(&As[r * LDA + quad * 4], v);
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < ng) {
+                f32x4 bq[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    bq[nb] = nd_ld4(wbase + ((size_t)((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 4);
+                f32x4 av[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[mb] = nd_ld4(&As[a_off[mb] + g * 8]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = nd_mfma(av[mb][k], bq[nb][k], acc[mb][nb]);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------ epilogue
+    float* out = a.d.out;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + (wn * NB + nb) * 32 + col;
+        if (n >= Cout) continue;
+        const float bias = a.d.bias ? a.d.bias[n] : 0.0f;
+        const float vadd = a.d.vec ? a.d.vec[(size_t)b * Cout + n] : 0.0f;
+        float gM = 0.0f, gA = 1.0f, gD = 0.0f;
+        if (a.d.gn_t) {
+            const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + n;
+            gM = m[0]; gA = m[Cout]; gD = m[2 * Cout];
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + (wm * MB + mb) * 32 + nd_acc_row(r, lane);
+                if (p < HW) {
+                    const size_t pix = (size_t)b * HW + p;
+                    float v = nd_act(acc[mb][nb][r] + bias, a.d.act);
+                    if (a.d.res0) v += a.d.res0[pix * a.d.ldr0 + n];
+                    if (a.d.res1) v += a.d.res1[pix * a.d.ldr1 + n];
+                    v += vadd;
+                    if (a.d.gn_t) v += nd_silu((a.d.gn_t[pix * a.d.ldt + n] - gM) * gA + gD);
+                    out[pix * a.d.ldo + n] = v;
+                }
+            }
+    }
+}
+
+// (cout, cin) -> [cinP/4][coutP][4], optional K permutation for pixel-unshuffled inputs
+__global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                      int cin, int cout, int cinP, int coutP, int unshuffle_c) {
+    const size_t total = (size_t)cinP * coutP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3;
+        size_t r = i >> 2;
+        const int n = r % coutP;
+        const int q = r / coutP;
+        const int kp = q * 4 + e;   // packed K index
+        float v = 0.0f;
+        if (n < cout && kp < cin) {
+            int k = kp;
+            if (unshuffle_c > 0) {   // packed order (p1 p2 c)  <-  torch order (c p1 p2)
+                const int sub = kp / unshuffle_c, c = kp - sub * unshuffle_c;
+                k = c * 4 + sub;
+            }
+            v = w[(size_t)n * cin + k];
+        }
+        out[i] = v;
+    }
+}
+
+template <int MB, int NB>
+void launch(const PwArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((pointwise_kernel<MB, NB>), dim3(a.total_wg), dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" int64_t nd_pack_pointwise_weight_floats(int cin, int cout) {
+    return (int64_t)nd_round_up(cin, 8) * nd_round_up(cout, 64);
+}
+
+extern "C" int nd_pack_pointwise_weight(const float* w, float* packed, int cin, int cout, int unshuffle_c, void* stream) {
+    ND_REQUIRE(w && packed, ND_E_BADARG, "nd_pack_pointwise_weight: null pointer");
+    ND_REQUIRE(cin > 0 && cout > 0, ND_E_BADARG, "nd_pack_pointwise_weight: non-positive size");
+    ND_REQUIRE(unshuffle_c == 0 || (unshuffle_c * 4 == cin && unshuffle_c % 4 == 0), ND_E_SHAPE,
+               "nd_pack_pointwise_weight: unshuffle_c=%d must be cin/4 and a multiple of 4", unshuffle_c);
+    const int cinP = nd_round_up(cin, 8), coutP = nd_round_up(cout, 64);
+    const size_t total = (size_t)cinP * coutP;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_pointwise_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, cinP, coutP, unshuffle_c);
+    return nd_launch_status("nd_pack_pointwise_weight");
+}
+
+extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
+    ND_REQUIRE(d, ND_E_BADARG, "nd_pointwise: null descriptor");
+    const nd_src& s = d->src;
+    ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_pointwise: null tensor pointer");
+    ND_REQUIRE(d->B > 0 && d->HW > 0 && d->cin > 0 && d->cout > 0, ND_E_BADARG, "nd_pointwise: non-positive size");
+    ND_REQUIRE(d->cin % 4 == 0, ND_E_SHAPE, "nd_pointwise: cin=%d must be a multiple of 4", d->cin);
+    ND_REQUIRE(s.c0 + s.c1 == d->cin && s.c0 % 4 == 0 && s.c1 % 4 == 0 && s.c0 > 0, ND_E_SHAPE,
+               "nd_pointwise: source channels %d+%d do not match cin=%d", s.c0, s.c1, d->cin);
+    ND_REQUIRE((s.c1 == 0) == (s.p1 == nullptr), ND_E_BADARG, "nd_pointwise: p1/c1 mismatch");
+    ND_REQUIRE(s.ld0 % 4 == 0 && (s.c1 == 0 || s.ld1 % 4 == 0), ND_E_ALIGN, "nd_pointwise: pixel strides must be multiples of 4");
+    ND_REQUIRE(nd_aligned16(s.p0) && nd_aligned16(s.p1) && nd_aligned16(d->weight) && nd_aligned16(s.vec) &&
+               nd_aligned16(s.gamma) && nd_aligned16(s.beta) && nd_aligned16(s.mad), ND_E_ALIGN, "nd_pointwise: pointers must be 16-byte aligned");
+    ND_REQUIRE(!s.upsample, ND_E_BADARG, "nd_pointwise: upsample is a conv3x3-only addressing mode");
+    if (s.unshuffle) {
+        ND_REQUIRE(s.c1 == 0 && d->W > 0 && d->HW % d->W == 0 && (s.c0 / 4) % 4 == 0 && s.mode == ND_PRO_NONE, ND_E_SHAPE,
+                   "nd_pointwise: unshuffle needs one source, W | HW, c0/4 %% 4 == 0, no prologue");
+        ND_REQUIRE(s.ld0 >= s.c0 / 4, ND_E_SHAPE, "nd_pointwise: ld0 < source channels");
+    } else {
+        ND_REQUIRE(s.ld0 >= s.c0 && (s.c1 == 0 || s.ld1 >= s.c1), ND_E_SHAPE, "nd_pointwise: ld < channels");
+    }
+    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_LAYERNORM || s.mode == ND_PRO_SILU || s.mode == ND_PRO_AFFINE_SILU,
+               ND_E_BADARG, "nd_pointwise: unsupported prologue %d", s.mode);
+    if (s.mode == ND_PRO_LAYERNORM)
+        ND_REQUIRE(s.gamma && s.beta && s.c1 == 0 && d->cin <= 1024, ND_E_SHAPE, "nd_pointwise: LayerNorm needs gamma/beta, one source, C <= 1024");
+    if (s.mode == ND_PRO_AFFINE_SILU) ND_REQUIRE(s.mad && s.c1 == 0, ND_E_BADARG, "nd_pointwise: affine prologue needs mad, one source");
+    ND_REQUIRE(d->ldo >= d->cout, ND_E_SHAPE, "nd_pointwise: ldo < cout");
+    ND_REQUIRE(!d->res0 || d->ldr0 >= d->cout, ND_E_SHAPE, "nd_pointwise: ldr0 < cout");
+    ND_REQUIRE(!d->res1 || d->ldr1 >= d->cout, ND_E_SHAPE, "nd_pointwise: ldr1 < cout");
+    ND_REQUIRE(!d->gn_t || (d->gn_mad && d->ldt >= d->cout), ND_E_BADARG, "nd_pointwise: gn_t needs gn_mad and ldt >= cout");
+    ND_REQUIRE(d->act >= ND_ACT_NONE && d->act <= ND_ACT_SILU, ND_E_BADARG, "nd_pointwise: bad act");
+
+    PwArgs a;
+    a.d = *d;
+    a.cinP = nd_round_up(d->cin, 8);
+    a.coutP = nd_round_up(d->cout, 64);
+    // tiling: 128x128, 128x64, 64x64 -- first with >= 2 workgroups per CU, else the smallest
+    int mb = 2, nb = (d->cout % 128 == 0) ? 2 : 1;
+    auto count = [&](int mb_, int nb_) { return (long)d->B * nd_cdiv(d->HW, 64 * mb_) * nd_cdiv(d->cout, 64 * nb_); };
+    if (nb == 2 && count(2, 2) < 512) nb = 1;
+    if (count(mb, nb) < 512) mb = 1;
+    a.m_tiles = nd_cdiv(d->HW, 64 * mb);
+    a.n_tiles = nd_cdiv(d->cout, 64 * nb);
+    const long wg = count(mb, nb);
+    ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_pointwise: grid too large");
+    a.total_wg = (int)wg;
+    hipStream_t st = (hipStream_t)stream;
+    if (mb == 2 && nb == 2) launch<2, 2>(a, st);
+    else if (mb == 2) launch<2, 1>(a, st);
+    else launch<1, 1>(a, st);
+    return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
+}

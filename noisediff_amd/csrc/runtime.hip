@@ -1,0 +1,90 @@
+// runtime.hip -- error reporting, stream / graph / event helpers of the C ABI.
+#include <stdarg.h>
+#include <string.h>
+#include "nd_common.h"
+
+static thread_local char g_err[512] = "";
+
+void nd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define ND_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) {                                             \
+            nd_set_error("%s: %s", #call, hipGetErrorString(e_));           \
+            return (int)e_;                                                 \
+        }                                                                   \
+    } while (0)
+
+extern "C" int nd_version(void) { return 1000 * 0 + 1; }
+extern "C" const char* nd_last_error(void) { return g_err; }
+
+extern "C" int nd_device_arch(char* buf, int n) {
+    ND_REQUIRE(buf && n > 0, ND_E_BADARG, "nd_device_arch: bad buffer");
+    int dev = 0;
+    ND_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    ND_HIP(hipGetDeviceProperties(&prop, dev));
+    strncpy(buf, prop.gcnArchName, n - 1);
+    buf[n - 1] = 0;
+    return 0;
+}
+
+extern "C" int nd_stream_create(void** stream) {
+    ND_REQUIRE(stream, ND_E_BADARG, "nd_stream_create: null");
+    hipStream_t s;
+    ND_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return 0;
+}
+extern "C" int nd_stream_destroy(void* stream) { ND_HIP(hipStreamDestroy((hipStream_t)stream)); return 0; }
+extern "C" int nd_stream_sync(void* stream) { ND_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+extern "C" int nd_graph_begin(void* stream) {
+    ND_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+extern "C" int nd_graph_end(void* stream, void** graph_exec) {
+    ND_REQUIRE(graph_exec, ND_E_BADARG, "nd_graph_end: null");
+    hipGraph_t g = nullptr;
+    ND_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        nd_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    *graph_exec = (void*)ge;
+    return 0;
+}
+extern "C" int nd_graph_launch(void* graph_exec, void* stream) {
+    ND_REQUIRE(graph_exec, ND_E_STATE, "nd_graph_launch: null graph");
+    ND_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int nd_graph_destroy(void* graph_exec) {
+    if (graph_exec) ND_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+extern "C" int nd_event_create(void** ev) {
+    ND_REQUIRE(ev, ND_E_BADARG, "nd_event_create: null");
+    hipEvent_t e;
+    ND_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return 0;
+}
+extern "C" int nd_event_record(void* ev, void* stream) { ND_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+extern "C" int nd_event_elapsed_ms(void* start, void* stop, float* ms) {
+    ND_REQUIRE(ms, ND_E_BADARG, "nd_event_elapsed_ms: null");
+    ND_HIP(hipEventSynchronize((hipEvent_t)stop));
+    ND_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+extern "C" int nd_event_destroy(void* ev) { ND_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }

@@ -1,0 +1,211 @@
+// small.hip -- the conditioning path (tiny dense ops on (B, K) rows), the two special
+// full-resolution layers with <= 4 input channels, and NCHW<->NHWC plumbing for the API tensors.
+#include "nd_common.h"
+
+namespace {
+
+// out[b, n] = act_out(sum_k act_in(in[b, k]) * W[n, k] + bias[n]); one wave per output column n,
+// the weight row lives in registers and is reused for every b.  K <= 2048.
+// time_mlp (models/archs/Diffusion_arch.py:502-507), all ResnetBlock.mlp projections stacked into
+// one tall matrix (:149-152,:161-164), CrossAttention.to_v/to_out on the ISO token (:385,:402).
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ld_out,
+                                                          int B, int K, int N, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    float w[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int k = lane + j * 64;
+        w[j] = k < K ? W[(size_t)n * K + k] : 0.0f;
+    }
+    const float bv = bias ? bias[n] : 0.0f;
+    for (int b = 0; b < B; ++b) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int k = lane + j * 64;
+            if (k < K) s += nd_act(in[(size_t)b * ld_in + k], act_in) * w[j];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) out[(size_t)b * ld_out + n] = nd_act(s + bv, act_out);
+    }
+}
+
+// SinusoidalPosEmb.forward (:100-107)
+__global__ void sinusoidal_kernel(const int64_t* __restrict__ time, const float* __restrict__ freqs, float* __restrict__ emb, int B, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    const float ang = (float)time[b] * freqs[j];
+    emb[(size_t)b * 2 * half + j] = sinf(ang);
+    emb[(size_t)b * 2 * half + half + j] = cosf(ang);
+}
+
+__global__ void embedding_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table, float* __restrict__ out, int B, int rows, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i - b * dim;
+    int64_t r = idx[b];
+    r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);   // host validates; clamp keeps a bad index from faulting
+    out[i] = table[r * dim + j];
+}
+
+// LearnedSinusoidalPosEmb.forward (:331-337): w = conv1x1(position); out = cat(w, sin(2 pi w), cos(2 pi w))
+__global__ __launch_bounds__(256) void pos_enc_kernel(const float* __restrict__ pos, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int B, int HW, int hid) {
+    const size_t total = (size_t)B * HW * hid;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % hid);
+        const size_t pix = i / hid;
+        const int b = (int)(pix / HW);
+        const size_t p = pix - (size_t)b * HW;
+        const float p0 = pos[((size_t)b * 2 + 0) * HW + p], p1 = pos[((size_t)b * 2 + 1) * HW + p];
+        const float v = fmaf(w[h * 2 + 1], p1, fmaf(w[h * 2], p0, bias[h]));
+        const float f = v * 2.0f * 3.14159265358979323846f;
+        float* o = out + pix * (3 * hid);
+        o[h] = v;
+        o[hid + h] = sinf(f);
+        o[2 * hid + h] = cosf(f);
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    const size_t total = (size_t)B * HW * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t pix = i / C;
+        const int b = (int)(pix / HW);
+        const size_t p = pix - (size_t)b * HW;
+        out[i] = in[((size_t)b * C + c) * HW + p];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    const size_t total = (size_t)B * HW * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i % HW;
+        const size_t bc = i / HW;
+        const int c = (int)(bc % C);
+        const int b = (int)(bc / C);
+        out[i] = in[((size_t)b * HW + p) * C + c];
+    }
+}
+
+// init_conv: Conv2d(4, cout, 7, padding=3) (:478).  16x16 output pixels per workgroup; the 22x22x4 input
+// patch sits in LDS, weights [49*4][cout] are wave-uniform and come through the scalar cache.
+constexpr int C7_T = 16, C7_HALO = C7_T + 6, C7_CO = 16;
+
+__global__ __launch_bounds__(256) void conv7x7_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int ldo, int H, int W, int cout) {
+    __shared__ __attribute__((aligned(16))) float tile[C7_HALO * C7_HALO * 4];
+    const int b = blockIdx.z, ty0 = blockIdx.y * C7_T, tx0 = blockIdx.x * C7_T;
+    for (int i = threadIdx.x; i < C7_HALO * C7_HALO; i += 256) {
+        const int hy = i / C7_HALO, hx = i - hy * C7_HALO;
+        const int y = ty0 + hy - 3, xx = tx0 + hx - 3;
+        f32x4 v = {0, 0, 0, 0};
+        if (y >= 0 && y < H && xx >= 0 && xx < W) v = nd_ld4(x + ((size_t)(b * H + y) * W + xx) * 4);
+        nd_st4(&tile[i * 4], v);
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    const int y = ty0 + ly, xx = tx0 + lx;
+    for (int co0 = 0; co0 < cout; co0 += C7_CO) {
+        float acc[C7_CO];
+#pragma unroll
+        for (int j = 0; j < C7_CO; ++j) acc[j] = (co0 + j < cout) ? bias[co0 + j] : 0.0f;
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const f32x4 v = nd_ld4(&tile[((ly + ky) * C7_HALO + lx + kx) * 4]);
+                const float* wr = wp + (size_t)((ky * 7 + kx) * 4) * cout + co0;   // uniform address
+#pragma unroll
+                for (int j = 0; j < C7_CO; ++j) {
+                    if (co0 + j < cout) {
+                        acc[j] = fmaf(v.x, wr[j], acc[j]);
+                        acc[j] = fmaf(v.y, wr[cout + j], acc[j]);
+                        acc[j] = fmaf(v.z, wr[2 * cout + j], acc[j]);
+                        acc[j] = fmaf(v.w, wr[3 * cout + j], acc[j]);
+                    }
+                }
+            }
+        if (y < H && xx < W) {
+            float* o = out + ((size_t)(b * H + y) * W + xx) * ldo + co0;
+#pragma unroll
+            for (int j = 0; j < C7_CO; ++j)
+                if (co0 + j < cout) o[j] = acc[j];
+        }
+    }
+}
+
+__global__ void pack_conv7x7_kernel(const float* __restrict__ w, float* __restrict__ out, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [49*4][cout]
+    if (i >= 196 * cout) return;
+    const int n = i % cout, k = i / cout, ci = k & 3, tap = k >> 2;
+    out[i] = w[((size_t)n * 4 + ci) * 49 + tap];
+}
+
+inline int grid_for(size_t total, int cap = 4096) {
+    const size_t g = (total + 255) / 256;
+    return (int)(g < (size_t)cap ? (g ? g : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int nd_linear_rows_f32(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out, int B,
+                                  int K, int N, int act_in, int act_out, void* stream) {
+    ND_REQUIRE(in && W && out, ND_E_BADARG, "nd_linear_rows: null pointer");
+    ND_REQUIRE(B > 0 && K > 0 && N > 0 && K <= 2048 && ld_in >= K && ld_out >= N, ND_E_SHAPE, "nd_linear_rows: B=%d K=%d N=%d (K <= 2048)", B, K, N);
+    hipLaunchKernelGGL(linear_rows_kernel, dim3(nd_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, in, ld_in, W, bias, out, ld_out, B, K, N, act_in, act_out);
+    return nd_launch_status("nd_linear_rows_f32");
+}
+
+extern "C" int nd_sinusoidal_time_emb_f32(const int64_t* time, const float* freqs, float* emb, int B, int half, void* stream) {
+    ND_REQUIRE(time && freqs && emb && B > 0 && half > 0, ND_E_BADARG, "nd_sinusoidal_time_emb: bad argument");
+    hipLaunchKernelGGL(sinusoidal_kernel, dim3(nd_cdiv(B * half, 256)), dim3(256), 0, (hipStream_t)stream, time, freqs, emb, B, half);
+    return nd_launch_status("nd_sinusoidal_time_emb_f32");
+}
+
+extern "C" int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, int B, int rows, int dim, void* stream) {
+    ND_REQUIRE(idx && table && out && B > 0 && rows > 0 && dim > 0, ND_E_BADARG, "nd_embedding_rows: bad argument");
+    hipLaunchKernelGGL(embedding_kernel, dim3(nd_cdiv(B * dim, 256)), dim3(256), 0, (hipStream_t)stream, idx, table, out, B, rows, dim);
+    return nd_launch_status("nd_embedding_rows_f32");
+}
+
+extern "C" int nd_pos_enc_f32(const float* position_nchw, const float* w, const float* bias, float* out, int B, int H, int W, int hid, void* stream) {
+    ND_REQUIRE(position_nchw && w && bias && out && B > 0 && H > 0 && W > 0 && hid > 0, ND_E_BADARG, "nd_pos_enc: bad argument");
+    const size_t total = (size_t)B * H * W * hid;
+    hipLaunchKernelGGL(pos_enc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, position_nchw, w, bias, out, B, H * W, hid);
+    return nd_launch_status("nd_pos_enc_f32");
+}
+
+extern "C" int nd_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, void* stream) {
+    ND_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0, ND_E_BADARG, "nd_nchw_to_nhwc: bad argument");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, C, H * W);
+    return nd_launch_status("nd_nchw_to_nhwc_f32");
+}
+
+extern "C" int nd_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, void* stream) {
+    ND_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0, ND_E_BADARG, "nd_nhwc_to_nchw: bad argument");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, C, H * W);
+    return nd_launch_status("nd_nhwc_to_nchw_f32");
+}
+
+extern "C" int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout, void* stream) {
+    ND_REQUIRE(oihw && packed && cout > 0, ND_E_BADARG, "nd_pack_conv7x7_weight: bad argument");
+    hipLaunchKernelGGL(pack_conv7x7_kernel, dim3(nd_cdiv(196 * cout, 256)), dim3(256), 0, (hipStream_t)stream, oihw, packed, cout);
+    return nd_launch_status("nd_pack_conv7x7_weight");
+}
+
+extern "C" int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo, int B, int H, int W,
+                                 int cout, void* stream) {
+    ND_REQUIRE(x && wpacked && bias && out, ND_E_BADARG, "nd_conv7x7_c4: null pointer");
+    ND_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && ldo >= cout, ND_E_SHAPE, "nd_conv7x7_c4: bad shape");
+    ND_REQUIRE(nd_aligned16(x), ND_E_ALIGN, "nd_conv7x7_c4: x must be 16-byte aligned");
+    ND_REQUIRE(B <= 65535 && nd_cdiv(H, C7_T) <= 65535, ND_E_SHAPE, "nd_conv7x7_c4: grid too large");
+    hipLaunchKernelGGL(conv7x7_kernel, dim3(nd_cdiv(W, C7_T), nd_cdiv(H, C7_T), B), dim3(256), 0, (hipStream_t)stream, x, wpacked,
+                       bias, out, ldo, H, W, cout);
+    return nd_launch_status("nd_conv7x7_c4_f32");
+}

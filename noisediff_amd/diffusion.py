@@ -1,0 +1,267 @@
+"""``GaussianDiffusion``: the reference's diffusion wrapper with the sampling loop on HIP.
+
+Same constructor, buffers, properties and ``.sample()`` signature as
+models/denoising_diffusion_pytorch.py:167-451, so ``Trainer.__init__`` / ``Trainer.test``
+(models/trainer_diffusion.py:77-86,286-294) work unchanged.  ``sample`` accepts two extra
+keyword-only arguments for reproducibility (``noise=`` explicit draws for parity, ``seed=``
+for the device Philox stream); the reference call signature is a strict subset.
+
+The loop itself is one captured hipGraph per step: [write t] -> time MLP -> U-Net -> fused
+x0 / clamp / posterior / noise update -> advance; T replays, no host<->device traffic inside.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib as L
+
+BUFFER_NAMES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
+                "loss_weight"]
+
+_SIGMOID = {"sigmoid1": (-3, 3, 0.5), "sigmoid2": (-7, 3, 0.7), "sigmoid3": (-10, 3, 0.7)}
+
+
+def make_betas(name: str, timesteps: int, **kw) -> torch.Tensor:
+    """fp64 beta schedules (denoising_diffusion_pytorch.py:96-164); unknown names raise as at :218
+    (the CLI default 'sigmoid' is NOT a valid name in the reference and stays invalid here)."""
+    f64 = torch.float64
+    if name == "linear":
+        scale = 1000 / timesteps
+        return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=f64)
+    grid = torch.linspace(0, timesteps, timesteps + 1, dtype=f64) / timesteps
+    if name == "cosine":
+        s = kw.get("s", 0.008)
+        bar = torch.cos((grid + s) / (1 + s) * torch.pi * 0.5) ** 2
+    elif name in _SIGMOID:
+        start, end, tau = _SIGMOID[name]
+        start, end, tau = kw.get("start", start), kw.get("end", end), kw.get("tau", tau)
+        lo, hi = torch.tensor(start / tau).sigmoid(), torch.tensor(end / tau).sigmoid()   # fp32 scalars, as upstream
+        bar = (hi - ((grid * (end - start) + start) / tau).sigmoid()) / (hi - lo)
+    else:
+        raise ValueError(f"unknown beta schedule {name}")
+    bar = bar / bar[0]
+    return torch.clip(1 - bar[1:] / bar[:-1], 0, 0.999)
+
+
+def make_buffers(betas: torch.Tensor, objective: str) -> Dict[str, torch.Tensor]:
+    """The 13 schedule buffers (:222-286), fp64 math, stored fp32."""
+    a = 1.0 - betas
+    ac = torch.cumprod(a, dim=0)
+    ac_prev = F.pad(ac[:-1], (1, 0), value=1.0)
+    pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+    snr = ac / (1 - ac)
+    lw = {"pred_noise": snr / snr, "pred_x0": snr.clone(), "pred_v": snr / (snr + 1)}[objective]
+    vals = [betas, ac, ac_prev, ac.sqrt(), (1.0 - ac).sqrt(), (1.0 - ac).log(), (1.0 / ac).sqrt(), (1.0 / ac - 1).sqrt(),
+            pv, pv.clamp(min=1e-20).log(), betas * ac_prev.sqrt() / (1.0 - ac), (1.0 - ac_prev) * a.sqrt() / (1.0 - ac), lw]
+    return {n: v.to(torch.float32) for n, v in zip(BUFFER_NAMES, vals)}
+
+
+def _unwrap(model: nn.Module) -> nn.Module:
+    return model.module if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else model
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, objective="pred_v",
+                 beta_schedule="sigmoid", schedule_fn_kwargs=dict(), ddim_sampling_eta=0., auto_normalize=False,
+                 offset_noise_strength=0., min_snr_gamma=5):
+        super().__init__()
+        net = _unwrap(model)       # the reference crashes on a bare module (:189); both forms are accepted here
+        assert not (type(self) == GaussianDiffusion and net.channels != net.out_dim)
+        assert not net.random_or_learned_sinusoidal_cond
+        self.model = model
+        self.channels = net.channels
+        self.self_condition = net.self_condition
+        self.image_size = image_size
+        self.objective = objective
+        assert objective in {"pred_noise", "pred_x0", "pred_v"}, \
+            "objective must be either pred_noise (predict noise) or pred_x0 (predict image start) or pred_v (predict v)"
+        betas = make_betas(beta_schedule, timesteps, **schedule_fn_kwargs)
+        self.num_timesteps = int(betas.shape[0])
+        self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else self.num_timesteps
+        assert self.sampling_timesteps <= self.num_timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < self.num_timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        for name, val in make_buffers(betas, objective).items():
+            self.register_buffer(name, val)
+        self.offset_noise_strength = offset_noise_strength
+        self.auto_normalize = auto_normalize
+        # rank shard bookkeeping for the device noise stream (see shard.py): global index of sample 0
+        self.sample_offset = 0
+        self._loop_cache: Dict[tuple, "_Loop"] = {}
+
+    # ------------------------------------------------------------------ reference-compatible helpers
+    def normalize(self, img):
+        return img * 2 - 1 if self.auto_normalize else img
+
+    def unnormalize(self, t):
+        return (t + 1) * 0.5 if self.auto_normalize else t
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def ddim_time_pairs(self):
+        times = torch.linspace(-1, self.num_timesteps - 1, steps=self.sampling_timesteps + 1)   # fp32, as :409
+        times = list(reversed(times.int().tolist()))
+        return list(zip(times[:-1], times[1:]))
+
+    # ------------------------------------------------------------------ per-step coefficient tables
+    def _tables(self):
+        """(t_cur, t_next, coef[n,8]) on the CPU, built from the fp32 buffers exactly as the
+        reference combines them per step (:322-329,:372 for DDPM; :427-431 for DDIM)."""
+        cpu = {n: getattr(self, n).detach().cpu() for n in BUFFER_NAMES}
+        rows: List[torch.Tensor] = []
+        if not self.is_ddim_sampling:
+            ts = list(reversed(range(self.num_timesteps)))
+            nxt = [t - 1 for t in ts]
+            for t in ts:
+                rows.append(torch.stack([cpu["sqrt_alphas_cumprod"][t], cpu["sqrt_one_minus_alphas_cumprod"][t],
+                                         cpu["sqrt_recip_alphas_cumprod"][t], cpu["sqrt_recipm1_alphas_cumprod"][t],
+                                         cpu["posterior_mean_coef1"][t], cpu["posterior_mean_coef2"][t],
+                                         (0.5 * cpu["posterior_log_variance_clipped"][t]).exp(),
+                                         torch.tensor(1.0 if t > 0 else 0.0)]))
+        else:
+            pairs = self.ddim_time_pairs()
+            ts, nxt = [p[0] for p in pairs], [p[1] for p in pairs]
+            ac, eta = cpu["alphas_cumprod"], self.ddim_sampling_eta
+            for t, tn in pairs:
+                head = [cpu["sqrt_alphas_cumprod"][t], cpu["sqrt_one_minus_alphas_cumprod"][t],
+                        cpu["sqrt_recip_alphas_cumprod"][t], cpu["sqrt_recipm1_alphas_cumprod"][t]]
+                if tn < 0:
+                    tail = [torch.tensor(0.0), torch.tensor(0.0), torch.tensor(0.0), torch.tensor(1.0)]
+                else:
+                    a, an = ac[t], ac[tn]
+                    sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+                    c = (1 - an - sigma ** 2).sqrt()
+                    tail = [an.sqrt(), c, sigma, torch.tensor(0.0)]
+                rows.append(torch.stack(head + tail))
+        return (torch.tensor(ts, dtype=torch.int32), torch.tensor(nxt, dtype=torch.int32),
+                torch.stack(rows).to(torch.float32).contiguous())
+
+    # ------------------------------------------------------------------ sampling
+    @torch.inference_mode()
+    def sample(self, batch_size=16, condition=None, return_all_timesteps=False, preset_mean=None, *,
+               noise: Optional[Dict[str, torch.Tensor]] = None, seed: Optional[int] = None):
+        """(B, C, H, W) fp32 samples, or (B, T+1, C, H, W) with ``return_all_timesteps`` (:446-451).
+
+        noise={'x_T': (B,C,H,W), 'steps': (n_draws,B,C,H,W)} injects the exact draws the reference would take
+        from torch.randn / randn_like (parity mode).  Otherwise x_T and the per-step noise come from the
+        device Philox stream keyed by (seed, global sample index, step); seed=None draws one from torch's
+        default generator, so torch.manual_seed() makes runs repeatable.
+        """
+        net = _unwrap(self.model)
+        if not hasattr(net, "hip_engine"):
+            raise TypeError("noisediff_amd.GaussianDiffusion drives noisediff_amd.NoiseDiffNet; got %s" % type(net).__name__)
+        dev = self.device
+        B, Cc, S = int(batch_size), self.channels, self.image_size
+        plan = net.hip_engine(dev).plan(B, S, S)
+        plan.set_condition(condition)
+        key = (id(plan), self.is_ddim_sampling, self.objective, self.sampling_timesteps, float(self.ddim_sampling_eta))
+        loop = self._loop_cache.get(key)
+        if loop is None:
+            loop = _Loop(self, plan)
+            self._loop_cache = {key: loop}
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ddim = self.is_ddim_sampling
+        x_T = None
+        if noise is not None and "x_T" in noise:
+            x_T = noise["x_T"]
+        if preset_mean is not None and not ddim:       # ddim_sample accepts but ignores preset_mean (:405,413)
+            x_T = preset_mean
+        ret = loop.run(x_T=x_T, step_noise=None if noise is None else noise.get("steps"), seed=seed,
+                       first_sample=int(self.sample_offset), return_all=return_all_timesteps)
+        return self.unnormalize(ret)
+
+    # ------------------------------------------------------------------ training entry points (not accelerated)
+    def forward(self, img, condition, *args, **kwargs):
+        raise NotImplementedError(
+            "noisediff_amd accelerates the sampling path (GaussianDiffusion.sample) only; train with the reference's "
+            "GaussianDiffusion.forward / p_losses (models/denoising_diffusion_pytorch.py:481-542) and load the weights here.")
+
+
+class _Loop:
+    """Device-resident sampler state + the captured step graph for one plan."""
+
+    def __init__(self, gd: GaussianDiffusion, plan):
+        self.gd, self.plan = gd, plan
+        dev = plan.dev
+        t_cur, t_next, coef = gd._tables()
+        self.n_steps = int(t_cur.numel())
+        with torch.cuda.device(dev):
+            self.t_cur, self.t_next, self.coef = t_cur.to(dev), t_next.to(dev), coef.to(dev)
+            self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+        st = L.SamplerState()
+        st.step, st.t_cur, st.t_next, st.coef = self.step.data_ptr(), self.t_cur.data_ptr(), self.t_next.data_ptr(), self.coef.data_ptr()
+        st.time_out, st.n_steps, st.B = plan.time.data_ptr(), self.n_steps, plan.B
+        self.state = st
+        self.graph = C.c_void_p()
+        self.graph_key = None
+        self.noise_nhwc = None
+
+    def _step_eager(self, noise_ptr, stride, seed, first):
+        p, e, st = self.plan, self.plan.e, self.plan.e.stream
+        L.call("nd_sampler_begin_step", C.byref(self.state), st)
+        p.run(p.step_ops)
+        fn = "nd_sampler_step_ddim_f32" if self.gd.is_ddim_sampling else "nd_sampler_step_ddpm_f32"
+        L.call(fn, p.x.data_ptr(), p.model_out.data_ptr(), noise_ptr, stride, C.byref(self.state),
+               L.OBJECTIVES[self.gd.objective], C.c_uint64(seed), first, p.B, p.H * p.W, e.inp_dim, st)
+        L.call("nd_sampler_advance", C.byref(self.state), st)
+
+    def _ensure_graph(self, noise_ptr, stride, seed, first):
+        key = (noise_ptr, stride, seed, first)
+        if self.graph_key == key:
+            return
+        st = self.plan.e.stream
+        if self.graph:
+            L.call("nd_graph_destroy", self.graph)
+            self.graph = C.c_void_p()
+        L.call("nd_graph_begin", st)
+        try:
+            self._step_eager(noise_ptr, stride, seed, first)
+        finally:
+            L.call("nd_graph_end", st, C.byref(self.graph))
+        self.graph_key = key
+
+    def run(self, x_T, step_noise, seed, first_sample, return_all=False, use_graph=True, on_step=None):
+        p, e, gd = self.plan, self.plan.e, self.gd
+        B, Cc, H, W = p.B, e.inp_dim, p.H, p.W
+        st = e.stream
+        with torch.cuda.device(p.dev):
+            self.step.zero_()
+            noise_ptr, stride = None, 0
+            if step_noise is not None:
+                need = self.n_steps - 1
+                if step_noise.shape[0] < need or tuple(step_noise.shape[1:]) != (B, Cc, H, W):
+                    raise ValueError(f"noise['steps'] must be (>={need}, {B}, {Cc}, {H}, {W}); got {tuple(step_noise.shape)}")
+                self.noise_nhwc = step_noise.to(p.dev, torch.float32).permute(0, 1, 3, 4, 2).contiguous()
+                noise_ptr, stride = self.noise_nhwc.data_ptr(), B * Cc * H * W
+            torch.cuda.synchronize(p.dev)
+            if x_T is not None:
+                if tuple(x_T.shape) != (B, Cc, H, W):
+                    raise ValueError(f"x_T / preset_mean must be {(B, Cc, H, W)}; got {tuple(x_T.shape)}")
+                p.load_x(x_T)
+            else:
+                L.call("nd_philox_normal_f32", p.x.data_ptr(), C.c_uint64(seed), first_sample, -1, B, H * W, Cc, st)
+            frames = [p.read_nchw(p.x)] if return_all else None
+            if use_graph:
+                self._ensure_graph(noise_ptr, stride, seed, first_sample)
+            for i in range(self.n_steps):
+                if use_graph:
+                    L.call("nd_graph_launch", self.graph, st)
+                else:
+                    self._step_eager(noise_ptr, stride, seed, first_sample)
+                if return_all:
+                    frames.append(p.read_nchw(p.x))
+                if on_step is not None:
+                    on_step(i)
+            out = p.read_nchw(p.x)       # synchronises the library stream
+        return torch.stack(frames, dim=1) if return_all else out

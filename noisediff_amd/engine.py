@@ -1,0 +1,526 @@
+"""Host-side sequencing of the HIP kernels: NoiseDiffNet.forward and the sampling loop.
+
+``Engine`` owns the packed weight arena (one flat fp32 tensor -- the only thing that has to be
+broadcast to other ranks), ``Plan`` owns the workspace and the recorded launch list for one
+(batch, height, width).  A plan is a list of ``(c_function, args)``; running it is a loop of
+ctypes calls on the library's own HIP stream, and the per-step part is captured once into a
+hipGraph and replayed for every diffusion step (the timestep and the sampler coefficients are
+read by the kernels from device memory, so the captured graph never changes).
+
+What is computed where (reference: models/archs/Diffusion_arch.py:577-646):
+  * once per condition (``set_condition``): pos_emb (:584-585), the two ResnetBlock2 scale/shift
+    maps (:188-190), iso embedding (:591) and every AttnBlock's per-sample vector
+    to_out(to_v(iso)) -- CrossAttention over a 1-token context is exactly that vector
+    (softmax over one key == 1), so to_q / to_k / norm1 never run;
+  * once per step (``step_ops``): time MLP + all 20 ResnetBlock.mlp projections as one tall
+    GEMV, then the U-Net body;
+  * once per step, sampler: nd_sampler_step_* in place on the NHWC state.
+PyTorch is used for allocation and host<->device copies only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, POS_GROUPS, RESNET_GROUPS, SHOT_GROUPS,
+                   attention_param_spec, noisediff_param_spec, stage_dims)
+
+GN_EPS = 1e-5
+_ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
+
+
+def _classify(name: str, shape: Sequence[int]) -> str:
+    """How a state-dict tensor is laid out in the arena."""
+    if ".attn.to_q." in name or ".attn.to_k." in name or ".norm1." in name:
+        return "skip"                       # dead with a 1-token context
+    if len(shape) == 4:
+        k = shape[-1]
+        if name == "pos_enc.weights.weight" or name.endswith(".g"):
+            return "raw"
+        if k == 7:
+            return "conv7"
+        if k == 3:
+            return "conv3"
+        if name.startswith("downs.") and name.endswith(".3.1.weight"):
+            return "pw_unshuffle"
+        return "pw"
+    if len(shape) == 2 and (".ff.net." in name):
+        return "pw"
+    return "raw"
+
+
+@dataclass
+class Slot:
+    offset: int
+    numel: int
+    kind: str
+    shape: Tuple[int, ...]
+
+
+class Engine:
+    """Packed weights of one NoiseDiffNet on one GPU."""
+
+    def __init__(self, dim: int, device: torch.device, mid_attn: bool = False, inp_dim: int = 4):
+        if device.type != "cuda":
+            raise L.HipError("noisediff_amd runs on MI355X only: got device %r (there is no CPU path)" % (device,))
+        self.lib = L.load()
+        self.dim, self.device, self.mid_attn, self.inp_dim = dim, device, mid_attn, inp_dim
+        self.spec = list(noisediff_param_spec(dim, inp_dim))
+        if mid_attn:
+            self.spec += attention_param_spec("mid_attn", 8 * dim)
+        self.resnet_names = [p.name[:-len(".mlp.1.weight")] for p in self.spec
+                             if p.name.endswith(".mlp.1.weight") and len(p.shape) == 2]
+        self.tproj_off: Dict[str, int] = {}
+        self._layout()
+        self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            s = C.c_void_p()
+            L.call("nd_stream_create", C.byref(s))
+        self.stream = s
+        self.plans: Dict[Tuple[int, int, int], "Plan"] = {}
+        self.loaded = False
+
+    # ------------------------------------------------------------------ arena layout
+    def _layout(self) -> None:
+        self.slots: Dict[str, Slot] = {}
+        off = 0
+
+        def add(name, numel, kind, shape):
+            nonlocal off
+            self.slots[name] = Slot(off, int(numel), kind, tuple(shape))
+            off += (int(numel) + _ALIGN - 1) // _ALIGN * _ALIGN
+
+        for p in self.spec:
+            kind = _classify(p.name, p.shape)
+            if kind == "skip":
+                continue
+            if kind == "conv3":
+                n = self.lib.nd_pack_conv3x3_weight_floats(p.shape[1], p.shape[0])
+            elif kind in ("pw", "pw_unshuffle"):
+                n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
+            elif kind == "conv7":
+                n = 196 * p.shape[0]
+            else:
+                n = math.prod(p.shape)
+            add(p.name, n, kind, p.shape)
+        # all ResnetBlock.mlp[1] Linears stacked into one (J, 4*dim) matrix
+        j = 0
+        for r in self.resnet_names:
+            self.tproj_off[r] = j
+            j += self.slots[r + ".mlp.1.weight"].shape[0]
+        self.tproj_rows = j
+        add("tproj.weight", j * 4 * self.dim, "derived", (j, 4 * self.dim))
+        add("tproj.bias", j, "derived", (j,))
+        add("time_freqs", self.dim // 2, "derived", (self.dim // 2,))
+        self.arena_floats = off
+
+    def view(self, name: str) -> torch.Tensor:
+        s = self.slots[name]
+        return self.arena[s.offset:s.offset + s.numel]
+
+    def p(self, name: str) -> int:
+        s = self.slots[name]
+        return self.arena.data_ptr() + 4 * s.offset
+
+    # ------------------------------------------------------------------ loading
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Pack a reference-layout state dict (any device) into the arena."""
+        st = self.stream
+        keep = []
+        with torch.cuda.device(self.device):
+            for p in self.spec:
+                if p.name not in self.slots:
+                    continue
+                t = sd[p.name].detach().to(device=self.device, dtype=torch.float32).contiguous()
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError(f"{p.name}: shape {tuple(t.shape)} != {tuple(p.shape)}")
+                keep.append(t)
+                kind = self.slots[p.name].kind
+                if kind == "raw":
+                    self.view(p.name).copy_(t.reshape(-1))
+            torch.cuda.synchronize(self.device)     # raw copies ran on torch's stream
+            for p, t in zip([q for q in self.spec if q.name in self.slots], keep):
+                kind, dst = self.slots[p.name].kind, self.p(p.name)
+                if kind == "conv3":
+                    L.call("nd_pack_conv3x3_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], st)
+                elif kind == "pw":
+                    L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
+                elif kind == "pw_unshuffle":
+                    L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], p.shape[1] // 4, st)
+                elif kind == "conv7":
+                    L.call("nd_pack_conv7x7_weight", t.data_ptr(), dst, p.shape[0], st)
+            L.call("nd_stream_sync", st)
+            tw = torch.cat([self.view(r + ".mlp.1.weight") for r in self.resnet_names])
+            tb = torch.cat([self.view(r + ".mlp.1.bias") for r in self.resnet_names])
+            self.view("tproj.weight").copy_(tw)
+            self.view("tproj.bias").copy_(tb)
+            # SinusoidalPosEmb frequencies, computed exactly as Diffusion_arch.py:102-104 (fp32 on the host)
+            half = self.dim // 2
+            e = math.log(10000) / (half - 1)
+            self.view("time_freqs").copy_(torch.exp(torch.arange(half) * -e).to(torch.float32))
+            torch.cuda.synchronize(self.device)
+        self.loaded = True
+
+    def broadcast(self, src: int = 0, group=None) -> None:
+        """The ONE collective of the sampling path: packed weights root -> all ranks (RCCL over xGMI)."""
+        import torch.distributed as dist
+        dist.broadcast(self.arena, src=src, group=group)
+        self.loaded = True
+
+    # ------------------------------------------------------------------ plans
+    def plan(self, B: int, H: int, W: int, debug: bool = False) -> "Plan":
+        if not self.loaded:
+            raise L.HipError("Engine has no weights: call load_state_dict() or broadcast() first")
+        key = (B, H, W, debug)
+        if key not in self.plans:
+            self.plans[key] = Plan(self, B, H, W, debug)
+        return self.plans[key]
+
+    def sync(self) -> None:
+        L.call("nd_stream_sync", self.stream)
+
+
+Op = Tuple[Callable, tuple]
+
+
+class Plan:
+    """Workspace + recorded launch lists of one (B, H, W) problem."""
+
+    def __init__(self, eng: Engine, B: int, H: int, W: int, debug: bool = False):
+        # debug=True: no workspace reuse and named intermediates kept in self.taps (tests / diagnosis only)
+        self.debug, self.taps = debug, {}
+        if H % 8 or W % 8:
+            raise AssertionError(f"your input dimensions {(H, W)} need to be divisible by 8, given the unet")  # :578
+        self.e, self.B, self.H, self.W = eng, B, H, W
+        self.dev = eng.device
+        self._keep: List[object] = []          # ctypes structs / tensors referenced by recorded ops
+        self._free: Dict[int, List[torch.Tensor]] = {}
+        self.workspace_floats = 0
+        d = eng.dim
+        with torch.cuda.device(self.dev):
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+            # API-side buffers (NHWC state; NCHW mirrors are made on demand)
+            self.x = f(B, H, W, eng.inp_dim)             # diffusion state x_t
+            self.clean = f(B, H, W, eng.inp_dim)
+            self.position = f(B, 2, H, W)                # NCHW as given
+            self.iso_idx = torch.zeros(B, dtype=torch.int64, device=self.dev)
+            self.time = torch.zeros(B, dtype=torch.int64, device=self.dev)
+            self.model_out = f(B, H, W, eng.inp_dim)
+            self.nchw_tmp = f(B, eng.inp_dim, H, W)
+            self.pos_emb = f(B, H, W, POS_DIM)
+            self.posmap1 = f(B, H, W, 2 * d)
+            self.posmap2 = f(B, H, W, 2 * d)
+            self.iso_emb = f(B, ISO_DIM)
+            self.attn_names = [p.name[:-len(".attn.to_v.weight")] for p in eng.spec if p.name.endswith(".attn.to_v.weight")]
+            self.cb = {n: f(B, eng.slots[n + ".proj_out.bias"].shape[0]) for n in self.attn_names}
+            self.emb = f(B, d)
+            self.t1 = f(B, 4 * d)
+            self.st = f(B, 4 * d)
+            self.tproj = f(B, eng.tproj_rows)
+        self.cond_ops: List[Op] = []
+        self.step_ops: List[Op] = []
+        self._ops = self.cond_ops
+        self._record_condition()
+        self._ops = self.step_ops
+        self._record_time()
+        self._record_net()
+        self.condition_set = False
+
+    # ------------------------------------------------------------------ tiny allocator
+    def _alloc(self, *shape) -> torch.Tensor:
+        n = math.prod(shape)
+        lst = self._free.get(n)
+        if lst:
+            return lst.pop().view(*shape)
+        self.workspace_floats += n
+        with torch.cuda.device(self.dev):
+            t = torch.empty(n, dtype=torch.float32, device=self.dev)
+        self._keep.append(t)
+        return t.view(*shape)
+
+    def _tap(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        if self.debug:
+            self.taps[name] = t
+        return t
+
+    def _release(self, *ts: torch.Tensor) -> None:
+        if self.debug:
+            return
+        for t in ts:
+            self._free.setdefault(t.numel(), []).append(t.reshape(-1))
+
+    # ------------------------------------------------------------------ op recording
+    def _add(self, name: str, *args) -> None:
+        fn = getattr(self.e.lib, name)
+        self._keep.append(args)
+        self._ops.append((fn, args, name))
+
+    def _src(self, t: torch.Tensor, t2: Optional[torch.Tensor] = None, mode=L.PRO_NONE, **kw) -> L.Src:
+        s = L.Src()
+        s.p0, s.c0, s.ld0 = t.data_ptr(), t.shape[-1], t.shape[-1]
+        if t2 is not None:
+            s.p1, s.c1, s.ld1 = t2.data_ptr(), t2.shape[-1], t2.shape[-1]
+        s.mode = mode
+        for k, v in kw.items():
+            setattr(s, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+        return s
+
+    def conv3(self, name: str, src: L.Src, cin: int, cout: int, H: int, W: int, stats: bool):
+        """nn.Conv2d(cin, cout, 3, padding=1); returns (out, stats, slot_count, slots)."""
+        e = self.e
+        out = self._alloc(self.B, H, W, cout)
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out = src, e.p(name + ".weight"), e.p(name + ".bias"), out.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, H, W, cin, cout, cout
+        st = sc = None
+        slots = 0
+        if stats:
+            slots = e.lib.nd_conv3x3_stat_slots(H, W, cout, self.B)
+            st = self._alloc(self.B, slots, cout, 2)
+            sc = self._alloc(slots)
+            d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
+        self._add("nd_conv3x3_nhwc_f32", C.byref(d), e.stream)
+        self._keep.append(d)
+        return out, st, sc, slots
+
+    def pw(self, name: str, src: L.Src, cin: int, cout: int, HW: int, W: int, act=L.ACT_NONE, bias=True,
+           res0=None, res1=None, vec=None, gn_t=None, gn_mad=None, out=None) -> torch.Tensor:
+        """1x1 conv / token Linear with fused prologue/epilogue."""
+        e = self.e
+        if out is None:
+            out = self._alloc(self.B, HW, cout)
+        d = L.Pointwise()
+        d.src, d.weight, d.out = src, e.p(name + ".weight"), out.data_ptr()
+        d.bias = e.p(name + ".bias") if bias else None
+        d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = self.B, HW, W, cin, cout, cout, act
+        if res0 is not None:
+            d.res0, d.ldr0 = res0.data_ptr(), res0.shape[-1]
+        if res1 is not None:
+            d.res1, d.ldr1 = res1.data_ptr(), res1.shape[-1]
+        if vec is not None:
+            d.vec = vec.data_ptr()
+        if gn_t is not None:
+            d.gn_t, d.ldt, d.gn_mad = gn_t.data_ptr(), gn_t.shape[-1], gn_mad.data_ptr()
+        self._add("nd_pointwise_gemm_nhwc_f32", C.byref(d), e.stream)
+        self._keep.append(d)
+        return out
+
+    def gn_finalize(self, st, sc, slots: int, norm: str, C_: int, groups: int, ss_off: Optional[int]) -> torch.Tensor:
+        e = self.e
+        mad = self._alloc(self.B, 3, C_)
+        ss = (self.tproj.data_ptr() + 4 * ss_off) if ss_off is not None else None
+        self._add("nd_groupnorm_finalize_f32", st.data_ptr(), sc.data_ptr(), slots, e.p(norm + ".weight"), e.p(norm + ".bias"),
+                  ss, e.tproj_rows, mad.data_ptr(), self.B, C_, groups, GN_EPS, e.stream)
+        return mad
+
+    def linear_rows(self, x: torch.Tensor, w: int, b: Optional[int], out: torch.Tensor, K: int, N: int, act_in=0, act_out=0):
+        self._add("nd_linear_rows_f32", x.data_ptr(), x.shape[-1], w, b, out.data_ptr(), out.shape[-1], self.B, K, N,
+                  act_in, act_out, self.e.stream)
+
+    # ------------------------------------------------------------------ composite layers
+    def resnet(self, name: str, x: torch.Tensor, skip: Optional[torch.Tensor], cout: int, H: int, W: int, groups: int,
+               posmap: Optional[torch.Tensor] = None, extra_res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ResnetBlock / ResnetBlock2 (Diffusion_arch.py:146-196) as 2 convs + 2 tiny finalizes + 1 tail."""
+        cin = x.shape[-1] + (skip.shape[-1] if skip is not None else 0)
+        HW = H * W
+        c1, st1, sc1, n1 = self.conv3(name + ".block1.proj", self._src(x, skip), cin, cout, H, W, stats=True)
+        ss_off = None if posmap is not None else self.e.tproj_off[name]
+        mad1 = self.gn_finalize(st1, sc1, n1, name + ".block1.norm", cout, groups, ss_off)
+        mode = L.PRO_AFFINE_MAP_SILU if posmap is not None else L.PRO_AFFINE_SILU
+        src2 = self._src(c1, None, mode, mad=mad1, **({"map": posmap} if posmap is not None else {}))
+        c2, st2, sc2, n2 = self.conv3(name + ".block2.proj", src2, cout, cout, H, W, stats=True)
+        mad2 = self.gn_finalize(st2, sc2, n2, name + ".block2.norm", cout, groups, None)
+        if cin != cout:       # h + res_conv(x): the 1x1 GEMM adds silu(GN(c2)) in its epilogue   :170
+            assert extra_res is None
+            out = self.pw(name + ".res_conv", self._src(x, skip), cin, cout, HW, W, gn_t=c2, gn_mad=mad2)
+        else:
+            assert skip is None
+            out = self._alloc(self.B, HW, cout)
+            self._add("nd_affine_silu_add_f32", c2.data_ptr(), cout, mad2.data_ptr(), x.data_ptr(), cout,
+                      extra_res.data_ptr() if extra_res is not None else None, cout, out.data_ptr(), cout,
+                      self.B, HW, cout, self.e.stream)
+        self._release(c1, st1, sc1, mad1, c2, st2, sc2, mad2)
+        return out.view(self.B, H, W, cout)
+
+    def attn_block(self, name: str, x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+        """AttnBlock (Diffusion_arch.py:434-443) with the 1-token CrossAttention folded into cb."""
+        Cc, HW = x.shape[-1], H * W
+        cb = self.cb[name]
+        ln = self._src(x, None, L.PRO_LAYERNORM, vec=cb, gamma=self.e.p(name + ".norm2.weight"), beta=self.e.p(name + ".norm2.bias"))
+        h1 = self.pw(name + ".ff.net.0.0", ln, Cc, 2 * Cc, HW, W, act=L.ACT_GELU)
+        x2 = self.pw(name + ".ff.net.2", self._src(h1), 2 * Cc, Cc, HW, W, res0=x, vec=cb)
+        y = self.pw(name + ".proj_out", self._src(x2), Cc, Cc, HW, W, res0=x)
+        self._release(h1, x2)
+        return y.view(self.B, H, W, Cc)
+
+    def mlp(self, name: str, src: L.Src, cin: int, hid: int, cout: int, H: int, W: int, res0=None) -> torch.Tensor:
+        h = self.pw(name + ".fc1", src, cin, hid, H * W, W, act=L.ACT_GELU)
+        o = self.pw(name + ".fc2", self._src(h), hid, cout, H * W, W, res0=res0)
+        self._release(h)
+        return o.view(self.B, H, W, cout)
+
+    # ------------------------------------------------------------------ recorded programs
+    def _record_condition(self) -> None:
+        e, B, H, W, st = self.e, self.B, self.H, self.W, self.e.stream
+        pe = self._alloc(B, H, W, 3 * POS_DIM)
+        self._add("nd_pos_enc_f32", self.position.data_ptr(), e.p("pos_enc.weights.weight"), e.p("pos_enc.weights.bias"),
+                  pe.data_ptr(), B, H, W, POS_DIM, st)
+        h = self.pw("pos_mlp.fc1", self._src(pe), 3 * POS_DIM, 2 * POS_DIM, H * W, W, act=L.ACT_GELU)
+        self.pw("pos_mlp.fc2", self._src(h), 2 * POS_DIM, POS_DIM, H * W, W, out=self.pos_emb)
+        for blk, dst in (("pos_block1", self.posmap1), ("pos_block2", self.posmap2)):
+            self.pw(blk + ".mlp.1", self._src(self.pos_emb, None, L.PRO_SILU), POS_DIM, 2 * e.dim, H * W, W, out=dst)
+        self._add("nd_embedding_rows_f32", self.iso_idx.data_ptr(), e.p("iso_embed.weight"), self.iso_emb.data_ptr(), B,
+                  ISO_TABLE_ROWS, ISO_DIM, st)
+        inner = ATTN_HEADS * ATTN_DIM_HEAD
+        v = self._alloc(B, inner)
+        for n in self.attn_names:
+            Cc = self.cb[n].shape[-1]
+            self.linear_rows(self.iso_emb, e.p(n + ".attn.to_v.weight"), None, v, ISO_DIM, inner)
+            self.linear_rows(v, e.p(n + ".attn.to_out.0.weight"), e.p(n + ".attn.to_out.0.bias"), self.cb[n], inner, Cc)
+        self._release(pe, h, v)
+
+    def _record_time(self) -> None:
+        e, d = self.e, self.e.dim
+        self._add("nd_sinusoidal_time_emb_f32", self.time.data_ptr(), e.p("time_freqs"), self.emb.data_ptr(), self.B, d // 2, e.stream)
+        self.linear_rows(self.emb, e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"), self.t1, d, 4 * d, act_out=L.ACT_GELU)
+        # every consumer applies SiLU first (ResnetBlock.mlp[0]), so it is applied once here
+        self.linear_rows(self.t1, e.p("time_mlp.3.weight"), e.p("time_mlp.3.bias"), self.st, 4 * d, 4 * d, act_out=L.ACT_SILU)
+        self.linear_rows(self.st, e.p("tproj.weight"), e.p("tproj.bias"), self.tproj, 4 * d, e.tproj_rows)
+
+    def _record_net(self) -> None:
+        e, B, H, W, d = self.e, self.B, self.H, self.W, self.e.dim
+        G = RESNET_GROUPS
+        # ---- shot-noise branch, full resolution (:598-604)
+        r_shot = self.mlp("shot_mlp1", self._src(self.clean, self.x), 2 * e.inp_dim, d, d, H, W)
+        s = self.attn_block("shot_attn", r_shot, H, W)
+        s2 = self.mlp("shot_mlp2", self._src(s), d, d, d, H, W)
+        s3 = self.resnet("shot_time", s2, None, d, H, W, SHOT_GROUPS, extra_res=r_shot)   # shot_time(...) + r
+        shot_noise = self._tap("shot_noise", self.mlp("shot_mlp3", self._src(s3), d, d, e.inp_dim, H, W))
+        for nm, tt in (("shot_mlp1", r_shot), ("shot_attn", s), ("shot_mlp2", s2), ("shot_time", s3)):
+            self._tap(nm, tt)
+        self._release(r_shot, s, s2, s3)
+        # ---- trunk
+        x0 = self._alloc(B, H, W, d)
+        self._add("nd_conv7x7_c4_f32", self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
+                  B, H, W, d, e.stream)
+        self._tap("init_conv", x0)
+        x = self._tap("pos_block1", self.resnet("pos_block1", x0, None, d, H, W, POS_GROUPS, posmap=self.posmap1))
+        hs: List[torch.Tensor] = []
+        h, w = H, W
+        for i, (cin, cout) in enumerate(stage_dims(d)):
+            p = f"downs.{i}"
+            x1 = self.resnet(p + ".0", x, None, cin, h, w, G)
+            if x is not x0:
+                self._release(x)
+            x2 = self.resnet(p + ".1", x1, None, cin, h, w, G)
+            hs += [x1, x2]
+            xa = self.attn_block(p + ".2", x2, h, w)
+            self._tap(p + ".0", x1); self._tap(p + ".1", x2); self._tap(p + ".2", xa)
+            if i == 3:
+                x, *_ = self.conv3(p + ".3", self._src(xa), cin, cout, h, w, stats=False)
+            else:
+                h, w = h // 2, w // 2
+                x = self.pw(p + ".3.1", self._src(xa, None, L.PRO_NONE, unshuffle=1, c0=4 * cin, ld0=cin), 4 * cin, cout,
+                            h * w, w).view(B, h, w, cout)
+            self._release(xa)
+            self._tap(f"down{i}", x)
+        mid = x.shape[-1]
+        xm = self.resnet("mid_block1", x, None, mid, h, w, G)
+        self._release(x)
+        if e.mid_attn:
+            xm = self._mid_attention(xm, h, w)
+        x = self._tap("mid", self.resnet("mid_block2", xm, None, mid, h, w, G))
+        self._release(xm)
+        for i, (cin, cout) in enumerate(reversed(stage_dims(d))):
+            p = f"ups.{i}"
+            sk = hs.pop()
+            x1 = self.resnet(p + ".0", x, sk, cout, h, w, G)
+            self._release(x, sk)
+            sk = hs.pop()
+            x2 = self.resnet(p + ".1", x1, sk, cout, h, w, G)
+            self._release(x1, sk)
+            xa = self.attn_block(p + ".2", x2, h, w)
+            self._release(x2)
+            if i == 3:
+                x, *_ = self.conv3(p + ".3", self._src(xa), cout, cin, h, w, stats=False)
+            else:
+                h, w = h * 2, w * 2
+                x, *_ = self.conv3(p + ".3.1", self._src(xa, None, L.PRO_NONE, upsample=1), cout, cin, h, w, stats=False)
+            self._release(xa)
+            self._tap(p + ".0", x1); self._tap(p + ".1", x2); self._tap(p + ".2", xa); self._tap(f"up{i}", x)
+        xp = self._tap("pos_block2", self.resnet("pos_block2", x, None, d, H, W, POS_GROUPS, posmap=self.posmap2))
+        self._release(x)
+        xf = self._tap("final_res_block", self.resnet("final_res_block", xp, x0, d, H, W, G))
+        self._release(xp, x0)
+        self.pw("final_conv", self._src(xf), d, e.inp_dim, H * W, W, res0=shot_noise, out=self.model_out)   # shot + read  :644
+        self._release(xf, shot_noise)
+
+    def _mid_attention(self, x: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """x = Attention(x) + x between the mid blocks (Diffusion_arch.py:237-266; BASELINE config 4)."""
+        e, B, Cc, N = self.e, self.B, x.shape[-1], h * w
+        hid = ATTN_HEADS * ATTN_DIM_HEAD
+        xn = self._alloc(B, N, Cc)
+        self._add("nd_rmsnorm_nhwc_f32", x.data_ptr(), Cc, e.p("mid_attn.norm.g"), xn.data_ptr(), Cc, B, N, Cc, e.stream)
+        qkv = self.pw("mid_attn.to_qkv", self._src(xn), Cc, 3 * hid, N, w, bias=False)
+        att = self._alloc(B, N, hid)
+        self._add("nd_attention_mfma_f32", qkv.data_ptr(), 3 * hid, att.data_ptr(), hid, B, N, ATTN_HEADS, ATTN_DIM_HEAD, e.stream)
+        y = self.pw("mid_attn.to_out", self._src(att), hid, Cc, N, w, res0=x)
+        self._release(xn, qkv, att, x)
+        return y.view(B, h, w, Cc)
+
+    # ------------------------------------------------------------------ execution
+    @staticmethod
+    def run(ops: List[Op]) -> None:
+        for fn, args, name in ops:
+            r = fn(*args)
+            if r != 0:
+                L.check(r, name)
+
+    def set_condition(self, condition: Dict[str, torch.Tensor]) -> None:
+        """Upload clean_img / position / iso_ratio_idx and run the step-invariant part once."""
+        B, H, W, e = self.B, self.H, self.W, self.e
+        clean, pos, iso = condition["clean_img"], condition["position"], condition["iso_ratio_idx"]
+        if tuple(clean.shape) != (B, e.inp_dim, H, W) or tuple(pos.shape) != (B, 2, H, W) or tuple(iso.shape) != (B,):
+            raise ValueError(f"condition shapes {tuple(clean.shape)}, {tuple(pos.shape)}, {tuple(iso.shape)} do not match batch {(B, H, W)}")
+        iso = iso.to(torch.int64)
+        if int(iso.min()) < 0 or int(iso.max()) >= ISO_TABLE_ROWS:
+            raise IndexError("iso_ratio_idx out of range for nn.Embedding(100, 16)")
+        with torch.cuda.device(self.dev):
+            self.nchw_tmp.copy_(clean.to(self.dev, torch.float32))
+            self.position.copy_(pos.to(self.dev, torch.float32))
+            self.iso_idx.copy_(iso.to(self.dev))        # the reference leaves it on the CPU (trainer_diffusion.py:135)
+            torch.cuda.synchronize(self.dev)
+            L.call("nd_nchw_to_nhwc_f32", self.nchw_tmp.data_ptr(), self.clean.data_ptr(), B, e.inp_dim, H, W, e.stream)
+            self.run(self.cond_ops)
+            e.sync()
+        self.condition_set = True
+
+    def load_x(self, x_nchw: torch.Tensor) -> None:
+        e = self.e
+        with torch.cuda.device(self.dev):
+            self.nchw_tmp.copy_(x_nchw.to(self.dev, torch.float32))
+            torch.cuda.synchronize(self.dev)
+            L.call("nd_nchw_to_nhwc_f32", self.nchw_tmp.data_ptr(), self.x.data_ptr(), self.B, e.inp_dim, self.H, self.W, e.stream)
+
+    def read_nchw(self, nhwc: torch.Tensor) -> torch.Tensor:
+        e = self.e
+        with torch.cuda.device(self.dev):
+            out = torch.empty(self.B, e.inp_dim, self.H, self.W, dtype=torch.float32, device=self.dev)
+            L.call("nd_nhwc_to_nchw_f32", nhwc.data_ptr(), out.data_ptr(), self.B, e.inp_dim, self.H, self.W, e.stream)
+            e.sync()
+        return out
+
+    def forward(self, x_nchw: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
+        """One NoiseDiffNet.forward on already-set conditions; returns NCHW."""
+        if not self.condition_set:
+            raise L.HipError("Plan.forward: set_condition() first")
+        with torch.cuda.device(self.dev):
+            self.time.copy_(time.to(self.dev, torch.int64))
+        self.load_x(x_nchw)
+        self.run(self.step_ops)
+        return self.read_nchw(self.model_out)

@@ -1,0 +1,120 @@
+"""``NoiseDiffNet``: the arch plug-in of the reference, backed by the HIP engine.
+
+Drop-in contract (models/modules.py:20-41, models/archs/Diffusion_arch.py:447-646):
+constructed as ``NoiseDiffNet(args)`` from the reference's argparse namespace; an ``nn.Module``
+whose state-dict has the reference's 416 names/shapes (so ``DiffusionNet_ckpt.pth`` loads with
+``strict=True`` and EMA deep-copies / DataParallel wrapping work); attributes ``channels``,
+``out_dim``, ``self_condition``, ``random_or_learned_sinusoidal_cond``, ``downsample_factor``;
+``forward(x, time, condition)`` with NCHW tensors and the ``clean_img`` / ``position`` /
+``iso_ratio_idx`` condition dict.
+
+The forward pass runs ONLY on the HIP library (engine.py).  There is no CPU or eager-PyTorch
+fallback: a CPU tensor, a missing library or an autograd call raises.
+"""
+from __future__ import annotations
+
+import math
+import threading
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .spec import attention_param_spec, noisediff_param_spec
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's parameter names."""
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
+    *path, leaf = dotted.split(".")
+    m = root
+    for part in path:
+        if part not in m._modules:
+            m.add_module(part, _Node())
+        m = m._modules[part]
+    m.register_parameter(leaf, param)
+
+
+def _init(p, gen: Optional[torch.Generator] = None) -> torch.Tensor:
+    """PyTorch's default layer init -- the reference never calls init_weights (modules.py:82)."""
+    t = torch.empty(p.shape, dtype=torch.float32)
+    if p.init == "uniform_fan_in":
+        b = 1.0 / math.sqrt(p.fan_in)
+        return t.uniform_(-b, b, generator=gen)
+    if p.init == "normal":
+        return t.normal_(0.0, 1.0, generator=gen)
+    return t.fill_(1.0 if p.init == "ones" else 0.0)
+
+
+class NoiseDiffNet(nn.Module):
+    def __init__(self, args, mid_attn: Optional[bool] = None):
+        super().__init__()
+        self.dim = int(args.dim)
+        if self.dim % 8 or self.dim < 16:
+            raise ValueError(f"dim={self.dim}: GroupNorm(8, dim) and the HIP tilings need a multiple of 8, >= 16")
+        self.channels = int(args.inp_dim)                       # :458,475
+        if self.channels != 4:
+            raise ValueError("inp_dim must be 4 (packed RGGB RAW); the 7x7 stem and the sampler kernels assume it")
+        self.out_dim = self.channels                            # :550-551
+        self.self_condition = args.self_condition               # :469
+        self.normalize_condition = args.normalize_condition     # :470
+        self.random_or_learned_sinusoidal_cond = False          # :493 (both flags are hard-wired False)
+        # BASELINE config 4 extension: Attention between the mid blocks (computed but never wired at :467-468,518)
+        self.mid_attn = bool(getattr(args, "mid_attn", False) if mid_attn is None else mid_attn)
+        spec = list(noisediff_param_spec(self.dim, self.channels))
+        if self.mid_attn:
+            spec += attention_param_spec("mid_attn", 8 * self.dim)
+        for p in spec:
+            _attach(self, p.name, nn.Parameter(_init(p)))
+        self._engines: Dict[int, object] = {}
+        self._engine_sig: Dict[int, tuple] = {}
+        self._lock = threading.Lock()
+
+    @property
+    def downsample_factor(self) -> int:                         # :573-575
+        return 8
+
+    # ------------------------------------------------------------------ engine management
+    def _signature(self) -> tuple:
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def hip_engine(self, device: torch.device):
+        """The packed-weight engine for ``device`` (rebuilt when parameters changed)."""
+        from .engine import Engine
+        if device.type != "cuda":
+            raise L.HipError(f"NoiseDiffNet runs on the HIP library only; tensor is on {device} and there is no CPU path")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        device = torch.device("cuda", idx)
+        with self._lock:
+            sig = self._signature()
+            eng = self._engines.get(idx)
+            if eng is None:
+                eng = Engine(self.dim, device, mid_attn=self.mid_attn, inp_dim=self.channels)
+                self._engines[idx] = eng
+                self._engine_sig[idx] = None
+            if self._engine_sig[idx] != sig:
+                eng.load_state_dict({k: v for k, v in self.state_dict().items()})
+                self._engine_sig[idx] = sig
+            return eng
+
+    def adopt_engine(self, eng) -> None:
+        """Use an engine whose arena was filled elsewhere (e.g. by the one RCCL broadcast)."""
+        with self._lock:
+            self._engines[eng.device.index] = eng
+            self._engine_sig[eng.device.index] = self._signature()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, time: torch.Tensor, condition=None) -> torch.Tensor:
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "noisediff_amd.NoiseDiffNet implements the inference (sampling) path only; call it under "
+                "torch.no_grad()/inference_mode().  Training stays on the reference network -- its weights load here unchanged.")
+        assert all(d % self.downsample_factor == 0 for d in x.shape[-2:]), \
+            f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {self.downsample_factor}, given the unet"
+        B, Cc, H, W = x.shape
+        plan = self.hip_engine(x.device).plan(B, H, W)
+        plan.set_condition(condition)
+        return plan.forward(x, time)

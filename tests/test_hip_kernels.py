@@ -1,0 +1,296 @@
+"""GPU parity of every C-ABI kernel against plain torch CPU ops (the oracle's building blocks).
+
+Each case calls libnoisediff_hip.so directly through ctypes; torch is only the allocator.
+Tolerance: 1e-3 relative fp32 is the north-star bound; kernels are exact-fp32 so tests use 2e-5
+(max-abs over max(1, |ref|)) unless a comment says otherwise.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from noisediff_amd import _lib as L, synth
+from oracle import noisediff_oracle as O
+from util import rel_err
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import hiputil
+    return hiputil.Ctx()
+
+
+def U(name, shape, lo=-1.0, hi=1.0):
+    return synth.uniform(11, name, shape, lo, hi)
+
+
+def test_library_is_gfx950(ctx):
+    buf = C.create_string_buffer(64)
+    L.call("nd_device_arch", buf, 64)
+    assert buf.value.decode().startswith("gfx950")
+
+
+# (B, H, W, cin, cout) -- chosen so that every tiling of conv3x3.hip's choose_tiling is exercised:
+CONV_CASES = {
+    "t8x8_bn64_masks": (2, 24, 40, 16, 16),        # (8,1,1): ragged edges in y and x, cout < 64
+    "t8x8_bn64_partial_chunk": (2, 16, 16, 48, 48),  # cin = 32 + 16 (partial K chunk), cout mask
+    "t16_bn128": (8, 64, 64, 32, 256),             # (16,2,2)
+    "t16_bn64": (16, 56, 72, 16, 64),              # (16,2,1) with a ragged right edge
+    "t8_bn128": (64, 8, 8, 16, 1024),              # (8,1,2)
+    "tiny_4x4": (2, 4, 4, 64, 128),                # image smaller than a tile
+}
+
+
+@pytest.mark.parametrize("case", sorted(CONV_CASES))
+def test_conv3x3_plain_and_stats(ctx, case):
+    import hiputil as hu
+    B, H, W, cin, cout = CONV_CASES[case]
+    x = U(case + ".x", (B, cin, H, W), -1.5, 1.5)
+    w = U(case + ".w", (cout, cin, 3, 3), -0.2, 0.2)
+    b = U(case + ".b", (cout,))
+    ref = F.conv2d(x, w, b, padding=1)
+    out, st, sc, slots = hu.conv3x3(ctx, hu.src(hu.nhwc(x)), hu.pack_conv3(ctx, w), hu.dev(b), B, H, W, cin, cout, stats=True)
+    got = hu.nchw(out)
+    assert not torch.isnan(got).any()
+    assert rel_err(got, ref) < TOL
+    # GroupNorm statistics through the finalize kernel == torch's group_norm of the same tensor
+    groups = 8 if cout % 8 == 0 else 2
+    gamma, beta = U(case + ".g", (cout,), 0.5, 1.5), U(case + ".be", (cout,))
+    mad = hu.gn_finalize(ctx, st, sc, slots, hu.dev(gamma), hu.dev(beta), None, B, cout, groups).cpu()
+    gn = F.group_norm(ref, groups, gamma, beta, eps=1e-5)
+    mine = (ref - mad[:, 0, :, None, None]) * mad[:, 1, :, None, None] + mad[:, 2, :, None, None]
+    assert rel_err(mine, gn) < TOL
+
+
+def test_conv3x3_concat_upsample_and_prologues(ctx):
+    import hiputil as hu
+    B, H, W = 2, 16, 24
+    # virtual concat == torch.cat(dim=1)
+    xa, xb = U("cc.a", (B, 16, H, W)), U("cc.b", (B, 32, H, W))
+    w, b = U("cc.w", (24, 48, 3, 3), -0.2, 0.2), U("cc.bias", (24,))
+    ref = F.conv2d(torch.cat((xa, xb), 1), w, b, padding=1)
+    out, *_ = hu.conv3x3(ctx, hu.src(hu.nhwc(xa), hu.nhwc(xb)), hu.pack_conv3(ctx, w), hu.dev(b), B, H, W, 48, 24)
+    assert rel_err(hu.nchw(out), ref) < TOL
+    # nearest x2 upsample folded into addressing == nn.Upsample + conv
+    xs = U("up.x", (B, 16, H // 2, W // 2))
+    w, b = U("up.w", (8, 16, 3, 3), -0.2, 0.2), U("up.b", (8,))
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)
+    out, *_ = hu.conv3x3(ctx, hu.src(hu.nhwc(xs), upsample=1), hu.pack_conv3(ctx, w), hu.dev(b), B, H, W, 16, 8)
+    assert rel_err(hu.nchw(out), ref) < TOL
+    # affine + SiLU prologue: conv(silu((x - M) * A + D)), zero padding applied AFTER the activation
+    x = U("af.x", (B, 16, H, W), -2, 2)
+    M, A, D = U("af.M", (B, 16)), U("af.A", (B, 16), 0.5, 1.5), U("af.D", (B, 16))
+    w, b = U("af.w", (16, 16, 3, 3), -0.2, 0.2), U("af.b", (16,))
+    act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+    ref = F.conv2d(act, w, b, padding=1)
+    mad = hu.dev(torch.stack((M, A, D), 1))
+    out, *_ = hu.conv3x3(ctx, hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=mad), hu.pack_conv3(ctx, w), hu.dev(b), B, H, W, 16, 16)
+    assert rel_err(hu.nchw(out), ref) < TOL
+    # ... plus per-pixel scale/shift maps (ResnetBlock2)
+    sc, sh = U("af.sc", (B, 16, H, W), -0.5, 0.5), U("af.sh", (B, 16, H, W), -0.5, 0.5)
+    act = F.silu(((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None]) * (sc + 1) + sh)
+    ref = F.conv2d(act, w, b, padding=1)
+    mp = hu.nhwc(torch.cat((sc, sh), 1))
+    out, *_ = hu.conv3x3(ctx, hu.src(hu.nhwc(x), None, L.PRO_AFFINE_MAP_SILU, mad=mad, map=mp), hu.pack_conv3(ctx, w), hu.dev(b), B, H, W, 16, 16)
+    assert rel_err(hu.nchw(out), ref) < TOL
+
+
+def test_conv3x3_rejects_bad_arguments(ctx):
+    import hiputil as hu
+    x = hu.nhwc(U("bad.x", (1, 12, 8, 8)))
+    d = L.Conv3x3()
+    d.src = hu.src(x)
+    d.weight = d.out = x.data_ptr()
+    d.B, d.H, d.W, d.cin, d.cout, d.ldo = 1, 8, 8, 12, 8, 8
+    assert ctx.lib.nd_conv3x3_nhwc_f32(C.byref(d), ctx.stream) == -2     # ND_E_SHAPE: cin % 8
+    assert b"multiple of 8" in ctx.lib.nd_last_error()
+    assert ctx.lib.nd_conv3x3_nhwc_f32(None, ctx.stream) == -1            # ND_E_BADARG
+
+
+PW_CASES = {  # (B, HW, W, cin, cout)
+    "c64": (2, 32 * 32, 32, 64, 64),
+    "k8_n64": (2, 16 * 16, 16, 8, 64),
+    "k24_n16": (1, 16 * 16, 16, 24, 16),
+    "n4": (2, 24 * 40, 40, 64, 4),
+    "wide": (16, 64 * 32, 32, 128, 256),          # (2,2) tiling
+    "c64_big": (64, 32 * 32, 32, 64, 64),         # (2,1) tiling
+    "ragged": (3, 25, 5, 192, 96),                # HW < tile, 3 K chunks
+}
+
+
+@pytest.mark.parametrize("case", sorted(PW_CASES))
+def test_pointwise_plain_and_epilogues(ctx, case):
+    import hiputil as hu
+    B, HW, W, cin, cout = PW_CASES[case]
+    x = U(case + ".x", (B, HW, cin), -1.5, 1.5)
+    w, b = U(case + ".w", (cout, cin), -0.3, 0.3), U(case + ".b", (cout,))
+    r0, r1, vec = U(case + ".r0", (B, HW, cout)), U(case + ".r1", (B, HW, cout)), U(case + ".v", (B, cout))
+    wp = hu.pack_pw(ctx, w)
+    out = hu.pointwise(ctx, hu.src(hu.dev(x)), wp, hu.dev(b), B, HW, W, cin, cout)
+    assert rel_err(out.cpu(), F.linear(x, w, b)) < TOL
+    out = hu.pointwise(ctx, hu.src(hu.dev(x)), wp, hu.dev(b), B, HW, W, cin, cout, act=L.ACT_GELU,
+                       res0=hu.dev(r0), res1=hu.dev(r1), vec=hu.dev(vec))
+    assert rel_err(out.cpu(), F.gelu(F.linear(x, w, b)) + r0 + r1 + vec[:, None, :]) < TOL
+    # fused ResnetBlock tail: W x + b + silu((t - M) * A + D)
+    t = U(case + ".t", (B, HW, cout), -2, 2)
+    mad = U(case + ".mad", (B, 3, cout), 0.5, 1.5)
+    ref = F.linear(x, w, b) + F.silu((t - mad[:, None, 0]) * mad[:, None, 1] + mad[:, None, 2])
+    out = hu.pointwise(ctx, hu.src(hu.dev(x)), wp, hu.dev(b), B, HW, W, cin, cout, gn_t=hu.dev(t), gn_mad=hu.dev(mad))
+    assert rel_err(out.cpu(), ref) < TOL
+
+
+def test_pointwise_prologues(ctx):
+    import hiputil as hu
+    B, H, W, Cc = 2, 16, 16, 64
+    x = U("pp.x", (B, H * W, Cc), -2, 2)
+    vec = U("pp.vec", (B, Cc))
+    g, be = U("pp.g", (Cc,), 0.5, 1.5), U("pp.be", (Cc,))
+    w, b = U("pp.w", (128, Cc), -0.3, 0.3), U("pp.b", (128,))
+    wp = hu.pack_pw(ctx, w)
+    # LayerNorm(x + vec) prologue (AttnBlock.norm2 on x + cross-attention bias)
+    ref = F.linear(F.layer_norm(x + vec[:, None], (Cc,), g, be, eps=1e-5), w, b)
+    s = hu.src(hu.dev(x), None, L.PRO_LAYERNORM, vec=hu.dev(vec), gamma=hu.dev(g), beta=hu.dev(be))
+    assert rel_err(hu.pointwise(ctx, s, wp, hu.dev(b), B, H * W, W, Cc, 128).cpu(), ref) < TOL
+    # wide LayerNorm (C = 512 -> two float4 per lane)
+    xw, gw, bw = U("pp.xw", (B, 64, 512), -2, 2), U("pp.gw", (512,), 0.5, 1.5), U("pp.bw", (512,))
+    ww = U("pp.ww", (64, 512), -0.1, 0.1)
+    ref = F.linear(F.layer_norm(xw, (512,), gw, bw, eps=1e-5), ww)
+    s = hu.src(hu.dev(xw), None, L.PRO_LAYERNORM, gamma=hu.dev(gw), beta=hu.dev(bw))
+    assert rel_err(hu.pointwise(ctx, s, hu.pack_pw(ctx, ww), None, B, 64, 8, 512, 64).cpu(), ref) < TOL
+    # SiLU prologue
+    ref = F.linear(F.silu(x), w, b)
+    assert rel_err(hu.pointwise(ctx, hu.src(hu.dev(x), None, L.PRO_SILU), wp, hu.dev(b), B, H * W, W, Cc, 128).cpu(), ref) < TOL
+    # virtual concat (shot_mlp1: cat[clean_img, x])
+    a4, b4 = U("pp.a4", (B, H * W, 4)), U("pp.b4", (B, H * W, 4))
+    w8 = U("pp.w8", (64, 8), -0.3, 0.3)
+    ref = F.linear(torch.cat((a4, b4), -1), w8)
+    assert rel_err(hu.pointwise(ctx, hu.src(hu.dev(a4), hu.dev(b4)), hu.pack_pw(ctx, w8), None, B, H * W, W, 8, 64).cpu(), ref) < TOL
+    # pixel-unshuffle addressing == einops 'b c (h p1) (w p2) -> b (c p1 p2) h w' + conv1x1 (Downsample)
+    xc = U("pp.xc", (B, 16, H, W))
+    wd, bd = U("pp.wd", (32, 64, 1, 1), -0.3, 0.3), U("pp.bd", (32,))
+    sd = {"d.1.weight": wd, "d.1.bias": bd}
+    ref = O.pixel_unshuffle_conv(sd, "d", xc)
+    s = hu.src(hu.nhwc(xc), None, L.PRO_NONE, unshuffle=1, c0=64, ld0=16)
+    out = hu.pointwise(ctx, s, hu.pack_pw(ctx, wd, unshuffle_c=16), hu.dev(bd), B, (H // 2) * (W // 2), W // 2, 64, 32)
+    assert rel_err(out.view(B, H // 2, W // 2, 32).permute(0, 3, 1, 2).cpu(), ref) < TOL
+
+
+def test_affine_silu_add_and_rmsnorm(ctx):
+    import hiputil as hu
+    B, HW, Cc = 3, 100, 48
+    t, r0, r1 = U("as.t", (B, HW, Cc), -2, 2), U("as.r0", (B, HW, Cc)), U("as.r1", (B, HW, Cc))
+    mad = U("as.mad", (B, 3, Cc), 0.5, 1.5)
+    out = torch.empty(B, HW, Cc, device=hu.DEV)
+    td, md, r0d, r1d = hu.dev(t), hu.dev(mad), hu.dev(r0), hu.dev(r1)
+    L.call("nd_affine_silu_add_f32", td.data_ptr(), Cc, md.data_ptr(), r0d.data_ptr(), Cc, r1d.data_ptr(), Cc, out.data_ptr(), Cc, B, HW, Cc, ctx.stream)
+    ctx.sync()
+    ref = F.silu((t - mad[:, None, 0]) * mad[:, None, 1] + mad[:, None, 2]) + r0 + r1
+    assert rel_err(out.cpu(), ref) < TOL
+    g = U("rms.g", (Cc,), 0.5, 1.5)
+    gd = hu.dev(g)
+    L.call("nd_rmsnorm_nhwc_f32", td.data_ptr(), Cc, gd.data_ptr(), out.data_ptr(), Cc, B, HW, Cc, ctx.stream)
+    ctx.sync()
+    ref = O.rms_norm(g.view(1, Cc, 1, 1), t.permute(0, 2, 1).reshape(B, Cc, HW, 1)).reshape(B, Cc, HW).permute(0, 2, 1)
+    assert rel_err(out.cpu(), ref) < TOL
+
+
+def test_small_ops(ctx):
+    import hiputil as hu
+    B, d = 5, 64
+    # sinusoidal embedding + time MLP rows
+    time = torch.tensor([0, 1, 500, 998, 999])
+    half = d // 2
+    freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).float()
+    emb = torch.empty(B, d, device=hu.DEV)
+    td, fd = hu.dev(time), hu.dev(freqs)
+    L.call("nd_sinusoidal_time_emb_f32", td.data_ptr(), fd.data_ptr(), emb.data_ptr(), B, half, ctx.stream)
+    ctx.sync()
+    assert rel_err(emb.cpu(), O.sinusoidal_pos_emb(time, d)) < 1e-5
+    K, N = 256, 333
+    x, w, b = U("lr.x", (B, K), -2, 2), U("lr.w", (N, K), -0.2, 0.2), U("lr.b", (N,))
+    out = torch.empty(B, N, device=hu.DEV)
+    xd, wd, bd = hu.dev(x), hu.dev(w), hu.dev(b)
+    L.call("nd_linear_rows_f32", xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), N, B, K, N, L.ACT_SILU, L.ACT_GELU, ctx.stream)
+    ctx.sync()
+    assert rel_err(out.cpu(), F.gelu(F.linear(F.silu(x), w, b))) < TOL
+    # embedding
+    table, idx = U("em.t", (100, 16)), torch.tensor([0, 74, 99, 3, 3])
+    o = torch.empty(B, 16, device=hu.DEV)
+    tabd, idxd = hu.dev(table), hu.dev(idx)
+    L.call("nd_embedding_rows_f32", idxd.data_ptr(), tabd.data_ptr(), o.data_ptr(), B, 100, 16, ctx.stream)
+    ctx.sync()
+    assert torch.equal(o.cpu(), table[idx])
+    # pos_enc
+    pos = synth.make_position(2, 24, seed=3)
+    w2, b2 = U("pe.w", (8, 2, 1, 1)), U("pe.b", (8,))
+    ref = O.learned_sinusoidal_pos_emb({"p.weights.weight": w2, "p.weights.bias": b2}, "p", pos)
+    o = torch.empty(2, 24, 24, 24, device=hu.DEV)
+    pd, w2d, b2d = hu.dev(pos), hu.dev(w2), hu.dev(b2)
+    L.call("nd_pos_enc_f32", pd.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), o.data_ptr(), 2, 24, 24, 8, ctx.stream)
+    ctx.sync()
+    assert rel_err(hu.nchw(o), ref) < 1e-5
+    # layout round trip
+    x4 = U("lay.x", (3, 4, 8, 16))
+    a, bb = torch.empty(3, 8, 16, 4, device=hu.DEV), torch.empty(3, 4, 8, 16, device=hu.DEV)
+    x4d = hu.dev(x4)
+    L.call("nd_nchw_to_nhwc_f32", x4d.data_ptr(), a.data_ptr(), 3, 4, 8, 16, ctx.stream)
+    L.call("nd_nhwc_to_nchw_f32", a.data_ptr(), bb.data_ptr(), 3, 4, 8, 16, ctx.stream)
+    ctx.sync()
+    assert torch.equal(a.cpu(), x4.permute(0, 2, 3, 1)) and torch.equal(bb.cpu(), x4)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 40, 24, 48), (2, 64, 64, 64)])
+def test_conv7x7(ctx, shape):
+    import hiputil as hu
+    B, H, W, cout = shape
+    x, w, b = U("c7.x", (B, 4, H, W), -1.5, 1.5), U("c7.w", (cout, 4, 7, 7), -0.1, 0.1), U("c7.b", (cout,))
+    wp, out = torch.empty(196 * cout, device=hu.DEV), torch.empty(B, H, W, cout, device=hu.DEV)
+    xd, wd, bd = hu.nhwc(x), hu.dev(w), hu.dev(b)
+    L.call("nd_pack_conv7x7_weight", wd.data_ptr(), wp.data_ptr(), cout, ctx.stream)
+    L.call("nd_conv7x7_c4_f32", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, B, H, W, cout, ctx.stream)
+    ctx.sync()
+    assert rel_err(hu.nchw(out), F.conv2d(x, w, b, padding=3)) < TOL
+
+
+@pytest.mark.parametrize("N", [64, 1024, 200])
+def test_attention_mfma(ctx, N):
+    import hiputil as hu
+    B, heads, dh = 2, 4, 32
+    qkv = U(f"att.{N}", (B, N, 3 * heads * dh), -2, 2)
+    out = torch.full((B, N, heads * dh), float("nan"), device=hu.DEV)
+    qd = hu.dev(qkv)
+    L.call("nd_attention_mfma_f32", qd.data_ptr(), 3 * heads * dh, out.data_ptr(), heads * dh, B, N, heads, dh, ctx.stream)
+    ctx.sync()
+    q, k, v = (t.reshape(B, N, heads, dh).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, -1) @ v
+    assert rel_err(out.cpu(), ref.permute(0, 2, 1, 3).reshape(B, N, heads * dh)) < TOL
+
+
+def test_philox_matches_oracle_and_is_shard_invariant(ctx):
+    import hiputil as hu
+    B, HW, Cc, seed = 3, 64, 4, 0x1234567890ABCDEF
+    out = torch.empty(B, HW, Cc, device=hu.DEV)
+    L.call("nd_philox_normal_f32", out.data_ptr(), C.c_uint64(seed), 5, 7, B, HW, Cc, ctx.stream)
+    ctx.sync()
+    q = np.arange(HW, dtype=np.uint32)
+    for b in range(B):
+        ctr = np.stack([q, np.full(HW, 5 + b, np.uint32), np.full(HW, 8, np.uint32), np.zeros(HW, np.uint32)], -1)
+        key = np.tile(np.array([[seed & 0xFFFFFFFF, seed >> 32]], dtype=np.uint32), (HW, 1))
+        ref = O.philox_normal4(O.philox4x32_10(ctr, key))
+        np.testing.assert_allclose(out[b].cpu().numpy(), ref, atol=2e-5, rtol=1e-4)
+    # rows of a shard starting at sample 6 == rows 1.. of the shard starting at 5
+    out2 = torch.empty(2, HW, Cc, device=hu.DEV)
+    L.call("nd_philox_normal_f32", out2.data_ptr(), C.c_uint64(seed), 6, 7, 2, HW, Cc, ctx.stream)
+    ctx.sync()
+    assert torch.equal(out2.cpu(), out[1:].cpu())
+    big = torch.empty(64, 4096, 4, device=hu.DEV)
+    L.call("nd_philox_normal_f32", big.data_ptr(), C.c_uint64(1), 0, -1, 64, 4096, 4, ctx.stream)
+    ctx.sync()
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3

@@ -1,0 +1,196 @@
+"""GPU parity of the whole hot path: NoiseDiffNet.forward and GaussianDiffusion.sample on HIP
+against the fixtures captured from the reference (tests/golden) and against the CPU oracle.
+
+north-star tolerance: 1e-3 relative fp32.  Bounds used here are tighter where the measured
+agreement allows; every bound is max|a-b| / max(1, max|ref|).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from noisediff_amd import GaussianDiffusion, NoiseDiffNet, synth
+from oracle import noisediff_oracle as O
+from util import noise_fn, rel_err, state_dict, sub
+
+DEV = torch.device("cuda", 0)
+NET_TOL = 2e-4
+SAMPLE_TOL = 1e-3
+
+
+def make_net(dim, mid_attn=False):
+    args = SimpleNamespace(dim=dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, mid_attn=mid_attn)
+    net = NoiseDiffNet(args)
+    net.load_state_dict(state_dict(dim, mid_attn=mid_attn), strict=True)
+    return net.to(DEV).eval()
+
+
+def to_dev(cond):
+    # the reference leaves iso_ratio_idx on the CPU (trainer_diffusion.py:135)
+    return {k: (v if k == "iso_ratio_idx" else v.to(DEV)) for k, v in cond.items()}
+
+
+@pytest.mark.parametrize("dim,H", [(16, 32), (32, 64)])
+def test_net_forward_matches_reference_golden(golden, dim, H):
+    B = 2
+    net = make_net(dim)
+    cond = synth.make_condition(B, H, seed=1)
+    x = synth.make_noise(2, "net.x", B, 4, H)
+    with torch.inference_mode():
+        for t in (0, 500, 999):
+            y = net(x.to(DEV), torch.full((B,), t, dtype=torch.long, device=DEV), to_dev(cond))
+            assert y.shape == (B, 4, H, H) and y.device.type == "cuda"
+            assert rel_err(y.cpu().numpy(), golden("net", f"net.d{dim}.h{H}.t{t}")) < NET_TOL, t
+        y = net(x.to(DEV), torch.tensor([3, 777], device=DEV), to_dev(cond))
+        assert rel_err(y.cpu().numpy(), golden("net", f"net.d{dim}.h{H}.tmixed")) < NET_TOL
+
+
+def test_net_intermediates_match_reference_taps(golden):
+    """Layer-by-layer agreement (debug plan keeps every named intermediate)."""
+    dim, H, B = 32, 64, 2
+    net = make_net(dim)
+    plan = net.hip_engine(DEV).plan(B, H, H, debug=True)
+    plan.set_condition(to_dev(synth.make_condition(B, H, seed=1)))
+    plan.forward(synth.make_noise(2, "net.x", B, 4, H).to(DEV), torch.full((B,), 500, dtype=torch.long))
+    for name in ("pos_block1", "down0", "down1", "down2", "down3", "mid", "up0", "up1", "up2", "up3", "shot_noise"):
+        t = plan.taps[name]
+        got = t.view(B, -1, t.shape[-1]).permute(0, 2, 1).contiguous().cpu()     # NHWC -> NCHW flattening
+        assert rel_err(sub(got), golden("net", f"net.d{dim}.h{H}.t500.tap.{name}")) < NET_TOL, name
+    pe = plan.pos_emb.view(B, -1, 8).permute(0, 2, 1).contiguous().cpu()
+    assert rel_err(sub(pe), golden("net", f"net.d{dim}.h{H}.t500.tap.pos_emb")) < 1e-5
+
+
+def test_net_forward_non_square_and_wrapped(golden):
+    """H != W, ragged tiles (40x24) and the DataParallel-wrapped form, against the oracle."""
+    dim, B, H, W = 16, 3, 40, 24
+    sd = state_dict(dim)
+    net = make_net(dim)
+    cond = {"clean_img": synth.uniform(5, "ns.clean", (B, 4, H, W), 0, 1),
+            "position": synth.uniform(5, "ns.pos", (B, 2, H, W), 0, 1),
+            "iso_ratio_idx": synth.randint(5, "ns.iso", (B,), 0, 75)}
+    x = synth.uniform(5, "ns.x", (B, 4, H, W), -2, 2)
+    t = torch.tensor([0, 123, 999])
+    with torch.no_grad():
+        ref = O.noisediff_forward(sd, x, t, cond)
+        got = torch.nn.DataParallel(net, device_ids=[0])(x.to(DEV), t.to(DEV), to_dev(cond))
+    assert rel_err(got.cpu().numpy(), ref.numpy()) < NET_TOL
+
+
+def test_net_refuses_cpu_and_autograd():
+    from noisediff_amd._lib import HipError
+    net = make_net(16)
+    cond = synth.make_condition(1, 16, seed=1)
+    x = torch.zeros(1, 4, 16, 16)
+    with torch.no_grad(), pytest.raises(HipError):
+        net(x, torch.zeros(1, dtype=torch.long), cond)                   # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        net(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), to_dev(cond))   # autograd requested
+
+
+def _sample(dim, B, H, T, S, eta=0.0, return_all=False, sched="sigmoid2", objective="pred_v", mid=False, preset=False):
+    net = make_net(dim, mid_attn=mid)
+    gd = GaussianDiffusion(torch.nn.DataParallel(net, device_ids=[0]), image_size=H, timesteps=T, sampling_timesteps=S,
+                           beta_schedule=sched, objective=objective, ddim_sampling_eta=eta).to(DEV)
+    n_draws = (S if S is not None else T) - 1
+    noise = {"steps": torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(n_draws)])}
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    kw = {"preset_mean": x_T.to(DEV)} if preset else {}
+    if not preset:
+        noise["x_T"] = x_T
+    out = gd.sample(batch_size=B, condition=to_dev(synth.make_condition(B, H, seed=1)), return_all_timesteps=return_all,
+                    noise=noise, **kw)
+    assert out.device.type == "cuda" and out.dtype == torch.float32
+    return out.cpu().numpy()
+
+
+def test_sampler_config1_ddim50(golden):
+    """BASELINE config 1 end to end: d=32, 64x64x4, 50-step DDIM, batch 4."""
+    assert rel_err(_sample(32, 4, 64, 1000, 50), golden("sampler", "samp.cfg1.out")) < SAMPLE_TOL
+
+
+def test_sampler_ddpm20_and_preset_mean(golden):
+    assert rel_err(_sample(16, 2, 32, 20, None), golden("sampler", "samp.ddpm20.out")) < SAMPLE_TOL
+    assert rel_err(_sample(16, 2, 32, 20, None, preset=True), golden("sampler", "samp.ddpm20_preset.out")) < SAMPLE_TOL
+
+
+def test_sampler_return_all_and_eta(golden):
+    res = _sample(16, 2, 32, 4, None, return_all=True)
+    assert res.shape == (2, 5, 4, 32, 32)
+    assert rel_err(res, golden("sampler", "samp.ddpm4_all.out")) < SAMPLE_TOL
+    res = _sample(16, 2, 32, 20, 5, eta=0.5, return_all=True)
+    assert res.shape == (2, 6, 4, 32, 32)
+    assert rel_err(res, golden("sampler", "samp.ddim5_eta.out")) < SAMPLE_TOL
+
+
+def test_sampler_other_objectives(golden):
+    assert rel_err(_sample(16, 2, 32, 50, None, sched="linear", objective="pred_noise"),
+                   golden("sampler", "samp.ddpm50_eps_linear.out")) < SAMPLE_TOL
+    assert rel_err(_sample(16, 2, 32, 20, 5, sched="cosine", objective="pred_x0"),
+                   golden("sampler", "samp.ddim5_x0_cosine.out")) < SAMPLE_TOL
+
+
+def test_sampler_config4_toy_mid_attention(golden):
+    assert rel_err(_sample(16, 2, 64, 1000, 10, mid=True), golden("sampler", "samp.cfg4toy.out")) < SAMPLE_TOL
+
+
+def test_pre_clamp_model_output_matches(golden):
+    """With random weights many final pixels saturate at the +-1 clamp; check the un-clamped v too."""
+    dim, B, H = 32, 4, 64
+    net = make_net(dim)
+    cond = to_dev(synth.make_condition(B, H, seed=1))
+    x = synth.make_noise(2, "x_T", B, 4, H)
+    with torch.inference_mode():
+        v0 = net(x.to(DEV), torch.full((B,), 999, dtype=torch.long), cond)
+    assert rel_err(v0.cpu().numpy(), golden("sampler", "samp.cfg1.v0")) < NET_TOL
+
+
+def test_device_noise_mode_properties():
+    """Throughput mode (Philox): repeatable for a seed, different across seeds, shard-invariant."""
+    dim, B, H = 16, 4, 32
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=50, sampling_timesteps=None, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(B, H, seed=1)
+    a = gd.sample(batch_size=B, condition=to_dev(cond), seed=7).cpu()
+    b = gd.sample(batch_size=B, condition=to_dev(cond), seed=7).cpu()
+    c = gd.sample(batch_size=B, condition=to_dev(cond), seed=8).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0 + 1e-6      # last step returns clamped mean
+    # rank shard [2, 4) of the same global batch reproduces rows 2..3 (no collective needed)
+    gd.sample_offset = 2
+    half = {k: v[2:] for k, v in cond.items()}
+    s = gd.sample(batch_size=2, condition=to_dev(half), seed=7).cpu()
+    gd.sample_offset = 0
+    assert rel_err(s.numpy(), a[2:].numpy()) < 1e-5
+    torch.manual_seed(3)
+    d1 = gd.sample(batch_size=B, condition=to_dev(cond)).cpu()
+    torch.manual_seed(3)
+    d2 = gd.sample(batch_size=B, condition=to_dev(cond)).cpu()
+    assert torch.equal(d1, d2)
+
+
+def test_graph_replay_equals_eager_launches():
+    dim, B, H = 16, 2, 32
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=30, beta_schedule="sigmoid2").to(DEV)
+    cond = to_dev(synth.make_condition(B, H, seed=1))
+    ref = gd.sample(batch_size=B, condition=cond, seed=11).cpu()
+    loop = next(iter(gd._loop_cache.values()))
+    eager = loop.run(x_T=None, step_noise=None, seed=11, first_sample=0, use_graph=False).cpu()
+    assert torch.equal(ref, eager)
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 shape (d=64, 128x128x4, batch 16), a few DDPM steps: size-independent properties --
+    per-sample independence (batch of 16 == the same samples run as batch of 4) and finiteness."""
+    dim, B, H = 64, 16, 128
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=1000, sampling_timesteps=4, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(B, H, seed=1)
+    full = gd.sample(batch_size=B, condition=to_dev(cond), seed=5).cpu()
+    assert torch.isfinite(full).all()
+    gd.sample_offset = 8
+    part = gd.sample(batch_size=4, condition=to_dev({k: v[8:12] for k, v in cond.items()}), seed=5).cpu()
+    assert rel_err(part.numpy(), full[8:12].numpy()) < 1e-4
