@@ -95,6 +95,8 @@ typedef struct nd_conv3x3 {
 
 int nd_conv3x3_nhwc_f32(const nd_conv3x3* d, void* stream);
 int nd_conv3x3_stat_slots(int H, int W, int cout, int B);
+/* which conv3x3_kernel<TW, MB, NB> instance a shape runs on: TW*100 + MB*10 + NB (for profiling reports) */
+int nd_conv3x3_tiling_id(int B, int H, int W, int cout);
 /* OIHW (cout,cin,3,3) -> [tap][cin/4][coutP][4], coutP = cout rounded up to 64; zero padded. */
 int64_t nd_pack_conv3x3_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream);

@@ -253,6 +253,12 @@ extern "C" int nd_conv3x3_stat_slots(int H, int W, int cout, int B) {
     return nd_cdiv(H, t.th) * nd_cdiv(W, t.tw) * 2;
 }
 
+extern "C" int nd_conv3x3_tiling_id(int B, int H, int W, int cout) {
+    if (H <= 0 || W <= 0 || cout <= 0 || B <= 0) return ND_E_BADARG;
+    const Tiling t = choose_tiling(B, H, W, cout);
+    return t.tw * 100 + t.mb * 10 + t.nb;   // matches the kernel's template arguments <TW, MB, NB>
+}
+
 extern "C" int64_t nd_pack_conv3x3_weight_floats(int cin, int cout) {
     return (int64_t)9 * cin * nd_round_up(cout, 64);
 }

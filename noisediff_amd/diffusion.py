@@ -195,7 +195,7 @@ class _Loop:
         dev = plan.dev
         t_cur, t_next, coef = gd._tables()
         self.n_steps = int(t_cur.numel())
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), torch.inference_mode(False):
             self.t_cur, self.t_next, self.coef = t_cur.to(dev), t_next.to(dev), coef.to(dev)
             self.step = torch.zeros(1, dtype=torch.int32, device=dev)
             torch.cuda.synchronize(dev)
@@ -231,10 +231,12 @@ class _Loop:
             L.call("nd_graph_end", st, C.byref(self.graph))
         self.graph_key = key
 
-    def run(self, x_T, step_noise, seed, first_sample, return_all=False, use_graph=True, on_step=None):
-        p, e, gd = self.plan, self.plan.e, self.gd
+    def start(self, x_T, step_noise, seed, first_sample, use_graph=True):
+        """Reset the device loop state, load or draw x_T and (re)capture the step graph."""
+        p, e = self.plan, self.plan.e
         B, Cc, H, W = p.B, e.inp_dim, p.H, p.W
         st = e.stream
+        self.use_graph = use_graph
         with torch.cuda.device(p.dev):
             self.step.zero_()
             noise_ptr, stride = None, 0
@@ -251,17 +253,27 @@ class _Loop:
                 p.load_x(x_T)
             else:
                 L.call("nd_philox_normal_f32", p.x.data_ptr(), C.c_uint64(seed), first_sample, -1, B, H * W, Cc, st)
-            frames = [p.read_nchw(p.x)] if return_all else None
+            self._args = (noise_ptr, stride, seed, first_sample)
             if use_graph:
-                self._ensure_graph(noise_ptr, stride, seed, first_sample)
-            for i in range(self.n_steps):
-                if use_graph:
-                    L.call("nd_graph_launch", self.graph, st)
-                else:
-                    self._step_eager(noise_ptr, stride, seed, first_sample)
-                if return_all:
-                    frames.append(p.read_nchw(p.x))
-                if on_step is not None:
-                    on_step(i)
-            out = p.read_nchw(p.x)       # synchronises the library stream
-        return torch.stack(frames, dim=1) if return_all else out
+                self._ensure_graph(*self._args)
+
+    def advance(self, n: int = 1) -> None:
+        """Enqueue n diffusion steps on the library stream (no host synchronisation)."""
+        st = self.plan.e.stream
+        for _ in range(n):
+            if self.use_graph:
+                L.call("nd_graph_launch", self.graph, st)
+            else:
+                self._step_eager(*self._args)
+
+    def run(self, x_T, step_noise, seed, first_sample, return_all=False, use_graph=True):
+        p = self.plan
+        self.start(x_T, step_noise, seed, first_sample, use_graph)
+        if not return_all:
+            self.advance(self.n_steps)
+            return p.read_nchw(p.x)          # synchronises the library stream
+        frames = [p.read_nchw(p.x)]
+        for _ in range(self.n_steps):
+            self.advance(1)
+            frames.append(p.read_nchw(p.x))
+        return torch.stack(frames, dim=1)

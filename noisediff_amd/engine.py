@@ -77,7 +77,8 @@ class Engine:
                              if p.name.endswith(".mlp.1.weight") and len(p.shape) == 2]
         self.tproj_off: Dict[str, int] = {}
         self._layout()
-        self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
+        with torch.inference_mode(False):      # buffers outlive any inference_mode() block of the caller
+            self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             s = C.c_void_p()
             L.call("nd_stream_create", C.byref(s))
@@ -202,7 +203,7 @@ class Plan:
         self._free: Dict[int, List[torch.Tensor]] = {}
         self.workspace_floats = 0
         d = eng.dim
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), torch.inference_mode(False):
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
             # API-side buffers (NHWC state; NCHW mirrors are made on demand)
             self.x = f(B, H, W, eng.inp_dim)             # diffusion state x_t
@@ -238,7 +239,7 @@ class Plan:
         if lst:
             return lst.pop().view(*shape)
         self.workspace_floats += n
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), torch.inference_mode(False):
             t = torch.empty(n, dtype=torch.float32, device=self.dev)
         self._keep.append(t)
         return t.view(*shape)
@@ -255,10 +256,10 @@ class Plan:
             self._free.setdefault(t.numel(), []).append(t.reshape(-1))
 
     # ------------------------------------------------------------------ op recording
-    def _add(self, name: str, *args) -> None:
+    def _add(self, name: str, *args, meta: Optional[dict] = None) -> None:
         fn = getattr(self.e.lib, name)
         self._keep.append(args)
-        self._ops.append((fn, args, name))
+        self._ops.append((fn, args, name, meta))
 
     def _src(self, t: torch.Tensor, t2: Optional[torch.Tensor] = None, mode=L.PRO_NONE, **kw) -> L.Src:
         s = L.Src()
@@ -284,7 +285,9 @@ class Plan:
             st = self._alloc(self.B, slots, cout, 2)
             sc = self._alloc(slots)
             d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
-        self._add("nd_conv3x3_nhwc_f32", C.byref(d), e.stream)
+        self._add("nd_conv3x3_nhwc_f32", C.byref(d), e.stream,
+                  meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout,
+                        "tiling": e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
         self._keep.append(d)
         return out, st, sc, slots
 
@@ -306,7 +309,8 @@ class Plan:
             d.vec = vec.data_ptr()
         if gn_t is not None:
             d.gn_t, d.ldt, d.gn_mad = gn_t.data_ptr(), gn_t.shape[-1], gn_mad.data_ptr()
-        self._add("nd_pointwise_gemm_nhwc_f32", C.byref(d), e.stream)
+        self._add("nd_pointwise_gemm_nhwc_f32", C.byref(d), e.stream,
+                  meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout})
         self._keep.append(d)
         return out
 
@@ -476,7 +480,7 @@ class Plan:
     # ------------------------------------------------------------------ execution
     @staticmethod
     def run(ops: List[Op]) -> None:
-        for fn, args, name in ops:
+        for fn, args, name, _meta in ops:
             r = fn(*args)
             if r != 0:
                 L.check(r, name)
@@ -509,7 +513,7 @@ class Plan:
 
     def read_nchw(self, nhwc: torch.Tensor) -> torch.Tensor:
         e = self.e
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), torch.inference_mode(False):
             out = torch.empty(self.B, e.inp_dim, self.H, self.W, dtype=torch.float32, device=self.dev)
             L.call("nd_nhwc_to_nchw_f32", nhwc.data_ptr(), out.data_ptr(), self.B, e.inp_dim, self.H, self.W, e.stream)
             e.sync()

@@ -63,9 +63,9 @@ class NoiseDiffNet(nn.Module):
         self.normalize_condition = args.normalize_condition     # :470
         self.random_or_learned_sinusoidal_cond = False          # :493 (both flags are hard-wired False)
         # BASELINE config 4 extension: Attention between the mid blocks (computed but never wired at :467-468,518)
-        self.mid_attn = bool(getattr(args, "mid_attn", False) if mid_attn is None else mid_attn)
+        self.has_mid_attn = bool(getattr(args, "mid_attn", False) if mid_attn is None else mid_attn)
         spec = list(noisediff_param_spec(self.dim, self.channels))
-        if self.mid_attn:
+        if self.has_mid_attn:
             spec += attention_param_spec("mid_attn", 8 * self.dim)
         for p in spec:
             _attach(self, p.name, nn.Parameter(_init(p)))
@@ -92,7 +92,7 @@ class NoiseDiffNet(nn.Module):
             sig = self._signature()
             eng = self._engines.get(idx)
             if eng is None:
-                eng = Engine(self.dim, device, mid_attn=self.mid_attn, inp_dim=self.channels)
+                eng = Engine(self.dim, device, mid_attn=self.has_mid_attn, inp_dim=self.channels)
                 self._engines[idx] = eng
                 self._engine_sig[idx] = None
             if self._engine_sig[idx] != sig:

@@ -18,12 +18,22 @@ class Ctx:
         L.call("nd_stream_sync", self.stream)
 
 
+def _settle(t):
+    # torch's copies / fills run on torch's stream; the library runs on its own non-blocking stream
+    torch.cuda.synchronize(DEV)
+    return t
+
+
 def dev(t):
-    return t.to(DEV).contiguous()
+    return _settle(t.to(DEV).contiguous())
+
+
+def full(shape, value=float("nan")):
+    return _settle(torch.full(shape, value, device=DEV))
 
 
 def nhwc(t):           # NCHW cpu -> NHWC gpu
-    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    return _settle(t.permute(0, 2, 3, 1).contiguous().to(DEV))
 
 
 def nchw(t):           # NHWC gpu -> NCHW cpu
@@ -38,6 +48,9 @@ def src(t, t2=None, mode=L.PRO_NONE, **kw):
     s.mode = mode
     for k, v in kw.items():
         setattr(s, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    # the struct only holds raw pointers: keep the tensors alive (a freed block would be recycled by
+    # torch's caching allocator for the next allocation, e.g. the NaN-filled output buffer)
+    s._refs = [t, t2] + list(kw.values())
     return s
 
 
@@ -61,7 +74,7 @@ def pack_pw(ctx, w, unshuffle_c=0):
 
 
 def conv3x3(ctx, s, wp, bias, B, H, W, cin, cout, stats=False):
-    out = torch.full((B, H, W, cout), float("nan"), device=DEV)
+    out = full((B, H, W, cout))
     d = L.Conv3x3()
     d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr()
     d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
@@ -69,8 +82,8 @@ def conv3x3(ctx, s, wp, bias, B, H, W, cin, cout, stats=False):
     slots = 0
     if stats:
         slots = ctx.lib.nd_conv3x3_stat_slots(H, W, cout, B)
-        st = torch.full((B, slots, cout, 2), float("nan"), device=DEV)
-        sc = torch.full((slots,), float("nan"), device=DEV)
+        st = full((B, slots, cout, 2))
+        sc = full((slots,))
         d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
     L.call("nd_conv3x3_nhwc_f32", C.byref(d), ctx.stream)
     ctx.sync()
@@ -78,7 +91,7 @@ def conv3x3(ctx, s, wp, bias, B, H, W, cin, cout, stats=False):
 
 
 def pointwise(ctx, s, wp, bias, B, HW, W, cin, cout, act=0, res0=None, res1=None, vec=None, gn_t=None, gn_mad=None):
-    out = torch.full((B, HW, cout), float("nan"), device=DEV)
+    out = full((B, HW, cout))
     d = L.Pointwise()
     d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr()
     d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = B, HW, W, cin, cout, cout, act
@@ -96,7 +109,7 @@ def pointwise(ctx, s, wp, bias, B, HW, W, cin, cout, act=0, res0=None, res1=None
 
 
 def gn_finalize(ctx, st, sc, slots, gamma, beta, ss, B, Cc, groups):
-    mad = torch.full((B, 3, Cc), float("nan"), device=DEV)
+    mad = full((B, 3, Cc))
     L.call("nd_groupnorm_finalize_f32", st.data_ptr(), sc.data_ptr(), slots, gamma.data_ptr(), beta.data_ptr(),
            None if ss is None else ss.data_ptr(), 0 if ss is None else ss.shape[-1], mad.data_ptr(), B, Cc, groups, 1e-5, ctx.stream)
     ctx.sync()

@@ -264,7 +264,7 @@ def test_attention_mfma(ctx, N):
     import hiputil as hu
     B, heads, dh = 2, 4, 32
     qkv = U(f"att.{N}", (B, N, 3 * heads * dh), -2, 2)
-    out = torch.full((B, N, heads * dh), float("nan"), device=hu.DEV)
+    out = hu.full((B, N, heads * dh))
     qd = hu.dev(qkv)
     L.call("nd_attention_mfma_f32", qd.data_ptr(), 3 * heads * dh, out.data_ptr(), heads * dh, B, N, heads, dh, ctx.stream)
     ctx.sync()
