@@ -77,6 +77,16 @@ class NoiseDiffNet(nn.Module):
     def downsample_factor(self) -> int:                         # :573-575
         return 8
 
+    # copies (EMA's deepcopy, pickling, DataParallel replicas) never share device engines
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engines"], state["_engine_sig"], state["_lock"] = {}, {}, None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._lock = threading.Lock()
+
     # ------------------------------------------------------------------ engine management
     def _signature(self) -> tuple:
         return tuple((p.data_ptr(), p._version) for p in self.parameters())

@@ -1,0 +1,190 @@
+"""CPU-side tests: host logic, C-ABI surface, schedule tables, 2-rank gloo sharding."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from noisediff_amd import _lib as L, synth
+from noisediff_amd.diffusion import BUFFER_NAMES, GaussianDiffusion, make_betas, make_buffers
+from noisediff_amd.net import NoiseDiffNet
+from noisediff_amd.shard import shard_bounds
+from noisediff_amd.spec import noisediff_param_spec
+from util import state_dict
+from types import SimpleNamespace
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def args(dim, **kw):
+    return SimpleNamespace(dim=dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, **kw)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """The drop-in boundary: every function include/noisediff_hip.h declares is exported and bound."""
+    header = open(os.path.join(REPO, "include", "noisediff_hip.h")).read()
+    declared = set(re.findall(r"\b(nd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"nd_src", "nd_conv3x3", "nd_pointwise", "nd_sampler_state"}
+    lib = L.load()
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.nd_version() >= 1
+    assert lib.nd_last_error() is not None
+
+
+def test_struct_layouts_match_the_header():
+    # sizes computed from the C declarations: pointers 8 B, int32 4 B, natural alignment
+    assert C.sizeof(L.Src) == 2 * 8 + 8 * 4 + 5 * 8
+    assert C.sizeof(L.Conv3x3) == C.sizeof(L.Src) + 5 * 8 + 6 * 4
+    assert C.sizeof(L.Pointwise) == C.sizeof(L.Src) + 8 * 8 + 10 * 4
+    assert C.sizeof(L.SamplerState) == 5 * 8 + 2 * 4
+
+
+def test_host_only_entry_points_validate_arguments():
+    lib = L.load()
+    assert lib.nd_pack_conv3x3_weight_floats(64, 64) == 9 * 64 * 64
+    assert lib.nd_pack_conv3x3_weight_floats(48, 48) == 9 * 48 * 64           # cout padded to 64
+    assert lib.nd_pack_pointwise_weight_floats(24, 16) == 24 * 64
+    assert lib.nd_conv3x3_stat_slots(256, 256, 64, 16) == (256 // 8) * (256 // 16) * 2
+    assert lib.nd_conv3x3_tiling_id(16, 256, 256, 64) == 1621
+    assert lib.nd_conv3x3_tiling_id(2, 8, 8, 64) == 811
+    assert lib.nd_conv3x3_stat_slots(0, 8, 8, 1) == -1
+    assert lib.nd_conv3x3_nhwc_f32(None, None) == -1 and b"null" in lib.nd_last_error()
+    assert lib.nd_pointwise_gemm_nhwc_f32(None, None) == -1
+    d = L.Conv3x3()
+    d.src.p0 = d.weight = d.out = 0x1000
+    d.src.c0, d.src.ld0 = 12, 12
+    d.B, d.H, d.W, d.cin, d.cout, d.ldo = 1, 8, 8, 12, 8, 8
+    assert lib.nd_conv3x3_nhwc_f32(C.byref(d), None) == -2                   # cin % 8 != 0 -> ND_E_SHAPE, nothing launched
+
+
+@pytest.mark.parametrize("sched", ["linear", "cosine", "sigmoid1", "sigmoid2", "sigmoid3"])
+def test_product_schedule_buffers_are_bit_identical_to_the_reference(golden, sched):
+    names = [str(n) for n in golden("schedules", "sched.names")]
+    assert names == BUFFER_NAMES
+    ref = golden("schedules", f"sched.{sched}.1000")
+    buf = make_buffers(make_betas(sched, 1000), "pred_v")
+    for i, n in enumerate(names):
+        assert np.array_equal(buf[n].numpy(), ref[i], equal_nan=True), n
+
+
+def test_default_beta_schedule_name_is_rejected_like_the_reference():
+    net = NoiseDiffNet(args(16))
+    with pytest.raises(ValueError, match="unknown beta schedule sigmoid"):
+        GaussianDiffusion(net, image_size=32)          # CLI default 'sigmoid' is not a valid name upstream either
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(net, image_size=32, beta_schedule="sigmoid2", objective="bogus")
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(net, image_size=32, beta_schedule="sigmoid2", timesteps=10, sampling_timesteps=11)
+
+
+def test_module_surface_matches_the_reference_plugin_contract(meta):
+    net = NoiseDiffNet(args(32))
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == meta["state_dict.d32"]
+    assert (net.channels, net.out_dim, net.self_condition, net.random_or_learned_sinusoidal_cond, net.downsample_factor) == (4, 4, False, False, 8)
+    net.load_state_dict(state_dict(32), strict=True)
+    # PyTorch default init statistics (the reference never calls init_weights)
+    w = NoiseDiffNet(args(32)).state_dict()["downs.0.0.block1.proj.weight"]
+    bound = 1 / np.sqrt(32 * 9)
+    assert float(w.abs().max()) <= bound and float(w.std()) == pytest.approx(bound / np.sqrt(3), rel=0.1)
+    import copy
+    copy.deepcopy(net)                                          # EMA(self.net) deep-copies  (trainer_diffusion.py:62-69)
+    wrapped = torch.nn.DataParallel(net)
+    gd = GaussianDiffusion(wrapped, image_size=64, timesteps=1000, sampling_timesteps=50, beta_schedule="sigmoid2")
+    assert gd.is_ddim_sampling and gd.num_timesteps == 1000 and gd.channels == 4 and gd.image_size == 64
+    assert gd.device.type == "cpu" and len(list(gd.buffers())) == 13
+    assert "mid_attn.to_qkv.weight" in NoiseDiffNet(args(16, mid_attn=True)).state_dict()
+
+
+def test_sampler_tables(golden):
+    net = NoiseDiffNet(args(16))
+    gd = GaussianDiffusion(net, image_size=32, timesteps=1000, sampling_timesteps=50, beta_schedule="sigmoid2")
+    t_cur, t_next, coef = gd._tables()
+    ref = golden("schedules", "ddim_times.1000.50").tolist()
+    assert t_cur.tolist() == ref[:-1] and t_next.tolist() == ref[1:]
+    assert coef.shape == (50, 8) and coef[-1, 7] == 1.0 and bool((coef[:-1, 7] == 0).all())
+    assert bool((coef[:, 6] == 0).all())                       # eta = 0 -> sigma = 0
+    a, an = gd.alphas_cumprod[999], gd.alphas_cumprod[979]
+    assert coef[0, 4] == an.sqrt() and coef[0, 5] == (1 - an).sqrt()
+    gd = GaussianDiffusion(net, image_size=32, timesteps=20, beta_schedule="sigmoid2")
+    t_cur, _, coef = gd._tables()
+    assert t_cur.tolist() == list(range(19, -1, -1)) and coef[-1, 7] == 0.0 and bool((coef[:-1, 7] == 1).all())
+    assert torch.equal(coef[:, 4], gd.posterior_mean_coef1.flip(0)) and torch.equal(coef[:, 6], (0.5 * gd.posterior_log_variance_clipped).exp().flip(0))
+
+
+def test_product_refuses_to_run_without_a_gpu():
+    net = NoiseDiffNet(args(16)).eval()
+    gd = GaussianDiffusion(net, image_size=16, timesteps=4, beta_schedule="sigmoid2")
+    cond = synth.make_condition(1, 16, seed=1)
+    with pytest.raises(L.HipError, match="no CPU path"):
+        gd.sample(batch_size=1, condition=cond)
+    with pytest.raises(NotImplementedError):
+        gd(torch.zeros(1, 4, 16, 16), cond)
+
+
+def test_shard_bounds_and_synthetic_shards():
+    for total, world in ((128, 8), (10, 4), (3, 8), (0, 2)):
+        spans = [shard_bounds(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    full = synth.make_condition(6, 16, seed=1)
+    part = synth.make_condition(2, 16, seed=1, first_sample=3, total=6)
+    for k in full:
+        assert torch.equal(full[k][3:5], part[k]), k
+    assert torch.equal(synth.make_noise(2, "x_T", 6, 4, 16)[3:5], synth.make_noise(2, "x_T", 2, 4, 16, first_sample=3))
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from noisediff_amd.shard import sample_sharded
+    from oracle import noisediff_oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dim, H, T, total = 16, 16, 3, 3
+    # the one collective: weights root -> all (a flat fp32 arena on the GPU path)
+    flat = torch.cat([v.reshape(-1) for v in state_dict(dim).values()]) if rank == 0 else torch.zeros(sum(np.prod(p.shape) for p in noisediff_param_spec(dim)), dtype=torch.float32)
+    dist.broadcast(flat, src=0)
+    sd, off = {}, 0
+    for p in noisediff_param_spec(dim):
+        n = int(np.prod(p.shape))
+        sd[p.name] = flat[off:off + n].view(p.shape)
+        off += n
+    state = {"lo": 0}
+
+    def sample_fn(batch_size, condition, seed):
+        lo = state["lo"]
+        return O.sample(sd, condition, image_size=H, batch_size=batch_size, timesteps=T, x_T=synth.make_noise(seed, "x_T", batch_size, 4, H, lo),
+                        noise=lambda i, shape: synth.make_noise(seed, f"noise.{i}", batch_size, 4, H, lo))
+
+    out = sample_sharded(sample_fn, total, lambda lo, hi: synth.make_condition(hi - lo, H, seed=1, first_sample=lo, total=total),
+                         seed=2, set_offset=lambda lo: state.update(lo=lo), gather=True)
+    if rank == 0:
+        q.put(out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sampling_equals_single_rank_gloo():
+    """world_size 2 on CPU (gloo): broadcast weights once, shard rows, gather -> same patches as one rank."""
+    import torch.multiprocessing as mp
+    from oracle import noisediff_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dim, H, T, total = 16, 16, 3, 3
+    ref = O.sample(state_dict(dim), synth.make_condition(total, H, seed=1), image_size=H, batch_size=total, timesteps=T,
+                   x_T=synth.make_noise(2, "x_T", total, 4, H), noise=lambda i, shape: synth.make_noise(2, f"noise.{i}", total, 4, H))
+    assert got.shape == (total, 4, H, H)
+    assert float(np.abs(got - ref.numpy()).max()) < 1e-5
