@@ -19,7 +19,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnoisediff_hip.so")
 SOURCES = ["runtime", "conv3x3", "pointwise", "norm", "small", "sampler", "attention"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc 7.2 parks
+# them in AGPRs and wraps every v_mfma_f32_32x32x2_f32 in v_accvgpr_read/write copies (8 VALU per MFMA, measured)
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc() -> str:

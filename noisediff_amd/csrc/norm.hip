@@ -3,54 +3,60 @@
 
 namespace {
 
-// One wave per (sample, group): Chan/Welford merge of the conv epilogue's per-(slot, channel)
+// One workgroup (4 waves) per (sample, group): Chan/Welford merge of the conv epilogue's per-(slot, channel)
 // {sum, M2} partials in fp64, fixed order => bitwise reproducible.  Then fold gamma/beta and the
 // time-embedding scale/shift so that  GN(x)*(scale+1)+shift == (x - M)*A + D
 // (Block.forward, models/archs/Diffusion_arch.py:137-141; nn.GroupNorm: biased variance, eps inside sqrt).
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ slot_count,
-                                                         int slots, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ ss, int ld_ss, float* __restrict__ mad,
-                                                         int C, int G, float eps) {
+struct Moments { double n, mean, m2; };
+
+__device__ __forceinline__ Moments merge(Moments a, Moments b) {   // symmetric: merge(a,b) == merge(b,a) bitwise
+    const double nt = a.n + b.n;
+    if (nt <= 0.0) return a;
+    const double dl = b.mean - a.mean;
+    Moments r;
+    r.mean = (a.mean * a.n + b.mean * b.n) / nt;
+    r.m2 = a.m2 + b.m2 + dl * dl * a.n * b.n / nt;
+    r.n = nt;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ slot_count,
+                                                          int slots, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ ss, int ld_ss, float* __restrict__ mad,
+                                                          int C, int G, float eps) {
+    __shared__ Moments part[4];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
-    const int cpg = C / G, lane = threadIdx.x;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
+    const int cpg = C / G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Moments m = {0.0, 0.0, 0.0};
     const int items = slots * cpg;
-    for (int i = lane; i < items; i += 64) {
+    for (int i = tid; i < items; i += 256) {
         const int slot = i / cpg, ch = g * cpg + (i - slot * cpg);
         const double ni = (double)slot_count[slot];
         if (ni > 0.0) {
             const float* st = stats + (((size_t)b * slots + slot) * C + ch) * 2;
-            const double mi = (double)st[0] / ni, m2i = (double)st[1];
-            const double nt = n + ni, dl = mi - mean;
-            mean += dl * ni / nt;
-            m2 += m2i + dl * dl * n * ni / nt;
-            n = nt;
+            const Moments p = {ni, (double)st[0] / ni, (double)st[1]};
+            m = merge(m, p);
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const double n2 = __shfl_xor(n, o), mean2 = __shfl_xor(mean, o), m22 = __shfl_xor(m2, o);
-        const double nt = n + n2;
-        if (nt > 0.0) {
-            const double dl = mean2 - mean;
-            // symmetric form so that both partners compute the same value
-            const double nm = (mean * n + mean2 * n2) / nt;
-            m2 = m2 + m22 + dl * dl * n * n2 / nt;
-            mean = nm;
-            n = nt;
-        }
+        const Moments p = {__shfl_xor(m.n, o), __shfl_xor(m.mean, o), __shfl_xor(m.m2, o)};
+        m = merge(m, p);
     }
-    const double var = n > 0.0 ? m2 / n : 0.0;
+    if (lane == 0) part[wave] = m;
+    __syncthreads();
+    m = merge(merge(part[0], part[1]), merge(part[2], part[3]));
+    const double var = m.n > 0.0 ? m.m2 / m.n : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float fmean = (float)mean;
-    for (int i = lane; i < cpg; i += 64) {
+    const float fmean = (float)m.mean;
+    for (int i = tid; i < cpg; i += 256) {
         const int ch = g * cpg + i;
         const float sc = ss ? ss[(size_t)b * ld_ss + ch] : 0.0f;
         const float sh = ss ? ss[(size_t)b * ld_ss + C + ch] : 0.0f;
-        float* m = mad + (size_t)b * 3 * C + ch;
-        m[0] = fmean;
-        m[C] = rstd * gamma[ch] * (sc + 1.0f);
-        m[2 * C] = beta[ch] * (sc + 1.0f) + sh;
+        float* o = mad + (size_t)b * 3 * C + ch;
+        o[0] = fmean;
+        o[C] = rstd * gamma[ch] * (sc + 1.0f);
+        o[2 * C] = beta[ch] * (sc + 1.0f) + sh;
     }
 }
 
@@ -102,7 +108,7 @@ extern "C" int nd_groupnorm_finalize_f32(const float* stats, const float* slot_c
     ND_REQUIRE(stats && slot_count && gamma && beta && mad, ND_E_BADARG, "nd_groupnorm_finalize: null pointer");
     ND_REQUIRE(B > 0 && C > 0 && groups > 0 && slots > 0 && C % groups == 0, ND_E_SHAPE, "nd_groupnorm_finalize: C=%d groups=%d", C, groups);
     ND_REQUIRE(!scale_shift || ld_ss >= 2 * C, ND_E_SHAPE, "nd_groupnorm_finalize: ld_ss < 2C");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
                        beta, scale_shift, ld_ss, mad, C, groups, eps);
     return nd_launch_status("nd_groupnorm_finalize_f32");
 }
