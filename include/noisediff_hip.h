@@ -69,6 +69,8 @@ typedef struct nd_src {
     const float* vec;     /* [B][C] per-sample vector added before LayerNorm            */
     const float* gamma;   /* [C] LayerNorm weight                                       */
     const float* beta;    /* [C] LayerNorm bias                                         */
+    const float* rowstats;/* [B*HW][2] per-pixel {mean, rstd} of (x + vec) from nd_layernorm_stats_f32;
+                             required for LAYERNORM when C > 64 (for C <= 64 the GEMM derives them itself) */
 } nd_src;
 
 enum nd_act { ND_ACT_NONE = 0, ND_ACT_GELU = 1, ND_ACT_SILU = 2 };
@@ -139,6 +141,11 @@ int nd_groupnorm_finalize_f32(const float* stats, const float* slot_count, int s
                               const float* gamma, const float* beta,
                               const float* scale_shift, int ld_ss,
                               float* mad, int B, int C, int groups, float eps, void* stream);
+
+/* Per-pixel LayerNorm statistics over channels of (x + vec[b]): stats[p] = {mean, 1/sqrt(var + eps)}
+ * (nn.LayerNorm: biased variance; AttnBlock.norm2, Diffusion_arch.py:430,439).  vec may be NULL. */
+int nd_layernorm_stats_f32(const float* x, int ldx, const float* vec, float* stats,
+                           int B, int HW, int C, float eps, void* stream);
 
 /* out = silu((t - M)*A + D) [+ res0] [+ res1]: the tail of ResnetBlock.forward (:168-170)
  * when res_conv is the identity, plus `shot_emb + r` (:603). */

@@ -28,7 +28,7 @@ class HipError(RuntimeError):
 class Src(C.Structure):
     _fields_ = [("p0", fptr), ("p1", fptr), ("c0", C.c_int32), ("c1", C.c_int32), ("ld0", C.c_int32), ("ld1", C.c_int32),
                 ("mode", C.c_int32), ("upsample", C.c_int32), ("unshuffle", C.c_int32), ("_pad", C.c_int32),
-                ("mad", fptr), ("map", fptr), ("vec", fptr), ("gamma", fptr), ("beta", fptr)]
+                ("mad", fptr), ("map", fptr), ("vec", fptr), ("gamma", fptr), ("beta", fptr), ("rowstats", fptr)]
 
 
 class Conv3x3(C.Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "nd_pack_pointwise_weight_floats": (i64, [i32, i32]),
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
+    "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_affine_silu_add_f32": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "nd_linear_rows_f32": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "nd_sinusoidal_time_emb_f32": (i32, [vp, vp, vp, i32, i32, vp]),

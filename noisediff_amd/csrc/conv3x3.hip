@@ -18,6 +18,7 @@
 //   * Epilogue: +bias, store, and per-(wave, channel) {sum, M2} partials of the output for the
 //     following GroupNorm (two-pass inside registers, so no E[x^2]-E[x]^2 cancellation).
 // K order inside a group of 8 channels: lane half h supplies channel 4h+s at k-step s.
+#include <stdlib.h>
 #include "nd_common.h"
 
 namespace {
@@ -213,6 +214,10 @@ Tiling choose_tiling(int B, int H, int W, int cout) {
     // candidates in order of preference (bigger tiles = more operand reuse); take the first that
     // still yields >= 2 workgroups per CU, otherwise the one with the most workgroups.
     const Tiling cand[4] = {{16, 2, 2, 8, 128}, {16, 2, 1, 8, 64}, {8, 1, 2, 8, 128}, {8, 1, 1, 8, 64}};
+    static const int force = getenv("ND_CONV_TILING") ? atoi(getenv("ND_CONV_TILING")) : 0;   // tuning knob, e.g. 811
+    if (force)
+        for (int i = 0; i < 4; ++i)
+            if (cand[i].tw * 100 + cand[i].mb * 10 + cand[i].nb == force && !(cand[i].tw == 16 && W < 16) && !(cand[i].bn == 128 && cout % 128)) return cand[i];
     int best = -1;
     long best_wg = -1;
     for (int i = 0; i < 4; ++i) {

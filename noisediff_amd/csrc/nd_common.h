@@ -66,6 +66,17 @@ __device__ __forceinline__ f32x4 nd_silu4(f32x4 v) {
     return r;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane.  Four VALU adds with DPP
+// operand swizzles (quad_perm xor1, quad_perm xor2, row_half_mirror, row_mirror) -- no LDS crossbar traffic,
+// unlike __shfl_xor which lowers to ds_bpermute_b32 + a full lgkmcnt wait per step.
+__device__ __forceinline__ float nd_row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 // exact-fp32 matrix FMA: D(32x32) += A(32x2) * B(2x32); lane l gives A[l&31][l>>5], B[l>>5][l&31]
 __device__ __forceinline__ f32x16 nd_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

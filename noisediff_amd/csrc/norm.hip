@@ -79,6 +79,49 @@ __global__ __launch_bounds__(256) void affine_silu_add_kernel(const float* __res
     }
 }
 
+// Per-pixel LayerNorm statistics of (x + vec[b]) over C channels.  A row's C/4 quads are spread over `lpr`
+// lanes (power of two <= 64, up to 4 quads per lane => C <= 1024); a wave handles 64/lpr rows per pass.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ vec,
+                                                       float* __restrict__ stats, int B, int HW, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    int lpr = 1;
+    while (lpr < 64 && lpr * 4 < C) lpr <<= 1;
+    const int rpp = 64 / lpr, sub = lane / lpr, ql = lane - sub * lpr;
+    const size_t npix = (size_t)B * HW;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r0 = wave * rpp; r0 < npix; r0 += nwaves * rpp) {
+        const size_t r = r0 + sub;
+        const size_t rs = r < npix ? r : npix - 1;
+        const int b = (int)(rs / HW);
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (ql + j * lpr) * 4, cs = c < C ? c : 0;
+            v[j] = nd_ld4(x + rs * ldx + cs);
+            if (vec) v[j] += nd_ld4(vec + (size_t)b * C + cs);
+            const f32x4 zero = {0, 0, 0, 0};
+            v[j] = c < C ? v[j] : zero;
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += v[j].x + v[j].y + v[j].z + v[j].w;
+        for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)C;
+        float m2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (ql + j * lpr) * 4;
+            const f32x4 dv = v[j] - mean;
+            m2 += c < C ? dv.x * dv.x + dv.y * dv.y + dv.z * dv.z + dv.w * dv.w : 0.0f;
+        }
+        for (int o = lpr >> 1; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+        if (ql == 0 && r < npix) {
+            stats[2 * r] = mean;
+            stats[2 * r + 1] = rsqrtf(m2 / (float)C + eps);
+        }
+    }
+}
+
 // RMSNorm.forward (Diffusion_arch.py:89-90): F.normalize(x, dim=channel) * g * sqrt(C); one wave per pixel.
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                       float* __restrict__ out, int ldo, size_t npix, int C) {
@@ -111,6 +154,17 @@ extern "C" int nd_groupnorm_finalize_f32(const float* stats, const float* slot_c
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
                        beta, scale_shift, ld_ss, mad, C, groups, eps);
     return nd_launch_status("nd_groupnorm_finalize_f32");
+}
+
+extern "C" int nd_layernorm_stats_f32(const float* x, int ldx, const float* vec, float* stats, int B, int HW, int C, float eps, void* stream) {
+    ND_REQUIRE(x && stats, ND_E_BADARG, "nd_layernorm_stats: null pointer");
+    ND_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldx >= C, ND_E_SHAPE, "nd_layernorm_stats: C=%d (multiple of 4, <= 1024)", C);
+    ND_REQUIRE(nd_aligned16(x) && nd_aligned16(vec), ND_E_ALIGN, "nd_layernorm_stats: alignment");
+    const size_t npix = (size_t)B * HW;
+    const size_t want = (npix + 15) / 16;
+    const int blocks = (int)(want < 4096 ? (want ? want : 1) : 4096);
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, vec, stats, B, HW, C, eps);
+    return nd_launch_status("nd_layernorm_stats_f32");
 }
 
 extern "C" int nd_affine_silu_add_f32(const float* t, int ldt, const float* mad, const float* res0, int ldr0, const float* res1,

@@ -11,6 +11,7 @@
 // tile (BM x 64 channels per chunk) is staged through LDS with the prologue applied on the way
 // (LayerNorm / SiLU / pixel-unshuffle addressing / virtual concat); B fragments come straight
 // from the packed weight [k/4][coutP][4] as coalesced 16-byte loads (see conv3x3.hip).
+#include <stdlib.h>
 #include "nd_common.h"
 
 namespace {
@@ -23,13 +24,17 @@ struct PwArgs {
     int m_tiles, n_tiles, coutP, cinP, total_wg;
 };
 
-template <int MB, int NB>
+// NOTE on code shape: every global load below is unconditional (clamped address + select) and the prologue mode is a
+// template parameter.  With data-dependent branches around loads hipcc emits s_waitcnt vmcnt(0) after each one, which
+// turned the staging pass and the residual reads into chains of serialized HBM round trips (measured 2-5x slower).
+template <int MB, int NB, int MODE>
 __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     constexpr int WM = 2, WN = 2;
     constexpr int BM = WM * MB * 32, BN = WN * NB * 32;
     constexpr int STAGE_IT = BM / 16;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
-    __shared__ float rowMean[BM], rowRstd[BM];
+    constexpr int LDO = BN + 4;                               // output tile row stride in LDS (floats)
+    constexpr int SMEM = BM * (LDA > LDO ? LDA : LDO);
+    __shared__ __attribute__((aligned(16))) float As[SMEM];   // A tile during the K loop, output tile in the epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -43,45 +48,6 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     const nd_src& s = a.d.src;
     const int HW = a.d.HW, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
     const int p0 = mt * BM, n0 = nt * BN;
-
-    // ---- LayerNorm row statistics (two-pass in registers), rows split over the 4 waves
-    if (s.mode == ND_PRO_LAYERNORM) {
-        for (int r = wave; r < BM; r += 4) {
-            const int p = p0 + r;
-            float mean = 0.0f, rstd = 0.0f;
-            if (p < HW) {
-                const float* row = s.p0 + ((size_t)b * HW + p) * s.ld0;
-                f32x4 v[4];
-                float sum = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = lane * 4 + j * 256;
-                    v[j] = (f32x4){0, 0, 0, 0};
-                    if (c < Cin) {
-                        v[j] = nd_ld4(row + c);
-                        if (s.vec) v[j] += nd_ld4(s.vec + (size_t)b * Cin + c);
-                        sum += v[j].x + v[j].y + v[j].z + v[j].w;
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                mean = sum / (float)Cin;
-                float m2 = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = lane * 4 + j * 256;
-                    if (c < Cin) {
-                        const f32x4 dv = v[j] - mean;
-                        m2 += dv.x * dv.x + dv.y * dv.y + dv.z * dv.z + dv.w * dv.w;
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
-                rstd = rsqrtf(m2 / (float)Cin + 1e-5f);
-            }
-            if (lane == 0) { rowMean[r] = mean; rowRstd[r] = rstd; }
-        }
-    }
 
     int a_off[MB];
 #pragma unroll
@@ -97,62 +63,88 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
     const int quad = tid & 15, prow = tid >> 4;
-    const int Cs = s.unshuffle ? (s.c0 >> 2) : 0;
+    const int Cs = s.unshuffle ? (s.c0 >> 2) : 1;
+    const int Hs2 = 2 * (HW / max(W, 1));                 // source height for the unshuffle addressing
 
     for (int cb = 0; cb < a.cinP; cb += KC) {
         const int ng = min(8, (a.cinP - cb) >> 3);
-        __syncthreads();   // previous chunk consumed (and LN statistics visible)
+        // all weight fragments of this chunk first: their L2 latency hides behind the activation loads below
+        f32x4 bq[8][NB];
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bq[g][nb] = nd_ld4(wbase + ((size_t)((cb >> 2) + 2 * min(g, ng - 1)) * a.coutP + nb * 32) * 4);
         {
             const int c = cb + quad * 4;
             const bool cvalid = c < Cin;
+            const int cs = cvalid ? c : 0;
             const float* base = s.p0;
-            int ld = s.ld0, cc = c, py = 0, px = 0;
+            int ld = s.ld0, cc = cs, py = 0, px = 0;
             if (s.unshuffle) {
-                const int sub = c / Cs;
-                cc = c - sub * Cs; py = sub >> 1; px = sub & 1;
-            } else if (c >= s.c0) {
-                base = s.p1; ld = s.ld1; cc = c - s.c0;
+                const int sub = cs / Cs;
+                cc = cs - sub * Cs; py = sub >> 1; px = sub & 1;
+            } else if (cs >= s.c0) {
+                base = s.p1; ld = s.ld1; cc = cs - s.c0;
             }
             f32x4 g4 = {1, 1, 1, 1}, b4 = {0, 0, 0, 0}, vec4 = {0, 0, 0, 0};
             f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
-            if (cvalid && s.mode == ND_PRO_LAYERNORM) {
-                g4 = nd_ld4(s.gamma + c); b4 = nd_ld4(s.beta + c);
-                if (s.vec) vec4 = nd_ld4(s.vec + (size_t)b * Cin + c);
+            if (MODE == ND_PRO_LAYERNORM) {
+                g4 = nd_ld4(s.gamma + cs); b4 = nd_ld4(s.beta + cs);
+                if (s.vec) vec4 = nd_ld4(s.vec + (size_t)b * Cin + cs);
             }
-            if (cvalid && s.mode == ND_PRO_AFFINE_SILU) {
-                const float* m = s.mad + (size_t)b * 3 * Cin + c;
+            if (MODE == ND_PRO_AFFINE_SILU) {
+                const float* m = s.mad + (size_t)b * 3 * Cin + cs;
                 tM = nd_ld4(m); tA = nd_ld4(m + Cin); tD = nd_ld4(m + 2 * Cin);
             }
+            f32x4 raw[STAGE_IT];
+            float rmean[STAGE_IT], rrstd[STAGE_IT];
+#pragma unroll
+            for (int it = 0; it < STAGE_IT; ++it) {
+                const int p = min(p0 + prow + it * 16, HW - 1);
+                size_t pix = (size_t)b * HW + p;
+                if (s.unshuffle) {
+                    const int y = p / W, x = p - y * W;
+                    pix = ((size_t)b * Hs2 + 2 * y + py) * (2 * W) + 2 * x + px;
+                }
+                raw[it] = nd_ld4(base + pix * ld + cc);
+                if (MODE == ND_PRO_LAYERNORM && s.rowstats) {
+                    rmean[it] = s.rowstats[2 * pix];
+                    rrstd[it] = s.rowstats[2 * pix + 1];
+                }
+            }
+            if (MODE == ND_PRO_LAYERNORM && !s.rowstats) {
+                // C <= 64: the 16 lanes {tid & ~15} hold the whole row (one quad each) -> two-pass statistics in
+                // registers with DPP row reductions, no extra memory or LDS traffic
+                const f32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+                for (int it = 0; it < STAGE_IT; ++it) {
+                    const f32x4 v = cvalid ? raw[it] + vec4 : zero;
+                    const float mean = nd_row16_sum(v.x + v.y + v.z + v.w) / (float)Cin;
+                    const f32x4 dv = cvalid ? v - mean : zero;
+                    const float m2 = nd_row16_sum(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z + dv.w * dv.w);
+                    rmean[it] = mean;
+                    rrstd[it] = rsqrtf(m2 / (float)Cin + 1e-5f);
+                }
+            }
+            __syncthreads();   // previous chunk consumed
 #pragma unroll
             for (int it = 0; it < STAGE_IT; ++it) {
                 const int r = prow + it * 16;
-                const int p = p0 + r;
-                f32x4 v = {0, 0, 0, 0};
-                if (cvalid && p < HW) {
-                    size_t pix;
-                    if (s.unshuffle) {
-                        const int y = p / W, x = p - y * W;
-                        pix = ((size_t)b * (2 * (HW / W)) + 2 * y + py) * (2 * W) + 2 * x + px;
-                    } else {
-                        pix = (size_t)b * HW + p;
-                    }
-                    v = nd_ld4(base + pix * ld + cc);
-                    if (s.mode == ND_PRO_LAYERNORM) v = ((v + vec4) - rowMean[r]) * rowRstd[r] * g4 + b4;
-                    else if (s.mode == ND_PRO_SILU) v = nd_silu4(v);
-                    else if (s.mode == ND_PRO_AFFINE_SILU) v = nd_silu4((v - tM) * tA + tD);
-                }
+                f32x4 v = raw[it];
+                if (MODE == ND_PRO_LAYERNORM) v = ((v + vec4) - rmean[it]) * rrstd[it] * g4 + b4;
+                else if (MODE == ND_PRO_SILU) v = nd_silu4(v);
+                else if (MODE == ND_PRO_AFFINE_SILU) v = nd_silu4((v - tM) * tA + tD);
+                const f32x4 zero = {0, 0, 0, 0};
+                v = (cvalid && p0 + r < HW) ? v : zero;
                 nd_st4(&As[r * LDA + quad * 4], v);
             }
         }
         __syncthreads();
 
+        if (ng == 8) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g < ng) {
-                f32x4 bq[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    bq[nb] = nd_ld4(wbase + ((size_t)((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 4);
+            for (int g = 0; g < 8; ++g) {
                 f32x4 av[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) av[mb] = nd_ld4(&As[a_off[mb] + g * 8]);
@@ -162,39 +154,96 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = nd_mfma(av[mb][k], bq[nb][k], acc[mb][nb]);
+                            acc[mb][nb] = nd_mfma(av[mb][k], bq[g][nb][k], acc[mb][nb]);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g < ng) {
+                    f32x4 av[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) av[mb] = nd_ld4(&As[a_off[mb] + g * 8]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = nd_mfma(av[mb][k], bq[g][nb][k], acc[mb][nb]);
+                }
             }
         }
     }
 
     // ------------------------------------------------------------ epilogue
-    float* out = a.d.out;
+    // Accumulators go through LDS so that every global access of the epilogue (residual reads, the store) is a
+    // 16-byte-per-lane, row-contiguous access like the staging loads -- 4x fewer memory instructions than storing
+    // the MFMA layout directly (one dword per lane), which capped these HBM-bound layers at ~1.7 TB/s of writes.
+    __syncthreads();                                          // all waves are done reading the A tile
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int n = n0 + (wn * NB + nb) * 32 + col;
-        if (n >= Cout) continue;
-        const float bias = a.d.bias ? a.d.bias[n] : 0.0f;
-        const float vadd = a.d.vec ? a.d.vec[(size_t)b * Cout + n] : 0.0f;
-        float gM = 0.0f, gA = 1.0f, gD = 0.0f;
-        if (a.d.gn_t) {
-            const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + n;
-            gM = m[0]; gA = m[Cout]; gD = m[2 * Cout];
-        }
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = p0 + (wm * MB + mb) * 32 + nd_acc_row(r, lane);
-                if (p < HW) {
-                    const size_t pix = (size_t)b * HW + p;
-                    float v = nd_act(acc[mb][nb][r] + bias, a.d.act);
-                    if (a.d.res0) v += a.d.res0[pix * a.d.ldr0 + n];
-                    if (a.d.res1) v += a.d.res1[pix * a.d.ldr1 + n];
-                    v += vadd;
-                    if (a.d.gn_t) v += nd_silu((a.d.gn_t[pix * a.d.ldt + n] - gM) * gA + gD);
-                    out[pix * a.d.ldo + n] = v;
+            for (int r = 0; r < 16; ++r)
+                As[((wm * MB + mb) * 32 + nd_acc_row(r, lane)) * LDO + (wn * NB + nb) * 32 + col] = acc[mb][nb][r];
+    __syncthreads();
+    {
+        constexpr int QPR = BN / 4;                           // quads per tile row
+        constexpr int RPI = 256 / QPR;                        // rows covered per pass of the 256 threads
+        const int q = tid % QPR, rbase = tid / QPR;
+        const int n = n0 + q * 4;
+        const bool nvalid = n < Cout;                         // Cout % 4 == 0 is not required: handled below
+        const int ns = (nvalid && n + 4 <= Cout) ? n : 0;
+        const bool vec_ok = nvalid && n + 4 <= Cout;          // whole quad inside the tensor -> 16-byte path
+        const f32x4 zero = {0, 0, 0, 0};
+        f32x4 bias4 = zero, vadd4 = zero, gM = zero, gA = {1, 1, 1, 1}, gD = zero;
+        if (vec_ok) {
+            if (a.d.bias) bias4 = nd_ld4(a.d.bias + ns);
+            if (a.d.vec) vadd4 = nd_ld4(a.d.vec + (size_t)b * Cout + ns);
+            if (a.d.gn_t) {
+                const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + ns;
+                gM = nd_ld4(m); gA = nd_ld4(m + Cout); gD = nd_ld4(m + 2 * Cout);
+            }
+        }
+        float* out = a.d.out;
+        if (vec_ok) {
+            f32x4 r0[BM / RPI], r1[BM / RPI], rt[BM / RPI];
+#pragma unroll
+            for (int j = 0; j < BM / RPI; ++j) {              // all residual reads in flight together
+                const size_t pix = (size_t)b * HW + min(p0 + rbase + j * RPI, HW - 1);
+                r0[j] = a.d.res0 ? nd_ld4(a.d.res0 + pix * a.d.ldr0 + ns) : zero;
+                r1[j] = a.d.res1 ? nd_ld4(a.d.res1 + pix * a.d.ldr1 + ns) : zero;
+                rt[j] = a.d.gn_t ? nd_ld4(a.d.gn_t + pix * a.d.ldt + ns) : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < BM / RPI; ++j) {
+                const int r = rbase + j * RPI;
+                f32x4 v = nd_ld4(&As[r * LDO + q * 4]) + bias4;
+                if (a.d.act == ND_ACT_GELU) { v.x = nd_gelu(v.x); v.y = nd_gelu(v.y); v.z = nd_gelu(v.z); v.w = nd_gelu(v.w); }
+                else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
+                v += r0[j] + r1[j] + vadd4;
+                if (a.d.gn_t) v += nd_silu4((rt[j] - gM) * gA + gD);
+                if (p0 + r < HW) nd_st4(out + ((size_t)b * HW + p0 + r) * a.d.ldo + n, v);
+            }
+        } else if (nvalid) {                                  // ragged channel tail (cout % 4 != 0): scalar path
+            for (int j = 0; j < BM / RPI; ++j) {
+                const int r = rbase + j * RPI;
+                if (p0 + r >= HW) continue;
+                const size_t pix = (size_t)b * HW + p0 + r;
+                for (int e = 0; e < 4 && n + e < Cout; ++e) {
+                    float v = nd_act(As[r * LDO + q * 4 + e] + (a.d.bias ? a.d.bias[n + e] : 0.0f), a.d.act);
+                    if (a.d.res0) v += a.d.res0[pix * a.d.ldr0 + n + e];
+                    if (a.d.res1) v += a.d.res1[pix * a.d.ldr1 + n + e];
+                    if (a.d.vec) v += a.d.vec[(size_t)b * Cout + n + e];
+                    if (a.d.gn_t) {
+                        const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + n + e;
+                        v += nd_silu((a.d.gn_t[pix * a.d.ldt + n + e] - m[0]) * m[Cout] + m[2 * Cout]);
+                    }
+                    out[pix * a.d.ldo + n + e] = v;
                 }
             }
+        }
     }
 }
 
@@ -223,7 +272,13 @@ __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __rest
 
 template <int MB, int NB>
 void launch(const PwArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((pointwise_kernel<MB, NB>), dim3(a.total_wg), dim3(256), 0, st, a);
+    const dim3 grid(a.total_wg), block(256);
+    switch (a.d.src.mode) {
+        case ND_PRO_LAYERNORM: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_LAYERNORM>), grid, block, 0, st, a); break;
+        case ND_PRO_SILU: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_SILU>), grid, block, 0, st, a); break;
+        case ND_PRO_AFFINE_SILU: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_AFFINE_SILU>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_NONE>), grid, block, 0, st, a);
+    }
 }
 
 }  // namespace
@@ -266,10 +321,16 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     }
     ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_LAYERNORM || s.mode == ND_PRO_SILU || s.mode == ND_PRO_AFFINE_SILU,
                ND_E_BADARG, "nd_pointwise: unsupported prologue %d", s.mode);
-    if (s.mode == ND_PRO_LAYERNORM)
+    if (s.mode == ND_PRO_LAYERNORM) {
         ND_REQUIRE(s.gamma && s.beta && s.c1 == 0 && d->cin <= 1024, ND_E_SHAPE, "nd_pointwise: LayerNorm needs gamma/beta, one source, C <= 1024");
+        ND_REQUIRE(d->cin <= 64 || s.rowstats, ND_E_BADARG, "nd_pointwise: LayerNorm over C=%d > 64 needs src.rowstats (nd_layernorm_stats_f32)", d->cin);
+    }
     if (s.mode == ND_PRO_AFFINE_SILU) ND_REQUIRE(s.mad && s.c1 == 0, ND_E_BADARG, "nd_pointwise: affine prologue needs mad, one source");
     ND_REQUIRE(d->ldo >= d->cout, ND_E_SHAPE, "nd_pointwise: ldo < cout");
+    ND_REQUIRE(d->ldo % 4 == 0 && (!d->res0 || d->ldr0 % 4 == 0) && (!d->res1 || d->ldr1 % 4 == 0) && (!d->gn_t || d->ldt % 4 == 0),
+               ND_E_ALIGN, "nd_pointwise: output / residual pixel strides must be multiples of 4");
+    ND_REQUIRE(nd_aligned16(d->out) && nd_aligned16(d->res0) && nd_aligned16(d->res1) && nd_aligned16(d->gn_t) && nd_aligned16(d->bias) &&
+               nd_aligned16(d->vec) && nd_aligned16(d->gn_mad), ND_E_ALIGN, "nd_pointwise: epilogue pointers must be 16-byte aligned");
     ND_REQUIRE(!d->res0 || d->ldr0 >= d->cout, ND_E_SHAPE, "nd_pointwise: ldr0 < cout");
     ND_REQUIRE(!d->res1 || d->ldr1 >= d->cout, ND_E_SHAPE, "nd_pointwise: ldr1 < cout");
     ND_REQUIRE(!d->gn_t || (d->gn_mad && d->ldt >= d->cout), ND_E_BADARG, "nd_pointwise: gn_t needs gn_mad and ldt >= cout");
@@ -280,9 +341,12 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     a.cinP = nd_round_up(d->cin, 8);
     a.coutP = nd_round_up(d->cout, 64);
     // tiling: 128x128, 128x64, 64x64 -- first with >= 2 workgroups per CU, else the smallest
-    int mb = 2, nb = (d->cout % 128 == 0) ? 2 : 1;
+    static const int force_mb = getenv("ND_PW_MB") ? atoi(getenv("ND_PW_MB")) : 0;   // tuning knob (tools/ only)
+    // 64-pixel tiles win on every layer of the bench workload (more workgroups in flight per CU; measured)
+    static const int force_nb = getenv("ND_PW_NB") ? atoi(getenv("ND_PW_NB")) : 0;
+    int mb = force_mb ? force_mb : 1, nb = force_nb ? force_nb : ((d->cout % 128 == 0) ? 2 : 1);
     auto count = [&](int mb_, int nb_) { return (long)d->B * nd_cdiv(d->HW, 64 * mb_) * nd_cdiv(d->cout, 64 * nb_); };
-    if (nb == 2 && count(2, 2) < 512) nb = 1;
+    if (nb == 2 && count(mb, 2) < 512) nb = 1;
     if (count(mb, nb) < 512) mb = 1;
     a.m_tiles = nd_cdiv(d->HW, 64 * mb);
     a.n_tiles = nd_cdiv(d->cout, 64 * nb);
@@ -292,6 +356,7 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (mb == 2 && nb == 2) launch<2, 2>(a, st);
     else if (mb == 2) launch<2, 1>(a, st);
+    else if (nb == 2) launch<1, 2>(a, st);
     else launch<1, 1>(a, st);
     return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
 }

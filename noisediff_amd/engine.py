@@ -355,11 +355,19 @@ class Plan:
         """AttnBlock (Diffusion_arch.py:434-443) with the 1-token CrossAttention folded into cb."""
         Cc, HW = x.shape[-1], H * W
         cb = self.cb[name]
-        ln = self._src(x, None, L.PRO_LAYERNORM, vec=cb, gamma=self.e.p(name + ".norm2.weight"), beta=self.e.p(name + ".norm2.bias"))
+        kw = {}
+        rs = None
+        if Cc > 64:      # wide rows: per-pixel {mean, rstd} from a streaming pre-pass (narrow rows: derived inside the GEMM)
+            rs = self._alloc(self.B, HW, 2)
+            self._add("nd_layernorm_stats_f32", x.data_ptr(), Cc, cb.data_ptr(), rs.data_ptr(), self.B, HW, Cc, 1e-5, self.e.stream)
+            kw["rowstats"] = rs
+        ln = self._src(x, None, L.PRO_LAYERNORM, vec=cb, gamma=self.e.p(name + ".norm2.weight"), beta=self.e.p(name + ".norm2.bias"), **kw)
         h1 = self.pw(name + ".ff.net.0.0", ln, Cc, 2 * Cc, HW, W, act=L.ACT_GELU)
         x2 = self.pw(name + ".ff.net.2", self._src(h1), 2 * Cc, Cc, HW, W, res0=x, vec=cb)
         y = self.pw(name + ".proj_out", self._src(x2), Cc, Cc, HW, W, res0=x)
         self._release(h1, x2)
+        if rs is not None:
+            self._release(rs)
         return y.view(self.B, H, W, Cc)
 
     def mlp(self, name: str, src: L.Src, cin: int, hid: int, cout: int, H: int, W: int, res0=None) -> torch.Tensor:

@@ -162,8 +162,26 @@ def test_pointwise_prologues(ctx):
     xw, gw, bw = U("pp.xw", (B, 64, 512), -2, 2), U("pp.gw", (512,), 0.5, 1.5), U("pp.bw", (512,))
     ww = U("pp.ww", (64, 512), -0.1, 0.1)
     ref = F.linear(F.layer_norm(xw, (512,), gw, bw, eps=1e-5), ww)
-    s = hu.src(hu.dev(xw), None, L.PRO_LAYERNORM, gamma=hu.dev(gw), beta=hu.dev(bw))
+    xwd = hu.dev(xw)
+    rs = hu.full((B, 64, 2))
+    L.call("nd_layernorm_stats_f32", xwd.data_ptr(), 512, None, rs.data_ptr(), B, 64, 512, 1e-5, ctx.stream)
+    ctx.sync()
+    mu, var = xw.mean(-1), xw.var(-1, unbiased=False)
+    assert rel_err(rs[..., 0].cpu(), mu) < TOL and rel_err(rs[..., 1].cpu(), (var + 1e-5).rsqrt()) < TOL
+    s = hu.src(xwd, None, L.PRO_LAYERNORM, gamma=hu.dev(gw), beta=hu.dev(bw), rowstats=rs)
     assert rel_err(hu.pointwise(ctx, s, hu.pack_pw(ctx, ww), None, B, 64, 8, 512, 64).cpu(), ref) < TOL
+    # a wide LayerNorm without the statistics is refused, not guessed
+    s2 = hu.src(xwd, None, L.PRO_LAYERNORM, gamma=hu.dev(gw), beta=hu.dev(bw))
+    d = L.Pointwise()
+    d.src, d.weight, d.out = s2, xwd.data_ptr(), xwd.data_ptr()
+    d.B, d.HW, d.W, d.cin, d.cout, d.ldo = B, 64, 8, 512, 64, 64
+    assert ctx.lib.nd_pointwise_gemm_nhwc_f32(C.byref(d), ctx.stream) == -1
+    # narrow LayerNorm with C = 48 (three of the sixteen row lanes idle)
+    x48, g48, b48, v48 = U("pp.x48", (B, 100, 48), -2, 2), U("pp.g48", (48,), 0.5, 1.5), U("pp.b48", (48,)), U("pp.v48", (B, 48))
+    w48 = U("pp.w48", (96, 48), -0.3, 0.3)
+    ref = F.linear(F.layer_norm(x48 + v48[:, None], (48,), g48, b48, eps=1e-5), w48)
+    s = hu.src(hu.dev(x48), None, L.PRO_LAYERNORM, vec=hu.dev(v48), gamma=hu.dev(g48), beta=hu.dev(b48))
+    assert rel_err(hu.pointwise(ctx, s, hu.pack_pw(ctx, w48), None, B, 100, 10, 48, 96).cpu(), ref) < TOL
     # SiLU prologue
     ref = F.linear(F.silu(x), w, b)
     assert rel_err(hu.pointwise(ctx, hu.src(hu.dev(x), None, L.PRO_SILU), wp, hu.dev(b), B, H * W, W, Cc, 128).cpu(), ref) < TOL
