@@ -26,12 +26,52 @@ namespace {
 constexpr int KC = 32;        // channels per staged chunk
 constexpr int LDA = KC + 4;   // LDS floats per staged pixel (16-byte pad keeps b128 reads spread over banks)
 
+#ifdef ND_STAMP
+// diagnostic build only (tools/conv_phases.py): per-workgroup phase timestamps, 100 MHz s_memrealtime ticks
+__device__ unsigned long long nd_dbg_stamps[16384 * 8];
+#define ND_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) nd_dbg_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ND_STAMP_AT(i) do {} while (0)
+#endif
+
 struct ConvArgs {
     nd_conv3x3 d;
     int tiles_x, tiles_y, n_tiles, coutP, slots, total_wg;
 };
 
-template <int TW, int MB, int NB>
+// One K-chunk of the implicit GEMM with NG (compile-time) groups of 8 channels: 9 taps, weight fragments of
+// tap t+1 in flight while tap t is multiplied.  Straight-line code on purpose: with any branch inside, hipcc
+// falls back to s_waitcnt vmcnt(0) and every tap then waits for the *next* tap's prefetch (measured).
+template <int TWH, int MB, int NB, int NG>
+__device__ __forceinline__ void conv_chunk(f32x16 (&acc)[MB][NB], f32x4 (&bq)[2][NB][4], const float* As, const int (&a_off)[MB],
+                                           const float* wchunk, const size_t tap_stride, const int coutP) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    bq[(tap + 1) & 1][nb][g] = nd_ld4(wchunk + (tap + 1) * tap_stride + ((size_t)(2 * g) * coutP + nb * 32) * 4);
+        }
+        const int toff = ((tap / 3) * TWH + (tap % 3)) * LDA;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 av[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = nd_ld4(&As[a_off[mb] + toff + g * 8]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = nd_mfma(av[mb][k], bq[tap & 1][nb][g][k], acc[mb][nb]);
+        }
+    }
+}
+
+template <int TW, int MB, int NB, int MODE>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     constexpr int WM = 2, WN = 2;
     constexpr int RB = 32 / TW;            // image rows covered by one 32-pixel M-block
@@ -40,12 +80,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     constexpr int NPIX = TWH * THH;
     constexpr int BN = WN * NB * 32;
     constexpr int STAGE_IT = (NPIX + 31) / 32;
-    __shared__ __attribute__((aligned(16))) float As[NPIX * LDA];
+    // rows NPIX .. STAGE_IT*32-1 are scratch so that the staging pass needs no bounds branch
+    __shared__ __attribute__((aligned(16))) float As[STAGE_IT * 32 * LDA];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, col = lane & 31;
 
+    ND_STAMP_AT(0);
+#ifdef ND_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        nd_dbg_stamps[blockIdx.x * 8 + 6] = hw; nd_dbg_stamps[blockIdx.x * 8 + 7] = xcc;
+    }
+    int stamp_i = 1;
+#endif
     int lid = nd_xcd_remap(blockIdx.x, a.total_wg);
     const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
     const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
@@ -54,7 +105,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
 
     const nd_src& s = a.d.src;
     const int H = a.d.H, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
-    const int sH = s.upsample ? (H >> 1) : H, sW = s.upsample ? (W >> 1) : W;
+    const int up = s.upsample ? 1 : 0;
+    const int sH = H >> up, sW = W >> up;
     const int Ctot = s.c0 + s.c1;
     const int n0 = nt * BN;
 
@@ -71,6 +123,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     }
     // B-fragment base: Wp[((tap*Q + q) * coutP + n) * 4]
     const int Q = Cin >> 2;
+    const size_t tap_stride = (size_t)Q * a.coutP * 4;
     const float* wbase = a.d.weight + ((size_t)half * a.coutP + n0 + wn * NB * 32 + col) * 4;
 
     f32x16 acc[MB][NB];
@@ -85,75 +138,69 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
 
     for (int cb = 0; cb < Cin; cb += KC) {
         const int ng = min(4, (Cin - cb) >> 3);   // groups of 8 channels in this chunk
-
-        auto load_b = [&](int buf, int tap) {
+        const float* wchunk = wbase + (size_t)(cb >> 2) * a.coutP * 4;
+        // tap-0 weight fragments first: their latency hides behind the activation loads below
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (g < ng)
-                        bq[buf][nb][g] = nd_ld4(wbase + ((size_t)(tap * Q + (cb >> 2) + 2 * g) * a.coutP + nb * 32) * 4);
-        };
-        load_b(0, 0);   // overlaps with the staging pass below
+            for (int g = 0; g < 4; ++g)
+                bq[0][nb][g] = nd_ld4(wchunk + ((size_t)(2 * min(g, ng - 1)) * a.coutP + nb * 32) * 4);
 
-        __syncthreads();   // everyone is done reading the previous chunk
-        {
+        {   // ---- stage the tile + halo of 32 channels: all loads issued back to back, no branches
             const int c = cb + quad * 4;
             const bool cvalid = c < Cin;
-            const float* base = s.p0;
-            int ld = s.ld0, cc = c;
-            if (c >= s.c0) { base = s.p1; ld = s.ld1; cc = c - s.c0; }
+            const int cs = cvalid ? c : 0;
+            const bool second = cs >= s.c0;
+            const float* base = second ? s.p1 : s.p0;
+            const int ld = second ? s.ld1 : s.ld0, cc = second ? cs - s.c0 : cs;
             f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
-            if (s.mode != ND_PRO_NONE && cvalid) {
-                const float* m = s.mad + (size_t)b * 3 * Ctot + c;
+            if (MODE != ND_PRO_NONE) {
+                const float* m = s.mad + (size_t)b * 3 * Ctot + cs;
                 tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
             }
+            f32x4 raw[STAGE_IT], msc[MODE == ND_PRO_AFFINE_MAP_SILU ? STAGE_IT : 1], msh[MODE == ND_PRO_AFFINE_MAP_SILU ? STAGE_IT : 1];
+            unsigned okmask = 0;
 #pragma unroll
             for (int it = 0; it < STAGE_IT; ++it) {
                 const int p = prow + it * 32;
-                if (p < NPIX) {
-                    const int hy = p / TWH, hx = p - hy * TWH;
-                    const int y = y0 + hy, x = x0 + hx;
-                    f32x4 v = {0, 0, 0, 0};
-                    if (cvalid && y >= 0 && y < H && x >= 0 && x < W) {
-                        const int sy = s.upsample ? (y >> 1) : y, sx = s.upsample ? (x >> 1) : x;
-                        v = nd_ld4(base + ((size_t)(b * sH + sy) * sW + sx) * ld + cc);
-                        if (s.mode != ND_PRO_NONE) {
-                            v = (v - tM) * tA + tD;
-                            if (s.mode == ND_PRO_AFFINE_MAP_SILU) {
-                                const float* mp = s.map + ((size_t)(b * H + y) * W + x) * (2 * Ctot) + c;
-                                const f32x4 sc = nd_ld4(mp), sh = nd_ld4(mp + Ctot);
-                                v = v * (sc + 1.0f) + sh;
-                            }
-                            v = nd_silu4(v);
-                        }
-                    }
-                    nd_st4(&As[p * LDA + quad * 4], v);
+                const int hy = p / TWH, hx = p - hy * TWH;
+                const int y = y0 + hy, x = x0 + hx;
+                const bool ok = cvalid && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                okmask |= (ok ? 1u : 0u) << it;
+                const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+                raw[it] = nd_ld4(base + ((size_t)(b * sH + (yc >> up)) * sW + (xc >> up)) * ld + cc);
+                if (MODE == ND_PRO_AFFINE_MAP_SILU) {
+                    const float* mp = s.map + ((size_t)(b * H + yc) * W + xc) * (2 * Ctot) + cs;
+                    msc[it] = nd_ld4(mp);
+                    msh[it] = nd_ld4(mp + Ctot);
                 }
+            }
+            __syncthreads();   // everyone is done reading the previous chunk
+#pragma unroll
+            for (int it = 0; it < STAGE_IT; ++it) {
+                f32x4 v = raw[it];
+                if (MODE != ND_PRO_NONE) {
+                    v = (v - tM) * tA + tD;
+                    if (MODE == ND_PRO_AFFINE_MAP_SILU) v = v * (msc[it] + 1.0f) + msh[it];
+                    v = nd_silu4(v);
+                }
+                const f32x4 zero = {0, 0, 0, 0};
+                v = ((okmask >> it) & 1u) ? v : zero;           // zero padding applies to the activated tensor
+                nd_st4(&As[(prow + it * 32) * LDA + quad * 4], v);
             }
         }
         __syncthreads();
+#ifdef ND_STAMP
+        if (stamp_i < 5) { ND_STAMP_AT(stamp_i); ++stamp_i; }
+#endif
 
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) load_b((tap + 1) & 1, tap + 1);
-            const int toff = ((tap / 3) * TWH + (tap % 3)) * LDA;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < ng) {
-                    f32x4 av[MB];
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) av[mb] = nd_ld4(&As[a_off[mb] + toff + g * 8]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[mb][nb] = nd_mfma(av[mb][k], bq[tap & 1][nb][g][k], acc[mb][nb]);
-                }
-            }
-        }
+        if (ng == 4) conv_chunk<TWH, MB, NB, 4>(acc, bq, As, a_off, wchunk, tap_stride, a.coutP);
+        else if (ng == 2) conv_chunk<TWH, MB, NB, 2>(acc, bq, As, a_off, wchunk, tap_stride, a.coutP);
+        else if (ng == 3) conv_chunk<TWH, MB, NB, 3>(acc, bq, As, a_off, wchunk, tap_stride, a.coutP);
+        else conv_chunk<TWH, MB, NB, 1>(acc, bq, As, a_off, wchunk, tap_stride, a.coutP);
+#ifdef ND_STAMP
+        if (stamp_i < 5) { ND_STAMP_AT(stamp_i); ++stamp_i; }
+#endif
     }
 
     // ------------------------------------------------------------ epilogue
@@ -163,6 +210,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     const int cnt = rows_valid * cols_valid;
     const int slot = (ty * a.tiles_x + tx) * WM + wm;
     float* out = a.d.out;
+    const bool interior = rows_valid == MB * RB && cols_valid == TW && n0 + BN <= Cout;   // uniform per wave
 
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -170,19 +218,33 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         const bool nvalid = n < Cout;
         const float bias = (nvalid && a.d.bias) ? a.d.bias[n] : 0.0f;
         float s1 = 0.0f;
+        if (interior) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = nd_acc_row(r, lane);
-                const int y = wrow0 + mb * RB + rr / TW, x = tx * TW + rr % TW;
-                const float v = acc[mb][nb][r] + bias;
-                acc[mb][nb][r] = v;
-                if (y < H && x < W) {
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = nd_acc_row(r, lane);
+                    const int y = wrow0 + mb * RB + rr / TW, x = tx * TW + rr % TW;
+                    const float v = acc[mb][nb][r] + bias;
+                    acc[mb][nb][r] = v;
                     s1 += v;
-                    if (nvalid) out[((size_t)(b * H + y) * W + x) * a.d.ldo + n] = v;
+                    out[((size_t)(b * H + y) * W + x) * a.d.ldo + n] = v;
                 }
-            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = nd_acc_row(r, lane);
+                    const int y = wrow0 + mb * RB + rr / TW, x = tx * TW + rr % TW;
+                    const float v = acc[mb][nb][r] + bias;
+                    acc[mb][nb][r] = v;
+                    if (y < H && x < W) {
+                        s1 += v;
+                        if (nvalid) out[((size_t)(b * H + y) * W + x) * a.d.ldo + n] = v;
+                    }
+                }
+        }
         if (a.d.stats) {
             s1 += __shfl_xor(s1, 32);
             const float mean = s1 / (float)max(cnt, 1);
@@ -194,7 +256,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
                     const int rr = nd_acc_row(r, lane);
                     const int y = wrow0 + mb * RB + rr / TW, x = tx * TW + rr % TW;
                     const float dv = acc[mb][nb][r] - mean;
-                    if (y < H && x < W) m2 += dv * dv;
+                    m2 += (interior || (y < H && x < W)) ? dv * dv : 0.0f;
                 }
             m2 += __shfl_xor(m2, 32);
             if (half == 0 && nvalid) {
@@ -205,6 +267,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         }
     }
     if (a.d.slot_count && b == 0 && nt == 0 && wn == 0 && lane == 0) a.d.slot_count[slot] = (float)cnt;
+    ND_STAMP_AT(5);
 }
 
 // ---------------------------------------------------------------- tiling choice (host)
@@ -233,7 +296,15 @@ Tiling choose_tiling(int B, int H, int W, int cout) {
 
 template <int TW, int MB, int NB>
 void launch(const ConvArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB>), dim3(a.total_wg), dim3(256), 0, st, a);
+    const dim3 grid(a.total_wg), block(256);
+    switch (a.d.src.mode) {
+        case ND_PRO_AFFINE_SILU:
+            hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB, ND_PRO_AFFINE_SILU>), grid, block, 0, st, a); break;
+        case ND_PRO_AFFINE_MAP_SILU:
+            hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB, ND_PRO_AFFINE_MAP_SILU>), grid, block, 0, st, a); break;
+        default:
+            hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB, ND_PRO_NONE>), grid, block, 0, st, a);
+    }
 }
 
 // OIHW -> [tap][cin/4][coutP][4], coutP = cout rounded up to 64
@@ -251,6 +322,12 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 }
 
 }  // namespace
+
+#ifdef ND_STAMP
+extern "C" int nd_dbg_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nd_dbg_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int nd_conv3x3_stat_slots(int H, int W, int cout, int B) {
     if (H <= 0 || W <= 0 || cout <= 0 || B <= 0) return ND_E_BADARG;
