@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for plumbing tests)")
+    ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0 (single-GPU box)")
     return ap.parse_args()
 
 
@@ -130,7 +132,7 @@ def cpu_baseline(sd, dim, size, timesteps):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cands = sorted({c for c in (4, 8, 16, 32, 64, avail) if c <= avail})
+    cands = sorted({c for c in (4, 8, 16, 32, 64, min(avail, 96)) if c <= avail})
     sd_small = synth.make_state_dict(noisediff_param_spec(32), 0)
     best, best_dt = cands[0], float("inf")
     with torch.no_grad():
@@ -178,12 +180,17 @@ def main():
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         a.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(a.backend)
 
     from noisediff_amd import GaussianDiffusion, NoiseDiffNet, synth, _lib as L
     from noisediff_amd.engine import Engine

@@ -53,6 +53,9 @@ __device__ __forceinline__ void conv_chunk(f32x16 (&acc)[MB][NB], f32x4 (&bq)[2]
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
                     bq[(tap + 1) & 1][nb][g] = nd_ld4(wchunk + (tap + 1) * tap_stride + ((size_t)(2 * g) * coutP + nb * 32) * 4);
+            // keep the prefetch HERE: left alone, the scheduler sinks these loads to just before their first use one tap
+            // later and every tap then opens with an exposed L2 round trip (~600 cycles per 2048 cycles of MFMA)
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int toff = ((tap / 3) * TWH + (tap % 3)) * LDA;
 #pragma unroll
@@ -97,22 +100,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     }
     int stamp_i = 1;
 #endif
-    int lid = nd_xcd_remap(blockIdx.x, a.total_wg);
-    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
-    const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
-    const int ty = lid % a.tiles_y;
-    const int b = lid / a.tiles_y;
-
     const nd_src& s = a.d.src;
     const int H = a.d.H, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
     const int up = s.upsample ? 1 : 0;
     const int sH = H >> up, sW = W >> up;
     const int Ctot = s.c0 + s.c1;
-    const int n0 = nt * BN;
-
-    // staging role: 8 channel-quads x 32 pixel slots
-    const int quad = tid & 7, prow = tid >> 3;
-    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+    const int quad = tid & 7, prow = tid >> 3;      // staging role: 8 channel-quads x 32 pixel slots
 
     // A-fragment LDS offsets (floats) of this lane for tap (0,0), group 0
     int a_off[MB];
@@ -121,9 +114,24 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         const int ly = (wm * MB + mb) * RB + col / TW, lx = col % TW;
         a_off[mb] = (ly * TWH + lx) * LDA + 4 * half;
     }
-    // B-fragment base: Wp[((tap*Q + q) * coutP + n) * 4]
     const int Q = Cin >> 2;
     const size_t tap_stride = (size_t)Q * a.coutP * 4;
+    f32x4 bq[2][NB][4];
+
+    // Persistent workgroup: a CONTIGUOUS range of tiles (n-tile fastest, then x, y, sample).  Consecutive tiles of
+    // a workgroup sit next to each other in the image, so their rows are the same pages (address translation
+    // stays warm: the first staging of a tile that starts cold costs ~13 us against ~3 us warm, measured with
+    // tools/conv_phases.py) and their halo columns are L2 hits.
+    const int t_begin = (int)((long)blockIdx.x * a.total_wg / gridDim.x), t_end = (int)((long)(blockIdx.x + 1) * a.total_wg / gridDim.x);
+    for (int t = t_begin; t < t_end; ++t) {
+    int lid = t;
+    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
+    const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
+    const int ty = lid % a.tiles_y;
+    const int b = lid / a.tiles_y;
+    const int n0 = nt * BN;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+    // B-fragment base: Wp[((tap*Q + q) * coutP + n) * 4]
     const float* wbase = a.d.weight + ((size_t)half * a.coutP + n0 + wn * NB * 32 + col) * 4;
 
     f32x16 acc[MB][NB];
@@ -133,8 +141,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
-
-    f32x4 bq[2][NB][4];
 
     for (int cb = 0; cb < Cin; cb += KC) {
         const int ng = min(4, (Cin - cb) >> 3);   // groups of 8 channels in this chunk
@@ -267,7 +273,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         }
     }
     if (a.d.slot_count && b == 0 && nt == 0 && wn == 0 && lane == 0) a.d.slot_count[slot] = (float)cnt;
-    ND_STAMP_AT(5);
+#ifdef ND_STAMP
+    if (t == t_begin) ND_STAMP_AT(5);
+#endif
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------- tiling choice (host)
@@ -294,16 +303,36 @@ Tiling choose_tiling(int B, int H, int W, int cout) {
     return cand[best];
 }
 
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int TW, int MB, int NB, int MODE>
+void launch_mode(const ConvArgs& a, hipStream_t st) {
+    static int per_cu = 0;   // resident workgroups per CU of this instantiation (occupancy query, once)
+    if (!per_cu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_kernel<TW, MB, NB, MODE>, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+        static const int force = getenv("ND_CONV_WG_PER_CU") ? atoi(getenv("ND_CONV_WG_PER_CU")) : 0;   // tuning knob
+        if (force > 0) per_cu = force;
+    }
+    const long resident = (long)device_cus() * per_cu;
+    const dim3 grid((unsigned)(a.total_wg < resident ? a.total_wg : resident)), block(256);
+    hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB, MODE>), grid, block, 0, st, a);
+}
+
 template <int TW, int MB, int NB>
 void launch(const ConvArgs& a, hipStream_t st) {
-    const dim3 grid(a.total_wg), block(256);
     switch (a.d.src.mode) {
-        case ND_PRO_AFFINE_SILU:
-            hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB, ND_PRO_AFFINE_SILU>), grid, block, 0, st, a); break;
-        case ND_PRO_AFFINE_MAP_SILU:
-            hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB, ND_PRO_AFFINE_MAP_SILU>), grid, block, 0, st, a); break;
-        default:
-            hipLaunchKernelGGL((conv3x3_kernel<TW, MB, NB, ND_PRO_NONE>), grid, block, 0, st, a);
+        case ND_PRO_AFFINE_SILU: launch_mode<TW, MB, NB, ND_PRO_AFFINE_SILU>(a, st); break;
+        case ND_PRO_AFFINE_MAP_SILU: launch_mode<TW, MB, NB, ND_PRO_AFFINE_MAP_SILU>(a, st); break;
+        default: launch_mode<TW, MB, NB, ND_PRO_NONE>(a, st);
     }
 }
 

@@ -3,52 +3,58 @@
 
 namespace {
 
-// One workgroup (4 waves) per (sample, group): Chan/Welford merge of the conv epilogue's per-(slot, channel)
-// {sum, M2} partials in fp64, fixed order => bitwise reproducible.  Then fold gamma/beta and the
+// One workgroup (4 waves) per (sample, group): pool the conv epilogue's per-(slot, channel) {sum, M2} partials
+// in fp64 (see below), then fold gamma/beta and the
 // time-embedding scale/shift so that  GN(x)*(scale+1)+shift == (x - M)*A + D
 // (Block.forward, models/archs/Diffusion_arch.py:137-141; nn.GroupNorm: biased variance, eps inside sqrt).
-struct Moments { double n, mean, m2; };
-
-__device__ __forceinline__ Moments merge(Moments a, Moments b) {   // symmetric: merge(a,b) == merge(b,a) bitwise
-    const double nt = a.n + b.n;
-    if (nt <= 0.0) return a;
-    const double dl = b.mean - a.mean;
-    Moments r;
-    r.mean = (a.mean * a.n + b.mean * b.n) / nt;
-    r.m2 = a.m2 + b.m2 + dl * dl * a.n * b.n / nt;
-    r.n = nt;
-    return r;
-}
-
+// Per item i (one wave-slot of one channel): n_i pixels, sum_i, M2_i (centred second moment).  Pooled over
+// the group:  N = sum n_i,  S = sum sum_i,  Q = sum (M2_i + sum_i^2 / n_i)   =>  mean = S/N,  var = Q/N - mean^2.
+// The per-item M2 was centred in fp32 registers; the pooling runs in fp64 (53 bits against fp32 inputs), so the
+// final subtraction loses nothing unless mean^2/var exceeds ~1e8.  Plain sums => independent loads, no serial
+// Welford chain, fixed reduction tree => bitwise reproducible.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ slot_count,
                                                           int slots, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ ss, int ld_ss, float* __restrict__ mad,
                                                           int C, int G, float eps) {
-    __shared__ Moments part[4];
+    __shared__ double part[4][3];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    Moments m = {0.0, 0.0, 0.0};
+    double N = 0.0, S = 0.0, Q = 0.0;
     const int items = slots * cpg;
-    for (int i = tid; i < items; i += 256) {
-        const int slot = i / cpg, ch = g * cpg + (i - slot * cpg);
-        const double ni = (double)slot_count[slot];
-        if (ni > 0.0) {
-            const float* st = stats + (((size_t)b * slots + slot) * C + ch) * 2;
-            const Moments p = {ni, (double)st[0] / ni, (double)st[1]};
-            m = merge(m, p);
+    const float2* st2 = reinterpret_cast<const float2*>(stats) + (size_t)b * slots * C + g * cpg;
+    for (int i0 = tid; i0 < items; i0 += 256 * 8) {       // 8 independent loads in flight per thread, no branches
+        float ni[8];
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 256, items - 1);
+            const int slot = i / cpg, j = i - slot * cpg;
+            ni[u] = (i0 + u * 256 < items) ? slot_count[slot] : 0.0f;
+            v[u] = st2[(size_t)slot * C + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = ni[u] > 0.0f;
+            const double n = ok ? (double)ni[u] : 1.0;
+            N += ok ? n : 0.0;
+            S += ok ? (double)v[u].x : 0.0;
+            Q += ok ? (double)v[u].y + (double)v[u].x * (double)v[u].x / n : 0.0;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const Moments p = {__shfl_xor(m.n, o), __shfl_xor(m.mean, o), __shfl_xor(m.m2, o)};
-        m = merge(m, p);
+        N += __shfl_xor(N, o); S += __shfl_xor(S, o); Q += __shfl_xor(Q, o);
     }
-    if (lane == 0) part[wave] = m;
+    if (lane == 0) { part[wave][0] = N; part[wave][1] = S; part[wave][2] = Q; }
     __syncthreads();
-    m = merge(merge(part[0], part[1]), merge(part[2], part[3]));
-    const double var = m.n > 0.0 ? m.m2 / m.n : 0.0;
+    N = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+    S = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+    Q = (part[0][2] + part[1][2]) + (part[2][2] + part[3][2]);
+    const double mean = N > 0.0 ? S / N : 0.0;
+    double var = N > 0.0 ? Q / N - mean * mean : 0.0;
+    var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float fmean = (float)m.mean;
+    const float fmean = (float)mean;
     for (int i = tid; i < cpg; i += 256) {
         const int ch = g * cpg + i;
         const float sc = ss ? ss[(size_t)b * ld_ss + ch] : 0.0f;
