@@ -93,7 +93,7 @@ def instrumented_pass(loop, plan, L, n_steps):
             ms = C.c_float()
             L.call("nd_event_elapsed_ms", evs[2 * j], evs[2 * j + 1], C.byref(ms))
             m = op[3]
-            d = per.setdefault(m["tiling"], {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
+            d = per.setdefault((m["tiling"], m["mode"]), {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
             d["ms"] += ms.value
             d["flop"] += conv_flops(m)
             d["bytes"] += conv_bytes(m)
@@ -273,22 +273,28 @@ def main():
         per = instrumented_pass(loop, plan, L, n_inst)
         tot_ms = sum(d["ms"] for d in per.values())
         tot_flop = sum(d["flop"] for d in per.values())
+        kname = lambda k: f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>"   # as rocprofv3 prints it
         dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tid, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+        traffic, tsrc = None, None
+        tfile = os.path.join(REPO, "profiles", "r1b_traffic.json")      # PMC passes cannot run inside this process
+        if os.path.exists(tfile) and (a.dim, a.size, a.batch) == (64, 256, 16):
+            tk = json.load(open(tfile))["kernels"].get(kname(tid))
+            if tk:
+                traffic, tsrc = tk["hbm_bytes_per_launch"], "profiles/r1b_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
         out["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": None,
-            "kernel": f"conv3x3_kernel<{tid // 100},{(tid // 10) % 10},{tid % 10}>",
+            "traffic": traffic, "traffic_source": tsrc,
+            "kernel": kname(tid),
             "avg_launch_ms": d["ms"] / d["launches"], "launches_per_step": d["launches"] // n_inst,
             "algorithmic_flop_per_launch": d["flop"] / d["launches"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "hbm_frac_at_algorithmic_bytes": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "all_conv3x3": {"tflops": tot_flop / (tot_ms * 1e-3) / 1e12, "ms_per_step": tot_ms / n_inst,
                             "share_of_step": (tot_ms / n_inst) / (per_step * 1e3) if not a.full else None},
-            "by_kernel": {f"<{k // 100},{(k // 10) % 10},{k % 10}>": {"tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
-                                                                    "avg_ms": v["ms"] / v["launches"], "launches_per_step": v["launches"] // n_inst}
-                          for k, v in sorted(per.items())},
+            "by_kernel": {kname(k): {"tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12, "avg_ms": v["ms"] / v["launches"],
+                                     "launches_per_step": v["launches"] // n_inst} for k, v in sorted(per.items())},
         }
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sd, a.dim, S, T)

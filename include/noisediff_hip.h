@@ -225,6 +225,12 @@ int nd_philox_normal_f32(float* out, uint64_t seed, int64_t first_sample, int32_
  * q | k | v thirds); out [B][N][heads*dh].  dh must be 32. */
 int nd_attention_mfma_f32(const float* qkv, int ld_qkv, float* out, int ld_out,
                           int B, int N, int heads, int dh, void* stream);
+/* LinearAttention.forward (:218-235) core, O(N dh^2): q softmax over channels (x dh^-1/2), k softmax over pixels,
+ * out = (k v^T)^T q per (b, head).  Same qkv / out layout as nd_attention_mfma_f32; `workspace` holds
+ * nd_linear_attention_workspace_floats(B, N, heads) floats.  Defined but not wired in the reference net. */
+int64_t nd_linear_attention_workspace_floats(int B, int N, int heads);
+int nd_linear_attention_f32(const float* qkv, int ld_qkv, float* out, int ld_out, float* workspace,
+                            int B, int N, int heads, int dh, void* stream);
 /* RMSNorm.forward (:89-90) over channels: out = x / max(||x||, 1e-12) * g * sqrt(C). */
 int nd_rmsnorm_nhwc_f32(const float* x, int ldx, const float* g, float* out, int ldo,
                         int B, int HW, int C, void* stream);

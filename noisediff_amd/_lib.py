@@ -79,6 +79,8 @@ SIGNATURES = {
     "nd_sampler_step_ddim_f32": (i32, [vp, vp, vp, i64, C.POINTER(SamplerState), i32, u64, i64, i32, i32, i32, vp]),
     "nd_philox_normal_f32": (i32, [vp, u64, i64, i32, i32, i32, i32, vp]),
     "nd_attention_mfma_f32": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "nd_linear_attention_workspace_floats": (i64, [i32, i32, i32]),
+    "nd_linear_attention_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "nd_rmsnorm_nhwc_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "nd_stream_create": (i32, [C.POINTER(vp)]),
     "nd_stream_destroy": (i32, [vp]),
@@ -94,7 +96,7 @@ SIGNATURES = {
 }
 
 _UNCHECKED = {"nd_version", "nd_last_error", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
-              "nd_pack_pointwise_weight_floats"}
+              "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats"}
 
 _lib: Optional[C.CDLL] = None
 

@@ -287,7 +287,7 @@ class Plan:
             d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
         self._add("nd_conv3x3_nhwc_f32", C.byref(d), e.stream,
                   meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout,
-                        "tiling": e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
+                        "tiling": e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout), "mode": int(src.mode)})
         self._keep.append(d)
         return out, st, sc, slots
 

@@ -312,3 +312,44 @@ def test_philox_matches_oracle_and_is_shard_invariant(ctx):
     L.call("nd_philox_normal_f32", big.data_ptr(), C.c_uint64(1), 0, -1, 64, 4096, 4, ctx.stream)
     ctx.sync()
     assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3
+
+
+@pytest.mark.parametrize("N", [64, 2048 + 200])
+def test_linear_attention_matches_reference_semantics(ctx, N, golden):
+    """LinearAttention core (Diffusion_arch.py:223-234) vs the oracle's einsum restatement; plus the whole block
+    (RMSNorm -> qkv -> core -> to_out -> RMSNorm) against the golden captured from the reference class."""
+    import hiputil as hu
+    B, heads, dh = 2, 4, 32
+    qkv = U(f"lat.{N}", (B, N, 3 * heads * dh), -2, 2)
+    out = hu.full((B, N, heads * dh))
+    ws = hu.full((ctx.lib.nd_linear_attention_workspace_floats(B, N, heads),))
+    qd = hu.dev(qkv)
+    L.call("nd_linear_attention_f32", qd.data_ptr(), 3 * heads * dh, out.data_ptr(), heads * dh, ws.data_ptr(), B, N, heads, dh, ctx.stream)
+    ctx.sync()
+    q, k, v = (t.reshape(B, N, heads, dh).permute(0, 2, 3, 1) for t in qkv.chunk(3, dim=-1))      # b h c n
+    q = q.softmax(dim=-2) * dh ** -0.5
+    k = k.softmax(dim=-1)
+    ref = torch.einsum("bhde,bhdn->bhen", torch.einsum("bhdn,bhen->bhde", k, v), q)                # b h e n
+    assert rel_err(out.cpu(), ref.permute(0, 3, 1, 2).reshape(B, N, heads * dh)) < TOL
+    if N != 64:
+        return
+    # full block on the golden input (B=2, C=128, 8x8)
+    from noisediff_amd.spec import attention_param_spec
+    Cc = 128
+    xa = synth.uniform(7, "mod.xa", (B, Cc, 8, 8), -1.5, 1.5)
+    sda = synth.make_state_dict(attention_param_spec("mid_attn", Cc), 0)
+    g2 = synth.uniform(7, "mod.lat_g", (1, Cc, 1, 1), 0.5, 1.5)
+    x = hu.nhwc(xa).view(B, 64, Cc)
+    xn, y, yn = hu.full((B, 64, Cc)), hu.full((B, 64, Cc)), hu.full((B, 64, Cc))
+    ones, g2d = hu.dev(torch.ones(Cc)), hu.dev(g2.reshape(-1))
+    L.call("nd_rmsnorm_nhwc_f32", x.data_ptr(), Cc, ones.data_ptr(), xn.data_ptr(), Cc, B, 64, Cc, ctx.stream)
+    ctx.sync()
+    qkv2 = hu.pointwise(ctx, hu.src(xn), hu.pack_pw(ctx, sda["mid_attn.to_qkv.weight"]), None, B, 64, 8, Cc, 384)
+    att = hu.full((B, 64, 128))
+    L.call("nd_linear_attention_f32", qkv2.data_ptr(), 384, att.data_ptr(), 128, ws.data_ptr(), B, 64, heads, dh, ctx.stream)
+    ctx.sync()
+    y = hu.pointwise(ctx, hu.src(att), hu.pack_pw(ctx, sda["mid_attn.to_out.weight"]), hu.dev(sda["mid_attn.to_out.bias"]), B, 64, 8, 128, Cc)
+    L.call("nd_rmsnorm_nhwc_f32", y.data_ptr(), Cc, g2d.data_ptr(), yn.data_ptr(), Cc, B, 64, Cc, ctx.stream)
+    ctx.sync()
+    got = yn.view(B, 8, 8, Cc).permute(0, 3, 1, 2).cpu().numpy()
+    assert rel_err(got, golden("modules", "mod.linear_attention")) < 1e-4
