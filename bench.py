@@ -64,7 +64,8 @@ def conv_bytes(m):
 def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
-    convs = [op for op in plan.step_ops if op[2] == "nd_conv3x3_nhwc_f32"]
+    CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32")
+    convs = [op for op in plan.step_ops if op[2] in CONV]
     n_ev = 2 * len(convs)
     evs = []
     for _ in range(n_ev):
@@ -76,7 +77,7 @@ def instrumented_pass(loop, plan, L, n_steps):
         L.call("nd_sampler_begin_step", C.byref(loop.state), st)
         i = 0
         for fn, args, name, meta in plan.step_ops:
-            if name == "nd_conv3x3_nhwc_f32":
+            if name in CONV:
                 L.call("nd_event_record", evs[2 * i], st)
                 L.check(fn(*args), name)
                 L.call("nd_event_record", evs[2 * i + 1], st)
@@ -273,7 +274,8 @@ def main():
         per = instrumented_pass(loop, plan, L, n_inst)
         tot_ms = sum(d["ms"] for d in per.values())
         tot_flop = sum(d["flop"] for d in per.values())
-        kname = lambda k: f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>"   # as rocprofv3 prints it
+        kname = lambda k: (f"wino_kernel<1, {k[1]}>" if k[0] == 9001 else
+                           f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
         dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tid, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12

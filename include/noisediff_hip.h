@@ -103,6 +103,14 @@ int nd_conv3x3_tiling_id(int B, int H, int W, int cout);
 int64_t nd_pack_conv3x3_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 
+/* Same operator, same descriptor, computed with Winograd F(2x2,3x3) (2.25x fewer multiplies; fp32 transforms,
+ * ~1e-6 relative difference to the direct form).  `weight` must come from nd_pack_conv3x3_wino_weight
+ * (U = G g G^T, [16][cin/4][coutP][4]); statistics slots: nd_conv3x3_wino_stat_slots.  Used for images >= 16x16. */
+int nd_conv3x3_wino_nhwc_f32(const nd_conv3x3* d, void* stream);
+int nd_conv3x3_wino_stat_slots(int H, int W);
+int64_t nd_pack_conv3x3_wino_weight_floats(int cin, int cout);
+int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
+
 /* ------------------------------------------------------------------ pointwise GEMM */
 
 /* out[p, n] = epi( sum_k pro(in[p, k]) * W[k, n] + bias[n] ) per pixel: nn.Conv2d(k=1) and

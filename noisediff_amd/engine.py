@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -31,6 +32,7 @@ from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, 
                    attention_param_spec, noisediff_param_spec, stage_dims)
 
 GN_EPS = 1e-5
+WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 
 
@@ -102,6 +104,7 @@ class Engine:
                 continue
             if kind == "conv3":
                 n = self.lib.nd_pack_conv3x3_weight_floats(p.shape[1], p.shape[0])
+                add(p.name + ".wino", self.lib.nd_pack_conv3x3_wino_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind in ("pw", "pw_unshuffle"):
                 n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
             elif kind == "conv7":
@@ -149,6 +152,7 @@ class Engine:
                 kind, dst = self.slots[p.name].kind, self.p(p.name)
                 if kind == "conv3":
                     L.call("nd_pack_conv3x3_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], st)
+                    L.call("nd_pack_conv3x3_wino_weight", t.data_ptr(), self.p(p.name + ".wino"), p.shape[1], p.shape[0], st)
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
                 elif kind == "pw_unshuffle":
@@ -275,19 +279,21 @@ class Plan:
         """nn.Conv2d(cin, cout, 3, padding=1); returns (out, stats, slot_count, slots)."""
         e = self.e
         out = self._alloc(self.B, H, W, cout)
+        # images of at least one 16x16 tile go through the Winograd F(2x2,3x3) kernel (2.25x fewer MFMAs)
+        wino = WINOGRAD and H >= 16 and W >= 16
         d = L.Conv3x3()
-        d.src, d.weight, d.bias, d.out = src, e.p(name + ".weight"), e.p(name + ".bias"), out.data_ptr()
+        d.src, d.weight, d.bias, d.out = src, e.p(name + (".weight.wino" if wino else ".weight")), e.p(name + ".bias"), out.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, H, W, cin, cout, cout
         st = sc = None
         slots = 0
         if stats:
-            slots = e.lib.nd_conv3x3_stat_slots(H, W, cout, self.B)
+            slots = e.lib.nd_conv3x3_wino_stat_slots(H, W) if wino else e.lib.nd_conv3x3_stat_slots(H, W, cout, self.B)
             st = self._alloc(self.B, slots, cout, 2)
             sc = self._alloc(slots)
             d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
-        self._add("nd_conv3x3_nhwc_f32", C.byref(d), e.stream,
-                  meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout,
-                        "tiling": e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout), "mode": int(src.mode)})
+        self._add("nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), e.stream,
+                  meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
+                        "tiling": 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
         self._keep.append(d)
         return out, st, sc, slots
 

@@ -353,3 +353,55 @@ def test_linear_attention_matches_reference_semantics(ctx, N, golden):
     ctx.sync()
     got = yn.view(B, 8, 8, Cc).permute(0, 3, 1, 2).cpu().numpy()
     assert rel_err(got, golden("modules", "mod.linear_attention")) < 1e-4
+
+
+WINO_CASES = {  # (B, H, W, cin, cout)
+    "square": (2, 32, 32, 32, 64),
+    "ragged_edges": (2, 24, 40, 16, 48),          # partial tiles in x and y, partial K chunk, cout mask
+    "wide_k": (1, 16, 16, 96, 128),               # 3 K chunks, two N tiles
+    "big": (4, 64, 64, 64, 64),
+}
+
+
+@pytest.mark.parametrize("case", sorted(WINO_CASES))
+def test_conv3x3_winograd_matches_direct_semantics(ctx, case):
+    """Winograd F(2x2,3x3) kernel == nn.Conv2d(3, padding=1) (tolerance 1e-5: fp32 transforms), stats included."""
+    import hiputil as hu
+    B, H, W, cin, cout = WINO_CASES[case]
+    x = U(case + ".wx", (B, cin, H, W), -1.5, 1.5)
+    w = U(case + ".ww", (cout, cin, 3, 3), -0.2, 0.2)
+    b = U(case + ".wb", (cout,))
+    ref = F.conv2d(x, w, b, padding=1)
+    wd = hu.dev(w)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+
+    def run(s):
+        out = hu.full((B, H, W, cout))
+        slots = ctx.lib.nd_conv3x3_wino_stat_slots(H, W)
+        st, sc = hu.full((B, slots, cout, 2)), hu.full((slots,))
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out, d.stats, d.slot_count = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st.data_ptr(), sc.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        L.call("nd_conv3x3_wino_nhwc_f32", C.byref(d), ctx.stream)
+        ctx.sync()
+        return out, st, sc, slots
+
+    bd = hu.dev(b)
+    out, st, sc, slots = run(hu.src(hu.nhwc(x)))
+    assert rel_err(hu.nchw(out), ref) < 1e-5
+    groups = 8 if cout % 8 == 0 else 2
+    gamma, beta = U(case + ".wg", (cout,), 0.5, 1.5), U(case + ".wbe", (cout,))
+    mad = hu.gn_finalize(ctx, st, sc, slots, hu.dev(gamma), hu.dev(beta), None, B, cout, groups).cpu()
+    gn = F.group_norm(ref, groups, gamma, beta, eps=1e-5)
+    mine = (ref - mad[:, 0, :, None, None]) * mad[:, 1, :, None, None] + mad[:, 2, :, None, None]
+    assert rel_err(mine, gn) < 1e-5
+    # fused prologue (GroupNorm-affine + SiLU, zero padding after the activation) and virtual concat
+    M, A, D = U(case + ".wM", (B, cin)), U(case + ".wA", (B, cin), 0.5, 1.5), U(case + ".wD", (B, cin))
+    act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+    out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
+    assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 1e-5
+    c0 = cin // 2 // 4 * 4
+    out, *_ = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))
+    assert rel_err(hu.nchw(out), ref) < 1e-5

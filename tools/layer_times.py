@@ -43,6 +43,7 @@ for i, (fn, args, name, meta) in enumerate(ops):
     kind = name.replace("nd_", "").replace("_f32", "").replace("_nhwc", "")
     desc, gbs, tf = "", 0.0, 0.0
     if meta and "H" in meta:
+        kind = "conv3x3_wino" if meta["tiling"] == 9001 else kind
         fl = 18.0 * meta["cin"] * meta["cout"] * meta["H"] * meta["W"] * meta["B"]
         by = 4.0 * meta["B"] * meta["H"] * meta["W"] * (meta["cin"] + meta["cout"])
         desc = f"{meta['layer']} {meta['cin']}->{meta['cout']} @{meta['H']}x{meta['W']} t{meta['tiling']}"
