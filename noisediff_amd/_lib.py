@@ -111,6 +111,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64; loading ours before torch's puts two HIP runtimes in the process
+    # and the second one to initialise reports "no ROCm-capable device"
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise HipError(f"{path} is missing: the HIP library is the product and there is no fallback. "
                        "Build it with `python -m noisediff_amd.build`.")
