@@ -48,8 +48,19 @@ __device__ __forceinline__ int nd_xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
-__device__ __forceinline__ float nd_silu(float v) { return v / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float nd_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// SiLU / exact-erf GELU with hardware reciprocal and exp (v_rcp_f32 / v_exp_f32, ~1 ulp) instead of the IEEE division
+// sequence and libm erff (~10 and ~40 instructions, the latter with divergent range branches): these run once per
+// activation in the conv staging pass and the pointwise epilogue and showed up as 25-45 % of those HBM-bound kernels.
+// erf: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute -- two orders below the fp32 parity budget.
+__device__ __forceinline__ float nd_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float nd_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(e, x);
+}
+__device__ __forceinline__ float nd_gelu(float v) { return 0.5f * v * (1.0f + nd_erf(v * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float nd_act(float v, int act) {
     if (act == ND_ACT_GELU) return nd_gelu(v);
