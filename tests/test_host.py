@@ -188,3 +188,25 @@ def test_two_rank_sharded_sampling_equals_single_rank_gloo():
                    x_T=synth.make_noise(2, "x_T", total, 4, H), noise=lambda i, shape: synth.make_noise(2, f"noise.{i}", total, 4, H))
     assert got.shape == (total, 4, H, H)
     assert float(np.abs(got - ref.numpy()).max()) < 1e-5
+
+
+def test_generated_npy_contract(tmp_path):
+    """file names, CHW fp32 payload, patch grid and the synth -> denoise composition."""
+    from noisediff_amd import io
+    grid = io.patch_grid(512)
+    assert len(grid) == 24 and grid[0] == (0, 0) and grid[5] == (2128 - 512, 0) and grid[-1] == (2128 - 512, 1424 - 512)
+    assert grid[1] == (384, 0) and grid[6] == (0, 384)
+    out = synth.make_noise(3, "npy", 2, 4, 16)
+    names = io.save_generated(str(tmp_path), out, ["00001_00_10s.ARW", "00002_00_10s.ARW"], ["00001_00_0.1s.ARW", None],
+                              [io.image_coord(384, 768), io.image_coord(0, 0)])
+    assert os.path.basename(names[0]) == "00001_00_10s+00001_00_0.1s+384_768.npy"
+    assert os.path.basename(names[1]) == "00002_00_10s+00002_00_10s+0_0.npy"
+    assert io.parse_generated_name(names[0]) == ("00001_00_10s", "00001_00_0.1s", 384, 768)
+    back = np.load(names[0])
+    assert back.dtype == np.float32 and back.shape == (4, 16, 16) and np.array_equal(back, out[0].numpy())
+    noise = torch.tensor([[-2.0, 0.5, 0.9]])
+    clean = torch.tensor([[0.3, 0.3, 0.3]])
+    assert torch.allclose(io.compose_noisy(noise, clean), torch.tensor([[0.0, 0.8, 1.0]]))
+    a = torch.rand(4, 8, 8)
+    assert io.psnr(a, a) == float("inf")
+    assert io.psnr(torch.zeros(4), torch.full((4,), 0.1)) == pytest.approx(20.0, abs=1e-4)
