@@ -49,7 +49,11 @@ enum nd_prologue {
                                 per-pixel scale/shift, Diffusion_arch.py:188-192           */
     ND_PRO_LAYERNORM   = 3,  /* LayerNorm over C of (x + vec[b,c]): AttnBlock.norm2 on
                                 x + CrossAttention(...), Diffusion_arch.py:438-439          */
-    ND_PRO_SILU        = 4   /* silu(x): ResnetBlock2.mlp[0], Diffusion_arch.py:177         */
+    ND_PRO_SILU        = 4,  /* silu(x): ResnetBlock2.mlp[0], Diffusion_arch.py:177         */
+    ND_PRO_LEAKY       = 5,  /* LeakyReLU(0.2)(x): LSID's nn.LeakyReLU after every conv,
+                                models/archs/SID_arch.py:58,108-168 (applied by the consumer)   */
+    ND_PRO_LEAKY_SECOND = 6  /* LeakyReLU(0.2) on the p1 channels of a virtual concat only:
+                                torch.cat((up(x), conv_k)), SID_arch.py:135,142,150,158          */
 };
 
 typedef struct nd_src {
@@ -131,6 +135,10 @@ typedef struct nd_pointwise {
     int32_t  B, HW, W;     /* HW = output pixels per sample; W = output width (unshuffle) */
     int32_t  cin, cout, ldo, ldr0, ldr1, ldt;
     int32_t  act;          /* enum nd_act                                                */
+    int32_t  shuffle_c;    /* > 0: ConvTranspose2d(k=2, s=2) scatter (SID_arch.py:84-99): cout = 4*shuffle_c ordered
+                              (p1 p2 c); row p=(y,x) writes channel c of output pixel (2y+p1, 2x+p2) of a
+                              (shuffle_h, shuffle_w) image (rows/cols beyond it are cropped, :135)   */
+    int32_t  shuffle_h, shuffle_w;
 } nd_pointwise;
 
 int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream);
@@ -187,9 +195,13 @@ int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout, void* str
  * w = conv1x1(position); cat(w, sin(2 pi w), cos(2 pi w)). */
 int nd_pos_enc_f32(const float* position_nchw, const float* w /*[hid][2]*/, const float* bias,
                    float* out, int B, int H, int W, int hid, void* stream);
+/* nn.MaxPool2d(2, 2, ceil_mode=True) on NHWC (SID_arch.py:60): out (ceil(H/2), ceil(W/2)). */
+int nd_maxpool2x2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C, void* stream);
 /* layout plumbing for the 4-channel API tensors (reference tensors are NCHW) */
 int nd_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, void* stream);
 int nd_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, void* stream);
+/* NCHW (B,C,H,W) -> NHWC with Cpad >= C channels, the tail zero-filled (a 4-channel image as an 8-channel conv input) */
+int nd_nchw_to_nhwc_pad_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, void* stream);
 
 /* ------------------------------------------------------------------ sampler */
 

@@ -1,7 +1,7 @@
 """MI355X-native sampling hot path of IVRL/NoiseDiff."""
 __version__ = "0.1.0"
 
-__all__ = ["GaussianDiffusion", "NoiseDiffNet", "__version__"]
+__all__ = ["GaussianDiffusion", "NoiseDiffNet", "LSID", "__version__"]
 
 
 def __getattr__(name):
@@ -12,4 +12,7 @@ def __getattr__(name):
     if name == "NoiseDiffNet":
         from .net import NoiseDiffNet
         return NoiseDiffNet
+    if name == "LSID":
+        from .lsid import LSID
+        return LSID
     raise AttributeError(name)

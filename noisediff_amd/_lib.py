@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libnoisediff_hip.so")
 
 # enum nd_prologue / nd_act
-PRO_NONE, PRO_AFFINE_SILU, PRO_AFFINE_MAP_SILU, PRO_LAYERNORM, PRO_SILU = 0, 1, 2, 3, 4
+PRO_NONE, PRO_AFFINE_SILU, PRO_AFFINE_MAP_SILU, PRO_LAYERNORM, PRO_SILU, PRO_LEAKY, PRO_LEAKY_SECOND = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 OBJECTIVES = {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}
 
@@ -39,7 +39,8 @@ class Conv3x3(C.Structure):
 class Pointwise(C.Structure):
     _fields_ = [("src", Src), ("weight", fptr), ("bias", fptr), ("out", fptr), ("res0", fptr), ("res1", fptr), ("vec", fptr),
                 ("gn_t", fptr), ("gn_mad", fptr), ("B", C.c_int32), ("HW", C.c_int32), ("W", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("ldo", C.c_int32), ("ldr0", C.c_int32), ("ldr1", C.c_int32), ("ldt", C.c_int32), ("act", C.c_int32)]
+                ("cout", C.c_int32), ("ldo", C.c_int32), ("ldr0", C.c_int32), ("ldr1", C.c_int32), ("ldt", C.c_int32), ("act", C.c_int32),
+                ("shuffle_c", C.c_int32), ("shuffle_h", C.c_int32), ("shuffle_w", C.c_int32)]
 
 
 class SamplerState(C.Structure):
@@ -75,6 +76,8 @@ SIGNATURES = {
     "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_pack_conv7x7_weight": (i32, [vp, vp, i32, vp]),
     "nd_pos_enc_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "nd_maxpool2x2_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "nd_nchw_to_nhwc_pad_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_nchw_to_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nd_nhwc_to_nchw_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nd_sampler_begin_step": (i32, [C.POINTER(SamplerState), vp]),

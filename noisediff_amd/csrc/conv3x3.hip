@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
             const float* base = second ? s.p1 : s.p0;
             const int ld = second ? s.ld1 : s.ld0, cc = second ? cs - s.c0 : cs;
             f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
-            if (MODE != ND_PRO_NONE) {
+            constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MODE == ND_PRO_AFFINE_MAP_SILU;
+            if (AFF) {
                 const float* m = s.mad + (size_t)b * 3 * Ctot + cs;
                 tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
             }
@@ -185,11 +186,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int it = 0; it < STAGE_IT; ++it) {
                 f32x4 v = raw[it];
-                if (MODE != ND_PRO_NONE) {
+                if (AFF) {
                     v = (v - tM) * tA + tD;
                     if (MODE == ND_PRO_AFFINE_MAP_SILU) v = v * (msc[it] + 1.0f) + msh[it];
                     v = nd_silu4(v);
                 }
+                if (MODE == ND_PRO_LEAKY || (MODE == ND_PRO_LEAKY_SECOND && second)) v = nd_leaky4(v);
                 const f32x4 zero = {0, 0, 0, 0};
                 v = ((okmask >> it) & 1u) ? v : zero;           // zero padding applies to the activated tensor
                 nd_st4(&As[(prow + it * 32) * LDA + quad * 4], v);
@@ -332,6 +334,8 @@ void launch(const ConvArgs& a, hipStream_t st) {
     switch (a.d.src.mode) {
         case ND_PRO_AFFINE_SILU: launch_mode<TW, MB, NB, ND_PRO_AFFINE_SILU>(a, st); break;
         case ND_PRO_AFFINE_MAP_SILU: launch_mode<TW, MB, NB, ND_PRO_AFFINE_MAP_SILU>(a, st); break;
+        case ND_PRO_LEAKY: launch_mode<TW, MB, NB, ND_PRO_LEAKY>(a, st); break;
+        case ND_PRO_LEAKY_SECOND: launch_mode<TW, MB, NB, ND_PRO_LEAKY_SECOND>(a, st); break;
         default: launch_mode<TW, MB, NB, ND_PRO_NONE>(a, st);
     }
 }
@@ -398,9 +402,10 @@ extern "C" int nd_conv3x3_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(nd_aligned16(s.p0) && nd_aligned16(s.p1) && nd_aligned16(d->weight) && nd_aligned16(s.mad) && nd_aligned16(s.map),
                ND_E_ALIGN, "nd_conv3x3: pointers must be 16-byte aligned");
     ND_REQUIRE(d->ldo >= d->cout, ND_E_SHAPE, "nd_conv3x3: ldo < cout");
-    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_AFFINE_SILU || s.mode == ND_PRO_AFFINE_MAP_SILU, ND_E_BADARG,
+    const bool affine = s.mode == ND_PRO_AFFINE_SILU || s.mode == ND_PRO_AFFINE_MAP_SILU;
+    ND_REQUIRE(s.mode == ND_PRO_NONE || affine || s.mode == ND_PRO_LEAKY || s.mode == ND_PRO_LEAKY_SECOND, ND_E_BADARG,
                "nd_conv3x3: unsupported prologue %d", s.mode);
-    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mad, ND_E_BADARG, "nd_conv3x3: affine prologue needs mad");
+    ND_REQUIRE(!affine || s.mad, ND_E_BADARG, "nd_conv3x3: affine prologue needs mad");
     ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || s.map, ND_E_BADARG, "nd_conv3x3: map prologue needs map");
     ND_REQUIRE(!s.upsample || (d->H % 2 == 0 && d->W % 2 == 0 && s.c1 == 0), ND_E_SHAPE, "nd_conv3x3: upsample needs even H, W and one source");
     ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3: unshuffle is a pointwise-only addressing mode");

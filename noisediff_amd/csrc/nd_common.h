@@ -77,6 +77,13 @@ __device__ __forceinline__ f32x4 nd_silu4(f32x4 v) {
     return r;
 }
 
+__device__ __forceinline__ f32x4 nd_leaky4(f32x4 v) {      // nn.LeakyReLU(negative_slope=0.2)
+    f32x4 r;
+    r.x = v.x > 0.0f ? v.x : 0.2f * v.x; r.y = v.y > 0.0f ? v.y : 0.2f * v.y;
+    r.z = v.z > 0.0f ? v.z : 0.2f * v.z; r.w = v.w > 0.0f ? v.w : 0.2f * v.w;
+    return r;
+}
+
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane.  Four VALU adds with DPP
 // operand swizzles (quad_perm xor1, quad_perm xor2, row_half_mirror, row_mirror) -- no LDS crossbar traffic,
 // unlike __shfl_xor which lowers to ds_bpermute_b32 + a full lgkmcnt wait per step.

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
                 if (MODE == ND_PRO_LAYERNORM) v = ((v + vec4) - rmean[it]) * rrstd[it] * g4 + b4;
                 else if (MODE == ND_PRO_SILU) v = nd_silu4(v);
                 else if (MODE == ND_PRO_AFFINE_SILU) v = nd_silu4((v - tM) * tA + tD);
+                else if (MODE == ND_PRO_LEAKY) v = nd_leaky4(v);
                 const f32x4 zero = {0, 0, 0, 0};
                 v = (cvalid && p0 + r < HW) ? v : zero;
                 nd_st4(&As[r * LDA + quad * 4], v);
@@ -224,7 +225,13 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
                 else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
                 v += r0[j] + r1[j] + vadd4;
                 if (a.d.gn_t) v += nd_silu4((rt[j] - gM) * gA + gD);
-                if (p0 + r < HW) nd_st4(out + ((size_t)b * HW + p0 + r) * a.d.ldo + n, v);
+                if (a.d.shuffle_c > 0) {       // ConvTranspose2d(2, stride 2): scatter to pixel (2y+p1, 2x+p2), channel c
+                    const int p = p0 + r, y = p / W, x = p - y * W;
+                    const int sub = n / a.d.shuffle_c, cch = n - sub * a.d.shuffle_c;
+                    const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
+                    if (p < HW && oy < a.d.shuffle_h && ox < a.d.shuffle_w)
+                        nd_st4(out + ((size_t)(b * a.d.shuffle_h + oy) * a.d.shuffle_w + ox) * a.d.ldo + cch, v);
+                } else if (p0 + r < HW) nd_st4(out + ((size_t)b * HW + p0 + r) * a.d.ldo + n, v);
             }
         } else if (nvalid) {                                  // ragged channel tail (cout % 4 != 0): scalar path
             for (int j = 0; j < BM / RPI; ++j) {
@@ -277,6 +284,7 @@ void launch(const PwArgs& a, hipStream_t st) {
         case ND_PRO_LAYERNORM: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_LAYERNORM>), grid, block, 0, st, a); break;
         case ND_PRO_SILU: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_SILU>), grid, block, 0, st, a); break;
         case ND_PRO_AFFINE_SILU: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_AFFINE_SILU>), grid, block, 0, st, a); break;
+        case ND_PRO_LEAKY: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_LEAKY>), grid, block, 0, st, a); break;
         default: hipLaunchKernelGGL((pointwise_kernel<MB, NB, ND_PRO_NONE>), grid, block, 0, st, a);
     }
 }
@@ -319,14 +327,18 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     } else {
         ND_REQUIRE(s.ld0 >= s.c0 && (s.c1 == 0 || s.ld1 >= s.c1), ND_E_SHAPE, "nd_pointwise: ld < channels");
     }
-    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_LAYERNORM || s.mode == ND_PRO_SILU || s.mode == ND_PRO_AFFINE_SILU,
-               ND_E_BADARG, "nd_pointwise: unsupported prologue %d", s.mode);
+    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_LAYERNORM || s.mode == ND_PRO_SILU || s.mode == ND_PRO_AFFINE_SILU ||
+               s.mode == ND_PRO_LEAKY, ND_E_BADARG, "nd_pointwise: unsupported prologue %d", s.mode);
+    if (d->shuffle_c > 0)
+        ND_REQUIRE(d->cout == 4 * d->shuffle_c && d->shuffle_c % 4 == 0 && d->W > 0 && d->HW % d->W == 0 && d->shuffle_h > 0 && d->shuffle_w > 0 &&
+                   d->ldo >= d->shuffle_c && !d->res0 && !d->res1 && !d->gn_t && !d->vec, ND_E_SHAPE,
+                   "nd_pointwise: shuffle_c=%d needs cout == 4*shuffle_c, W | HW, an output size and no residual operands", d->shuffle_c);
     if (s.mode == ND_PRO_LAYERNORM) {
         ND_REQUIRE(s.gamma && s.beta && s.c1 == 0 && d->cin <= 1024, ND_E_SHAPE, "nd_pointwise: LayerNorm needs gamma/beta, one source, C <= 1024");
         ND_REQUIRE(d->cin <= 64 || s.rowstats, ND_E_BADARG, "nd_pointwise: LayerNorm over C=%d > 64 needs src.rowstats (nd_layernorm_stats_f32)", d->cin);
     }
     if (s.mode == ND_PRO_AFFINE_SILU) ND_REQUIRE(s.mad && s.c1 == 0, ND_E_BADARG, "nd_pointwise: affine prologue needs mad, one source");
-    ND_REQUIRE(d->ldo >= d->cout, ND_E_SHAPE, "nd_pointwise: ldo < cout");
+    ND_REQUIRE(d->ldo >= d->cout || d->shuffle_c > 0, ND_E_SHAPE, "nd_pointwise: ldo < cout");
     ND_REQUIRE(d->ldo % 4 == 0 && (!d->res0 || d->ldr0 % 4 == 0) && (!d->res1 || d->ldr1 % 4 == 0) && (!d->gn_t || d->ldt % 4 == 0),
                ND_E_ALIGN, "nd_pointwise: output / residual pixel strides must be multiples of 4");
     ND_REQUIRE(nd_aligned16(d->out) && nd_aligned16(d->res0) && nd_aligned16(d->res1) && nd_aligned16(d->gn_t) && nd_aligned16(d->bias) &&

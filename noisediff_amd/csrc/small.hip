@@ -83,6 +83,39 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// NCHW -> NHWC with the channel tail zero-filled up to Cpad
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW, int Cpad) {
+    const size_t total = (size_t)B * HW * Cpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const size_t pix = i / Cpad;
+        const int b = (int)(pix / HW);
+        const size_t p = pix - (size_t)b * HW;
+        out[i] = c < C ? in[((size_t)b * C + c) * HW + p] : 0.0f;
+    }
+}
+
+// nn.MaxPool2d(2, 2, ceil_mode=True): windows hanging over the border use the in-bounds elements only
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C) {
+    const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1, cq = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        size_t r = i / cq;
+        const int x = (int)(r % Wo); r /= Wo;
+        const int y = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const int y1 = min(2 * y + 1, H - 1), x1 = min(2 * x + 1, W - 1);
+        const float* base = in + (size_t)b * H * W * C + c;
+        const f32x4 v00 = nd_ld4(base + ((size_t)(2 * y) * W + 2 * x) * C), v01 = nd_ld4(base + ((size_t)(2 * y) * W + x1) * C);
+        const f32x4 v10 = nd_ld4(base + ((size_t)y1 * W + 2 * x) * C), v11 = nd_ld4(base + ((size_t)y1 * W + x1) * C);
+        f32x4 m;
+        m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)); m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+        m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)); m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+        nd_st4(out + i * 4, m);
+    }
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
     const size_t total = (size_t)B * HW * C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -185,6 +218,20 @@ extern "C" int nd_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, in
     ND_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0, ND_E_BADARG, "nd_nchw_to_nhwc: bad argument");
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, C, H * W);
     return nd_launch_status("nd_nchw_to_nhwc_f32");
+}
+
+extern "C" int nd_nchw_to_nhwc_pad_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, void* stream) {
+    ND_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, ND_E_BADARG, "nd_nchw_to_nhwc_pad: bad argument");
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((size_t)B * Cpad * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, C, H * W, Cpad);
+    return nd_launch_status("nd_nchw_to_nhwc_pad_f32");
+}
+
+extern "C" int nd_maxpool2x2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+    ND_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, ND_E_BADARG, "nd_maxpool2x2: bad argument (C %% 4 == 0)");
+    ND_REQUIRE(nd_aligned16(in) && nd_aligned16(out), ND_E_ALIGN, "nd_maxpool2x2: alignment");
+    const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C);
+    return nd_launch_status("nd_maxpool2x2_nhwc_f32");
 }
 
 extern "C" int nd_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, void* stream) {

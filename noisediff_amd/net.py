@@ -45,7 +45,7 @@ def _init(p, gen: Optional[torch.Generator] = None) -> torch.Tensor:
         b = 1.0 / math.sqrt(p.fan_in)
         return t.uniform_(-b, b, generator=gen)
     if p.init == "normal":
-        return t.normal_(0.0, 1.0, generator=gen)
+        return t.normal_(0.0, float(getattr(p, "std", 1.0)), generator=gen)
     return t.fill_(1.0 if p.init == "ones" else 0.0)
 
 

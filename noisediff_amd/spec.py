@@ -32,6 +32,7 @@ class ParamSpec:
     shape: Tuple[int, ...]
     init: str          # uniform_fan_in | ones | zeros | normal
     fan_in: int = 0
+    std: float = 1.0   # standard deviation for init == "normal"
 
 
 class _Lister:
@@ -157,3 +158,33 @@ def attention_param_spec(prefix: str, dim: int, heads: int = 4, dim_head: int = 
         ParamSpec(f"{prefix}.to_out.weight", (dim, hidden, 1, 1), "uniform_fan_in", hidden),
         ParamSpec(f"{prefix}.to_out.bias", (dim,), "uniform_fan_in", hidden),
     ]
+
+
+LSID_STAGES = (32, 64, 128, 256, 512)      # models/archs/SID_arch.py:57-75
+
+
+def lsid_param_spec(inchannel: int = 4) -> List[ParamSpec]:
+    """State-dict tensors of ``LSID(args)`` (models/archs/SID_arch.py:49-103) in registration order.
+    Init as upstream: Conv2d / ConvTranspose2d weights ~ N(0, sqrt(2 / (k*k*out_channels))), biases 0 (:96-103)."""
+    import math
+    items: List[ParamSpec] = []
+
+    def conv(name, cin, cout, k):
+        items.append(ParamSpec(f"{name}.weight", (cout, cin, k, k), "normal", std=math.sqrt(2.0 / (k * k * cout))))
+        items.append(ParamSpec(f"{name}.bias", (cout,), "zeros"))
+
+    def up(name, cin, cout):       # ConvTranspose2d weight is (in, out, kH, kW); no bias (:77)
+        items.append(ParamSpec(f"{name}.weight", (cin, cout, 2, 2), "normal", std=math.sqrt(2.0 / (4 * cout))))
+
+    prev = inchannel
+    for i, c in enumerate(LSID_STAGES, start=1):
+        conv(f"conv{i}_1", prev, c, 3)
+        conv(f"conv{i}_2", c, c, 3)
+        prev = c
+    for i, c in zip(range(6, 10), reversed(LSID_STAGES[:-1])):
+        up(f"up{i}", prev, c)
+        conv(f"conv{i}_1", 2 * c, c, 3)
+        conv(f"conv{i}_2", c, c, 3)
+        prev = c
+    conv("conv10", prev, inchannel, 1)
+    return items

@@ -99,7 +99,7 @@ def make_state_dict(spec: Iterable, seed: int = 0) -> Dict[str, torch.Tensor]:
         elif p.init == "zeros":
             out[p.name] = torch.zeros(p.shape, dtype=torch.float32)
         elif p.init == "normal":
-            out[p.name] = normal(seed, p.name, p.shape)
+            out[p.name] = normal(seed, p.name, p.shape) * float(getattr(p, "std", 1.0))
         else:  # pragma: no cover - spec bug
             raise ValueError(f"unknown init kind {p.init!r} for {p.name}")
     return out

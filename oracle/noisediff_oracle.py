@@ -421,6 +421,39 @@ def sample(sd: SD, condition: Dict[str, torch.Tensor], *, image_size: int, batch
         return p_sample_loop(net, buf, objective, x_T, noise, return_all, on_step)
 
 
+# --------------------------------------------------------------------------- LSID denoiser (next row)
+
+
+def lsid_forward(sd: SD, x: torch.Tensor) -> torch.Tensor:
+    """LSID.forward  models/archs/SID_arch.py:105-175: 4 x (conv3x3, LeakyReLU 0.2) x 2 + MaxPool(2, ceil), bottleneck,
+    4 x (ConvTranspose 2x2 s2, crop, cat with the encoder feature, 2 convs), 1x1 head."""
+    def cc(name, t):
+        return F.leaky_relu(conv(sd, name, t, padding=1), 0.2)
+
+    feats = []
+    for i in range(1, 5):
+        x = cc(f"conv{i}_2", cc(f"conv{i}_1", x))
+        feats.append(x)
+        x = F.max_pool2d(x, 2, 2, 0, ceil_mode=True)                                  # :60
+    x = cc("conv5_2", cc("conv5_1", x))
+    for i in range(6, 10):
+        skip = feats.pop()
+        x = F.conv_transpose2d(x, sd[f"up{i}.weight"], stride=2)
+        x = torch.cat((x[:, :, :skip.shape[2], :skip.shape[3]], skip), 1)             # :135
+        x = cc(f"conv{i}_2", cc(f"conv{i}_1", x))
+    return conv(sd, "conv10", x)
+
+
+def compose_and_denoise(sd_lsid: SD, noise: torch.Tensor, clean: torch.Tensor):
+    """Synth -> denoise composition of BASELINE config 5: noisy = clip(clip(noise,-1,1) + clean, 0, 1)
+    (dataloader/dataset_denoising.py:140-151), LSID forward, clamp to [0,1], PSNR = 10 log10(1/MSE)
+    (test_denoising.py:220-226,334-343)."""
+    noisy = (noise.clamp(-1.0, 1.0) + clean).clamp(0.0, 1.0)
+    out = lsid_forward(sd_lsid, noisy).clamp(0.0, 1.0)
+    mse = torch.mean((out.double() - clean.double()) ** 2).item()
+    return noisy, out, 10.0 * math.log10(1.0 / mse)
+
+
 # --------------------------------------------------------------------------- device RNG restatement
 
 

@@ -194,3 +194,79 @@ def test_full_size_properties_config2():
     gd.sample_offset = 8
     part = gd.sample(batch_size=4, condition=to_dev({k: v[8:12] for k, v in cond.items()}), seed=5).cpu()
     assert rel_err(part.numpy(), full[8:12].numpy()) < 1e-4
+
+
+# --------------------------------------------------------------------------- next row 8f-1: LSID + config-5 composition
+
+def make_lsid():
+    from noisediff_amd import LSID
+    from noisediff_amd.spec import lsid_param_spec
+    net = LSID(SimpleNamespace())
+    net.load_state_dict(synth.make_state_dict(lsid_param_spec(), 0), strict=True)
+    return net.to(DEV).eval()
+
+
+def test_lsid_forward_matches_reference_golden(golden):
+    net = make_lsid()
+    with torch.inference_mode():
+        for (B, H, W) in ((2, 64, 64), (1, 36, 44)):          # second size: ceil-mode pooling + crop after ConvTranspose
+            x = synth.uniform(9, f"lsid.x.{H}x{W}", (B, 4, H, W), 0.0, 1.0)
+            y = net(x.to(DEV))
+            assert y.shape == (B, 4, H, W)
+            assert rel_err(y.cpu().numpy(), golden("lsid", f"lsid.{H}x{W}")) < NET_TOL
+
+
+def test_maxpool_and_conv_transpose_kernels():
+    """nn.MaxPool2d(2, 2, ceil_mode=True) and ConvTranspose2d(2, stride=2) + crop through the C ABI."""
+    import ctypes as C
+    import torch.nn.functional as F
+    import hiputil as hu
+    from noisediff_amd import _lib as L
+    ctx = hu.Ctx()
+    x = synth.uniform(4, "mp.x", (2, 8, 9, 7), -1, 1)
+    xd, out = hu.nhwc(x), hu.full((2, 5, 4, 8))
+    L.call("nd_maxpool2x2_nhwc_f32", xd.data_ptr(), out.data_ptr(), 2, 9, 7, 8, ctx.stream)
+    ctx.sync()
+    assert torch.equal(hu.nchw(out), F.max_pool2d(x, 2, 2, 0, ceil_mode=True))
+    xi = synth.uniform(4, "ct.x", (2, 16, 5, 6), -1, 1)
+    w = synth.uniform(4, "ct.w", (16, 8, 2, 2), -0.3, 0.3)
+    ref = F.conv_transpose2d(F.leaky_relu(xi, 0.2), w, stride=2)[:, :, :9, :11]          # cropped like SID_arch.py:135
+    wp = hu.pack_pw(ctx, w.permute(2, 3, 1, 0).reshape(32, 16).contiguous())
+    outp = hu.full((2, 9, 11, 8))
+    d = L.Pointwise()
+    xid = hu.nhwc(xi)
+    d.src, d.weight, d.out = hu.src(xid, None, L.PRO_LEAKY), wp.data_ptr(), outp.data_ptr()
+    d.B, d.HW, d.W, d.cin, d.cout, d.ldo = 2, 30, 6, 16, 32, 8
+    d.shuffle_c, d.shuffle_h, d.shuffle_w = 8, 9, 11
+    L.call("nd_pointwise_gemm_nhwc_f32", C.byref(d), ctx.stream)
+    ctx.sync()
+    assert rel_err(hu.nchw(outp), ref) < 2e-5
+
+
+def test_config5_noise_synthesis_feeds_denoiser_psnr(golden):
+    """End to end (BASELINE config 5, scaled down): sampled noise -> clip/compose -> LSID -> PSNR, HIP vs oracle;
+    plus the composition fixture captured from the reference's LSID."""
+    from noisediff_amd import io
+    from noisediff_amd.spec import lsid_param_spec
+    lsid = make_lsid()
+    sd_l = synth.make_state_dict(lsid_param_spec(), 0)
+    clean = synth.uniform(9, "lsid.clean", (2, 4, 64, 64), 0.0, 1.0)
+    noise = synth.make_noise(9, "lsid.noise", 2, 4, 64) * 0.1
+    with torch.inference_mode():
+        den = lsid(io.compose_noisy(noise, clean).to(DEV)).clamp(0, 1).cpu()
+    assert rel_err(den.numpy(), golden("lsid", "lsid.compose.out")) < NET_TOL
+    assert abs(io.psnr(den, clean) - float(golden("lsid", "lsid.compose.psnr"))) < 1e-3
+    # sampler -> denoiser: 8-step DDIM noise patches from the HIP sampler, then the same chain on both sides
+    dim, B, H = 16, 2, 64
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=1000, sampling_timesteps=8, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(B, H, seed=1)
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(7)])
+    with torch.inference_mode():
+        gen = gd.sample(batch_size=B, condition=to_dev(cond), noise={"x_T": x_T, "steps": steps})
+        den = lsid(io.compose_noisy(gen, cond["clean_img"].to(DEV))).cpu()
+    ref_gen = O.sample(state_dict(dim), cond, image_size=H, batch_size=B, timesteps=1000, sampling_timesteps=8, x_T=x_T, noise=lambda i, s: steps[i])
+    _, ref_den, ref_psnr = O.compose_and_denoise(sd_l, ref_gen, cond["clean_img"])
+    assert rel_err(gen.cpu().numpy(), ref_gen.numpy()) < SAMPLE_TOL
+    assert abs(io.psnr(den, cond["clean_img"]) - ref_psnr) < 1e-2

@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header():
     # sizes computed from the C declarations: pointers 8 B, int32 4 B, natural alignment
     assert C.sizeof(L.Src) == 2 * 8 + 8 * 4 + 6 * 8
     assert C.sizeof(L.Conv3x3) == C.sizeof(L.Src) + 5 * 8 + 6 * 4
-    assert C.sizeof(L.Pointwise) == C.sizeof(L.Src) + 8 * 8 + 10 * 4
+    assert C.sizeof(L.Pointwise) == C.sizeof(L.Src) + 8 * 8 + 13 * 4 + 4     # 13 int32 + tail padding to 8
     assert C.sizeof(L.SamplerState) == 5 * 8 + 2 * 4
 
 

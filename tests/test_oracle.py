@@ -231,3 +231,18 @@ def test_philox_known_answers():
     k = np.array([[0xA4093822, 0x299F31D0]], np.uint32)
     z = O.philox4x32_10(c, k)[0]
     assert [hex(int(v)) for v in z] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_lsid_oracle_matches_reference_golden(golden):
+    """Next row 8f-1: LSID forward (incl. ceil-mode pooling + crop at an odd size) and the synth->denoise PSNR."""
+    from noisediff_amd.spec import lsid_param_spec
+    sd = synth.make_state_dict(lsid_param_spec(), 0)
+    with torch.no_grad():
+        for (B, H, W) in ((2, 64, 64), (1, 36, 44)):
+            x = synth.uniform(9, f"lsid.x.{H}x{W}", (B, 4, H, W), 0.0, 1.0)
+            assert rel_err(O.lsid_forward(sd, x).numpy(), golden("lsid", f"lsid.{H}x{W}")) < TOL
+        clean = synth.uniform(9, "lsid.clean", (2, 4, 64, 64), 0.0, 1.0)
+        noise = synth.make_noise(9, "lsid.noise", 2, 4, 64) * 0.1
+        _, out, psnr = O.compose_and_denoise(sd, noise, clean)
+    assert rel_err(out.numpy(), golden("lsid", "lsid.compose.out")) < TOL
+    assert abs(psnr - float(golden("lsid", "lsid.compose.psnr"))) < 1e-3
