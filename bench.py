@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=16, help="patches per GPU (weak scaling)")
     ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--sampling-timesteps", type=int, default=None, help="DDIM steps (default: DDPM over all timesteps)")
+    ap.add_argument("--mid-attn", action="store_true", help="Attention between the mid blocks (BASELINE config 4 extension)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4"], default=None,
+                    help="BASELINE.json presets: cfg2 d64/128x128/B16 DDPM; cfg3 (default workload) d64/256x256/B16 per GPU DDPM; "
+                         "cfg4 d128 + mid attention/256x256/B8 per GPU/250-step DDIM")
     ap.add_argument("--full", action="store_true", help="time whole 1000-step sample() calls instead of K steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
@@ -175,6 +180,10 @@ def np_exp_half(v):
 
 def main():
     a = parse()
+    if a.config == "cfg2":
+        a.dim, a.size, a.batch = 64, 128, 16
+    elif a.config == "cfg4":
+        a.dim, a.size, a.batch, a.sampling_timesteps, a.mid_attn = 128, 256, 8, 250, True
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -200,20 +209,26 @@ def main():
     from noisediff_amd.spec import noisediff_param_spec
 
     B, S, T = a.batch, a.size, a.timesteps
-    net = NoiseDiffNet(SimpleNamespace(dim=a.dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False))
+    net = NoiseDiffNet(SimpleNamespace(dim=a.dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False,
+                                       mid_attn=a.mid_attn))
     sd = None
     if rank == 0:
         sd = synth.make_state_dict(noisediff_param_spec(a.dim), 0)      # synthetic weights, PyTorch default-init statistics
+        if a.mid_attn:
+            from noisediff_amd.spec import attention_param_spec
+            sd.update(synth.make_state_dict(attention_param_spec("mid_attn", 8 * a.dim), 0))
         net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
     if world > 1:
         # the ONE collective of the data path: packed weight arena, rank 0 -> everyone, over xGMI
-        eng = Engine(a.dim, dev)
+        eng = Engine(a.dim, dev, mid_attn=a.mid_attn)
         if rank == 0:
             eng.load_state_dict(sd)
         eng.broadcast(src=0)
         net.adopt_engine(eng)
-    gd = GaussianDiffusion(net, image_size=S, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+    gd = GaussianDiffusion(net, image_size=S, timesteps=T, sampling_timesteps=a.sampling_timesteps, beta_schedule="sigmoid2",
+                           objective="pred_v").to(dev)
+    n_sample_steps = a.sampling_timesteps or T
     gd.sample_offset = rank * B
     cond = synth.make_condition(B, S, seed=1, first_sample=rank * B, total=world * B)
     plan = net.hip_engine(dev).plan(B, S, S)
@@ -252,22 +267,23 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         per_step = dt / a.steps
-        value = world * B / (T * per_step)
+        value = world * B / (n_sample_steps * per_step)
     if world > 1:
         tt = torch.tensor([per_step], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         per_step = float(tt.item())
-        value = world * B / per_step if a.full else world * B / (T * per_step)
+        value = world * B / per_step if a.full else world * B / (n_sample_steps * per_step)
 
     out = {
         "metric": "sampled RAW patches/sec (256x256x4, 1000-step DDPM)", "value": value, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"NoiseDiffNet dim={a.dim}, {S}x{S}x4 patches, {T}-step DDPM (sigmoid2, pred_v), "
+        "config": {"workload": f"NoiseDiffNet dim={a.dim}{' + mid Attention' if a.mid_attn else ''}, {S}x{S}x4 patches, " +
+                               (f"{a.sampling_timesteps}-step DDIM of {T}" if a.sampling_timesteps else f"{T}-step DDPM") + " (sigmoid2, pred_v), "
                                f"{B} patches per GPU; a step = " +
                                ("one full 1000-step sample() call" if a.full else
                                 "one reverse-diffusion step (U-Net forward + fused posterior/noise update) over the per-GPU batch; "
-                                f"patches/s = n_gpus*{B}/({T}*s_per_step)"),
+                                f"patches/s = n_gpus*{B}/({n_sample_steps}*s_per_step)"),
                    "global_batch": world * B, "launch": "eager" if a.eager else "hipGraph replay",
                    "noise": "device Philox4x32-10"},
     }
@@ -301,7 +317,7 @@ def main():
                                      "launches_per_step": v["launches"] // n_inst} for k, v in sorted(per.items())},
         }
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(sd, a.dim, S, T)
+        out["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items() if not k.startswith("mid_attn.")}, a.dim, S, n_sample_steps)
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
