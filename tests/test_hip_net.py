@@ -270,3 +270,21 @@ def test_config5_noise_synthesis_feeds_denoiser_psnr(golden):
     _, ref_den, ref_psnr = O.compose_and_denoise(sd_l, ref_gen, cond["clean_img"])
     assert rel_err(gen.cpu().numpy(), ref_gen.numpy()) < SAMPLE_TOL
     assert abs(io.psnr(den, cond["clean_img"]) - ref_psnr) < 1e-2
+
+
+def test_condition_batch_mismatch_and_bad_iso_are_rejected():
+    """Trainer.test passes batch_size=args.batch_size even for a short last batch (trainer_diffusion.py:286): the
+    reference fails deep inside torch.cat; here the mismatch is reported up front.  Out-of-range ISO indices raise
+    like nn.Embedding does."""
+    net = make_net(16)
+    gd = GaussianDiffusion(net, image_size=32, timesteps=4, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(3, 32, seed=1)
+    with pytest.raises(ValueError, match="do not match batch"):
+        gd.sample(batch_size=4, condition=to_dev(cond))
+    bad = dict(cond, iso_ratio_idx=torch.tensor([0, 100, 5]))
+    with pytest.raises(IndexError):
+        gd.sample(batch_size=3, condition=to_dev(bad))
+    with pytest.raises(AssertionError, match="divisible by 8"):
+        net.hip_engine(DEV).plan(1, 20, 32)
+    out = gd.sample(batch_size=3, condition=to_dev(cond), seed=1)
+    assert out.shape == (3, 4, 32, 32)
