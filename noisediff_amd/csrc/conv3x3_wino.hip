@@ -92,7 +92,11 @@ __device__ __forceinline__ void wino_chunk(f32x16 (&Y)[2][2][NB], const float* A
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int nu = np * 2 + j;
+#if defined(ND_WINO_ABLATE) && ND_WINO_ABLATE == 2      // diagnostic: no column transform
+                    const f32x4 V = T[nu];
+#else
                     const f32x4 V = bt_s1(nu) * T[bt_r1(nu)] + bt_s2(nu) * T[bt_r2(nu)];
+#endif
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -107,7 +111,11 @@ __device__ __forceinline__ void wino_chunk(f32x16 (&Y)[2][2][NB], const float* A
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+#if defined(ND_WINO_ABLATE) && ND_WINO_ABLATE == 1      // diagnostic: one fold per position instead of ~2.25
+                        const int cf = (a == (xi & 1) && b == (j & 1)) ? 1 : 0;
+#else
                         const int cf = at_coef(a, xi) * at_coef(b, np * 2 + j);
+#endif
                         if (cf != 0) {
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb)
