@@ -71,7 +71,7 @@ def conv_bytes(m):
 def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
-    CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32")
+    CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32")
     convs = [op for op in plan.step_ops if op[2] in CONV]
     n_ev = 2 * len(convs)
     evs = []
@@ -292,7 +292,7 @@ def main():
         per = instrumented_pass(loop, plan, L, n_inst)
         tot_ms = sum(d["ms"] for d in per.values())
         tot_flop = sum(d["flop"] for d in per.values())
-        kname = lambda k: (f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
+        kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
                            f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
         dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tid, d = dom

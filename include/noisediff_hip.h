@@ -109,8 +109,12 @@ int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, 
 
 /* Same operator, same descriptor, computed with Winograd F(2x2,3x3) (2.25x fewer multiplies; fp32 transforms,
  * ~1e-6 relative difference to the direct form).  `weight` must come from nd_pack_conv3x3_wino_weight
- * (U = G g G^T, [16][cin/4][coutP][4]); statistics slots: nd_conv3x3_wino_stat_slots.  Used for images >= 16x16. */
+ * (U = G g G^T in 128 KB blocks [cinP/32][coutP/64][16 positions][8 quads][64][4]); statistics slots:
+ * nd_conv3x3_wino_stat_slots.  Used for images >= 16x16. */
 int nd_conv3x3_wino_nhwc_f32(const nd_conv3x3* d, void* stream);
+/* Same contract, one-workgroup-per-CU variant: all 16 Winograd position accumulators stay in registers across the
+ * K loop and the halo tile is double-buffered in LDS (conv3x3_wino2.hip). */
+int nd_conv3x3_wino2_nhwc_f32(const nd_conv3x3* d, void* stream);
 int nd_conv3x3_wino_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int cout, void* stream);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "nd_pack_conv3x3_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_weight": (i32, [vp, vp, i32, i32, vp]),
     "nd_conv3x3_wino_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
+    "nd_conv3x3_wino2_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_conv3x3_wino_stat_slots": (i32, [i32, i32]),
     "nd_pack_conv3x3_wino_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_wino_weight": (i32, [vp, vp, i32, i32, vp]),

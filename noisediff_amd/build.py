@@ -17,12 +17,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnoisediff_hip.so")
-SOURCES = ["runtime", "conv3x3", "conv3x3_wino", "pointwise", "norm", "small", "sampler", "attention", "linattn"]
+SOURCES = ["runtime", "conv3x3", "conv3x3_wino", "conv3x3_wino2", "pointwise", "norm", "small", "sampler",
+           "attention", "linattn"]
 ARCH = "gfx950"
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc 7.2 parks
 # them in AGPRs and wraps every v_mfma_f32_32x32x2_f32 in v_accvgpr_read/write copies (8 VALU per MFMA, measured)
-FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+BASE_FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# object name -> (source file, flags).  conv3x3_wino2 keeps its 256 accumulator registers in the AGPR half of the
+# file on purpose (no VGPR-form switch) and its K loop must be unrolled completely (16 steps x 16 MFMA slices).
+SPECIAL = {
+    "conv3x3_wino2": ("conv3x3_wino2", BASE_FLAGS + ["-mllvm", "-pragma-unroll-threshold=1000000"]),
+}
 
 
 def _hipcc() -> str:
@@ -45,9 +51,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, "nd_common.h"), os.path.join(HERE, "..", "include", "noisediff_hip.h")]
     jobs = []
     for name in SOURCES:
-        src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(OBJ, name + ".o")
+        srcname, flags = SPECIAL.get(name, (name, FLAGS))
+        src, obj = os.path.join(CSRC, srcname + ".hip"), os.path.join(OBJ, name + ".o")
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *flags, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

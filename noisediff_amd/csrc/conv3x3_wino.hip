@@ -30,6 +30,7 @@ constexpr int HT = 18;              // halo tile side (16 + 2)
 constexpr int PW = 12;              // pixels per plane row: 9 used, padded so that 2 plane rows = 8 (mod 16) slots
 constexpr int NPIX = HT * HT;       // 324
 constexpr int PLANE = HT * PW;      // pixel slots per plane
+constexpr int WBLOCK = 16 * 8 * 64 * 4;   // floats per packed weight block (one K chunk of 32 x 64 output channels)
 
 struct WinoArgs {
     nd_conv3x3 d;
@@ -47,8 +48,8 @@ __device__ __forceinline__ constexpr int at_coef(int a, int xi) {
 }
 
 template <int NB, int NG, int LDA>
-__device__ __forceinline__ void wino_chunk(f32x16 (&Y)[2][2][NB], const float* As, const int a_base, const float* wchunk,
-                                           const size_t pos_stride, const int coutP) {
+__device__ __forceinline__ void wino_chunk(f32x16 (&Y)[2][2][NB], const float* As, const int a_base, const float* wchunk) {
+    static_assert(NB == 1, "the packed weight block is 64 output channels wide");
     // step = ((xi * 2 + np) * NG + g): positions (xi, nu = 2*np, 2*np+1), channel group g.  Two position accumulators
     // in flight keep the register budget at 3 waves per SIMD; the price is that the column terms T_c are rebuilt for
     // each nu pair (1 LDS b128 read per MFMA -- still only ~25 % of the LDS rate at the fp32 MFMA issue rate).
@@ -59,7 +60,7 @@ __device__ __forceinline__ void wino_chunk(f32x16 (&Y)[2][2][NB], const float* A
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                bw[buf][j][nb] = nd_ld4(wchunk + (size_t)(xi * 4 + np * 2 + j) * pos_stride + ((size_t)(2 * g) * coutP + nb * 32) * 4);
+                bw[buf][j][nb] = nd_ld4(wchunk + ((xi * 4 + np * 2 + j) * 8 + 2 * g) * 256);
     };
     load_b(0, 0);
 #pragma unroll
@@ -144,8 +145,6 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void wino_kernel(const WinoA
     const int up = s.upsample ? 1 : 0;
     const int sH = H >> up, sW = W >> up;
     const int Ctot = s.c0 + s.c1;
-    const int Q = Cin >> 2;
-    const size_t pos_stride = (size_t)Q * a.coutP * 4;
     const int quad = tid % QPP;
 
     // lane (block row 4*wm + col/8, block column col%8): halo-tile pixel (2*by, 2*bx) -> plane 0, plane column bx
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void wino_kernel(const WinoA
         const int b = lid / a.tiles_y;
         const int n0 = nt * BN;
         const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;
-        const float* wbase = a.d.weight + ((size_t)half * a.coutP + n0 + wn * NB * 32 + col) * 4;
+        const float* wbase = a.d.weight + (size_t)nt * WBLOCK + (half * 64 + wn * 32 + col) * 4;   // this lane's column of block (chunk 0, nt)
 
         f32x16 Y[2][2][NB];
 #pragma unroll
@@ -224,11 +223,11 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void wino_kernel(const WinoA
             }
             __syncthreads();
 
-            const float* wchunk = wbase + (size_t)(cb >> 2) * a.coutP * 4;
-            if (KC == 32 && ng == 4) wino_chunk<NB, 4, LDA>(Y, As, a_base, wchunk, pos_stride, a.coutP);
-            else if (ng == 2) wino_chunk<NB, 2, LDA>(Y, As, a_base, wchunk, pos_stride, a.coutP);
-            else if (KC == 32 && ng == 3) wino_chunk<NB, 3, LDA>(Y, As, a_base, wchunk, pos_stride, a.coutP);
-            else wino_chunk<NB, 1, LDA>(Y, As, a_base, wchunk, pos_stride, a.coutP);
+            const float* wchunk = wbase + (size_t)(cb >> 5) * a.n_tiles * WBLOCK + ((cb & 31) >> 2) * 256;
+            if (KC == 32 && ng == 4) wino_chunk<NB, 4, LDA>(Y, As, a_base, wchunk);
+            else if (ng == 2) wino_chunk<NB, 2, LDA>(Y, As, a_base, wchunk);
+            else if (KC == 32 && ng == 3) wino_chunk<NB, 3, LDA>(Y, As, a_base, wchunk);
+            else wino_chunk<NB, 1, LDA>(Y, As, a_base, wchunk);
         }
 
         // ------------------------------------------------------------ epilogue
@@ -287,19 +286,20 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void wino_kernel(const WinoA
     }
 }
 
-// OIHW -> U = G g G^T, packed [pos = xi*4 + nu][cin/4][coutP][4], coutP = cout rounded up to 64
-__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int coutP) {
+// OIHW -> U = G g G^T, packed as 128 KB blocks [cinP/32][coutP/64] of [pos = xi*4 + nu][8 channel quads][64 n][4]:
+// everything one workgroup reads for one K chunk is contiguous and every fragment address is block base + a
+// compile-time offset.  coutP = cout rounded up to 64, cinP = cin rounded up to 32 (zero fill).
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cinP, int cout, int coutP) {
     const float G[4][3] = {{1.0f, 0.0f, 0.0f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.0f, 0.0f, 1.0f}};
-    const size_t total = (size_t)16 * cin * coutP;
+    const size_t total = (size_t)16 * cinP * coutP;
+    const int n_tiles = coutP >> 6;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int e = i & 3;
-        size_t r = i >> 2;
-        const int n = r % coutP; r /= coutP;
-        const int q = r % (cin >> 2);
-        const int pos = r / (cin >> 2);
-        const int xi = pos >> 2, nu = pos & 3, ci = q * 4 + e;
+        const int e = i & 3, n64 = (i >> 2) & 63, q = (i >> 8) & 7, pos = (i >> 11) & 15;
+        const size_t blk = i >> 15;
+        const int n = (int)(blk % n_tiles) * 64 + n64, ci = (int)(blk / n_tiles) * 32 + q * 4 + e;
+        const int xi = pos >> 2, nu = pos & 3;
         float u = 0.0f;
-        if (n < cout) {
+        if (n < cout && ci < cin) {
             const float* g = w + ((size_t)n * cin + ci) * 9;
             float tmp[3];                                   // row xi of G g
 #pragma unroll
@@ -358,16 +358,16 @@ extern "C" int nd_conv3x3_wino_stat_slots(int H, int W) {
 }
 
 extern "C" int64_t nd_pack_conv3x3_wino_weight_floats(int cin, int cout) {
-    return (int64_t)16 * cin * nd_round_up(cout, 64);
+    return (int64_t)16 * nd_round_up(cin, 32) * nd_round_up(cout, 64);
 }
 
 extern "C" int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
     ND_REQUIRE(oihw && packed, ND_E_BADARG, "nd_pack_conv3x3_wino_weight: null pointer");
     ND_REQUIRE(cin > 0 && cout > 0 && cin % 8 == 0, ND_E_SHAPE, "nd_pack_conv3x3_wino_weight: cin=%d must be a positive multiple of 8", cin);
-    const int coutP = nd_round_up(cout, 64);
-    const size_t total = (size_t)16 * cin * coutP;
+    const int coutP = nd_round_up(cout, 64), cinP = nd_round_up(cin, 32);
+    const size_t total = (size_t)16 * cinP * coutP;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cout, coutP);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cinP, cout, coutP);
     return nd_launch_status("nd_pack_conv3x3_wino_weight");
 }
 

@@ -96,6 +96,12 @@ __device__ __forceinline__ float nd_row16_sum(float v) {
 }
 
 // exact-fp32 matrix FMA: D(32x32) += A(32x2) * B(2x32); lane l gives A[l&31][l>>5], B[l>>5][l&31]
+__device__ __forceinline__ f32x16 nd_zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
 __device__ __forceinline__ f32x16 nd_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

@@ -33,6 +33,7 @@ from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, 
 
 GN_EPS = 1e-5
 WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
+WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two-waves-per-SIMD Winograd kernel (conv3x3_wino.hip)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 
 
@@ -291,9 +292,13 @@ class Plan:
             st = self._alloc(self.B, slots, cout, 2)
             sc = self._alloc(slots)
             d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
-        self._add("nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), e.stream,
+        # both Winograd kernels share weights, statistics slots and descriptor; wino2 (one resident wave per SIMD,
+        # all 16 position accumulators in registers) is the default, wino covers what it does not take
+        wino2 = wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
+        entry = "nd_conv3x3_wino2_nhwc_f32" if wino2 else "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32"
+        self._add(entry, C.byref(d), e.stream,
                   meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
-                        "tiling": 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
+                        "tiling": 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
         self._keep.append(d)
         return out, st, sc, slots
 

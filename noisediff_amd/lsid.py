@@ -3,7 +3,7 @@ consumer of the synthesized noise (BASELINE config 5).
 
 Same plug-in contract as NoiseDiffNet: ``LSID(args)``, reference state-dict names/shapes (strict load),
 ``forward(x)`` with an NCHW (B, 4, H, W) tensor.  It reuses the sampler's kernels: every ``Conv2d(3x3)`` is
-``nd_conv3x3(_wino)_nhwc_f32`` storing the *pre-activation*; ``LeakyReLU(0.2)`` is applied by the consumer's
+``nd_conv3x3(_wino2)_nhwc_f32`` storing the *pre-activation*; ``LeakyReLU(0.2)`` is applied by the consumer's
 prologue (ND_PRO_LEAKY; it commutes with max-pooling, and ND_PRO_LEAKY_SECOND handles
 ``cat(up(x), skip)`` where only the skip is activated); ``ConvTranspose2d(2, s=2)`` is one pointwise GEMM to
 4*C' columns with a pixel-shuffle store that also performs the crop.  Inference only; no CPU fallback.
@@ -126,7 +126,7 @@ class _LsidPlan:
         d = L.Conv3x3()
         d.src, d.weight, d.bias, d.out = src, self.w[name + ".weight"][1 if wino else 0].data_ptr(), self.w[name + ".bias"].data_ptr(), out.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, h, w, cin, cout, cout
-        self._add("nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), self.stream)
+        self._add("nd_conv3x3_wino2_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), self.stream)
         self.keep.append(d)
         return out
 

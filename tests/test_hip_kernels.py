@@ -363,8 +363,12 @@ WINO_CASES = {  # (B, H, W, cin, cout)
 }
 
 
+WINO_ENTRIES = ["nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32"]
+
+
+@pytest.mark.parametrize("entry", WINO_ENTRIES)
 @pytest.mark.parametrize("case", sorted(WINO_CASES))
-def test_conv3x3_winograd_matches_direct_semantics(ctx, case):
+def test_conv3x3_winograd_matches_direct_semantics(ctx, case, entry):
     """Winograd F(2x2,3x3) kernel == nn.Conv2d(3, padding=1) (tolerance 1e-5: fp32 transforms), stats included."""
     import hiputil as hu
     B, H, W, cin, cout = WINO_CASES[case]
@@ -384,7 +388,7 @@ def test_conv3x3_winograd_matches_direct_semantics(ctx, case):
         d = L.Conv3x3()
         d.src, d.weight, d.bias, d.out, d.stats, d.slot_count = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st.data_ptr(), sc.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
-        L.call("nd_conv3x3_wino_nhwc_f32", C.byref(d), ctx.stream)
+        L.call(entry, C.byref(d), ctx.stream)
         ctx.sync()
         return out, st, sc, slots
 

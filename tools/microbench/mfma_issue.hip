@@ -1,0 +1,74 @@
+// Microbenchmark: how much other work one wave can issue between two fp32 MFMAs without slowing the matrix pipe.
+// One workgroup per CU, WAVES waves per SIMD (1 or 2); each wave loops over {1 x v_mfma_f32_32x32x2_f32 (rotating over 4
+// accumulators) + N x filler}; prints shader cycles per MFMA per SIMD for N = 0..NMAX and filler kinds
+// VALU (v_add_f32), PK (v_pk_add_f32), LDS (ds_read_b128), VMEM (global_load_dwordx4 from an L2-resident line).
+//   hipcc -O3 --offload-arch=gfx950 tools/microbench/mfma_issue.hip -o tools/_build/mfma_issue && tools/_build/mfma_issue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// SPLIT: waves 0..3 issue only the MFMAs, waves 4..7 (the second wave of each SIMD) only the fillers
+template <int KIND, int N, bool SPLIT = false>
+__global__ __launch_bounds__(512, 1) void k(unsigned long long* out, const float* gsrc, int iters) {
+    const bool do_mfma = !SPLIT || threadIdx.x < 256, do_fill = !SPLIT || threadIdx.x >= 256;
+    extern __shared__ float lds[];
+    f32x16 acc[4];
+    for (int p = 0; p < 4; ++p) for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = 1.0f;
+    float v[8]; for (int i = 0; i < 8; ++i) v[i] = i + threadIdx.x;
+    f32x4 d[4]; for (int i = 0; i < 4; ++i) d[i] = f32x4{0, 0, 0, 0};
+    const float* lp = lds + (threadIdx.x & 63) * 4;
+    const float* gp = gsrc + (threadIdx.x & 63) * 4;
+    lds[threadIdx.x] = 0.f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (do_mfma) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(a), "v"(b));
+            if (do_fill)
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[n & 7]) : "v"(b));
+                if (KIND == 1) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(*reinterpret_cast<double*>(&d[n & 3])));
+                if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(d[n & 3]) : "v"((unsigned)(size_t)lp));
+                if (KIND == 3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[n & 3]) : "v"(gp));
+            }
+        }
+        if (KIND >= 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sink = 0; for (int p = 0; p < 4; ++p) sink += acc[p][0]; for (int i = 0; i < 8; ++i) sink += v[i]; for (int i = 0; i < 4; ++i) sink += d[i][0];
+    if (sink == 123.456f) out[1] = 1;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) atomicMax(out, t1 - t0);     // slowest wave of workgroup 0
+}
+
+template <int KIND, int N, bool SPLIT = false>
+double run(int waves_per_simd, unsigned long long* dout, const float* gsrc) {
+    const int iters = 200;
+    hipLaunchKernelGGL((k<KIND, N, SPLIT>), dim3(256), dim3(256 * waves_per_simd), 4096, 0, dout, gsrc, iters);
+    hipMemset(dout, 0, 8);
+    hipLaunchKernelGGL((k<KIND, N, SPLIT>), dim3(256), dim3(256 * waves_per_simd), 4096, 0, dout, gsrc, iters);
+    unsigned long long h = 0;
+    hipMemcpy(&h, dout, 8, hipMemcpyDeviceToHost);
+    return (double)h / (iters * 16.0 * (SPLIT ? 1 : waves_per_simd));      // cycles per MFMA per SIMD
+}
+
+template <int KIND, int N>
+void row(const char* name, unsigned long long* dout, const float* gsrc) {
+    printf("%-5s N=%2d  1 wave/SIMD: %6.1f   2 waves/SIMD: %6.1f   2 waves, MFMA wave + filler wave: %6.1f   (cycles per MFMA per SIMD, N fillers per MFMA)\n",
+           name, N, run<KIND, N>(1, dout, gsrc), run<KIND, N>(2, dout, gsrc), run<KIND, N, true>(2, dout, gsrc));
+}
+
+int main() {
+    unsigned long long* dout; float* gsrc;
+    hipMalloc(&dout, 64); hipMalloc(&gsrc, 4096); hipMemset(gsrc, 0, 4096); hipMemset(dout, 0, 64);
+    row<0, 0>("none", dout, gsrc);
+    row<0, 2>("VALU", dout, gsrc); row<0, 4>("VALU", dout, gsrc); row<0, 8>("VALU", dout, gsrc); row<0, 12>("VALU", dout, gsrc); row<0, 16>("VALU", dout, gsrc);
+    row<1, 4>("PK", dout, gsrc); row<1, 8>("PK", dout, gsrc);
+    row<2, 1>("LDS", dout, gsrc); row<2, 2>("LDS", dout, gsrc); row<2, 4>("LDS", dout, gsrc);
+    row<3, 1>("VMEM", dout, gsrc); row<3, 2>("VMEM", dout, gsrc);
+    return 0;
+}

@@ -8,6 +8,7 @@ if os.environ.get("ND_LIB"):
     L.load(os.environ["ND_LIB"])
 import hiputil as hu
 ctx = hu.Ctx()
+ENTRY = os.environ.get("ND_WINO_ENTRY", "nd_conv3x3_wino_nhwc_f32")
 def bench(B, H, W, cin, cout, mode=0, reps=5):
     x = torch.randn(B, H, W, cin, device=hu.DEV); w = torch.randn(cout, cin, 3, 3) * 0.05
     wd = hu.dev(w); wp = torch.empty(ctx.lib.nd_pack_conv3x3_wino_weight_floats(cin, cout), device=hu.DEV)
@@ -21,12 +22,12 @@ def bench(B, H, W, cin, cout, mode=0, reps=5):
     d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
     d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
     e0, e1 = C.c_void_p(), C.c_void_p(); L.call("nd_event_create", C.byref(e0)); L.call("nd_event_create", C.byref(e1))
-    L.call("nd_conv3x3_wino_nhwc_f32", C.byref(d), ctx.stream); ctx.sync()
+    L.call(ENTRY, C.byref(d), ctx.stream); ctx.sync()
     L.call("nd_event_record", e0, ctx.stream)
-    for _ in range(reps): L.call("nd_conv3x3_wino_nhwc_f32", C.byref(d), ctx.stream)
+    for _ in range(reps): L.call(ENTRY, C.byref(d), ctx.stream)
     L.call("nd_event_record", e1, ctx.stream); ms = C.c_float(); L.call("nd_event_elapsed_ms", e0, e1, C.byref(ms))
     t = ms.value / reps
     return t * 1e3, 18.0 * cin * cout * H * W * B / t / 1e9
 for sh in [(16, 256, 256, 64, 64), (16, 256, 256, 128, 64), (16, 64, 64, 256, 256), (16, 32, 32, 512, 512)]:
     us, tf = bench(*sh)
-    print(os.environ.get("ND_LIB", "default")[-20:], sh, f"{us:8.1f} us {tf:6.1f} TF(alg)", flush=True)
+    print(ENTRY[12:18], os.environ.get("ND_LIB", "default")[-20:], sh, f"{us:8.1f} us {tf:6.1f} TF(alg)", flush=True)
