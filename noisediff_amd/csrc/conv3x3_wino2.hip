@@ -121,8 +121,6 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     unsigned okmask = 0;                                   // bit it: halo pixel inside the image and channel valid
     bool second = false;
     const int stid = tid >> 3;                             // staging pixel of iteration 0
-    const float* ibase = nullptr;
-    const float* imap = nullptr;
     unsigned ild4 = 0;
 #pragma unroll
     for (int it = 0; it < STAGE_IT; ++it) {
@@ -149,29 +147,40 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     unsigned mask_cur = 0, mask_next = 0;                  // inside-image masks of this tile and the next one
     int par = 0;                                           // table of this tile; the next tile's is par ^ 1
     int ipar = 0;                                          // table of the item being staged
+    // activations, like the weights, come through buffer loads (SGPR resource + scalar channel offset, 32-bit lane
+    // offset = pixel * stride + quad): cheap to issue, and a lane whose channels lie beyond the tensor reads zeros.
+    // A K chunk never straddles the two concat sources (host check), so the source is wave-uniform per chunk.
+    const long src_px = (long)a.d.B * sH * sW;
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(src_px * s.ld0 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(src_px * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MAP ? s.map : s.p0), 0, MAP ? (int)(src_px * 2 * Ctot * 4) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t irsrc = rsrc0;
+    int isoff = 0, imoff = 0;                              // scalar byte offsets: channel base inside the source / the map
     auto issue_begin = [&](int b_, int cb_, int par_, unsigned tilemask) {   // per chunk: channel quad of this thread
         ipar = par_;
+        const bool sec = cb_ >= s.c0;                      // wave-uniform
+        second = sec;
+        irsrc = sec ? rsrc1 : rsrc0;
+        ild4 = (unsigned)(sec ? s.ld1 : s.ld0) * 4u;
+        isoff = (sec ? cb_ - s.c0 : cb_) * 4;
         const int c = cb_ + quad * 4;
         const bool cvalid = c < Cin;
         const int cs = cvalid ? c : 0;
-        second = cs >= s.c0;
-        ibase = (second ? s.p1 : s.p0) + (second ? cs - s.c0 : cs);
-        ild4 = (unsigned)(second ? s.ld1 : s.ld0) * 4u;
         if (AFF) {
             const float* m = s.mad + (size_t)b_ * 3 * Ctot + cs;
             tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
             tD = tD - tM * tA;                             // (v - M) * A + D = v * A + (D - M * A)
         }
-        if (MAP) imap = s.map + cs;
+        if (MAP) imoff = cb_ * 4;
         okmask = cvalid ? tilemask : 0u;
     };
     auto issue_one = [&](int it) {
         const unsigned pix = tab[((1 + ipar) * STAGE_IT + it) * 256];
-        raw[it] = nd_ld4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ibase) + (size_t)pix * ild4));
+        raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, (unsigned)(__umul24(pix, ild4) + quad * 16), isoff, 0));
         if (MAP) {                                         // the map has the conv's resolution (host: no upsample with MAP)
-            const float* mp = imap + (size_t)pix * (unsigned)(2 * Ctot);
-            msc[it] = nd_ld4(mp);
-            msh[it] = nd_ld4(mp + Ctot);
+            const unsigned mo = (unsigned)(__umul24(pix, 2 * Ctot * 4) + quad * 16);
+            msc[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, imoff, 0));
+            msh[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, imoff + Ctot * 4, 0));
         }
     };
     auto commit = [&](int it, float* dst) {                // prologue transform + zero padding, registers -> LDS
@@ -209,12 +218,14 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     int cur = 0;
     const unsigned voff = (half * 64 + wn * 32 + col) * 16;                 // per-lane byte offset inside a weight block
     const int n_chunks = (Cin + KC - 1) / KC;
-    auto block_ptr = [&](int ch_, int nt_) {              // wave-uniform by construction; say so (SGPR base + 32-bit lane offset loads)
-        const unsigned long long p = reinterpret_cast<unsigned long long>(a.d.weight + ((size_t)ch_ * a.n_tiles + nt_) * WBLOCK);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-        return (gchar_p)(((unsigned long long)hi << 32) | lo);
+    // the weight stream goes through buffer loads: one resource for the whole packed tensor, the per-lane offset in a
+    // VGPR (constant), block and fragment offsets in the scalar offset -- an SGPR-addressed load costs the in-order
+    // wave ~5 issue cycles, a 64-bit per-lane address ~16 plus the adds (tools/microbench/mfma_issue.hip)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.d.weight), 0, (int)(((Cin + 31) & ~31) * 16 * a.coutP * 4), 0x00020000);
+    auto block_off = [&](int ch_, int nt_) {              // byte offset of weight block (chunk, n tile); wave-uniform
+        return __builtin_amdgcn_readfirstlane((ch_ * a.n_tiles + nt_) * (WBLOCK * 4));
     };
-
     // ---- the K loop.  A chunk is 16 steps (xi, channel group g) of 16 MFMAs; the 8 patch-row reads and the 4 column
     //      terms of a step serve all four nu positions.  Software pipeline, one in-order wave per SIMD: LDS rows are
     //      read two steps ahead, the transformed operands V of step s+1 are built during step s, weight fragments are
@@ -224,9 +235,9 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     //      most ~60 cycles of other instructions sit between two MFMAs and the matrix pipe never waits for the wave.
     constexpr int S = 16, LAG = 3, WD = 2;
     f32x4 bw[4][4], dr[2][8], Vc[4], Vn[4], T[4];
-    auto load_w1 = [&](gchar_p wb, int step, int nu) {
+    auto load_w1 = [&](int wb, int step, int nu) {
         const int g = step & 3, xi = step >> 2;
-        bw[step & 3][nu] = *(gf32x4_p)(wb + (voff + (unsigned)(((xi * 4 + nu) * 8 + 2 * g) * 1024)));
+        bw[step & 3][nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, wb + ((xi * 4 + nu) * 8 + 2 * g) * 1024, 0));
     };
     auto load_d1 = [&](const float* src, int step, int c, int which) {
         const int g = step & 3, xi = step >> 2;
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         V[nu] = nu == 0 ? w2_bt<0>(r1, r2) : nu == 1 ? w2_bt<1>(r1, r2) : nu == 2 ? w2_bt<2>(r1, r2) : w2_bt<3>(r1, r2);
 #endif
     };
-    gchar_p wblock = block_ptr(0, nt);
+    int wblock = block_off(0, nt);
 #pragma unroll
     for (int w = 0; w < WD; ++w)
 #pragma unroll
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             // the item after the very last one is a harmless re-stage of this tile's first chunk: no branch in the loop
             if (last_chunk) issue_begin(nb_, 0, more_tiles ? par ^ 1 : par, more_tiles ? mask_next : mask_cur);
             else issue_begin(b, (ch + 1) * KC, par, mask_cur);
-            gchar_p wnext = last_chunk ? block_ptr(0, nnt) : block_ptr(ch + 1, nt);
+            const int wnext = last_chunk ? block_off(0, nnt) : block_off(ch + 1, nt);
 
 #pragma unroll
             for (int c = 0; c < 8; ++c) load_d1(src, 0, c >> 1, c & 1);
@@ -477,8 +488,17 @@ extern "C" int W2_ENTRY(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3_wino2: unshuffle is a pointwise-only addressing mode");
     ND_REQUIRE(!(s.mode == ND_PRO_AFFINE_MAP_SILU && s.upsample), ND_E_BADARG,
                "nd_conv3x3_wino2: map prologue with upsample is not supported here (use nd_conv3x3_wino_nhwc_f32)");
-    ND_REQUIRE((long)d->B * d->H * d->W < (1L << 31) && (long)(7 * d->W + 7) * d->ldo < (1L << 31), ND_E_SHAPE,
-               "nd_conv3x3_wino2: image too large for 32-bit pixel indices");
+    ND_REQUIRE((long)d->B * d->H * d->W < (1L << 24) && (long)(7 * d->W + 7) * d->ldo < (1L << 31), ND_E_SHAPE,
+               "nd_conv3x3_wino2: more than 2^24 pixels (use nd_conv3x3_wino_nhwc_f32)");
+    {
+        const long px = (long)d->B * (d->H >> (s.upsample ? 1 : 0)) * (d->W >> (s.upsample ? 1 : 0));
+        const long widest = s.mode == ND_PRO_AFFINE_MAP_SILU ? 2L * (s.c0 + s.c1) : 0;
+        ND_REQUIRE(px * s.ld0 * 4 < (1L << 31) && px * s.ld1 * 4 < (1L << 31) && px * widest * 4 < (1L << 31), ND_E_SHAPE,
+                   "nd_conv3x3_wino2: a source tensor of 2 GiB or more (use nd_conv3x3_wino_nhwc_f32)");
+    }
+    ND_REQUIRE(s.c1 == 0 || s.c0 % 32 == 0, ND_E_SHAPE,
+               "nd_conv3x3_wino2: first concat source has %d channels; a 32-channel K chunk must not straddle the sources "
+               "(use nd_conv3x3_wino_nhwc_f32)", s.c0);
 #ifndef W2_STAMP
     ND_REQUIRE((d->stats == nullptr) == (d->slot_count == nullptr), ND_E_BADARG, "nd_conv3x3_wino2: stats and slot_count go together");
 #endif

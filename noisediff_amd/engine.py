@@ -294,7 +294,9 @@ class Plan:
             d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
         # both Winograd kernels share weights, statistics slots and descriptor; wino2 (one resident wave per SIMD,
         # all 16 position accumulators in registers) is the default, wino covers what it does not take
-        wino2 = wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
+        wino2 = (wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
+                 and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
+                 and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
         entry = "nd_conv3x3_wino2_nhwc_f32" if wino2 else "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32"
         self._add(entry, C.byref(d), e.stream,
                   meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),

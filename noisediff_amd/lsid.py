@@ -126,7 +126,8 @@ class _LsidPlan:
         d = L.Conv3x3()
         d.src, d.weight, d.bias, d.out = src, self.w[name + ".weight"][1 if wino else 0].data_ptr(), self.w[name + ".bias"].data_ptr(), out.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, h, w, cin, cout, cout
-        self._add("nd_conv3x3_wino2_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), self.stream)
+        wino2 = wino and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * h * w < (1 << 24) and self.B * h * w * 4 * max(src.ld0, src.ld1) < (1 << 31)
+        self._add("nd_conv3x3_wino2_nhwc_f32" if wino2 else "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), self.stream)
         self.keep.append(d)
         return out
 

@@ -356,6 +356,7 @@ def test_linear_attention_matches_reference_semantics(ctx, N, golden):
 
 
 WINO_CASES = {  # (B, H, W, cin, cout)
+    "concat_uneven": (2, 32, 48, 96, 32),         # 64 + 32 channel sources with different pixel strides
     "square": (2, 32, 32, 32, 64),
     "ragged_edges": (2, 24, 40, 16, 48),          # partial tiles in x and y, partial K chunk, cout mask
     "wide_k": (1, 16, 16, 96, 128),               # 3 K chunks, two N tiles
@@ -407,5 +408,13 @@ def test_conv3x3_winograd_matches_direct_semantics(ctx, case, entry):
     out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
     assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 1e-5
     c0 = cin // 2 // 4 * 4
+    if entry == "nd_conv3x3_wino2_nhwc_f32" and c0 % 32:
+        # a 32-channel K chunk must not straddle the concat sources there: refused loudly, the engine routes such layers
+        # to nd_conv3x3_wino_nhwc_f32; where it fits, split on the chunk boundary instead
+        with pytest.raises(L.HipError, match="straddle"):
+            run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))
+        if cin <= 32:
+            return
+        c0 = 32
     out, *_ = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))
     assert rel_err(hu.nchw(out), ref) < 1e-5

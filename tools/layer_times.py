@@ -43,10 +43,11 @@ for i, (fn, args, name, meta) in enumerate(ops):
     kind = name.replace("nd_", "").replace("_f32", "").replace("_nhwc", "")
     desc, gbs, tf = "", 0.0, 0.0
     if meta and "H" in meta:
-        kind = "conv3x3_wino" if meta["tiling"] == 9001 else kind
+        kind = "conv3x3_wino" if meta["tiling"] == 9001 else "conv3x3_wino2" if meta["tiling"] == 9002 else kind
+        desc_mode = meta.get("mode", 0)
         fl = 18.0 * meta["cin"] * meta["cout"] * meta["H"] * meta["W"] * meta["B"]
         by = 4.0 * meta["B"] * meta["H"] * meta["W"] * (meta["cin"] + meta["cout"])
-        desc = f"{meta['layer']} {meta['cin']}->{meta['cout']} @{meta['H']}x{meta['W']} t{meta['tiling']}"
+        desc = f"{meta['layer']} {meta['cin']}->{meta['cout']} @{meta['H']}x{meta['W']} t{meta['tiling']} m{desc_mode}"
         gbs, tf = by / ms / 1e6, fl / ms / 1e9
     elif meta:
         fl = 2.0 * meta["cin"] * meta["cout"] * meta["HW"] * meta["B"]

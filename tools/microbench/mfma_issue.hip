@@ -21,6 +21,12 @@ __global__ __launch_bounds__(512, 1) void k(unsigned long long* out, const float
     f32x4 d[4]; for (int i = 0; i < 4; ++i) d[i] = f32x4{0, 0, 0, 0};
     const float* lp = lds + (threadIdx.x & 63) * 4;
     const float* gp = gsrc + (threadIdx.x & 63) * 4;
+    const unsigned goff = (threadIdx.x & 63) * 16;
+    float* gdst = const_cast<float*>(gsrc) + 4096 + blockIdx.x * 1024;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 rsrc;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(size_t)gsrc); rsrc[1] = __builtin_amdgcn_readfirstlane((int)((size_t)gsrc >> 32));
+    rsrc[2] = 1 << 20; rsrc[3] = 0x00020000;
     lds[threadIdx.x] = 0.f;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -35,6 +41,12 @@ __global__ __launch_bounds__(512, 1) void k(unsigned long long* out, const float
                 if (KIND == 1) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(*reinterpret_cast<double*>(&d[n & 3])));
                 if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(d[n & 3]) : "v"((unsigned)(size_t)lp));
                 if (KIND == 3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[n & 3]) : "v"(gp));
+                if (KIND == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d[n & 3]) : "v"(goff), "s"(gsrc));
+                if (KIND == 5) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d[n & 3]) : "v"(goff), "s"(rsrc));
+                if (KIND == 6) asm volatile("global_load_dword %0, %1, %2" : "=v"(d[n & 3][0]) : "v"(goff), "s"(gsrc));
+                if (KIND == 7) asm volatile("ds_write_b128 %0, %1" :: "v"((unsigned)(size_t)lp), "v"(d[n & 3]) : "memory");
+                if (KIND == 8) asm volatile("global_store_dword %0, %1, %2" :: "v"(goff), "v"(d[n & 3][0]), "s"(gdst) : "memory");
+                if (KIND == 9) asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(goff), "v"(d[n & 3]), "s"(gdst) : "memory");
             }
         }
         if (KIND >= 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -64,11 +76,18 @@ void row(const char* name, unsigned long long* dout, const float* gsrc) {
 
 int main() {
     unsigned long long* dout; float* gsrc;
-    hipMalloc(&dout, 64); hipMalloc(&gsrc, 4096); hipMemset(gsrc, 0, 4096); hipMemset(dout, 0, 64);
+    hipMalloc(&dout, 64); hipMalloc(&gsrc, 8 << 20); hipMemset(gsrc, 0, 8 << 20); hipMemset(dout, 0, 64);
     row<0, 0>("none", dout, gsrc);
     row<0, 2>("VALU", dout, gsrc); row<0, 4>("VALU", dout, gsrc); row<0, 8>("VALU", dout, gsrc); row<0, 12>("VALU", dout, gsrc); row<0, 16>("VALU", dout, gsrc);
     row<1, 4>("PK", dout, gsrc); row<1, 8>("PK", dout, gsrc);
     row<2, 1>("LDS", dout, gsrc); row<2, 2>("LDS", dout, gsrc); row<2, 4>("LDS", dout, gsrc);
     row<3, 1>("VMEM", dout, gsrc); row<3, 2>("VMEM", dout, gsrc);
+    row<4, 1>("GLDs4", dout, gsrc); row<4, 2>("GLDs4", dout, gsrc);
+    row<5, 1>("BUF4", dout, gsrc); row<5, 2>("BUF4", dout, gsrc);
+    row<6, 1>("GLDs1", dout, gsrc); row<6, 2>("GLDs1", dout, gsrc); row<6, 4>("GLDs1", dout, gsrc);
+    row<7, 1>("DSW", dout, gsrc); row<7, 2>("DSW", dout, gsrc);
+    row<8, 1>("GST1", dout, gsrc); row<8, 2>("GST1", dout, gsrc); row<8, 4>("GST1", dout, gsrc);
+    row<9, 1>("GST4", dout, gsrc); row<9, 2>("GST4", dout, gsrc);
+    row<2, 8>("LDS", dout, gsrc);
     return 0;
 }
