@@ -151,6 +151,34 @@ int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream);
 int64_t nd_pack_pointwise_weight_floats(int cin, int cout);
 int nd_pack_pointwise_weight(const float* w, float* packed, int cin, int cout, int unshuffle_c, void* stream);
 
+/* ------------------------------------------------------------------ chained pointwise layers
+ * Two or three per-pixel Linear layers in one kernel, the intermediate activations never leaving registers:
+ *   Mlp (Diffusion_arch.py:340-356):            out = fc2(act(fc1(x)))
+ *   AttnBlock tail (:405-443, with src.vec = v): out = proj_out(ff2(GELU(ff1(LN(x + v)))) + x + v) + x
+ * src: p0/p1 virtual concat, mode ND_PRO_NONE or ND_PRO_LAYERNORM (gamma, beta; src.vec[b] is added to the row first).
+ * Stage i computes  h = act_i(W_i . h_prev + bias_i + res_i)  with res_i one of enum nd_chain_res.  Weights come from
+ * nd_pack_chain_weight (operand order of the transposed MFMA product, K padded to 8 for the first stage and to 32 for
+ * the later ones, N to 32).  Only the width combinations NoiseDiffNet uses are instantiated
+ * (nd_pointwise_chain_supported); HW must be a multiple of 32. */
+enum nd_chain_res { ND_CHAIN_RES_NONE = 0, ND_CHAIN_RES_INPUT = 1 /* + x + v */, ND_CHAIN_RES_INPUT_RAW = 2 /* + x */ };
+typedef struct nd_chain_stage {
+    const float* weight;
+    const float* bias;     /* [cout] or NULL */
+    int32_t  cin, cout;
+    int32_t  act;          /* enum nd_act, applied after bias and residual */
+    int32_t  res;          /* enum nd_chain_res; needs cout == input width */
+} nd_chain_stage;
+typedef struct nd_chain {
+    nd_src   src;
+    nd_chain_stage st[3];
+    float*   out;
+    int32_t  n_stages, B, HW, ldo;
+} nd_chain;
+int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream);
+int nd_pointwise_chain_supported(int cin, int n1, int n2, int n3);   /* n3 = 0: two stages */
+int64_t nd_pack_chain_weight_floats(int cin, int cout, int first_stage);
+int nd_pack_chain_weight(const float* w, float* packed, int cin, int cout, int first_stage, void* stream);
+
 /* ------------------------------------------------------------------ GroupNorm plumbing */
 
 /* Combine conv partials (Chan's parallel variance, fp64) into per-(b, group) mean / rstd

@@ -43,6 +43,18 @@ class Pointwise(C.Structure):
                 ("shuffle_c", C.c_int32), ("shuffle_h", C.c_int32), ("shuffle_w", C.c_int32)]
 
 
+class ChainStage(C.Structure):
+    _fields_ = [("weight", fptr), ("bias", fptr), ("cin", C.c_int32), ("cout", C.c_int32), ("act", C.c_int32), ("res", C.c_int32)]
+
+
+class Chain(C.Structure):
+    _fields_ = [("src", Src), ("st", ChainStage * 3), ("out", fptr), ("n_stages", C.c_int32), ("B", C.c_int32), ("HW", C.c_int32),
+                ("ldo", C.c_int32)]
+
+
+CHAIN_RES_NONE, CHAIN_RES_INPUT, CHAIN_RES_INPUT_RAW = 0, 1, 2
+
+
 class SamplerState(C.Structure):
     _fields_ = [("step", fptr), ("t_cur", fptr), ("t_next", fptr), ("coef", fptr), ("time_out", fptr),
                 ("n_steps", C.c_int32), ("B", C.c_int32)]
@@ -66,6 +78,10 @@ SIGNATURES = {
     "nd_pack_conv3x3_wino_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_wino_weight": (i32, [vp, vp, i32, i32, vp]),
     "nd_pointwise_gemm_nhwc_f32": (i32, [C.POINTER(Pointwise), vp]),
+    "nd_pointwise_chain_nhwc_f32": (i32, [C.POINTER(Chain), vp]),
+    "nd_pointwise_chain_supported": (i32, [i32, i32, i32, i32]),
+    "nd_pack_chain_weight_floats": (i64, [i32, i32, i32]),
+    "nd_pack_chain_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_floats": (i64, [i32, i32]),
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),

@@ -1,0 +1,355 @@
+// pwchain.hip -- two or three chained per-pixel Linear layers (1x1 convs) in one kernel, activations never leaving
+// registers:   Mlp = fc2(GELU(fc1(x)))                                   (Diffusion_arch.py:340-356)
+//              AttnBlock tail = proj_out(ff.net.2(GELU(ff.net.0(LN(x + v)))) + x + v) + x        (:405-443, v = the 1-token
+//              cross-attention output, a per-sample vector)
+// Unfused, each layer streams its input and output through HBM (the 2C-wide hidden tensor of the FeedForward alone is
+// 2 x 268 MB per call at 256x256x16); fused, a chain reads x once and writes y once and is bounded by the fp32 MFMA.
+//
+// The products are computed TRANSPOSED, D^T = W . X^T, one 32-pixel column tile per wave:
+//   v_mfma_f32_32x32x2_f32  A = weights (lane l: W[n = l & 31][k(j, l >> 5)])   B = activations (lane l: X[pixel l & 31][k(j, l >> 5)])
+//   accumulator register r of lane (pixel, half) = output channel 32*nt + (r & 3) + 8*(r >> 2) + 4*half
+// With K paired as k(j, half) = 8*(j >> 2) + (j & 3) + 4*half, accumulator register r of n-tile nt IS operand j = 16*nt + r
+// of the next layer: the chain flows register to register with no shuffle, no LDS round trip, and the residual / bias /
+// activation are plain per-register VALU work.  The input row of a pixel is loaded in the same pairing (lane (pixel, half)
+// reads channels 8q + 4*half .. +3), so LayerNorm statistics are an in-lane sum plus one cross-half exchange, and the
+// output is written as 16-byte pieces.
+//
+// Weights (packed in operand order by nd_pack_chain_weight), biases and LayerNorm gamma/beta of all stages sit in LDS for
+// the lifetime of the persistent workgroup (80 KB at C = 64): an A fragment is one ds_read_b128 per four MFMAs.  Two waves
+// per SIMD (512 threads, <= 256 registers each) let one wave's activation VALU run under the other's MFMAs.
+#include <type_traits>
+#include "nd_common.h"
+
+namespace {
+
+struct ChainArgs {
+    nd_chain d;
+    int n_tiles;            // 32-pixel tiles in total
+    int tiles_per_sample;
+};
+
+template <int K, int N>
+__device__ __forceinline__ void chain_gemm(const float (&in)[K / 2], const float* __restrict__ w, const float* __restrict__ bias,
+                                           f32x16 (&acc)[N / 32], const int lane) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = nd_ld4(bias + 32 * nt + 8 * g + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = b4[i];
+        }
+#pragma unroll
+    for (int jq = 0; jq < K / 8; ++jq)
+#pragma unroll
+        for (int nt = 0; nt < N / 32; ++nt) {
+            const f32x4 a4 = nd_ld4(w + ((nt * (K / 8) + jq) * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nt] = nd_mfma(a4[i], in[4 * jq + i], acc[nt]);
+        }
+}
+
+template <int N>
+__device__ __forceinline__ void chain_act(f32x16 (&acc)[N / 32], const int act) {
+    if (act == ND_ACT_NONE) return;
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = act == ND_ACT_GELU ? nd_gelu(acc[nt][r]) : nd_silu(acc[nt][r]);
+}
+
+// acc[nt][r] += x[q = 4*nt + (r >> 2)][r & 3] (- v): the residual lives in the input registers
+template <int K0, int N>
+__device__ __forceinline__ void chain_res(f32x16 (&acc)[N / 32], const f32x4 (&x)[K0 / 8], const float* vstash, const int res, const int half) {
+    if (res == ND_CHAIN_RES_NONE) return;
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q = 4 * nt + g;
+            if (q < K0 / 8) {
+                f32x4 v = x[q];
+                if (res == ND_CHAIN_RES_INPUT_RAW && vstash) v -= nd_ld4(vstash + 8 * q + 4 * half);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] += v[i];
+            }
+        }
+}
+
+template <int N>
+__device__ __forceinline__ void chain_store(const f32x16 (&acc)[N / 32], float* row, const int cout, const int half) {
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = 32 * nt + 8 * g + 4 * half;
+            if (n0 < cout) {
+                const f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                nd_st4(row + n0, v);
+            }
+        }
+}
+
+// K0: stage-0 input channels rounded up to 8; N1, N2, N3: stage widths rounded up to 32 (N3 = 0: two stages)
+template <int K0, int N1, int N2, int N3, int MODE>
+__global__ __launch_bounds__(512, 1) void chain_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NL = N3 > 0 ? N3 : N2;                 // last stage width
+    float* w1 = lds;
+    float* w2 = w1 + N1 * K0;
+    float* w3 = w2 + N2 * N1;
+    float* b1 = w3 + N3 * N2;
+    float* b2 = b1 + N1;
+    float* b3 = b2 + N2;
+    float* gam = b3 + (N3 > 0 ? N3 : 0);
+    float* bet = gam + K0;
+    float* vst = bet + K0;                                // [8 waves][K0]: this wave's per-sample vector
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const nd_src& s = a.d.src;
+    const int cin = s.c0 + s.c1;
+
+    // ---- weights, biases, gamma/beta -> LDS (once per persistent workgroup)
+    {
+        auto copy4 = [&](float* dst, const float* src, int n) {
+            for (int i = tid * 4; i < n; i += 512 * 4) nd_st4(dst + i, nd_ld4(src + i));
+        };
+        auto copy_pad = [&](float* dst, const float* src, int n, int npad, float fill) {
+            for (int i = tid; i < npad; i += 512) dst[i] = (src && i < n) ? src[i] : fill;
+        };
+        copy4(w1, a.d.st[0].weight, N1 * K0);
+        copy4(w2, a.d.st[1].weight, N2 * N1);
+        copy_pad(b1, a.d.st[0].bias, a.d.st[0].cout, N1, 0.0f);
+        copy_pad(b2, a.d.st[1].bias, a.d.st[1].cout, N2, 0.0f);
+        if (N3 > 0) {
+            copy4(w3, a.d.st[2].weight, N3 * N2);
+            copy_pad(b3, a.d.st[2].bias, a.d.st[2].cout, N3, 0.0f);
+        }
+        if (MODE == ND_PRO_LAYERNORM) {
+            copy_pad(gam, s.gamma, cin, K0, 0.0f);        // zero gamma/beta: padded channels stay exactly 0
+            copy_pad(bet, s.beta, cin, K0, 0.0f);
+        }
+    }
+    __syncthreads();
+
+    // ---- contiguous range of 32-pixel tiles for this wave (a sample's vector is reloaded only when b changes)
+    const int n_waves = gridDim.x * 8, wid = blockIdx.x * 8 + wave;
+    const int t_begin = (int)((long)wid * a.n_tiles / n_waves), t_end = (int)((long)(wid + 1) * a.n_tiles / n_waves);
+    float* myv = vst + wave * K0;
+    int b_cur = -1;
+    const int cout_last = a.d.st[N3 > 0 ? 2 : 1].cout;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int b = t / a.tiles_per_sample;             // wave-uniform
+        const size_t pix = (size_t)t * 32 + (lane & 31);
+        if (s.vec && b != b_cur) {                         // stash vec[b] for this wave
+            for (int c = lane; c < K0; c += 64) myv[c] = c < cin ? s.vec[(size_t)b * cin + c] : 0.0f;
+            b_cur = b;
+        }
+        // ---- this pixel's input row, channels 8q + 4*half .. +3 (two sources = virtual concat)
+        f32x4 X[K0 / 8];
+#pragma unroll
+        for (int q = 0; q < K0 / 8; ++q) {
+            const int c = 8 * q + 4 * half;
+            const f32x4 zero = {0, 0, 0, 0};
+            X[q] = zero;
+            if (c < s.c0) X[q] = nd_ld4(s.p0 + pix * s.ld0 + c);
+            else if (c < cin) X[q] = nd_ld4(s.p1 + pix * s.ld1 + (c - s.c0));
+            if (s.vec) X[q] += nd_ld4(myv + c);
+        }
+        // ---- prologue -> operands of stage 0
+        float in0[K0 / 2];
+        if (MODE == ND_PRO_LAYERNORM) {                    // nn.LayerNorm over the cin channels of (x + v): biased variance, eps 1e-5
+            float sum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < K0 / 8; ++q) sum += (X[q][0] + X[q][1]) + (X[q][2] + X[q][3]);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)cin;
+            float m2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < K0 / 8; ++q) {
+                if (8 * q + 4 * half < cin) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float dv = X[q][i] - mean; m2 = fmaf(dv, dv, m2); }
+                }
+            }
+            m2 += __shfl_xor(m2, 32);
+            const float rstd = rsqrtf(m2 / (float)cin + 1e-5f);
+#pragma unroll
+            for (int q = 0; q < K0 / 8; ++q) {
+                const f32x4 g4 = nd_ld4(gam + 8 * q + 4 * half), be4 = nd_ld4(bet + 8 * q + 4 * half);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) in0[4 * q + i] = (X[q][i] - mean) * rstd * g4[i] + be4[i];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < K0 / 8; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) in0[4 * q + i] = X[q][i];
+        }
+
+        // ---- stage 0
+        f32x16 H1[N1 / 32];
+        chain_gemm<K0, N1>(in0, w1, b1, H1, lane);
+        chain_res<K0, N1>(H1, X, s.vec ? myv : nullptr, a.d.st[0].res, half);
+        chain_act<N1>(H1, a.d.st[0].act);
+        // ---- stage 1: accumulator register r of n-tile nt is operand 16*nt + r
+        float in1[N1 / 2];
+#pragma unroll
+        for (int nt = 0; nt < N1 / 32; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in1[16 * nt + r] = H1[nt][r];
+        f32x16 H2[N2 / 32];
+        chain_gemm<N1, N2>(in1, w2, b2, H2, lane);
+        chain_res<K0, N2>(H2, X, s.vec ? myv : nullptr, a.d.st[1].res, half);
+        chain_act<N2>(H2, a.d.st[1].act);
+        float* row = a.d.out + pix * a.d.ldo;
+        if (N3 > 0) {
+            float in2[N2 / 2];
+#pragma unroll
+            for (int nt = 0; nt < N2 / 32; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) in2[16 * nt + r] = H2[nt][r];
+            f32x16 H3[(N3 > 0 ? N3 : 32) / 32];
+            chain_gemm<N2, (N3 > 0 ? N3 : 32)>(in2, w3, b3, H3, lane);
+            chain_res<K0, (N3 > 0 ? N3 : 32)>(H3, X, s.vec ? myv : nullptr, a.d.st[2].res, half);
+            chain_act<(N3 > 0 ? N3 : 32)>(H3, a.d.st[2].act);
+            chain_store<(N3 > 0 ? N3 : 32)>(H3, row, cout_last, half);
+        } else {
+            chain_store<N2>(H2, row, cout_last, half);
+        }
+    }
+}
+
+// (cout, cin) row-major -> operand order [nt][jq][lane][4]: element i of lane l = W[32*nt + (l & 31)][8*jq + i + 4*(l >> 5)]
+__global__ void pack_chain_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int KP, int NP) {
+    const int total = KP * NP;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int i = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8;
+        const int jq = rest % (KP / 8), nt = rest / (KP / 8);
+        const int n = 32 * nt + (l & 31), k = 8 * jq + i + 4 * (l >> 5);
+        out[idx] = (n < cout && k < cin) ? w[(size_t)n * cin + k] : 0.0f;
+    }
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int K0, int N1, int N2, int N3, int MODE>
+int launch(const ChainArgs& a, hipStream_t st) {
+    static bool configured = false;
+    const size_t lds = (size_t)(N1 * K0 + N2 * N1 + N3 * N2 + N1 + N2 + N3 + 2 * K0 + 8 * K0) * sizeof(float);
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            nd_set_error("nd_pointwise_chain: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        configured = true;
+    }
+    const int waves = nd_cdiv(a.n_tiles, 1);
+    const int grid = waves / 8 < device_cus() ? (waves / 8 > 0 ? waves / 8 : 1) : device_cus();
+    hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE>), dim3(grid), dim3(512), lds, st, a);
+    return 0;
+}
+
+template <int K0, int N1, int N2, int N3>
+int launch_mode(const ChainArgs& a, hipStream_t st) {
+    if (a.d.src.mode == ND_PRO_LAYERNORM) return launch<K0, N1, N2, N3, ND_PRO_LAYERNORM>(a, st);
+    return launch<K0, N1, N2, N3, ND_PRO_NONE>(a, st);
+}
+
+}  // namespace
+
+extern "C" int64_t nd_pack_chain_weight_floats(int cin, int cout, int first_stage) {
+    return (int64_t)nd_round_up(cin, first_stage ? 8 : 32) * nd_round_up(cout, 32);
+}
+
+extern "C" int nd_pack_chain_weight(const float* w, float* packed, int cin, int cout, int first_stage, void* stream) {
+    ND_REQUIRE(w && packed, ND_E_BADARG, "nd_pack_chain_weight: null pointer");
+    ND_REQUIRE(cin > 0 && cout > 0, ND_E_SHAPE, "nd_pack_chain_weight: non-positive size");
+    const int KP = nd_round_up(cin, first_stage ? 8 : 32), NP = nd_round_up(cout, 32);   // later stages read whole 32-wide n-tiles
+    const int total = KP * NP;
+    hipLaunchKernelGGL(pack_chain_kernel, dim3(nd_cdiv(total, 256) < 1024 ? nd_cdiv(total, 256) : 1024), dim3(256), 0, (hipStream_t)stream,
+                       w, packed, cin, cout, KP, NP);
+    return nd_launch_status("nd_pack_chain_weight");
+}
+
+// the (K0, N1, N2, N3) shapes this build instantiates: NoiseDiffNet's Mlp / AttnBlock chains at dim 16, 32, 48, 64
+extern "C" int nd_pointwise_chain_supported(int cin, int n1, int n2, int n3) {
+    const int K0 = nd_round_up(cin, 8), N1 = nd_round_up(n1, 32), N2 = nd_round_up(n2, 32), N3 = n3 > 0 ? nd_round_up(n3, 32) : 0;
+    static const int table[][4] = {{8, 32, 32, 0},  {16, 32, 32, 0}, {16, 32, 32, 32}, {32, 32, 32, 0}, {32, 64, 32, 32},
+                                   {8, 64, 64, 0},  {48, 64, 64, 0}, {48, 96, 64, 64}, {64, 64, 64, 0}, {64, 128, 64, 64},
+                                   {64, 64, 32, 0}, {32, 32, 32, 32}, {48, 64, 32, 0}};
+    for (const auto& e : table)
+        if (e[0] == K0 && e[1] == N1 && e[2] == N2 && e[3] == N3) return 1;
+    return 0;
+}
+
+extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) {
+    ND_REQUIRE(d, ND_E_BADARG, "nd_pointwise_chain: null descriptor");
+    const nd_src& s = d->src;
+    ND_REQUIRE(d->n_stages == 2 || d->n_stages == 3, ND_E_BADARG, "nd_pointwise_chain: n_stages=%d (2 or 3)", d->n_stages);
+    ND_REQUIRE(s.p0 && d->out, ND_E_BADARG, "nd_pointwise_chain: null tensor pointer");
+    ND_REQUIRE(d->B > 0 && d->HW > 0 && d->HW % 32 == 0, ND_E_SHAPE, "nd_pointwise_chain: HW=%d must be a positive multiple of 32", d->HW);
+    ND_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0) == (s.p1 == nullptr), ND_E_SHAPE,
+               "nd_pointwise_chain: source channels %d+%d (multiples of 4; p1 iff c1)", s.c0, s.c1);
+    const int cin = s.c0 + s.c1;
+    ND_REQUIRE(s.ld0 >= s.c0 && s.ld0 % 4 == 0 && (s.c1 == 0 || (s.ld1 >= s.c1 && s.ld1 % 4 == 0)), ND_E_ALIGN,
+               "nd_pointwise_chain: pixel strides must be >= channels and multiples of 4");
+    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_LAYERNORM, ND_E_BADARG, "nd_pointwise_chain: unsupported prologue %d", s.mode);
+    ND_REQUIRE(s.mode != ND_PRO_LAYERNORM || (s.gamma && s.beta), ND_E_BADARG, "nd_pointwise_chain: LayerNorm needs gamma and beta");
+    ND_REQUIRE(!s.upsample && !s.unshuffle && !s.rowstats, ND_E_BADARG, "nd_pointwise_chain: plain pixel addressing only");
+    int width = cin;
+    for (int i = 0; i < d->n_stages; ++i) {
+        const nd_chain_stage& g = d->st[i];
+        ND_REQUIRE(g.weight && g.cin == width && g.cout > 0, ND_E_SHAPE, "nd_pointwise_chain: stage %d is %d->%d, expected input width %d", i,
+                   g.cin, g.cout, width);
+        ND_REQUIRE(g.res == ND_CHAIN_RES_NONE || g.cout == cin, ND_E_SHAPE, "nd_pointwise_chain: stage %d residual needs cout == input width", i);
+        ND_REQUIRE(nd_aligned16(g.weight), ND_E_ALIGN, "nd_pointwise_chain: weights must be 16-byte aligned");
+        width = g.cout;
+    }
+    ND_REQUIRE(width % 4 == 0 && d->ldo >= width && d->ldo % 4 == 0, ND_E_SHAPE, "nd_pointwise_chain: output width %d, ldo %d", width, d->ldo);
+    ND_REQUIRE(nd_aligned16(s.p0) && nd_aligned16(s.p1) && nd_aligned16(d->out), ND_E_ALIGN, "nd_pointwise_chain: tensors must be 16-byte aligned");
+    const int n3 = d->n_stages == 3 ? d->st[2].cout : 0;
+    ND_REQUIRE(nd_pointwise_chain_supported(cin, d->st[0].cout, d->st[1].cout, n3), ND_E_SHAPE,
+               "nd_pointwise_chain: widths %d->%d->%d->%d are not instantiated (use nd_pointwise_gemm_nhwc_f32 per layer)", cin,
+               d->st[0].cout, d->st[1].cout, n3);
+    ChainArgs a;
+    a.d = *d;
+    a.tiles_per_sample = d->HW / 32;
+    const long tiles = (long)d->B * a.tiles_per_sample;
+    ND_REQUIRE(tiles < (1L << 31), ND_E_SHAPE, "nd_pointwise_chain: too many pixels");
+    a.n_tiles = (int)tiles;
+    hipStream_t st = (hipStream_t)stream;
+    const int K0 = nd_round_up(cin, 8), N1 = nd_round_up(d->st[0].cout, 32), N2 = nd_round_up(d->st[1].cout, 32), N3 = n3 ? nd_round_up(n3, 32) : 0;
+    int rc = ND_E_SHAPE;
+#define ND_CHAIN_CASE(k0, n1, n2, n3) \
+    if (K0 == k0 && N1 == n1 && N2 == n2 && N3 == n3) rc = launch_mode<k0, n1, n2, n3>(a, st);
+    ND_CHAIN_CASE(8, 32, 32, 0)
+    ND_CHAIN_CASE(16, 32, 32, 0)
+    ND_CHAIN_CASE(16, 32, 32, 32)
+    ND_CHAIN_CASE(32, 32, 32, 0)
+    ND_CHAIN_CASE(32, 32, 32, 32)
+    ND_CHAIN_CASE(32, 64, 32, 32)
+    ND_CHAIN_CASE(8, 64, 64, 0)
+    ND_CHAIN_CASE(48, 64, 64, 0)
+    ND_CHAIN_CASE(48, 96, 64, 64)
+    ND_CHAIN_CASE(64, 64, 64, 0)
+    ND_CHAIN_CASE(64, 64, 32, 0)
+    ND_CHAIN_CASE(48, 64, 32, 0)
+    ND_CHAIN_CASE(64, 128, 64, 64)
+#undef ND_CHAIN_CASE
+    if (rc) return rc;
+    return nd_launch_status("nd_pointwise_chain_nhwc_f32");
+}

@@ -33,6 +33,9 @@ from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, 
 
 GN_EPS = 1e-5
 WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
+CHAIN = os.environ.get("ND_CHAIN", "1") != "0"           # A-B knob: 0 = one pointwise GEMM launch per Linear layer
+_CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that can open / continue a fused chain (pwchain.hip)
+_CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
 WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two-waves-per-SIMD Winograd kernel (conv3x3_wino.hip)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 
@@ -108,6 +111,9 @@ class Engine:
                 add(p.name + ".wino", self.lib.nd_pack_conv3x3_wino_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind in ("pw", "pw_unshuffle"):
                 n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
+                if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
+                    first = int(p.name.endswith(_CHAIN_FIRST))
+                    add(p.name + ".chain", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
             elif kind == "conv7":
                 n = 196 * p.shape[0]
             else:
@@ -156,6 +162,9 @@ class Engine:
                     L.call("nd_pack_conv3x3_wino_weight", t.data_ptr(), self.p(p.name + ".wino"), p.shape[1], p.shape[0], st)
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
+                    if p.name + ".chain" in self.slots:
+                        L.call("nd_pack_chain_weight", t.data_ptr(), self.p(p.name + ".chain"), p.shape[1], p.shape[0],
+                               int(p.name.endswith(_CHAIN_FIRST)), st)
                 elif kind == "pw_unshuffle":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], p.shape[1] // 4, st)
                 elif kind == "conv7":
@@ -364,10 +373,36 @@ class Plan:
         self._release(c1, st1, sc1, mad1, c2, st2, sc2, mad2)
         return out.view(self.B, H, W, cout)
 
+    def chain(self, name: str, src: L.Src, stages, HW: int) -> torch.Tensor:
+        """Fused per-pixel Linear chain; stages = [(layer, cin, cout, act, res)]."""
+        e = self.e
+        out = self._alloc(self.B, HW, stages[-1][2])
+        d = L.Chain()
+        d.src, d.out, d.n_stages, d.B, d.HW, d.ldo = src, out.data_ptr(), len(stages), self.B, HW, stages[-1][2]
+        for i, (layer, cin, cout, act, res) in enumerate(stages):
+            d.st[i].weight, d.st[i].bias = e.p(layer + ".weight.chain"), e.p(layer + ".bias")
+            d.st[i].cin, d.st[i].cout, d.st[i].act, d.st[i].res = cin, cout, act, res
+        self._add("nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
+                  meta={"layer": name, "B": self.B, "HW": HW, "cin": stages[0][1], "cout": stages[-1][2],
+                        "flop_per_px": 2.0 * sum(c_in * c_out for _, c_in, c_out, _, _ in stages)})
+        self._keep.append(d)
+        return out
+
+    def _chain_ok(self, HW: int, widths) -> bool:
+        w = list(widths) + [0] * (4 - len(widths))
+        return CHAIN and HW % 32 == 0 and bool(self.e.lib.nd_pointwise_chain_supported(*w))
+
     def attn_block(self, name: str, x: torch.Tensor, H: int, W: int) -> torch.Tensor:
         """AttnBlock (Diffusion_arch.py:434-443) with the 1-token CrossAttention folded into cb."""
         Cc, HW = x.shape[-1], H * W
         cb = self.cb[name]
+        if self._chain_ok(HW, (Cc, 2 * Cc, Cc, Cc)):
+            ln = self._src(x, None, L.PRO_LAYERNORM, vec=cb, gamma=self.e.p(name + ".norm2.weight"), beta=self.e.p(name + ".norm2.bias"))
+            y = self.chain(name + ".ff+proj_out", ln,
+                           [(name + ".ff.net.0.0", Cc, 2 * Cc, L.ACT_GELU, L.CHAIN_RES_NONE),
+                            (name + ".ff.net.2", 2 * Cc, Cc, L.ACT_NONE, L.CHAIN_RES_INPUT),
+                            (name + ".proj_out", Cc, Cc, L.ACT_NONE, L.CHAIN_RES_INPUT_RAW)], HW)
+            return y.view(self.B, H, W, Cc)
         kw = {}
         rs = None
         if Cc > 64:      # wide rows: per-pixel {mean, rstd} from a streaming pre-pass (narrow rows: derived inside the GEMM)
@@ -384,6 +419,10 @@ class Plan:
         return y.view(self.B, H, W, Cc)
 
     def mlp(self, name: str, src: L.Src, cin: int, hid: int, cout: int, H: int, W: int, res0=None) -> torch.Tensor:
+        if res0 is None and src.mode == L.PRO_NONE and self._chain_ok(H * W, (cin, hid, cout)):
+            o = self.chain(name, src, [(name + ".fc1", cin, hid, L.ACT_GELU, L.CHAIN_RES_NONE),
+                                       (name + ".fc2", hid, cout, L.ACT_NONE, L.CHAIN_RES_NONE)], H * W)
+            return o.view(self.B, H, W, cout)
         h = self.pw(name + ".fc1", src, cin, hid, H * W, W, act=L.ACT_GELU)
         o = self.pw(name + ".fc2", self._src(h), hid, cout, H * W, W, res0=res0)
         self._release(h)

@@ -146,6 +146,64 @@ def test_pointwise_plain_and_epilogues(ctx, case):
     assert rel_err(out.cpu(), ref) < TOL
 
 
+CHAIN_CASES = {  # (B, HW, [widths]): Mlp chains (two stages) and AttnBlock tails (three stages, LayerNorm + residuals)
+    "mlp1_d64": (2, 64, [8, 64, 64]),
+    "mlp2_d64": (2, 96, [64, 64, 64]),
+    "mlp3_d64": (3, 32, [64, 64, 4]),
+    "mlp_d16": (2, 64, [16, 16, 16]),
+    "mlp_d48": (2, 64, [48, 48, 48]),
+    "ff_d64": (3, 160, [64, 128, 64, 64]),
+    "ff_d48": (2, 64, [48, 96, 48, 48]),
+    "ff_d32": (2, 64, [32, 64, 32, 32]),
+    "ff_d16": (2, 32, [16, 32, 16, 16]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CHAIN_CASES))
+def test_pointwise_chain_matches_layer_by_layer(ctx, case):
+    """nd_pointwise_chain_nhwc_f32 == the same Linear layers applied one by one (Mlp :340-356, AttnBlock tail :405-443)."""
+    import hiputil as hu
+    B, HW, widths = CHAIN_CASES[case]
+    n = len(widths) - 1
+    x = U(case + ".x", (B, HW, widths[0]), -1.5, 1.5)
+    ws = [U(f"{case}.w{i}", (widths[i + 1], widths[i]), -0.3, 0.3) for i in range(n)]
+    bs = [U(f"{case}.b{i}", (widths[i + 1],)) for i in range(n)]
+    keep = []
+    d = L.Chain()
+    for i in range(n):
+        wd = hu.dev(ws[i])
+        wp = hu.full((ctx.lib.nd_pack_chain_weight_floats(widths[i], widths[i + 1], int(i == 0)),))
+        L.call("nd_pack_chain_weight", wd.data_ptr(), wp.data_ptr(), widths[i], widths[i + 1], int(i == 0), ctx.stream)
+        bd = hu.dev(bs[i])
+        keep += [wd, wp, bd]
+        d.st[i].weight, d.st[i].bias, d.st[i].cin, d.st[i].cout = wp.data_ptr(), bd.data_ptr(), widths[i], widths[i + 1]
+    ctx.sync()
+    out = hu.full((B, HW, widths[-1]))
+    d.out, d.n_stages, d.B, d.HW, d.ldo = out.data_ptr(), n, B, HW, widths[-1]
+    if n == 2:          # Mlp: fc2(GELU(fc1(x))); the 8-wide case is the virtual concat cat[clean_img, x] of shot_mlp1
+        if widths[0] == 8:
+            d.src = hu.src(hu.dev(x[..., :4].contiguous()), hu.dev(x[..., 4:].contiguous()))
+        else:
+            d.src = hu.src(hu.dev(x))
+        d.st[0].act = L.ACT_GELU
+        ref = F.linear(F.gelu(F.linear(x, ws[0], bs[0])), ws[1], bs[1])
+    else:               # AttnBlock tail
+        Cc = widths[0]
+        vec, g, be = U(case + ".v", (B, Cc)), U(case + ".g", (Cc,), 0.5, 1.5), U(case + ".be", (Cc,))
+        d.src = hu.src(hu.dev(x), None, L.PRO_LAYERNORM, vec=hu.dev(vec), gamma=hu.dev(g), beta=hu.dev(be))
+        d.st[0].act, d.st[1].res, d.st[2].res = L.ACT_GELU, L.CHAIN_RES_INPUT, L.CHAIN_RES_INPUT_RAW
+        x1 = x + vec[:, None]
+        h = F.gelu(F.linear(F.layer_norm(x1, (Cc,), g, be, eps=1e-5), ws[0], bs[0]))
+        ref = F.linear(F.linear(h, ws[1], bs[1]) + x1, ws[2], bs[2]) + x
+    L.call("nd_pointwise_chain_nhwc_f32", C.byref(d), ctx.stream)
+    ctx.sync()
+    assert rel_err(out.cpu(), ref) < TOL
+    # widths this build does not instantiate are refused, not approximated
+    d.st[0].cout = d.st[1].cin = 160
+    assert ctx.lib.nd_pointwise_chain_nhwc_f32(C.byref(d), ctx.stream) != 0
+    assert b"not instantiated" in ctx.lib.nd_last_error()
+
+
 def test_pointwise_prologues(ctx):
     import hiputil as hu
     B, H, W, Cc = 2, 16, 16, 64

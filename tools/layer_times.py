@@ -50,7 +50,7 @@ for i, (fn, args, name, meta) in enumerate(ops):
         desc = f"{meta['layer']} {meta['cin']}->{meta['cout']} @{meta['H']}x{meta['W']} t{meta['tiling']} m{desc_mode}"
         gbs, tf = by / ms / 1e6, fl / ms / 1e9
     elif meta:
-        fl = 2.0 * meta["cin"] * meta["cout"] * meta["HW"] * meta["B"]
+        fl = meta.get("flop_per_px", 2.0 * meta["cin"] * meta["cout"]) * meta["HW"] * meta["B"]
         by = 4.0 * meta["B"] * meta["HW"] * (meta["cin"] + meta["cout"])
         desc = f"{meta['layer']} {meta['cin']}->{meta['cout']} @{meta['HW']}px"
         gbs, tf = by / ms / 1e6, fl / ms / 1e9
