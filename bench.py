@@ -298,11 +298,11 @@ def main():
         tid, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
         traffic, tsrc = None, None
-        tfile = os.path.join(REPO, "profiles", "r1c_traffic.json")      # PMC passes cannot run inside this process
+        tfile = os.path.join(REPO, "profiles", "r1d_traffic.json")      # PMC passes cannot run inside this process
         if os.path.exists(tfile) and (a.dim, a.size, a.batch) == (64, 256, 16):
             tk = json.load(open(tfile))["kernels"].get(kname(tid))
             if tk:
-                traffic, tsrc = tk["hbm_bytes_per_launch"], "profiles/r1c_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+                traffic, tsrc = tk["hbm_bytes_per_launch"], "profiles/r1d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
         out["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "traffic_source": tsrc,
