@@ -127,48 +127,80 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     }
 }
 
-// init_conv: Conv2d(4, cout, 7, padding=3) (:478).  16x16 output pixels per workgroup; the 22x22x4 input
-// patch sits in LDS, weights [49*4][cout] are wave-uniform and come through the scalar cache.
-constexpr int C7_T = 16, C7_HALO = C7_T + 6, C7_CO = 16;
+// init_conv: Conv2d(4, cout, 7, padding=3) (:478) as an implicit GEMM on the fp32 MFMA, K = 49 taps x 4 channels.
+// Transposed product (rows = output channels, columns = 32 pixels of one image row) so that a lane ends up with 16
+// channels of ONE pixel and stores 16-byte pieces.  A wave owns one 32-channel n-tile: its 98 weight operands
+// (lane (n, half): W[n][tap][c], instruction 2*tap + jj pairs channels (jj, jj + 2)) stay in registers for the whole
+// persistent kernel; the pixel operand of a tap is one ds_read_b64 from the zero-padded 22 x 38 x 4 halo tile in LDS
+// (lane (p, half) reads channels 2*half, 2*half + 1 of pixel p + dx: 512 contiguous bytes per wave, conflict-free).
+// Per 32 pixels x 32 channels: 49 LDS reads, 98 MFMAs, no VALU in the loop.
+constexpr int C7_TH = 16, C7_TW = 32, C7_HH = C7_TH + 6, C7_HW = C7_TW + 6;
 
-__global__ __launch_bounds__(256) void conv7x7_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int ldo, int H, int W, int cout) {
-    __shared__ __attribute__((aligned(16))) float tile[C7_HALO * C7_HALO * 4];
-    const int b = blockIdx.z, ty0 = blockIdx.y * C7_T, tx0 = blockIdx.x * C7_T;
-    for (int i = threadIdx.x; i < C7_HALO * C7_HALO; i += 256) {
-        const int hy = i / C7_HALO, hx = i - hy * C7_HALO;
-        const int y = ty0 + hy - 3, xx = tx0 + hx - 3;
-        f32x4 v = {0, 0, 0, 0};
-        if (y >= 0 && y < H && xx >= 0 && xx < W) v = nd_ld4(x + ((size_t)(b * H + y) * W + xx) * 4);
-        nd_st4(&tile[i * 4], v);
+template <int NT>   // n-tiles of 32 output channels (power of two, <= 8); 8 waves = NT n-tiles x 8/NT row groups
+__global__ __launch_bounds__(512, 1) void conv7x7_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int ldo, int B, int H, int W, int cout) {
+    __shared__ __attribute__((aligned(16))) float tile[C7_HH * C7_HW * 4];
+    constexpr int RG = 8 / NT;                           // row groups; a wave takes rows rg, rg + RG, ...
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int nt = wave % NT, rg = wave / NT;
+    const int n = nt * 32 + col;
+    // ---- this wave's weights: packed [tap*4 + c][cout]
+    float wr[98];
+#pragma unroll
+    for (int t = 0; t < 49; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) wr[2 * t + jj] = n < cout ? wp[(size_t)(t * 4 + jj + 2 * half) * cout + n] : 0.0f;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n0 = nt * 32 + 8 * g + 4 * half;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[g][i] = n0 + i < cout ? bias[n0 + i] : 0.0f;
     }
-    __syncthreads();
-    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
-    const int y = ty0 + ly, xx = tx0 + lx;
-    for (int co0 = 0; co0 < cout; co0 += C7_CO) {
-        float acc[C7_CO];
+    const int tiles_x = (W + C7_TW - 1) / C7_TW, tiles_y = (H + C7_TH - 1) / C7_TH;
+    const int n_tiles = B * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int ty0 = ty * C7_TH, tx0 = tx * C7_TW;
+        __syncthreads();                                   // previous tile consumed
+        for (int i = tid; i < C7_HH * C7_HW; i += 512) {
+            const int hy = i / C7_HW, hx = i - hy * C7_HW;
+            const int y = ty0 + hy - 3, xx = tx0 + hx - 3;
+            f32x4 v = {0, 0, 0, 0};
+            if (y >= 0 && y < H && xx >= 0 && xx < W) v = nd_ld4(x + ((size_t)(b * H + y) * W + xx) * 4);
+            nd_st4(&tile[i * 4], v);
+        }
+        __syncthreads();
+        for (int ly = rg; ly < C7_TH; ly += RG) {
+            f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < C7_CO; ++j) acc[j] = (co0 + j < cout) ? bias[co0 + j] : 0.0f;
-        for (int ky = 0; ky < 7; ++ky)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const f32x4 v = nd_ld4(&tile[((ly + ky) * C7_HALO + lx + kx) * 4]);
-                const float* wr = wp + (size_t)((ky * 7 + kx) * 4) * cout + co0;   // uniform address
+                for (int i = 0; i < 4; ++i) acc[4 * g + i] = bias4[g][i];
+            const float* base = &tile[(ly * C7_HW + col) * 4 + 2 * half];
 #pragma unroll
-                for (int j = 0; j < C7_CO; ++j) {
-                    if (co0 + j < cout) {
-                        acc[j] = fmaf(v.x, wr[j], acc[j]);
-                        acc[j] = fmaf(v.y, wr[cout + j], acc[j]);
-                        acc[j] = fmaf(v.z, wr[2 * cout + j], acc[j]);
-                        acc[j] = fmaf(v.w, wr[3 * cout + j], acc[j]);
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const float2 v = *reinterpret_cast<const float2*>(base + (ky * C7_HW + kx) * 4);
+                    acc = nd_mfma(wr[2 * (ky * 7 + kx)], v.x, acc);
+                    acc = nd_mfma(wr[2 * (ky * 7 + kx) + 1], v.y, acc);
+                }
+            const int y = ty0 + ly, xx = tx0 + col;
+            if (y < H && xx < W) {
+                float* o = out + ((size_t)(b * H + y) * W + xx) * ldo;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n0 = nt * 32 + 8 * g + 4 * half;
+                    if (n0 + 4 <= cout) {
+                        nd_st4(o + n0, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]});
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (n0 + i < cout) o[n0 + i] = acc[4 * g + i];
                     }
                 }
             }
-        if (y < H && xx < W) {
-            float* o = out + ((size_t)(b * H + y) * W + xx) * ldo + co0;
-#pragma unroll
-            for (int j = 0; j < C7_CO; ++j)
-                if (co0 + j < cout) o[j] = acc[j];
         }
     }
 }
@@ -251,8 +283,22 @@ extern "C" int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const flo
     ND_REQUIRE(x && wpacked && bias && out, ND_E_BADARG, "nd_conv7x7_c4: null pointer");
     ND_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && ldo >= cout, ND_E_SHAPE, "nd_conv7x7_c4: bad shape");
     ND_REQUIRE(nd_aligned16(x), ND_E_ALIGN, "nd_conv7x7_c4: x must be 16-byte aligned");
-    ND_REQUIRE(B <= 65535 && nd_cdiv(H, C7_T) <= 65535, ND_E_SHAPE, "nd_conv7x7_c4: grid too large");
-    hipLaunchKernelGGL(conv7x7_kernel, dim3(nd_cdiv(W, C7_T), nd_cdiv(H, C7_T), B), dim3(256), 0, (hipStream_t)stream, x, wpacked,
-                       bias, out, ldo, H, W, cout);
+    ND_REQUIRE(cout <= 256 && ldo % 4 == 0 && nd_aligned16(out), ND_E_SHAPE, "nd_conv7x7_c4: cout <= 256, ldo %% 4 == 0, out 16-byte aligned");
+    const long tiles = (long)B * nd_cdiv(H, C7_TH) * nd_cdiv(W, C7_TW);
+    ND_REQUIRE(tiles < (1L << 31), ND_E_SHAPE, "nd_conv7x7_c4: grid too large");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), block(512);
+    const int ntiles = nd_cdiv(cout, 32);
+#define ND_C7_LAUNCH(NT) hipLaunchKernelGGL(conv7x7_kernel<NT>, grid, block, 0, (hipStream_t)stream, x, wpacked, bias, out, ldo, B, H, W, cout)
+    if (ntiles <= 1) ND_C7_LAUNCH(1);
+    else if (ntiles <= 2) ND_C7_LAUNCH(2);
+    else if (ntiles <= 4) ND_C7_LAUNCH(4);
+    else ND_C7_LAUNCH(8);
+#undef ND_C7_LAUNCH
     return nd_launch_status("nd_conv7x7_c4_f32");
 }

@@ -322,7 +322,7 @@ def test_small_ops(ctx):
     assert torch.equal(a.cpu(), x4.permute(0, 2, 3, 1)) and torch.equal(bb.cpu(), x4)
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 40, 24, 48), (2, 64, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 40, 24, 48), (2, 64, 64, 64), (1, 19, 45, 128), (1, 16, 32, 20)])
 def test_conv7x7(ctx, shape):
     import hiputil as hu
     B, H, W, cout = shape
