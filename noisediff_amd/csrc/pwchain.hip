@@ -95,7 +95,6 @@ __device__ __forceinline__ void chain_store(const f32x16 (&acc)[N / 32], float* 
 template <int K0, int N1, int N2, int N3, int MODE>
 __global__ __launch_bounds__(512, 1) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NL = N3 > 0 ? N3 : N2;                 // last stage width
     float* w1 = lds;
     float* w2 = w1 + N1 * K0;
     float* w3 = w2 + N2 * N1;
