@@ -15,8 +15,8 @@
 // output is written as 16-byte pieces.
 //
 // Weights (packed in operand order by nd_pack_chain_weight), biases and LayerNorm gamma/beta of all stages sit in LDS for
-// the lifetime of the persistent workgroup (80 KB at C = 64): an A fragment is one ds_read_b128 per four MFMAs.  Two waves
-// per SIMD (512 threads, <= 256 registers each) let one wave's activation VALU run under the other's MFMAs.
+// the lifetime of the persistent workgroup (80 KB at C = 64): an A fragment is one ds_read_b128 per four MFMAs.  Three or
+// four waves per SIMD (768 / 1024 threads) let one wave's activation VALU run under the others' MFMAs.
 #include <type_traits>
 #include "nd_common.h"
 
@@ -92,8 +92,13 @@ __device__ __forceinline__ void chain_store(const f32x16 (&acc)[N / 32], float* 
 }
 
 // K0: stage-0 input channels rounded up to 8; N1, N2, N3: stage widths rounded up to 32 (N3 = 0: two stages)
+// waves per workgroup: as many as the register budget of the widest stage allows (3 or 4 per SIMD) -- the activation
+// VALU of one wave runs under the MFMAs of the others
+constexpr int chain_threads(int n1) { return n1 >= 128 ? 768 : 1024; }
+
 template <int K0, int N1, int N2, int N3, int MODE>
-__global__ __launch_bounds__(512, 1) void chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const ChainArgs a) {
+    constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w1 = lds;
     float* w2 = w1 + N1 * K0;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const ChainArgs a) {
     float* b3 = b2 + N2;
     float* gam = b3 + (N3 > 0 ? N3 : 0);
     float* bet = gam + K0;
-    float* vst = bet + K0;                                // [8 waves][K0]: this wave's per-sample vector
+    float* vst = bet + K0;                                // [WAVES][K0]: this wave's per-sample vector
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const nd_src& s = a.d.src;
@@ -112,10 +117,10 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const ChainArgs a) {
     // ---- weights, biases, gamma/beta -> LDS (once per persistent workgroup)
     {
         auto copy4 = [&](float* dst, const float* src, int n) {
-            for (int i = tid * 4; i < n; i += 512 * 4) nd_st4(dst + i, nd_ld4(src + i));
+            for (int i = tid * 4; i < n; i += THREADS * 4) nd_st4(dst + i, nd_ld4(src + i));
         };
         auto copy_pad = [&](float* dst, const float* src, int n, int npad, float fill) {
-            for (int i = tid; i < npad; i += 512) dst[i] = (src && i < n) ? src[i] : fill;
+            for (int i = tid; i < npad; i += THREADS) dst[i] = (src && i < n) ? src[i] : fill;
         };
         copy4(w1, a.d.st[0].weight, N1 * K0);
         copy4(w2, a.d.st[1].weight, N2 * N1);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(512, 1) void chain_kernel(const ChainArgs a) {
     __syncthreads();
 
     // ---- contiguous range of 32-pixel tiles for this wave (a sample's vector is reloaded only when b changes)
-    const int n_waves = gridDim.x * 8, wid = blockIdx.x * 8 + wave;
+    const int n_waves = gridDim.x * WAVES, wid = blockIdx.x * WAVES + wave;
     const int t_begin = (int)((long)wid * a.n_tiles / n_waves), t_end = (int)((long)(wid + 1) * a.n_tiles / n_waves);
     float* myv = vst + wave * K0;
     int b_cur = -1;
@@ -246,7 +251,8 @@ int device_cus() {
 template <int K0, int N1, int N2, int N3, int MODE>
 int launch(const ChainArgs& a, hipStream_t st) {
     static bool configured = false;
-    const size_t lds = (size_t)(N1 * K0 + N2 * N1 + N3 * N2 + N1 + N2 + N3 + 2 * K0 + 8 * K0) * sizeof(float);
+    constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
+    const size_t lds = (size_t)(N1 * K0 + N2 * N1 + N3 * N2 + N1 + N2 + N3 + 2 * K0 + WAVES * K0) * sizeof(float);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -256,9 +262,9 @@ int launch(const ChainArgs& a, hipStream_t st) {
         }
         configured = true;
     }
-    const int waves = nd_cdiv(a.n_tiles, 1);
-    const int grid = waves / 8 < device_cus() ? (waves / 8 > 0 ? waves / 8 : 1) : device_cus();
-    hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE>), dim3(grid), dim3(512), lds, st, a);
+    const int wgs = nd_cdiv(a.n_tiles, WAVES);
+    const int grid = wgs < device_cus() ? wgs : device_cus();
+    hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE>), dim3(grid), dim3(THREADS), lds, st, a);
     return 0;
 }
 
