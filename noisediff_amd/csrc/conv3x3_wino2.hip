@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     };
     unsigned mask_cur = 0, mask_next = 0;                  // inside-image masks of this tile and the next one
     int par = 0;                                           // table of this tile; the next tile's is par ^ 1
-    int ipar = 0;                                          // table of the item being staged
+    const unsigned* itab = tab;                            // pixel table of the item being staged
     // activations, like the weights, come through buffer loads (SGPR resource + scalar channel offset, 32-bit lane
     // offset = pixel * stride + quad): cheap to issue, and a lane whose channels lie beyond the tensor reads zeros.
     // A K chunk never straddles the two concat sources (host check), so the source is wave-uniform per chunk.
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     __amdgpu_buffer_rsrc_t irsrc = rsrc0;
     int isoff = 0, imoff = 0;                              // scalar byte offsets: channel base inside the source / the map
     auto issue_begin = [&](int b_, int cb_, int par_, unsigned tilemask) {   // per chunk: channel quad of this thread
-        ipar = par_;
+        itab = tab + (1 + par_) * STAGE_IT * 256;
         const bool sec = cb_ >= s.c0;                      // wave-uniform
         second = sec;
         irsrc = sec ? rsrc1 : rsrc0;
@@ -175,12 +175,14 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         okmask = cvalid ? tilemask : 0u;
     };
     auto issue_one = [&](int it) {
-        const unsigned pix = tab[((1 + ipar) * STAGE_IT + it) * 256];
-        raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, (unsigned)(__umul24(pix, ild4) + quad * 16), isoff, 0));
+        const unsigned pix = itab[it * 256];
+        // the scalar offsets are wave-uniform by construction; saying so keeps hipcc from wrapping each load in a waterfall loop
+        raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, (unsigned)(__umul24(pix, ild4) + quad * 16),
+                                                                                  __builtin_amdgcn_readfirstlane(isoff), 0));
         if (MAP) {                                         // the map has the conv's resolution (host: no upsample with MAP)
             const unsigned mo = (unsigned)(__umul24(pix, 2 * Ctot * 4) + quad * 16);
-            msc[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, imoff, 0));
-            msh[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, imoff + Ctot * 4, 0));
+            msc[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, __builtin_amdgcn_readfirstlane(imoff), 0));
+            msh[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, __builtin_amdgcn_readfirstlane(imoff + Ctot * 4), 0));
         }
     };
     auto commit = [&](int it, float* dst) {                // prologue transform + zero padding, registers -> LDS
