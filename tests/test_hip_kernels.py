@@ -102,6 +102,43 @@ def test_conv3x3_concat_upsample_and_prologues(ctx):
     assert rel_err(hu.nchw(out), ref) < TOL
 
 
+@pytest.mark.parametrize("entry", ["nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32"])
+def test_conv3x3_winograd_addressing_and_prologues(ctx, entry):
+    """Both Winograd kernels: nearest-x2 upsample addressing, the per-pixel scale/shift map (ResnetBlock2), the LSID
+    LeakyReLU prologues (whole input / second concat source only), on image sizes that are not multiples of the tile."""
+    import hiputil as hu
+
+    def run(s, w, b, B, H, W):
+        cout, cin = w.shape[:2]
+        wd = hu.dev(w)
+        wp = hu.full((ctx.lib.nd_pack_conv3x3_wino_weight_floats(cin, cout),))
+        L.call("nd_pack_conv3x3_wino_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+        out, bd = hu.full((B, H, W, cout)), hu.dev(b)
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        L.call(entry, C.byref(d), ctx.stream)
+        ctx.sync()
+        return hu.nchw(out)
+
+    B, H, W = 2, 36, 52                                    # 3 x 4 tiles, ragged on both axes
+    xs = U("wa.up", (B, 32, H // 2, W // 2))
+    w, b = U("wa.w", (40, 32, 3, 3), -0.2, 0.2), U("wa.b", (40,))
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)
+    assert rel_err(run(hu.src(hu.nhwc(xs), upsample=1), w, b, B, H, W), ref) < 1e-5
+    x = U("wa.x", (B, 32, H, W), -2, 2)
+    M, A, D = U("wa.M", (B, 32)), U("wa.A", (B, 32), 0.5, 1.5), U("wa.D", (B, 32))
+    sc, sh = U("wa.sc", (B, 32, H, W), -0.5, 0.5), U("wa.sh", (B, 32, H, W), -0.5, 0.5)
+    act = F.silu(((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None]) * (sc + 1) + sh)
+    s = hu.src(hu.nhwc(x), None, L.PRO_AFFINE_MAP_SILU, mad=hu.dev(torch.stack((M, A, D), 1)), map=hu.nhwc(torch.cat((sc, sh), 1)))
+    assert rel_err(run(s, w, b, B, H, W), F.conv2d(act, w, b, padding=1)) < 1e-5
+    assert rel_err(run(hu.src(hu.nhwc(x), None, L.PRO_LEAKY), w, b, B, H, W), F.conv2d(F.leaky_relu(x, 0.2), w, b, padding=1)) < 1e-5
+    x2 = U("wa.x2", (B, 32, H, W), -2, 2)                  # cat(up, skip): LeakyReLU on the skip only (SID_arch.py:135-139)
+    w2 = U("wa.w2", (24, 64, 3, 3), -0.2, 0.2)
+    ref = F.conv2d(torch.cat((x, F.leaky_relu(x2, 0.2)), 1), w2, b[:24], padding=1)
+    assert rel_err(run(hu.src(hu.nhwc(x), hu.nhwc(x2), L.PRO_LEAKY_SECOND), w2, b[:24], B, H, W), ref) < 1e-5
+
+
 def test_conv3x3_rejects_bad_arguments(ctx):
     import hiputil as hu
     x = hu.nhwc(U("bad.x", (1, 12, 8, 8)))
