@@ -303,6 +303,12 @@ def main():
             tk = json.load(open(tfile))["kernels"].get(kname(tid))
             if tk:
                 traffic, tsrc = tk["hbm_bytes_per_launch"], "profiles/r1d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+        busy_pmc = None
+        bfile = os.path.join(REPO, "profiles", "r1d_mfma_busy.json")     # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), own PMC pass
+        if os.path.exists(bfile) and (a.dim, a.size, a.batch) == (64, 256, 16):
+            bk = json.load(open(bfile))["kernels"].get(kname(tid))
+            if bk:
+                busy_pmc = bk["matrix_pipe_busy_frac"]
         out["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "traffic_source": tsrc,
@@ -310,6 +316,7 @@ def main():
             # Winograd F(2x2,3x3) kernels issue 2.25x fewer MFMA FLOPs than the algorithmic count `achieved` is priced in,
             # so frac can exceed 1; matrix_pipe_frac = issued MFMA FLOP/s over the same peak
             "matrix_pipe_frac": ach / (2.25 if tid[0] >= 9001 else 1.0) / PEAK_FP32_MFMA_TFLOPS,
+            "matrix_pipe_busy_pmc": busy_pmc,
             "avg_launch_ms": d["ms"] / d["launches"], "launches_per_step": d["launches"] // n_inst,
             "algorithmic_flop_per_launch": d["flop"] / d["launches"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
