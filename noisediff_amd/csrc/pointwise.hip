@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     int a_off[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) a_off[mb] = ((wm * MB + mb) * 32 + col) * LDA + 4 * half;
-    const float* wbase = a.d.weight + ((size_t)half * a.coutP + n0 + wn * NB * 32 + col) * 4;
+    // weight fragments through buffer loads: resource + scalar chunk offset + constant lane offset (cheaper to issue
+    // next to the MFMAs than 64-bit per-lane addresses, tools/microbench/mfma_issue.hip)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d.weight), 0, a.cinP * a.coutP * 4, 0x00020000);
+    const unsigned wvoff = (unsigned)((half * a.coutP + n0 + wn * NB * 32 + col) * 16);
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
         for (int g = 0; g < 8; ++g)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                bq[g][nb] = nd_ld4(wbase + ((size_t)((cb >> 2) + 2 * min(g, ng - 1)) * a.coutP + nb * 32) * 4);
+                bq[g][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, wvoff, __builtin_amdgcn_readfirstlane((((cb >> 2) + 2 * min(g, ng - 1)) * a.coutP + nb * 32) * 16), 0));
         {
             const int c = cb + quad * 4;
             const bool cvalid = c < Cin;
