@@ -203,14 +203,25 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #pragma unroll
     for (int p = 0; p < 16; ++p) M[p] = nd_zero16();
 
+    // tile coordinates of this tile, the next one and the one after: decoded once, then advanced with carries
+    // (the three integer divisions of decode() cost the in-order wave several hundred cycles per tile)
+    auto advance = [&](int& b_, int& ty_, int& tx_, int& nt_) {
+        if (++nt_ == a.n_tiles) {
+            nt_ = 0;
+            if (++tx_ == a.tiles_x) {
+                tx_ = 0;
+                if (++ty_ == a.tiles_y) { ty_ = 0; ++b_; }
+            }
+        }
+    };
     int b, ty, tx, nt;
     decode(t_begin, b, ty, tx, nt);
+    int b1 = b, ty1 = ty, tx1 = tx, nt1 = nt;
+    advance(b1, ty1, tx1, nt1);
+    int b2 = b1, ty2 = ty1, tx2 = tx1, nt2 = nt1;
+    advance(b2, ty2, tx2, nt2);
     mask_cur = tile_table(0, b, ty, tx);
-    if (t_begin + 1 < t_end) {
-        int b1, ty1, tx1, nt1;
-        decode(t_begin + 1, b1, ty1, tx1, nt1);
-        mask_next = tile_table(1, b1, ty1, tx1);
-    }
+    if (t_begin + 1 < t_end) mask_next = tile_table(1, b1, ty1, tx1);
     issue_begin(b, 0, 0, mask_cur);
 #pragma unroll
     for (int it = 0; it < STAGE_IT; ++it) issue_one(it);
@@ -267,9 +278,8 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         for (int nu = 0; nu < 4; ++nu) load_w1(wblock, w, nu);
 
     for (int t = t_begin; t < t_end; ++t) {
-        int nb_ = b, nty = ty, ntx = tx, nnt = nt;
         const bool more_tiles = t + 1 < t_end;
-        if (more_tiles) decode(t + 1, nb_, nty, ntx, nnt);
+        const int nb_ = more_tiles ? b1 : b, nnt = more_tiles ? nt1 : nt;   // the tile whose first chunk is staged during this tile's last one
 
         for (int ch = 0; ch < n_chunks; ++ch) {
             const float* src = As + cur * BUF;
@@ -331,11 +341,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         W2_MFMA_DRAIN();
         // this tile's pixel table is free now: fill it for the tile after next (its staging starts one tile from now)
         mask_cur = mask_next;
-        if (t + 2 < t_end) {
-            int b2, ty2, tx2, nt2;
-            decode(t + 2, b2, ty2, tx2, nt2);
-            mask_next = tile_table(par, b2, ty2, tx2);
-        }
+        if (t + 2 < t_end) mask_next = tile_table(par, b2, ty2, tx2);
         par ^= 1;
 #ifdef W2_STAMP
         const unsigned long long stamp_e0 = __builtin_amdgcn_s_memtime();
@@ -356,6 +362,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             float* lane_out = a.d.out + ((size_t)(b * H + wrow0) * W + tx * 16 + 8 * half) * a.d.ldo + n;
             const bool full = rows_valid == 8 && cols_valid == 16 && nt * 64 + 64 <= Cout;   // wave-uniform
             float pivot = 0.0f, sS = 0.0f, sQ = 0.0f;
+            f32x2 sS2 = {0.0f, 0.0f}, sQ2 = {0.0f, 0.0f};
             int Wt = W, ldot = a.d.ldo;
             asm volatile("" : "+s"(Wt), "+s"(ldot));      // per tile: keeps 64 store offsets from being hoisted into (spilled) SGPRs
             auto emit = [&](auto full_c) {
@@ -383,9 +390,11 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
                             const int dy = 2 * (r >> 2) + i, dx = 2 * (r & 3) + j + 8 * half;
                             float* dstp = lane_out + (size_t)(((2 * (r >> 2) + i) * Wt + 2 * (r & 3) + j) * ldot);
                             if (FULL) {
-                                const float dv = y[r] - pivot;
-                                sS += dv;
-                                sQ = fmaf(dv, dv, sQ);
+                                if ((r & 1) == 0) {        // shifted sums two values per VALU slot
+                                    const f32x2 dv = f32x2{y[r], y[r + 1]} - pivot;
+                                    sS2 += dv;
+                                    sQ2 += dv * dv;
+                                }
                                 *dstp = y[r];
                             } else if (dy < rows_valid && dx < cols_valid) {
                                 const float dv = y[r] - pivot;
@@ -404,6 +413,8 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) M[p] = nd_zero16();
             if (a.d.stats) {
+                sS += sS2[0] + sS2[1];
+                sQ += sQ2[0] + sQ2[1];
                 sS += __shfl_xor(sS, 32);
                 sQ += __shfl_xor(sQ, 32);
                 if (half == 0 && nvalid) {
@@ -420,7 +431,9 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #ifdef W2_STAMP
         stamp_epi += __builtin_amdgcn_s_memtime() - stamp_e0;
 #endif
-        b = nb_; ty = nty; tx = ntx; nt = nnt;
+        b = b1; ty = ty1; tx = tx1; nt = nt1;
+        b1 = b2; ty1 = ty2; tx1 = tx2; nt1 = nt2;
+        advance(b2, ty2, tx2, nt2);
     }
 #ifdef W2_STAMP
     if (tid == 0) {
