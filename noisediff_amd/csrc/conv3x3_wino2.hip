@@ -130,8 +130,21 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         tab[it * 256] = slot | ((unsigned)hy << 20) | ((unsigned)hx << 26);
     }
     // per tile: clamped source pixel of every halo pixel of this thread -> table `par`; returns the inside-image mask
+    unsigned mask_all = 0;                                 // bit it: iteration it of this thread is a real halo pixel
+#pragma unroll
+    for (int it = 0; it < STAGE_IT; ++it) mask_all |= (stid + it * 32 < NPIX ? 1u : 0u) << it;
     auto tile_table = [&](int par, int b_, int ty_, int tx_) -> unsigned {
         const int y0 = ty_ * 16 - 1, x0 = tx_ * 16 - 1;
+        unsigned* dstt = tab + (1 + par) * STAGE_IT * 256;
+        if (ty_ > 0 && tx_ > 0 && y0 + HT <= H && x0 + HT <= W) {      // halo entirely inside the image (wave-uniform): no clamps, no tests
+#pragma unroll
+            for (int it = 0; it < STAGE_IT; ++it) {
+                const unsigned c = tab[it * 256];
+                const int y = y0 + (int)((c >> 20) & 31u), x = x0 + (int)(c >> 26);      // dummy lanes (31, 31): some pixel of the image, masked
+                dstt[it * 256] = (unsigned)((b_ * sH + (min(y, H - 1) >> up)) * sW + (min(x, W - 1) >> up));
+            }
+            return mask_all;
+        }
         unsigned mask = 0;
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             const bool ok = (c >> 26) != 31u && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             mask |= (ok ? 1u : 0u) << it;
             const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-            tab[((1 + par) * STAGE_IT + it) * 256] = (unsigned)((b_ * sH + (yc >> up)) * sW + (xc >> up));
+            dstt[it * 256] = (unsigned)((b_ * sH + (yc >> up)) * sW + (xc >> up));
         }
         return mask;
     };
