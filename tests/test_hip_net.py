@@ -48,6 +48,22 @@ def test_net_forward_matches_reference_golden(golden, dim, H):
         assert rel_err(y.cpu().numpy(), golden("net", f"net.d{dim}.h{H}.tmixed")) < NET_TOL
 
 
+@pytest.mark.parametrize("dim,H", [(48, 64), (64, 32)])
+def test_net_forward_other_widths_match_oracle(dim, H):
+    """Widths the fixtures do not cover: 48 (the reference's default --dim: channel counts that are not multiples of 32,
+    K chunks straddling concat sources -> the fallback kernels) and 64 (the benchmark width), against the pinned oracle."""
+    B = 2
+    net = make_net(dim)
+    sd = state_dict(dim)
+    cond = synth.make_condition(B, H, seed=3)
+    x = synth.make_noise(4, "net.x", B, 4, H)
+    t = torch.tensor([17, 640])
+    with torch.inference_mode():
+        y = net(x.to(DEV), t.to(DEV), to_dev(cond)).cpu()
+        ref = O.noisediff_forward(sd, x, t, cond)
+    assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
+
+
 def test_net_intermediates_match_reference_taps(golden):
     """Layer-by-layer agreement (debug plan keeps every named intermediate)."""
     dim, H, B = 32, 64, 2
