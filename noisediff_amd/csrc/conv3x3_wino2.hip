@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         tab[it * 256] = slot | ((unsigned)hy << 20) | ((unsigned)hx << 26);
     }
     // per tile: clamped source pixel of every halo pixel of this thread -> table `par`; returns the inside-image mask
+    const unsigned px_oob = (unsigned)a.d.B * (unsigned)sH * (unsigned)sW;   // < 2^24 (host check): offset == num_records, out of range
     unsigned mask_all = 0;                                 // bit it: iteration it of this thread is a real halo pixel
 #pragma unroll
     for (int it = 0; it < STAGE_IT; ++it) mask_all |= (stid + it * 32 < NPIX ? 1u : 0u) << it;
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             const bool ok = (c >> 26) != 31u && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             mask |= (ok ? 1u : 0u) << it;
             const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-            dstt[it * 256] = (unsigned)((b_ * sH + (yc >> up)) * sW + (xc >> up));
+            // outside the image: the pixel index one past the tensor, so the buffer load itself returns the zero padding
+            dstt[it * 256] = ok ? (unsigned)((b_ * sH + (yc >> up)) * sW + (xc >> up)) : px_oob;
         }
         return mask;
     };
@@ -206,8 +208,10 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             v = nd_silu4(v);
         }
         if (MODE == ND_PRO_LEAKY || (MODE == ND_PRO_LEAKY_SECOND && second)) v = nd_leaky4(v);
-        const f32x4 zero = {0, 0, 0, 0};
-        v = ((okmask >> it) & 1u) ? v : zero;
+        if (AFF) {                                         // silu(affine(0)) != 0: the padding is applied after the activation
+            const f32x4 zero = {0, 0, 0, 0};
+            v = ((okmask >> it) & 1u) ? v : zero;
+        }   // otherwise out-of-image pixels were loaded as zeros (px_oob) and channels beyond cin meet zero weights
         const unsigned slot = tab[it * 256] & 0xFFFFFu;
         nd_st4(reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + slot), v);
     };

@@ -77,11 +77,9 @@ __device__ __forceinline__ f32x4 nd_silu4(f32x4 v) {
     return r;
 }
 
-__device__ __forceinline__ f32x4 nd_leaky4(f32x4 v) {      // nn.LeakyReLU(negative_slope=0.2)
-    f32x4 r;
-    r.x = v.x > 0.0f ? v.x : 0.2f * v.x; r.y = v.y > 0.0f ? v.y : 0.2f * v.y;
-    r.z = v.z > 0.0f ? v.z : 0.2f * v.z; r.w = v.w > 0.0f ? v.w : 0.2f * v.w;
-    return r;
+__device__ __forceinline__ f32x4 nd_leaky4(f32x4 v) {      // nn.LeakyReLU(negative_slope=0.2) == max(v, 0.2 v)
+    const f32x4 w = v * 0.2f;
+    return f32x4{fmaxf(v[0], w[0]), fmaxf(v[1], w[1]), fmaxf(v[2], w[2]), fmaxf(v[3], w[3])};
 }
 
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane.  Four VALU adds with DPP
