@@ -41,6 +41,8 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(L.Conv3x3) == C.sizeof(L.Src) + 5 * 8 + 6 * 4
     assert C.sizeof(L.Pointwise) == C.sizeof(L.Src) + 8 * 8 + 13 * 4 + 4     # 13 int32 + tail padding to 8
     assert C.sizeof(L.SamplerState) == 5 * 8 + 2 * 4
+    assert C.sizeof(L.ChainStage) == 2 * 8 + 4 * 4
+    assert C.sizeof(L.Chain) == C.sizeof(L.Src) + 3 * C.sizeof(L.ChainStage) + 8 + 4 * 4
 
 
 def test_host_only_entry_points_validate_arguments():
@@ -59,6 +61,20 @@ def test_host_only_entry_points_validate_arguments():
     d.src.c0, d.src.ld0 = 12, 12
     d.B, d.H, d.W, d.cin, d.cout, d.ldo = 1, 8, 8, 12, 8, 8
     assert lib.nd_conv3x3_nhwc_f32(C.byref(d), None) == -2                   # cin % 8 != 0 -> ND_E_SHAPE, nothing launched
+    # Winograd weights: 128 KB blocks [cin/32][cout/64][16 positions][8 quads][64][4], zero padded
+    assert lib.nd_pack_conv3x3_wino_weight_floats(64, 64) == 16 * 64 * 64
+    assert lib.nd_pack_conv3x3_wino_weight_floats(48, 40) == 16 * 64 * 64
+    assert lib.nd_conv3x3_wino_stat_slots(256, 256) == 16 * 16 * 2
+    assert lib.nd_conv3x3_wino2_nhwc_f32(None, None) == -1
+    d.src.c0 = d.src.ld0 = d.cin = 48
+    d.src.p1, d.src.c1, d.src.ld1, d.cin = 0x2000, 16, 16, 64
+    d.H = d.W = 32
+    assert lib.nd_conv3x3_wino2_nhwc_f32(C.byref(d), None) == -2 and b"straddle" in lib.nd_last_error()
+    # fused Linear chains: only NoiseDiffNet's width combinations are instantiated; weights padded to MFMA operand tiles
+    assert lib.nd_pointwise_chain_supported(64, 128, 64, 64) == 1 and lib.nd_pointwise_chain_supported(8, 64, 64, 0) == 1
+    assert lib.nd_pointwise_chain_supported(48, 96, 48, 48) == 1 and lib.nd_pointwise_chain_supported(64, 160, 64, 64) == 0
+    assert lib.nd_pack_chain_weight_floats(8, 64, 1) == 8 * 64 and lib.nd_pack_chain_weight_floats(48, 4, 0) == 64 * 32
+    assert lib.nd_pointwise_chain_nhwc_f32(None, None) == -1
 
 
 @pytest.mark.parametrize("sched", ["linear", "cosine", "sigmoid1", "sigmoid2", "sigmoid3"])
