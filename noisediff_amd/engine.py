@@ -33,6 +33,7 @@ from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, 
 
 GN_EPS = 1e-5
 WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
+PREACT = os.environ.get("ND_PREACT", "1") != "0"         # A-B knob: 0 = GroupNorm+SiLU always fused into block2's conv prologue
 CHAIN = os.environ.get("ND_CHAIN", "1") != "0"           # A-B knob: 0 = one pointwise GEMM launch per Linear layer
 _CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that can open / continue a fused chain (pwchain.hip)
 _CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
@@ -357,9 +358,20 @@ class Plan:
         c1, st1, sc1, n1 = self.conv3(name + ".block1.proj", self._src(x, skip), cin, cout, H, W, stats=True)
         ss_off = None if posmap is not None else self.e.tproj_off[name]
         mad1 = self.gn_finalize(st1, sc1, n1, name + ".block1.norm", cout, groups, ss_off)
-        mode = L.PRO_AFFINE_MAP_SILU if posmap is not None else L.PRO_AFFINE_SILU
-        src2 = self._src(c1, None, mode, mad=mad1, **({"map": posmap} if posmap is not None else {}))
+        a1 = None
+        if PREACT and posmap is None and cout >= 128 and H >= 16 and W >= 16:
+            # every 64-channel output slice of block2 would re-apply GroupNorm+SiLU to the same input tile (cout/64 times);
+            # on these small, wide tensors one elementwise pass (tens of MB) is cheaper than that VALU work next to the MFMAs
+            a1 = self._alloc(self.B, HW, cout)
+            self._add("nd_affine_silu_add_f32", c1.data_ptr(), cout, mad1.data_ptr(), None, cout, None, cout, a1.data_ptr(), cout,
+                      self.B, HW, cout, self.e.stream)
+            src2 = self._src(a1)
+        else:
+            mode = L.PRO_AFFINE_MAP_SILU if posmap is not None else L.PRO_AFFINE_SILU
+            src2 = self._src(c1, None, mode, mad=mad1, **({"map": posmap} if posmap is not None else {}))
         c2, st2, sc2, n2 = self.conv3(name + ".block2.proj", src2, cout, cout, H, W, stats=True)
+        if a1 is not None:
+            self._release(a1)
         mad2 = self.gn_finalize(st2, sc2, n2, name + ".block2.norm", cout, groups, None)
         if cin != cout:       # h + res_conv(x): the 1x1 GEMM adds silu(GN(c2)) in its epilogue   :170
             assert extra_res is None
