@@ -139,6 +139,31 @@ def test_conv3x3_winograd_addressing_and_prologues(ctx, entry):
     assert rel_err(run(hu.src(hu.nhwc(x), hu.nhwc(x2), L.PRO_LEAKY_SECOND), w2, b[:24], B, H, W), ref) < 1e-5
 
 
+def test_conv3x3_wino2_is_bitwise_repeatable(ctx):
+    """The kernel issues its MFMAs through inline asm, outside the compiler's hazard bookkeeping: a missed wait state would
+    show as run-to-run differences.  Same launch five times -> identical bits (outputs and GroupNorm partials)."""
+    import hiputil as hu
+    B, H, W, cin, cout = 4, 64, 64, 64, 64
+    x, w, b = U("rp.x", (B, cin, H, W), -1.5, 1.5), U("rp.w", (cout, cin, 3, 3), -0.2, 0.2), U("rp.b", (cout,))
+    M, A, D = U("rp.M", (B, cin)), U("rp.A", (B, cin), 0.5, 1.5), U("rp.D", (B, cin))
+    xd, wd, bd, mad = hu.nhwc(x), hu.dev(w), hu.dev(b), hu.dev(torch.stack((M, A, D), 1))
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    slots = ctx.lib.nd_conv3x3_wino_stat_slots(H, W)
+    runs = []
+    for _ in range(5):
+        out, st, sc = hu.full((B, H, W, cout)), hu.full((B, slots, cout, 2)), hu.full((slots,))
+        d = L.Conv3x3()
+        d.src = hu.src(xd, None, L.PRO_AFFINE_SILU, mad=mad)
+        d.weight, d.bias, d.out, d.stats, d.slot_count = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st.data_ptr(), sc.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        L.call("nd_conv3x3_wino2_nhwc_f32", C.byref(d), ctx.stream)
+        ctx.sync()
+        runs.append((out.cpu(), st.cpu()))
+    assert torch.isfinite(runs[0][0]).all() and torch.isfinite(runs[0][1]).all()
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+
+
 def test_conv3x3_rejects_bad_arguments(ctx):
     import hiputil as hu
     x = hu.nhwc(U("bad.x", (1, 12, 8, 8)))
