@@ -12,6 +12,7 @@
 // (LayerNorm / SiLU / pixel-unshuffle addressing / virtual concat); B fragments come straight
 // from the packed weight [k/4][coutP][4] as coalesced 16-byte loads (see conv3x3.hip).
 #include <stdlib.h>
+#include <type_traits>
 #include "nd_common.h"
 
 namespace {
@@ -23,6 +24,239 @@ struct PwArgs {
     nd_pointwise d;
     int m_tiles, n_tiles, coutP, cinP, total_wg;
 };
+
+// Epilogue shared by both kernels: accumulators -> LDS -> (bias, activation, residuals, fused ResnetBlock tail) -> global.
+template <int MB, int NB>
+__device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][NB], float* As, int b, int p0, int n0) {
+    constexpr int BM = 2 * MB * 32, BN = 2 * NB * 32;
+    constexpr int LDO = BN + 4;                               // output tile row stride in LDS (floats)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int col = lane & 31;
+    const int HW = a.d.HW, W = a.d.W, Cout = a.d.cout;
+    // ------------------------------------------------------------ epilogue
+    // Accumulators go through LDS so that every global access of the epilogue (residual reads, the store) is a
+    // 16-byte-per-lane, row-contiguous access like the staging loads -- 4x fewer memory instructions than storing
+    // the MFMA layout directly (one dword per lane), which capped these HBM-bound layers at ~1.7 TB/s of writes.
+    __syncthreads();                                          // all waves are done reading the A tile
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                As[((wm * MB + mb) * 32 + nd_acc_row(r, lane)) * LDO + (wn * NB + nb) * 32 + col] = acc[mb][nb][r];
+    __syncthreads();
+    {
+        constexpr int QPR = BN / 4;                           // quads per tile row
+        constexpr int RPI = 256 / QPR;                        // rows covered per pass of the 256 threads
+        const int q = tid % QPR, rbase = tid / QPR;
+        const int n = n0 + q * 4;
+        const bool nvalid = n < Cout;                         // Cout % 4 == 0 is not required: handled below
+        const int ns = (nvalid && n + 4 <= Cout) ? n : 0;
+        const bool vec_ok = nvalid && n + 4 <= Cout;          // whole quad inside the tensor -> 16-byte path
+        const f32x4 zero = {0, 0, 0, 0};
+        f32x4 bias4 = zero, vadd4 = zero, gM = zero, gA = {1, 1, 1, 1}, gD = zero;
+        if (vec_ok) {
+            if (a.d.bias) bias4 = nd_ld4(a.d.bias + ns);
+            if (a.d.vec) vadd4 = nd_ld4(a.d.vec + (size_t)b * Cout + ns);
+            if (a.d.gn_t) {
+                const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + ns;
+                gM = nd_ld4(m); gA = nd_ld4(m + Cout); gD = nd_ld4(m + 2 * Cout);
+            }
+        }
+        float* out = a.d.out;
+        if (vec_ok) {
+            f32x4 r0[BM / RPI], r1[BM / RPI], rt[BM / RPI];
+#pragma unroll
+            for (int j = 0; j < BM / RPI; ++j) {              // all residual reads in flight together
+                const size_t pix = (size_t)b * HW + min(p0 + rbase + j * RPI, HW - 1);
+                r0[j] = a.d.res0 ? nd_ld4(a.d.res0 + pix * a.d.ldr0 + ns) : zero;
+                r1[j] = a.d.res1 ? nd_ld4(a.d.res1 + pix * a.d.ldr1 + ns) : zero;
+                rt[j] = a.d.gn_t ? nd_ld4(a.d.gn_t + pix * a.d.ldt + ns) : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < BM / RPI; ++j) {
+                const int r = rbase + j * RPI;
+                f32x4 v = nd_ld4(&As[r * LDO + q * 4]) + bias4;
+                if (a.d.act == ND_ACT_GELU) { v.x = nd_gelu(v.x); v.y = nd_gelu(v.y); v.z = nd_gelu(v.z); v.w = nd_gelu(v.w); }
+                else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
+                v += r0[j] + r1[j] + vadd4;
+                if (a.d.gn_t) v += nd_silu4((rt[j] - gM) * gA + gD);
+                if (a.d.shuffle_c > 0) {       // ConvTranspose2d(2, stride 2): scatter to pixel (2y+p1, 2x+p2), channel c
+                    const int p = p0 + r, y = p / W, x = p - y * W;
+                    const int sub = n / a.d.shuffle_c, cch = n - sub * a.d.shuffle_c;
+                    const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
+                    if (p < HW && oy < a.d.shuffle_h && ox < a.d.shuffle_w)
+                        nd_st4(out + ((size_t)(b * a.d.shuffle_h + oy) * a.d.shuffle_w + ox) * a.d.ldo + cch, v);
+                } else if (p0 + r < HW) nd_st4(out + ((size_t)b * HW + p0 + r) * a.d.ldo + n, v);
+            }
+        } else if (nvalid) {                                  // ragged channel tail (cout % 4 != 0): scalar path
+            for (int j = 0; j < BM / RPI; ++j) {
+                const int r = rbase + j * RPI;
+                if (p0 + r >= HW) continue;
+                const size_t pix = (size_t)b * HW + p0 + r;
+                for (int e = 0; e < 4 && n + e < Cout; ++e) {
+                    float v = nd_act(As[r * LDO + q * 4 + e] + (a.d.bias ? a.d.bias[n + e] : 0.0f), a.d.act);
+                    if (a.d.res0) v += a.d.res0[pix * a.d.ldr0 + n + e];
+                    if (a.d.res1) v += a.d.res1[pix * a.d.ldr1 + n + e];
+                    if (a.d.vec) v += a.d.vec[(size_t)b * Cout + n + e];
+                    if (a.d.gn_t) {
+                        const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + n + e;
+                        v += nd_silu((a.d.gn_t[pix * a.d.ldt + n + e] - m[0]) * m[Cout] + m[2 * Cout]);
+                    }
+                    out[pix * a.d.ldo + n + e] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- software-pipelined variant for cin % 32 == 0 (every C >= 64 layer of the net): K in chunks of 32, A tile and
+// weight fragments double-buffered (LDS / registers).  The global loads of chunk c+1 are issued before the MFMAs of
+// chunk c and written to the other LDS buffer after them, so a workgroup's HBM/L2 round trip rides under its own
+// matrix work instead of relying on a second resident workgroup to fill the gap; one barrier per chunk.
+constexpr int PKC = 32, PLDA = PKC + 4;
+
+template <int MB, int NB, int MODE>
+__global__ __launch_bounds__(256) void pointwise_pipe_kernel(const PwArgs a) {
+    constexpr int BM = 2 * MB * 32, BN = 2 * NB * 32;
+    constexpr int SIT = BM / 32;                              // staging passes: BM rows x 8 channel quads / 256 threads
+    constexpr int LDO = BN + 4;
+    constexpr int ABUF = BM * PLDA;
+    constexpr int SMEM = 2 * ABUF > BM * LDO ? 2 * ABUF : BM * LDO;
+    __shared__ __attribute__((aligned(16))) float As[SMEM];   // two A buffers during the K loop, output tile in the epilogue
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, col = lane & 31;
+
+    int lid = nd_xcd_remap(blockIdx.x, a.total_wg);
+    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
+    const int mt = lid % a.m_tiles;
+    const int b = lid / a.m_tiles;
+
+    const nd_src& s = a.d.src;
+    const int HW = a.d.HW, Cin = a.d.cin;
+    const int p0 = mt * BM, n0 = nt * BN;
+
+    int a_off[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_off[mb] = ((wm * MB + mb) * 32 + col) * PLDA + 4 * half;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d.weight), 0, a.cinP * a.coutP * 4, 0x00020000);
+    const unsigned wvoff = (unsigned)((half * a.coutP + n0 + wn * NB * 32 + col) * 16);
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+    const int quad = tid & 7, prow = tid >> 3;
+    // per-thread rows of the A tile: the same pixels for every chunk
+    size_t pixoff0[SIT], pixoff1[SIT];
+    float rmean[SIT], rrstd[SIT];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const size_t pix = (size_t)b * HW + min(p0 + prow + it * 32, HW - 1);
+        pixoff0[it] = pix * s.ld0;
+        pixoff1[it] = pix * s.ld1;
+        rmean[it] = 0.0f; rrstd[it] = 1.0f;
+        if (MODE == ND_PRO_LAYERNORM) {                       // host: rowstats present (rows wider than one chunk)
+            rmean[it] = s.rowstats[2 * pix];
+            rrstd[it] = s.rowstats[2 * pix + 1];
+        }
+    }
+
+    f32x4 bq[2][4][NB], raw[2][SIT];
+    f32x4 pA[2], pB[2], pC[2];                                // per-chunk channel constants of the prologue
+    auto stage_load = [&](auto sel, int cb) {
+        constexpr int S = decltype(sel)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bq[S][g][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, wvoff, __builtin_amdgcn_readfirstlane((((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 16), 0));
+        const int c = cb + quad * 4;                          // < Cin: cin % 32 == 0
+        const bool sec = c >= s.c0;
+        const float* base = sec ? s.p1 : s.p0;
+        const int cc = sec ? c - s.c0 : c;
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) raw[S][it] = nd_ld4(base + (sec ? pixoff1[it] : pixoff0[it]) + cc);
+        if (MODE == ND_PRO_LAYERNORM) {
+            const f32x4 zero = {0, 0, 0, 0};
+            pA[S] = nd_ld4(s.gamma + c); pB[S] = nd_ld4(s.beta + c);
+            pC[S] = s.vec ? nd_ld4(s.vec + (size_t)b * Cin + c) : zero;
+        }
+        if (MODE == ND_PRO_AFFINE_SILU) {
+            const float* m = s.mad + (size_t)b * 3 * Cin + c;
+            pA[S] = nd_ld4(m); pB[S] = nd_ld4(m + Cin); pC[S] = nd_ld4(m + 2 * Cin);
+        }
+    };
+    auto stage_write = [&](auto sel, float* dst) {
+        constexpr int S = decltype(sel)::value;
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int r = prow + it * 32;
+            f32x4 v = raw[S][it];
+            if (MODE == ND_PRO_LAYERNORM) v = ((v + pC[S]) - rmean[it]) * rrstd[it] * pA[S] + pB[S];
+            else if (MODE == ND_PRO_SILU) v = nd_silu4(v);
+            else if (MODE == ND_PRO_AFFINE_SILU) v = nd_silu4((v - pA[S]) * pB[S] + pC[S]);
+            else if (MODE == ND_PRO_LEAKY) v = nd_leaky4(v);
+            const f32x4 zero = {0, 0, 0, 0};
+            v = (p0 + r < HW) ? v : zero;
+            nd_st4(&dst[r * PLDA + quad * 4], v);
+        }
+    };
+    auto mma = [&](auto sel, const float* src) {
+        constexpr int S = decltype(sel)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 av[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = nd_ld4(&src[a_off[mb] + g * 8]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = nd_mfma(av[mb][k], bq[S][g][nb][k], acc[mb][nb]);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    const int n_chunks = a.cinP / PKC;
+    stage_load(S0{}, 0);
+    stage_write(S0{}, As);
+    __syncthreads();
+    // No branch sits between a load and the MFMAs it overlaps: hipcc counts outstanding loads (vmcnt) along the path with
+    // the fewest, so a conditional prefetch in front of an MFMA block makes that block wait for the prefetch itself.
+    // sched_barriers: hipcc otherwise sinks the prefetch loads to just before their LDS writes (shorter live ranges),
+    // which is exactly the overlap this kernel exists for
+#define PW_STEP(LD, MM, WR)                         \
+    LD; __builtin_amdgcn_sched_barrier(0);          \
+    MM; __builtin_amdgcn_sched_barrier(0);          \
+    WR; __syncthreads()
+    int c = 0;
+    for (; c + 2 < n_chunks; c += 2) {
+        PW_STEP(stage_load(S1{}, (c + 1) * PKC), mma(S0{}, As), stage_write(S1{}, As + ABUF));
+        PW_STEP(stage_load(S0{}, (c + 2) * PKC), mma(S1{}, As + ABUF), stage_write(S0{}, As));
+    }
+    if (n_chunks - c == 2) {
+        PW_STEP(stage_load(S1{}, (c + 1) * PKC), mma(S0{}, As), stage_write(S1{}, As + ABUF));
+        mma(S1{}, As + ABUF);
+    } else {
+        mma(S0{}, As);
+    }
+#undef PW_STEP
+
+    pw_epilogue<MB, NB>(a, acc, As, b, p0, n0);
+}
 
 // NOTE on code shape: every global load below is unconditional (clamped address + select) and the prologue mode is a
 // template parameter.  With data-dependent branches around loads hipcc emits s_waitcnt vmcnt(0) after each one, which
@@ -46,7 +280,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     const int b = lid / a.m_tiles;
 
     const nd_src& s = a.d.src;
-    const int HW = a.d.HW, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
+    const int HW = a.d.HW, W = a.d.W, Cin = a.d.cin;
     const int p0 = mt * BM, n0 = nt * BN;
 
     int a_off[MB];
@@ -180,82 +414,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
         }
     }
 
-    // ------------------------------------------------------------ epilogue
-    // Accumulators go through LDS so that every global access of the epilogue (residual reads, the store) is a
-    // 16-byte-per-lane, row-contiguous access like the staging loads -- 4x fewer memory instructions than storing
-    // the MFMA layout directly (one dword per lane), which capped these HBM-bound layers at ~1.7 TB/s of writes.
-    __syncthreads();                                          // all waves are done reading the A tile
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                As[((wm * MB + mb) * 32 + nd_acc_row(r, lane)) * LDO + (wn * NB + nb) * 32 + col] = acc[mb][nb][r];
-    __syncthreads();
-    {
-        constexpr int QPR = BN / 4;                           // quads per tile row
-        constexpr int RPI = 256 / QPR;                        // rows covered per pass of the 256 threads
-        const int q = tid % QPR, rbase = tid / QPR;
-        const int n = n0 + q * 4;
-        const bool nvalid = n < Cout;                         // Cout % 4 == 0 is not required: handled below
-        const int ns = (nvalid && n + 4 <= Cout) ? n : 0;
-        const bool vec_ok = nvalid && n + 4 <= Cout;          // whole quad inside the tensor -> 16-byte path
-        const f32x4 zero = {0, 0, 0, 0};
-        f32x4 bias4 = zero, vadd4 = zero, gM = zero, gA = {1, 1, 1, 1}, gD = zero;
-        if (vec_ok) {
-            if (a.d.bias) bias4 = nd_ld4(a.d.bias + ns);
-            if (a.d.vec) vadd4 = nd_ld4(a.d.vec + (size_t)b * Cout + ns);
-            if (a.d.gn_t) {
-                const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + ns;
-                gM = nd_ld4(m); gA = nd_ld4(m + Cout); gD = nd_ld4(m + 2 * Cout);
-            }
-        }
-        float* out = a.d.out;
-        if (vec_ok) {
-            f32x4 r0[BM / RPI], r1[BM / RPI], rt[BM / RPI];
-#pragma unroll
-            for (int j = 0; j < BM / RPI; ++j) {              // all residual reads in flight together
-                const size_t pix = (size_t)b * HW + min(p0 + rbase + j * RPI, HW - 1);
-                r0[j] = a.d.res0 ? nd_ld4(a.d.res0 + pix * a.d.ldr0 + ns) : zero;
-                r1[j] = a.d.res1 ? nd_ld4(a.d.res1 + pix * a.d.ldr1 + ns) : zero;
-                rt[j] = a.d.gn_t ? nd_ld4(a.d.gn_t + pix * a.d.ldt + ns) : zero;
-            }
-#pragma unroll
-            for (int j = 0; j < BM / RPI; ++j) {
-                const int r = rbase + j * RPI;
-                f32x4 v = nd_ld4(&As[r * LDO + q * 4]) + bias4;
-                if (a.d.act == ND_ACT_GELU) { v.x = nd_gelu(v.x); v.y = nd_gelu(v.y); v.z = nd_gelu(v.z); v.w = nd_gelu(v.w); }
-                else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
-                v += r0[j] + r1[j] + vadd4;
-                if (a.d.gn_t) v += nd_silu4((rt[j] - gM) * gA + gD);
-                if (a.d.shuffle_c > 0) {       // ConvTranspose2d(2, stride 2): scatter to pixel (2y+p1, 2x+p2), channel c
-                    const int p = p0 + r, y = p / W, x = p - y * W;
-                    const int sub = n / a.d.shuffle_c, cch = n - sub * a.d.shuffle_c;
-                    const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
-                    if (p < HW && oy < a.d.shuffle_h && ox < a.d.shuffle_w)
-                        nd_st4(out + ((size_t)(b * a.d.shuffle_h + oy) * a.d.shuffle_w + ox) * a.d.ldo + cch, v);
-                } else if (p0 + r < HW) nd_st4(out + ((size_t)b * HW + p0 + r) * a.d.ldo + n, v);
-            }
-        } else if (nvalid) {                                  // ragged channel tail (cout % 4 != 0): scalar path
-            for (int j = 0; j < BM / RPI; ++j) {
-                const int r = rbase + j * RPI;
-                if (p0 + r >= HW) continue;
-                const size_t pix = (size_t)b * HW + p0 + r;
-                for (int e = 0; e < 4 && n + e < Cout; ++e) {
-                    float v = nd_act(As[r * LDO + q * 4 + e] + (a.d.bias ? a.d.bias[n + e] : 0.0f), a.d.act);
-                    if (a.d.res0) v += a.d.res0[pix * a.d.ldr0 + n + e];
-                    if (a.d.res1) v += a.d.res1[pix * a.d.ldr1 + n + e];
-                    if (a.d.vec) v += a.d.vec[(size_t)b * Cout + n + e];
-                    if (a.d.gn_t) {
-                        const float* m = a.d.gn_mad + (size_t)b * 3 * Cout + n + e;
-                        v += nd_silu((a.d.gn_t[pix * a.d.ldt + n + e] - m[0]) * m[Cout] + m[2 * Cout]);
-                    }
-                    out[pix * a.d.ldo + n + e] = v;
-                }
-            }
-        }
-    }
+    pw_epilogue<MB, NB>(a, acc, As, b, p0, n0);
 }
 
 // (cout, cin) -> [cinP/4][coutP][4], optional K permutation for pixel-unshuffled inputs
@@ -278,6 +437,18 @@ __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __rest
             v = w[(size_t)n * cin + k];
         }
         out[i] = v;
+    }
+}
+
+template <int MB, int NB>
+void launch_pipe(const PwArgs& a, hipStream_t st) {
+    const dim3 grid(a.total_wg), block(256);
+    switch (a.d.src.mode) {
+        case ND_PRO_LAYERNORM: hipLaunchKernelGGL((pointwise_pipe_kernel<MB, NB, ND_PRO_LAYERNORM>), grid, block, 0, st, a); break;
+        case ND_PRO_SILU: hipLaunchKernelGGL((pointwise_pipe_kernel<MB, NB, ND_PRO_SILU>), grid, block, 0, st, a); break;
+        case ND_PRO_AFFINE_SILU: hipLaunchKernelGGL((pointwise_pipe_kernel<MB, NB, ND_PRO_AFFINE_SILU>), grid, block, 0, st, a); break;
+        case ND_PRO_LEAKY: hipLaunchKernelGGL((pointwise_pipe_kernel<MB, NB, ND_PRO_LEAKY>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((pointwise_pipe_kernel<MB, NB, ND_PRO_NONE>), grid, block, 0, st, a);
     }
 }
 
@@ -370,6 +541,17 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_pointwise: grid too large");
     a.total_wg = (int)wg;
     hipStream_t st = (hipStream_t)stream;
+    // software-pipelined kernel: whole 32-channel chunks, LayerNorm statistics from the pre-pass, plain addressing
+    static const bool use_pipe = !(getenv("ND_PW_PIPE") && atoi(getenv("ND_PW_PIPE")) == 0);   // A/B knob (tools/ only)
+    const bool pipe = use_pipe && d->cin % PKC == 0 && d->cin >= 2 * PKC && !s.unshuffle &&
+                      (s.mode != ND_PRO_LAYERNORM || s.rowstats) && (s.c1 == 0 || nd_aligned16(s.p1));
+    if (pipe) {
+        if (mb == 2 && nb == 2) launch_pipe<2, 2>(a, st);
+        else if (mb == 2) launch_pipe<2, 1>(a, st);
+        else if (nb == 2) launch_pipe<1, 2>(a, st);
+        else launch_pipe<1, 1>(a, st);
+        return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
+    }
     if (mb == 2 && nb == 2) launch<2, 2>(a, st);
     else if (mb == 2) launch<2, 1>(a, st);
     else if (nb == 2) launch<1, 2>(a, st);

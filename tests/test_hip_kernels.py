@@ -320,6 +320,38 @@ def test_pointwise_prologues(ctx):
     assert rel_err(out.view(B, H // 2, W // 2, 32).permute(0, 3, 1, 2).cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("cin", [96, 160, 224, 64])
+def test_pointwise_pipelined_chunks_concat_and_prologues(ctx, cin):
+    """The software-pipelined kernel (cin % 32 == 0): odd and even numbers of 32-channel chunks (the loop is unrolled by
+    two with a peeled tail), a concat boundary inside a chunk, ragged pixel tiles, and every prologue it takes."""
+    import hiputil as hu
+    B, HW, W, cout = 3, 150, 15, 128
+    x = U(f"pl{cin}.x", (B, HW, cin), -1.5, 1.5)
+    w, b = U(f"pl{cin}.w", (cout, cin), -0.3, 0.3), U(f"pl{cin}.b", (cout,))
+    wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
+    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(x, w, b)) < TOL
+    # virtual concat whose boundary (c0 = cin/2 + 16 or so) falls inside a 32-channel chunk
+    c0 = cin // 2 + (16 if (cin // 2) % 32 == 0 else 0)
+    xa, xb = hu.dev(x[..., :c0].contiguous()), hu.dev(x[..., c0:].contiguous())
+    assert rel_err(hu.pointwise(ctx, hu.src(xa, xb), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(x, w, b)) < TOL
+    # SiLU / LeakyReLU / GroupNorm-affine + SiLU prologues
+    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_SILU), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(F.silu(x), w, b)) < TOL
+    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_LEAKY), wp, bd, B, HW, W, cin, cout).cpu(),
+                   F.linear(F.leaky_relu(x, 0.2), w, b)) < TOL
+    mad = U(f"pl{cin}.mad", (B, 3, cin), 0.5, 1.5)
+    ref = F.linear(F.silu((x - mad[:, None, 0]) * mad[:, None, 1] + mad[:, None, 2]), w, b)
+    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_AFFINE_SILU, mad=hu.dev(mad)), wp, bd, B, HW, W, cin, cout).cpu(), ref) < TOL
+    # LayerNorm(x + vec) with row statistics from the pre-pass (the wide-row form; narrow rows without rowstats stay on
+    # the single-chunk kernel, covered by test_pointwise_prologues)
+    vec, g, be = U(f"pl{cin}.v", (B, cin)), U(f"pl{cin}.g", (cin,), 0.5, 1.5), U(f"pl{cin}.be", (cin,))
+    rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
+    L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
+    ctx.sync()
+    s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
+    ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
+    assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
+
+
 def test_affine_silu_add_and_rmsnorm(ctx):
     import hiputil as hu
     B, HW, Cc = 3, 100, 48
