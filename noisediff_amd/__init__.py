@@ -1,7 +1,8 @@
 """MI355X-native sampling hot path of IVRL/NoiseDiff."""
 __version__ = "0.1.0"
 
-__all__ = ["GaussianDiffusion", "NoiseDiffNet", "LSID", "__version__"]
+__all__ = ["GaussianDiffusion", "NoiseDiffNet", "UNet_PosEmbV2", "UNet_PosEmbV2_NoPosition", "UNet_PosEmbV2_CameraCond", "LSID",
+           "__version__"]
 
 
 def __getattr__(name):
@@ -9,9 +10,9 @@ def __getattr__(name):
     if name == "GaussianDiffusion":
         from .diffusion import GaussianDiffusion
         return GaussianDiffusion
-    if name == "NoiseDiffNet":
-        from .net import NoiseDiffNet
-        return NoiseDiffNet
+    if name in ("NoiseDiffNet", "UNet_PosEmbV2", "UNet_PosEmbV2_NoPosition", "UNet_PosEmbV2_CameraCond"):
+        from . import net
+        return getattr(net, name)
     if name == "LSID":
         from .lsid import LSID
         return LSID

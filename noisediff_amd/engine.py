@@ -29,7 +29,7 @@ import torch
 
 from . import _lib as L
 from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, POS_GROUPS, RESNET_GROUPS, SHOT_GROUPS,
-                   attention_param_spec, noisediff_param_spec, stage_dims)
+                   arch_param_spec, arch_traits, attention_param_spec, stage_dims)
 
 GN_EPS = 1e-5
 WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
@@ -53,8 +53,8 @@ def _classify(name: str, shape: Sequence[int]) -> str:
             return "conv7"
         if k == 3:
             return "conv3"
-        if name.startswith("downs.") and name.endswith(".3.1.weight"):
-            return "pw_unshuffle"
+        if name.startswith("downs.") and name.endswith((".3.1.weight", ".2.1.weight")):
+            return "pw_unshuffle"           # Downsample = Rearrange + conv1x1 (stage index 3 with an AttnBlock, 2 without)
         return "pw"
     if len(shape) == 2 and (".ff.net." in name):
         return "pw"
@@ -70,14 +70,15 @@ class Slot:
 
 
 class Engine:
-    """Packed weights of one NoiseDiffNet on one GPU."""
+    """Packed weights of one U-Net (NoiseDiffNet or one of the UNet_PosEmbV2* ablation nets) on one GPU."""
 
-    def __init__(self, dim: int, device: torch.device, mid_attn: bool = False, inp_dim: int = 4):
+    def __init__(self, dim: int, device: torch.device, mid_attn: bool = False, inp_dim: int = 4, arch: str = "NoiseDiffNet"):
         if device.type != "cuda":
             raise L.HipError("noisediff_amd runs on MI355X only: got device %r (there is no CPU path)" % (device,))
         self.lib = L.load()
         self.dim, self.device, self.mid_attn, self.inp_dim = dim, device, mid_attn, inp_dim
-        self.spec = list(noisediff_param_spec(dim, inp_dim))
+        self.arch, self.traits = arch, arch_traits(arch)
+        self.spec = list(arch_param_spec(arch, dim, inp_dim))
         if mid_attn:
             self.spec += attention_param_spec("mid_attn", 8 * dim)
         self.resnet_names = [p.name[:-len(".mlp.1.weight")] for p in self.spec
@@ -356,7 +357,7 @@ class Plan:
         cin = x.shape[-1] + (skip.shape[-1] if skip is not None else 0)
         HW = H * W
         c1, st1, sc1, n1 = self.conv3(name + ".block1.proj", self._src(x, skip), cin, cout, H, W, stats=True)
-        ss_off = None if posmap is not None else self.e.tproj_off[name]
+        ss_off = None if posmap is not None else self.e.tproj_off.get(name)     # blocks built with time_emb_dim=None have no mlp
         mad1 = self.gn_finalize(st1, sc1, n1, name + ".block1.norm", cout, groups, ss_off)
         a1 = None
         if PREACT and posmap is None and cout >= 128 and H >= 16 and W >= 16:
@@ -443,22 +444,34 @@ class Plan:
     # ------------------------------------------------------------------ recorded programs
     def _record_condition(self) -> None:
         e, B, H, W, st = self.e, self.B, self.H, self.W, self.e.stream
-        pe = self._alloc(B, H, W, 3 * POS_DIM)
-        self._add("nd_pos_enc_f32", self.position.data_ptr(), e.p("pos_enc.weights.weight"), e.p("pos_enc.weights.bias"),
-                  pe.data_ptr(), B, H, W, POS_DIM, st)
-        h = self.pw("pos_mlp.fc1", self._src(pe), 3 * POS_DIM, 2 * POS_DIM, H * W, W, act=L.ACT_GELU)
-        self.pw("pos_mlp.fc2", self._src(h), 2 * POS_DIM, POS_DIM, H * W, W, out=self.pos_emb)
-        for blk, dst in (("pos_block1", self.posmap1), ("pos_block2", self.posmap2)):
-            self.pw(blk + ".mlp.1", self._src(self.pos_emb, None, L.PRO_SILU), POS_DIM, 2 * e.dim, H * W, W, out=dst)
-        self._add("nd_embedding_rows_f32", self.iso_idx.data_ptr(), e.p("iso_embed.weight"), self.iso_emb.data_ptr(), B,
-                  ISO_TABLE_ROWS, ISO_DIM, st)
-        inner = ATTN_HEADS * ATTN_DIM_HEAD
-        v = self._alloc(B, inner)
-        for n in self.attn_names:
-            Cc = self.cb[n].shape[-1]
-            self.linear_rows(self.iso_emb, e.p(n + ".attn.to_v.weight"), None, v, ISO_DIM, inner)
-            self.linear_rows(v, e.p(n + ".attn.to_out.0.weight"), e.p(n + ".attn.to_out.0.bias"), self.cb[n], inner, Cc)
-        self._release(pe, h, v)
+        tr = e.traits
+        if tr.position:
+            pe = self._alloc(B, H, W, 3 * POS_DIM)
+            self._add("nd_pos_enc_f32", self.position.data_ptr(), e.p("pos_enc.weights.weight"), e.p("pos_enc.weights.bias"),
+                      pe.data_ptr(), B, H, W, POS_DIM, st)
+            h = self.pw("pos_mlp.fc1", self._src(pe), 3 * POS_DIM, 2 * POS_DIM, H * W, W, act=L.ACT_GELU)
+            self.pw("pos_mlp.fc2", self._src(h), 2 * POS_DIM, POS_DIM, H * W, W, out=self.pos_emb)
+            for blk, dst in (("pos_block1", self.posmap1), ("pos_block2", self.posmap2)):
+                self.pw(blk + ".mlp.1", self._src(self.pos_emb, None, L.PRO_SILU), POS_DIM, 2 * e.dim, H * W, W, out=dst)
+            self._release(pe, h)
+        if tr.iso_attn:
+            self._add("nd_embedding_rows_f32", self.iso_idx.data_ptr(), e.p("iso_embed.weight"), self.iso_emb.data_ptr(), B,
+                      ISO_TABLE_ROWS, ISO_DIM, st)
+            inner = ATTN_HEADS * ATTN_DIM_HEAD
+            v = self._alloc(B, inner)
+            for n in self.attn_names:
+                Cc = self.cb[n].shape[-1]
+                self.linear_rows(self.iso_emb, e.p(n + ".attn.to_v.weight"), None, v, ISO_DIM, inner)
+                self.linear_rows(v, e.p(n + ".attn.to_out.0.weight"), e.p(n + ".attn.to_out.0.bias"), self.cb[n], inner, Cc)
+            self._release(v)
+        self.clean_emb = None
+        if tr.cond_branch:
+            # clean-image encoding of the UNet_PosEmbV2* nets (others_arch.py:491-492): step-invariant, so it runs here
+            ce = self._alloc(B, H, W, e.dim)
+            self._add("nd_conv7x7_c4_f32", self.clean.data_ptr(), e.p("cond_init_conv.weight"), e.p("cond_init_conv.bias"),
+                      ce.data_ptr(), e.dim, B, H, W, e.dim, st)
+            self.clean_emb = self._tap("clean_emb", self.resnet("cond_res_block1", ce, None, e.dim, H, W, RESNET_GROUPS))
+            self._release(ce)                  # clean_emb itself is never released: every step reads it
 
     def _record_time(self) -> None:
         e, d = self.e, self.e.dim
@@ -470,40 +483,50 @@ class Plan:
 
     def _record_net(self) -> None:
         e, B, H, W, d = self.e, self.B, self.H, self.W, self.e.dim
-        G = RESNET_GROUPS
-        # ---- shot-noise branch, full resolution (:598-604)
-        r_shot = self.mlp("shot_mlp1", self._src(self.clean, self.x), 2 * e.inp_dim, d, d, H, W)
-        s = self.attn_block("shot_attn", r_shot, H, W)
-        s2 = self.mlp("shot_mlp2", self._src(s), d, d, d, H, W)
-        s3 = self.resnet("shot_time", s2, None, d, H, W, SHOT_GROUPS, extra_res=r_shot)   # shot_time(...) + r
-        shot_noise = self._tap("shot_noise", self.mlp("shot_mlp3", self._src(s3), d, d, e.inp_dim, H, W))
-        for nm, tt in (("shot_mlp1", r_shot), ("shot_attn", s), ("shot_mlp2", s2), ("shot_time", s3)):
-            self._tap(nm, tt)
-        self._release(r_shot, s, s2, s3)
+        G, tr = RESNET_GROUPS, self.e.traits
+        shot_noise = None
+        if tr.shot_branch:
+            # ---- shot-noise branch, full resolution (:598-604)
+            r_shot = self.mlp("shot_mlp1", self._src(self.clean, self.x), 2 * e.inp_dim, d, d, H, W)
+            s = self.attn_block("shot_attn", r_shot, H, W)
+            s2 = self.mlp("shot_mlp2", self._src(s), d, d, d, H, W)
+            s3 = self.resnet("shot_time", s2, None, d, H, W, SHOT_GROUPS, extra_res=r_shot)   # shot_time(...) + r
+            shot_noise = self._tap("shot_noise", self.mlp("shot_mlp3", self._src(s3), d, d, e.inp_dim, H, W))
+            for nm, tt in (("shot_mlp1", r_shot), ("shot_attn", s), ("shot_mlp2", s2), ("shot_time", s3)):
+                self._tap(nm, tt)
+            self._release(r_shot, s, s2, s3)
         # ---- trunk
         x0 = self._alloc(B, H, W, d)
         self._add("nd_conv7x7_c4_f32", self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
                   B, H, W, d, e.stream)
         self._tap("init_conv", x0)
-        x = self._tap("pos_block1", self.resnet("pos_block1", x0, None, d, H, W, POS_GROUPS, posmap=self.posmap1))
+        xin = x0
+        if tr.cond_branch:          # x = cond_concat_conv(cat[init_conv(x), clean_emb])   others_arch.py:495-498
+            xin, *_ = self.conv3("cond_concat_conv", self._src(x0, self.clean_emb), 2 * d, d, H, W, stats=False)
+            self._tap("cond_concat", xin)
+        pm1, pm2 = (self.posmap1, self.posmap2) if tr.position else (None, None)   # else plain ResnetBlocks without time
+        x = self._tap("pos_block1", self.resnet("pos_block1", xin, None, d, H, W, POS_GROUPS, posmap=pm1))
+        if xin is not x0:
+            self._release(xin)
+        rs = 3 if tr.iso_attn else 2            # stage index of the resampling layer
         hs: List[torch.Tensor] = []
         h, w = H, W
         for i, (cin, cout) in enumerate(stage_dims(d)):
             p = f"downs.{i}"
             x1 = self.resnet(p + ".0", x, None, cin, h, w, G)
-            if x is not x0:
-                self._release(x)
+            self._release(x)
             x2 = self.resnet(p + ".1", x1, None, cin, h, w, G)
             hs += [x1, x2]
-            xa = self.attn_block(p + ".2", x2, h, w)
+            xa = self.attn_block(p + ".2", x2, h, w) if tr.iso_attn else x2
             self._tap(p + ".0", x1); self._tap(p + ".1", x2); self._tap(p + ".2", xa)
             if i == 3:
-                x, *_ = self.conv3(p + ".3", self._src(xa), cin, cout, h, w, stats=False)
+                x, *_ = self.conv3(f"{p}.{rs}", self._src(xa), cin, cout, h, w, stats=False)
             else:
                 h, w = h // 2, w // 2
-                x = self.pw(p + ".3.1", self._src(xa, None, L.PRO_NONE, unshuffle=1, c0=4 * cin, ld0=cin), 4 * cin, cout,
+                x = self.pw(f"{p}.{rs}.1", self._src(xa, None, L.PRO_NONE, unshuffle=1, c0=4 * cin, ld0=cin), 4 * cin, cout,
                             h * w, w).view(B, h, w, cout)
-            self._release(xa)
+            if xa is not x2:
+                self._release(xa)
             self._tap(f"down{i}", x)
         mid = x.shape[-1]
         xm = self.resnet("mid_block1", x, None, mid, h, w, G)
@@ -520,21 +543,25 @@ class Plan:
             sk = hs.pop()
             x2 = self.resnet(p + ".1", x1, sk, cout, h, w, G)
             self._release(x1, sk)
-            xa = self.attn_block(p + ".2", x2, h, w)
-            self._release(x2)
+            xa = self.attn_block(p + ".2", x2, h, w) if tr.iso_attn else x2
+            if xa is not x2:
+                self._release(x2)
             if i == 3:
-                x, *_ = self.conv3(p + ".3", self._src(xa), cout, cin, h, w, stats=False)
+                x, *_ = self.conv3(f"{p}.{rs}", self._src(xa), cout, cin, h, w, stats=False)
             else:
                 h, w = h * 2, w * 2
-                x, *_ = self.conv3(p + ".3.1", self._src(xa, None, L.PRO_NONE, upsample=1), cout, cin, h, w, stats=False)
+                x, *_ = self.conv3(f"{p}.{rs}.1", self._src(xa, None, L.PRO_NONE, upsample=1), cout, cin, h, w, stats=False)
             self._release(xa)
             self._tap(p + ".0", x1); self._tap(p + ".1", x2); self._tap(p + ".2", xa); self._tap(f"up{i}", x)
-        xp = self._tap("pos_block2", self.resnet("pos_block2", x, None, d, H, W, POS_GROUPS, posmap=self.posmap2))
+        xp = self._tap("pos_block2", self.resnet("pos_block2", x, None, d, H, W, POS_GROUPS, posmap=pm2))
         self._release(x)
         xf = self._tap("final_res_block", self.resnet("final_res_block", xp, x0, d, H, W, G))
         self._release(xp, x0)
-        self.pw("final_conv", self._src(xf), d, e.inp_dim, H * W, W, res0=shot_noise, out=self.model_out)   # shot + read  :644
-        self._release(xf, shot_noise)
+        # NoiseDiffNet: shot + read (:644); the ablation nets return final_conv(x) alone
+        self.pw("final_conv", self._src(xf), d, e.inp_dim, H * W, W, res0=shot_noise, out=self.model_out)
+        self._release(xf)
+        if shot_noise is not None:
+            self._release(shot_noise)
 
     def _mid_attention(self, x: torch.Tensor, h: int, w: int) -> torch.Tensor:
         """x = Attention(x) + x between the mid blocks (Diffusion_arch.py:237-266; BASELINE config 4)."""
@@ -557,19 +584,33 @@ class Plan:
             if r != 0:
                 L.check(r, name)
 
-    def set_condition(self, condition: Dict[str, torch.Tensor]) -> None:
-        """Upload clean_img / position / iso_ratio_idx and run the step-invariant part once."""
+    def set_condition(self, condition) -> None:
+        """Upload clean_img / position / iso_ratio_idx and run the step-invariant part once.  Nets without the position
+        or ISO inputs ignore those keys; UNet_PosEmbV2_NoPosition also takes the bare clean image (others_arch.py:658)."""
         B, H, W, e = self.B, self.H, self.W, self.e
-        clean, pos, iso = condition["clean_img"], condition["position"], condition["iso_ratio_idx"]
-        if tuple(clean.shape) != (B, e.inp_dim, H, W) or tuple(pos.shape) != (B, 2, H, W) or tuple(iso.shape) != (B,):
-            raise ValueError(f"condition shapes {tuple(clean.shape)}, {tuple(pos.shape)}, {tuple(iso.shape)} do not match batch {(B, H, W)}")
-        iso = iso.to(torch.int64)
-        if int(iso.min()) < 0 or int(iso.max()) >= ISO_TABLE_ROWS:
-            raise IndexError("iso_ratio_idx out of range for nn.Embedding(100, 16)")
+        tr = e.traits
+        if torch.is_tensor(condition):
+            if tr.position or tr.iso_attn:
+                raise TypeError(f"{e.arch} needs the condition dict (clean_img, position, iso_ratio_idx), got a tensor")
+            condition = {"clean_img": condition}
+        clean = condition["clean_img"]
+        if tuple(clean.shape) != (B, e.inp_dim, H, W):
+            raise ValueError(f"condition shapes: clean_img {tuple(clean.shape)} do not match batch {(B, e.inp_dim, H, W)}")
         with torch.cuda.device(self.dev):
             self.nchw_tmp.copy_(clean.to(self.dev, torch.float32))
-            self.position.copy_(pos.to(self.dev, torch.float32))
-            self.iso_idx.copy_(iso.to(self.dev))        # the reference leaves it on the CPU (trainer_diffusion.py:135)
+            if tr.position:
+                pos = condition["position"]
+                if tuple(pos.shape) != (B, 2, H, W):
+                    raise ValueError(f"condition shapes: position {tuple(pos.shape)} do not match batch {(B, 2, H, W)}")
+                self.position.copy_(pos.to(self.dev, torch.float32))
+            if tr.iso_attn:
+                iso = condition["iso_ratio_idx"]
+                if tuple(iso.shape) != (B,):
+                    raise ValueError(f"condition shapes: iso_ratio_idx {tuple(iso.shape)} do not match batch {(B,)}")
+                iso = iso.to(torch.int64)
+                if int(iso.min()) < 0 or int(iso.max()) >= ISO_TABLE_ROWS:
+                    raise IndexError("iso_ratio_idx out of range for nn.Embedding(100, 16)")
+                self.iso_idx.copy_(iso.to(self.dev))    # the reference leaves it on the CPU (trainer_diffusion.py:135)
             torch.cuda.synchronize(self.dev)
             L.call("nd_nchw_to_nhwc_f32", self.nchw_tmp.data_ptr(), self.clean.data_ptr(), B, e.inp_dim, H, W, e.stream)
             self.run(self.cond_ops)

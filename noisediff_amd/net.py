@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .spec import attention_param_spec, noisediff_param_spec
+from .spec import arch_param_spec, arch_traits, attention_param_spec
 
 
 class _Node(nn.Module):
@@ -50,6 +50,8 @@ def _init(p, gen: Optional[torch.Generator] = None) -> torch.Tensor:
 
 
 class NoiseDiffNet(nn.Module):
+    ARCH = "NoiseDiffNet"          # subclasses below: the UNet_PosEmbV2* ablation nets of models/archs/others_arch.py
+
     def __init__(self, args, mid_attn: Optional[bool] = None):
         super().__init__()
         self.dim = int(args.dim)
@@ -64,7 +66,9 @@ class NoiseDiffNet(nn.Module):
         self.random_or_learned_sinusoidal_cond = False          # :493 (both flags are hard-wired False)
         # BASELINE config 4 extension: Attention between the mid blocks (computed but never wired at :467-468,518)
         self.has_mid_attn = bool(getattr(args, "mid_attn", False) if mid_attn is None else mid_attn)
-        spec = list(noisediff_param_spec(self.dim, self.channels))
+        if arch_traits(self.ARCH).cond_branch and int(getattr(args, "cond_dim", 4)) != 4:
+            raise ValueError("cond_dim must be 4 (the clean image is packed RGGB RAW like the input; 7x7 stem kernel)")
+        spec = list(arch_param_spec(self.ARCH, self.dim, self.channels))
         if self.has_mid_attn:
             spec += attention_param_spec("mid_attn", 8 * self.dim)
         for p in spec:
@@ -95,14 +99,14 @@ class NoiseDiffNet(nn.Module):
         """The packed-weight engine for ``device`` (rebuilt when parameters changed)."""
         from .engine import Engine
         if device.type != "cuda":
-            raise L.HipError(f"NoiseDiffNet runs on the HIP library only; tensor is on {device} and there is no CPU path")
+            raise L.HipError(f"{self.ARCH} runs on the HIP library only; tensor is on {device} and there is no CPU path")
         idx = device.index if device.index is not None else torch.cuda.current_device()
         device = torch.device("cuda", idx)
         with self._lock:
             sig = self._signature()
             eng = self._engines.get(idx)
             if eng is None:
-                eng = Engine(self.dim, device, mid_attn=self.has_mid_attn, inp_dim=self.channels)
+                eng = Engine(self.dim, device, mid_attn=self.has_mid_attn, inp_dim=self.channels, arch=self.ARCH)
                 self._engines[idx] = eng
                 self._engine_sig[idx] = None
             if self._engine_sig[idx] != sig:
@@ -120,7 +124,7 @@ class NoiseDiffNet(nn.Module):
     def forward(self, x: torch.Tensor, time: torch.Tensor, condition=None) -> torch.Tensor:
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
-                "noisediff_amd.NoiseDiffNet implements the inference (sampling) path only; call it under "
+                f"noisediff_amd.{self.ARCH} implements the inference (sampling) path only; call it under "
                 "torch.no_grad()/inference_mode().  Training stays on the reference network -- its weights load here unchanged.")
         assert all(d % self.downsample_factor == 0 for d in x.shape[-2:]), \
             f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {self.downsample_factor}, given the unet"
@@ -128,3 +132,20 @@ class NoiseDiffNet(nn.Module):
         plan = self.hip_engine(x.device).plan(B, H, W)
         plan.set_condition(condition)
         return plan.forward(x, time)
+
+
+class UNet_PosEmbV2(NoiseDiffNet):
+    """models/archs/others_arch.py:364-537: no shot branch, no ISO attention; clean image through cond_init_conv ->
+    cond_res_block1 -> cond_concat_conv; condition dict with ``clean_img`` and ``position``."""
+    ARCH = "UNet_PosEmbV2"
+
+
+class UNet_PosEmbV2_NoPosition(NoiseDiffNet):
+    """models/archs/others_arch.py:540-707: as UNet_PosEmbV2 without the positional inputs (pos_block1/2 are plain
+    ResnetBlocks); ``condition`` is the clean image tensor itself (:658) -- a dict with ``clean_img`` is accepted too."""
+    ARCH = "UNet_PosEmbV2_NoPosition"
+
+
+class UNet_PosEmbV2_CameraCond(NoiseDiffNet):
+    """models/archs/others_arch.py:796-985: UNet_PosEmbV2 plus the ISO-conditioned AttnBlock after every stage."""
+    ARCH = "UNet_PosEmbV2_CameraCond"

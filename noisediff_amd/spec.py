@@ -149,6 +149,86 @@ def noisediff_param_spec(dim: int, inp_dim: int = 4) -> List[ParamSpec]:
     return L.items
 
 
+ARCHS = ("NoiseDiffNet", "UNet_PosEmbV2", "UNet_PosEmbV2_NoPosition", "UNet_PosEmbV2_CameraCond")
+
+
+@dataclass(frozen=True)
+class ArchTraits:
+    """What distinguishes the four U-Nets the reference ships (Diffusion_arch.py:447-646, others_arch.py:364-985)."""
+    shot_branch: bool      # shot_mlp1..3 / shot_attn / shot_time, output = shot + read   (NoiseDiffNet only)
+    iso_attn: bool         # AttnBlock(ISO context) after every stage's two ResnetBlocks
+    position: bool         # pos_enc + pos_mlp, pos_block1/2 are ResnetBlock2 (else plain ResnetBlocks without time)
+    cond_branch: bool      # cond_init_conv 7x7 -> cond_res_block1 -> cond_concat_conv on cat[init_conv(x), clean_emb]
+
+
+def arch_traits(arch: str) -> ArchTraits:
+    if arch == "NoiseDiffNet":
+        return ArchTraits(True, True, True, False)
+    if arch == "UNet_PosEmbV2":                 # others_arch.py:364-537
+        return ArchTraits(False, False, True, True)
+    if arch == "UNet_PosEmbV2_NoPosition":      # others_arch.py:540-707
+        return ArchTraits(False, False, False, True)
+    if arch == "UNet_PosEmbV2_CameraCond":      # others_arch.py:796-985
+        return ArchTraits(False, True, True, True)
+    raise KeyError(f"unknown arch {arch!r}; this build has {ARCHS}")
+
+
+def posemb_unet_param_spec(arch: str, dim: int, inp_dim: int = 4, cond_dim: int = 4) -> List[ParamSpec]:
+    """State-dict tensors of the ``UNet_PosEmbV2*`` ablation nets (others_arch.py:364-985) in registration order."""
+    tr = arch_traits(arch)
+    assert tr.cond_branch, arch
+    L = _Lister()
+    time_dim = dim * 4
+    in_out = stage_dims(dim)
+    n_res = len(in_out)
+    rs = 3 if tr.iso_attn else 2                                           # index of the resampling layer in a stage
+
+    L.conv("init_conv", inp_dim, dim, 7)                                  # :394 / :570 / :826
+    if tr.iso_attn:
+        L.items.append(ParamSpec("iso_embed.weight", (ISO_TABLE_ROWS, ISO_DIM), "normal"))   # :833-834
+    L.linear("time_mlp.1", dim, time_dim)
+    L.linear("time_mlp.3", time_dim, time_dim)
+    for i, (cin, cout) in enumerate(in_out):                              # :437-444 / :869-877
+        L.resnet(f"downs.{i}.0", cin, cin, time_dim)
+        L.resnet(f"downs.{i}.1", cin, cin, time_dim)
+        if tr.iso_attn:
+            L.attn_block(f"downs.{i}.2", cin)
+        if i >= n_res - 1:
+            L.conv(f"downs.{i}.{rs}", cin, cout, 3)
+        else:
+            L.conv(f"downs.{i}.{rs}.1", cin * 4, cout, 1)
+    for i, (cin, cout) in enumerate(reversed(in_out)):                    # :450-457 / :883-891
+        L.resnet(f"ups.{i}.0", cout + cin, cout, time_dim)
+        L.resnet(f"ups.{i}.1", cout + cin, cout, time_dim)
+        if tr.iso_attn:
+            L.attn_block(f"ups.{i}.2", cout)
+        if i == n_res - 1:
+            L.conv(f"ups.{i}.{rs}", cout, cin, 3)
+        else:
+            L.conv(f"ups.{i}.{rs}.1", cout, cin, 3)
+    mid = in_out[-1][1]
+    L.resnet("mid_block1", mid, mid, time_dim)
+    L.resnet("mid_block2", mid, mid, time_dim)
+    L.resnet("final_res_block", dim * 2, dim, time_dim)
+    L.conv("final_conv", dim, inp_dim, 1)
+    if tr.position:
+        L.conv("pos_enc.weights", 2, POS_DIM, 1)                          # :467-471
+        L.mlp("pos_mlp", POS_DIM * 3, POS_DIM * 2, POS_DIM)
+        L.resnet_pos("pos_block1", dim, dim, POS_DIM)
+        L.resnet_pos("pos_block2", dim, dim, POS_DIM)
+    else:
+        L._blocks("pos_block1", dim, dim)                                 # ResnetBlock(time_emb_dim=None, groups=2)  :644-646
+        L._blocks("pos_block2", dim, dim)
+    L.conv("cond_init_conv", cond_dim, dim, 7)                            # :474-477
+    L._blocks("cond_res_block1", dim, dim)                                # ResnetBlock(time_emb_dim=None, groups=8)
+    L.conv("cond_concat_conv", dim * 2, dim, 3)
+    return L.items
+
+
+def arch_param_spec(arch: str, dim: int, inp_dim: int = 4) -> List[ParamSpec]:
+    return noisediff_param_spec(dim, inp_dim) if arch == "NoiseDiffNet" else posemb_unet_param_spec(arch, dim, inp_dim)
+
+
 def attention_param_spec(prefix: str, dim: int, heads: int = 4, dim_head: int = 32) -> List[ParamSpec]:
     """Standalone ``Attention`` block (Diffusion_arch.py:237-253), config-4 extension."""
     hidden = heads * dim_head

@@ -314,6 +314,60 @@ def noisediff_forward(sd: SD, x: torch.Tensor, time: torch.Tensor, condition: Di
     return shot_noise + read_noise                                             # :644
 
 
+def posemb_unet_forward(sd: SD, arch: str, x: torch.Tensor, time: torch.Tensor, condition,
+                        taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """The ``UNet_PosEmbV2*`` ablation nets, forward as in models/archs/others_arch.py:
+    ``UNet_PosEmbV2`` :483-537, ``UNet_PosEmbV2_NoPosition`` :655-707 (``condition`` is the clean image itself, :658;
+    a dict with ``clean_img`` is accepted too), ``UNet_PosEmbV2_CameraCond`` :919-985.  Parity status: PINNED by
+    ``tests/golden/variants.npz`` (captured from the reference by ``tests/golden/capture_variants.py``)."""
+    dim = net_dim(sd)
+    assert x.shape[-1] % 8 == 0 and x.shape[-2] % 8 == 0
+    position_aware = arch != "UNet_PosEmbV2_NoPosition"
+    camera = arch == "UNet_PosEmbV2_CameraCond"
+    clean = condition["clean_img"] if isinstance(condition, dict) else condition
+    G = 8
+
+    def tap(name: str, t: torch.Tensor) -> torch.Tensor:
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    pos_emb = mlp(sd, "pos_mlp", learned_sinusoidal_pos_emb(sd, "pos_enc", condition["position"])) if position_aware else None
+    clean_emb = conv(sd, "cond_init_conv", clean, padding=3)                    # :491 / :662 / :928
+    clean_emb = tap("clean_emb", resnet_block(sd, "cond_res_block1", clean_emb, None, G))
+    iso = F.embedding(condition["iso_ratio_idx"].long(), sd["iso_embed.weight"]).unsqueeze(1) if camera else None   # :931-933
+    x = conv(sd, "init_conv", x, padding=3)                                     # :495
+    r = x
+    x = tap("cond_concat", conv(sd, "cond_concat_conv", torch.cat([x, clean_emb], dim=1), padding=1))   # :498
+    t = time_mlp(sd, time, dim)
+    pos_block = (lambda p, v: resnet_block_pos(sd, p, v, pos_emb, groups=2)) if position_aware else \
+                (lambda p, v: resnet_block(sd, p, v, None, groups=2))           # :644-646, :675
+    x = tap("pos_block1", pos_block("pos_block1", x))
+    rs = 3 if camera else 2
+    hs: List[torch.Tensor] = []
+    for i in range(4):                                                          # :507-515 / :947-957
+        p = f"downs.{i}"
+        x = resnet_block(sd, p + ".0", x, t, G); hs.append(x)
+        x = resnet_block(sd, p + ".1", x, t, G); hs.append(x)
+        if camera:
+            x = attn_block(sd, p + ".2", x, iso)
+        x = conv(sd, f"{p}.{rs}", x, padding=1) if i == 3 else pixel_unshuffle_conv(sd, f"{p}.{rs}", x)
+        tap(f"down{i}", x)
+    x = resnet_block(sd, "mid_block1", x, t, G)
+    x = tap("mid", resnet_block(sd, "mid_block2", x, t, G))
+    for i in range(4):                                                          # :520-527 / :962-971
+        p = f"ups.{i}"
+        x = resnet_block(sd, p + ".0", torch.cat((x, hs.pop()), dim=1), t, G)
+        x = resnet_block(sd, p + ".1", torch.cat((x, hs.pop()), dim=1), t, G)
+        if camera:
+            x = attn_block(sd, p + ".2", x, iso)
+        x = conv(sd, f"{p}.{rs}", x, padding=1) if i == 3 else upsample_conv(sd, f"{p}.{rs}", x)
+        tap(f"up{i}", x)
+    x = tap("pos_block2", pos_block("pos_block2", x))
+    x = resnet_block(sd, "final_res_block", torch.cat((x, r), dim=1), t, G)     # :531-536
+    return conv(sd, "final_conv", x)
+
+
 # --------------------------------------------------------------------------- the sampler
 
 NetFn = Callable[[torch.Tensor, torch.Tensor], torch.Tensor]
