@@ -60,6 +60,13 @@ def parse():
     return ap.parse_args()
 
 
+def _latest_profile(kind):
+    """profiles/r<round><letter>_<kind>.json of the newest build that has one (written by tools/pmc_*.py on the GPU box)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{kind}.json")))
+    return files[-1] if files else ""
+
+
 def conv_flops(m):
     return 18.0 * m["cin"] * m["cout"] * m["H"] * m["W"] * m["B"]          # SURVEY 8d: 2 * 9 * Cin * Cout per output pixel
 
@@ -72,7 +79,8 @@ def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
     CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32")
-    convs = [op for op in plan.step_ops if op[2] in CONV]
+    STREAM = "nd_affine_silu_add_f32"           # the HBM-bound family: GroupNorm-apply + SiLU + residual adds, one pass
+    convs = [op for op in plan.step_ops if op[2] in CONV or (op[2] == STREAM and op[3])]
     n_ev = 2 * len(convs)
     evs = []
     for _ in range(n_ev):
@@ -84,7 +92,7 @@ def instrumented_pass(loop, plan, L, n_steps):
         L.call("nd_sampler_begin_step", C.byref(loop.state), st)
         i = 0
         for fn, args, name, meta in plan.step_ops:
-            if name in CONV:
+            if name in CONV or (name == STREAM and meta):
                 L.call("nd_event_record", evs[2 * i], st)
                 L.check(fn(*args), name)
                 L.call("nd_event_record", evs[2 * i + 1], st)
@@ -101,6 +109,12 @@ def instrumented_pass(loop, plan, L, n_steps):
             ms = C.c_float()
             L.call("nd_event_elapsed_ms", evs[2 * j], evs[2 * j + 1], C.byref(ms))
             m = op[3]
+            if op[2] == STREAM:
+                d = per.setdefault(("stream", 0), {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
+                d["ms"] += ms.value
+                d["bytes"] += m["stream_bytes"]
+                d["launches"] += 1
+                continue
             d = per.setdefault((m["tiling"], m["mode"]), {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
             d["ms"] += ms.value
             d["flop"] += conv_flops(m)
@@ -290,6 +304,7 @@ def main():
     if rank == 0 and not a.no_roofline:
         n_inst = min(max(a.steps, 1), 3)
         per = instrumented_pass(loop, plan, L, n_inst)
+        stream = per.pop(("stream", 0), None)
         tot_ms = sum(d["ms"] for d in per.values())
         tot_flop = sum(d["flop"] for d in per.values())
         kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
@@ -298,13 +313,13 @@ def main():
         tid, d = dom
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
         traffic, tsrc = None, None
-        tfile = os.path.join(REPO, "profiles", "r1d_traffic.json")      # PMC passes cannot run inside this process
+        tfile = _latest_profile("traffic")                               # PMC passes cannot run inside this process
         if os.path.exists(tfile) and (a.dim, a.size, a.batch) == (64, 256, 16):
             tk = json.load(open(tfile))["kernels"].get(kname(tid))
             if tk:
-                traffic, tsrc = tk["hbm_bytes_per_launch"], "profiles/r1d_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+                traffic, tsrc = tk["hbm_bytes_per_launch"], f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
         busy_pmc = None
-        bfile = os.path.join(REPO, "profiles", "r1d_mfma_busy.json")     # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), own PMC pass
+        bfile = _latest_profile("mfma_busy")                             # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), own PMC pass
         if os.path.exists(bfile) and (a.dim, a.size, a.batch) == (64, 256, 16):
             bk = json.load(open(bfile))["kernels"].get(kname(tid))
             if bk:
@@ -326,6 +341,14 @@ def main():
             "by_kernel": {kname(k): {"tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12, "avg_ms": v["ms"] / v["launches"],
                                      "launches_per_step": v["launches"] // n_inst} for k, v in sorted(per.items())},
         }
+        if stream:
+            # the step's HBM-bound family, judged on GB/s: algorithmic bytes (every operand read once, the result written
+            # once) over the summed launch time of the same instrumented pass
+            gbs = stream["bytes"] / (stream["ms"] * 1e-3) / 1e9
+            out["roofline"]["hbm_bound_family"] = {
+                "kernel": "affine_silu_add_kernel", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": gbs / PEAK_HBM_GBS, "launches_per_step": stream["launches"] // n_inst,
+                "ms_per_step": stream["ms"] / n_inst}
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items() if not k.startswith("mid_attn.")}, a.dim, S, n_sample_steps)
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -365,7 +365,8 @@ class Plan:
             # on these small, wide tensors one elementwise pass (tens of MB) is cheaper than that VALU work next to the MFMAs
             a1 = self._alloc(self.B, HW, cout)
             self._add("nd_affine_silu_add_f32", c1.data_ptr(), cout, mad1.data_ptr(), None, cout, None, cout, a1.data_ptr(), cout,
-                      self.B, HW, cout, self.e.stream)
+                      self.B, HW, cout, self.e.stream,
+                      meta={"layer": name + ".block1.act", "stream_bytes": 4.0 * self.B * HW * cout * 2})
             src2 = self._src(a1)
         else:
             mode = L.PRO_AFFINE_MAP_SILU if posmap is not None else L.PRO_AFFINE_SILU
@@ -382,7 +383,8 @@ class Plan:
             out = self._alloc(self.B, HW, cout)
             self._add("nd_affine_silu_add_f32", c2.data_ptr(), cout, mad2.data_ptr(), x.data_ptr(), cout,
                       extra_res.data_ptr() if extra_res is not None else None, cout, out.data_ptr(), cout,
-                      self.B, HW, cout, self.e.stream)
+                      self.B, HW, cout, self.e.stream,
+                      meta={"layer": name + ".tail", "stream_bytes": 4.0 * self.B * HW * cout * (4 if extra_res is not None else 3)})
         self._release(c1, st1, sc1, mad1, c2, st2, sc2, mad2)
         return out.view(self.B, H, W, cout)
 

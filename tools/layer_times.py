@@ -49,6 +49,8 @@ for i, (fn, args, name, meta) in enumerate(ops):
         by = 4.0 * meta["B"] * meta["H"] * meta["W"] * (meta["cin"] + meta["cout"])
         desc = f"{meta['layer']} {meta['cin']}->{meta['cout']} @{meta['H']}x{meta['W']} t{meta['tiling']} m{desc_mode}"
         gbs, tf = by / ms / 1e6, fl / ms / 1e9
+    elif meta and "stream_bytes" in meta:
+        desc, gbs = meta["layer"], meta["stream_bytes"] / ms / 1e6
     elif meta:
         fl = meta.get("flop_per_px", 2.0 * meta["cin"] * meta["cout"]) * meta["HW"] * meta["B"]
         by = 4.0 * meta["B"] * meta["HW"] * (meta["cin"] + meta["cout"])
