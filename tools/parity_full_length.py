@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Full-length parity at the headline configuration: ONE patch, d=64, 256x256x4, 1000-step DDPM (sigmoid2, pred_v), the HIP
+sampler against the CPU oracle on identical weights, conditions, x_T and per-step noise (the explicit-noise parity mode of
+GaussianDiffusion.sample).  The committed goldens cover 50-step DDIM and 20-step DDPM; this shows what 1000 chained steps do to
+the difference.  Takes several minutes of host time (the oracle runs ~0.4 s per step); progress is printed every 50 steps.
+usage: python tools/parity_full_length.py [--size 256] [--steps 1000] [--dim 64] -> gpurun_out/parity_full_length.json"""
+import argparse, json, os, sys, time
+from types import SimpleNamespace
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+from noisediff_amd import GaussianDiffusion, NoiseDiffNet, synth
+from noisediff_amd.spec import noisediff_param_spec
+from oracle import noisediff_oracle as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=256); ap.add_argument("--steps", type=int, default=1000)
+ap.add_argument("--dim", type=int, default=64); ap.add_argument("--threads", type=int, default=16)
+a = ap.parse_args()
+torch.set_num_threads(a.threads)
+dev = torch.device("cuda", 0)
+B, S, T = 1, a.size, a.steps
+sd = synth.make_state_dict(noisediff_param_spec(a.dim), 0)
+cond = synth.make_condition(B, S, seed=1)
+x_T = synth.make_noise(2, "x_T", B, 4, S)
+steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, S) for i in range(T - 1)])
+
+net = NoiseDiffNet(SimpleNamespace(dim=a.dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False))
+net.load_state_dict(sd, strict=True)
+net = net.to(dev).eval()
+gd = GaussianDiffusion(net, image_size=S, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+t0 = time.time()
+with torch.inference_mode():
+    traj = gd.sample(batch_size=B, condition={k: v.to(dev) for k, v in cond.items()}, return_all_timesteps=True,
+                     noise={"x_T": x_T, "steps": steps}).cpu()            # (B, T+1, C, H, W)
+print(f"HIP sampler: {time.time() - t0:.1f} s", flush=True)
+
+buf = O.schedule_buffers("sigmoid2", T, "pred_v")
+errs, t0 = {}, time.time()
+state = {"k": 0}
+
+def on_step(t, img, out):
+    k = state["k"]                                    # img is the oracle's x_t before step k (k = 0: x_T)
+    ref = img.numpy()
+    e = float(np.max(np.abs(traj[:, k].numpy() - ref)) / max(1.0, float(np.max(np.abs(ref)))))
+    errs[k] = e
+    if k % 50 == 0:
+        print(f"step {k:4d} (t={t:3d}): rel err of x_t {e:.3e}   [{time.time() - t0:.0f} s]", flush=True)
+    state["k"] = k + 1
+
+with torch.no_grad():
+    ref = O.p_sample_loop(lambda v, tt: O.noisediff_forward(sd, v, tt, cond), buf, "pred_v", x_T, lambda i, shape: steps[i],
+                          on_step=on_step)
+final = float(np.max(np.abs(traj[:, -1].numpy() - ref.numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
+res = {"config": f"d={a.dim}, {S}x{S}x4, {T}-step DDPM, B=1, explicit noise", "final_rel_err": final,
+       "max_rel_err_over_trajectory": max(errs.values()), "rel_err_every_100_steps": {str(k): errs[k] for k in sorted(errs) if k % 100 == 0},
+       "tolerance": 1e-3, "oracle_seconds": time.time() - t0}
+os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(REPO, "gpurun_out", "parity_full_length.json"), "w"), indent=1)
+print(json.dumps(res), flush=True)
