@@ -28,7 +28,7 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
 def broadcast_weights(net, device: torch.device, src: int = 0, group=None):
     """Fill this rank's engine from rank `src`'s packed arena: the one collective of the data path."""
     from .engine import Engine
-    eng = Engine(net.dim, device, mid_attn=net.has_mid_attn, inp_dim=net.channels)
+    eng = Engine(net.dim, device, mid_attn=net.has_mid_attn, inp_dim=net.channels, arch=getattr(net, "ARCH", "NoiseDiffNet"))
     if dist.get_rank(group) == src:
         eng.load_state_dict(net.state_dict())
     eng.broadcast(src=src, group=group)

@@ -84,3 +84,25 @@ def test_variant_hip_forward_and_sampler(golden, arch):
         steps = torch.stack([synth.make_noise(5, f"noise.{i}", B, 4, S) for i in range(7)])
         res = gd.sample(batch_size=B, condition=ref_cond, noise={"x_T": synth.make_noise(5, "x_T", B, 4, S), "steps": steps})
     assert rel_err(res.cpu().numpy(), golden("variants", f"{arch}.ddim8")) < 1e-3      # north-star tolerance
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", VARIANTS)
+def test_variant_hip_forward_at_bench_width_matches_oracle(arch):
+    """d=64 (the benchmark width: Winograd convs, fused chains and the pipelined pointwise GEMM all active), 64x64, B=2,
+    against the oracle (itself pinned by the d=16 reference goldens above)."""
+    import noisediff_amd as nd
+    dev = torch.device("cuda", 0)
+    dim, b, size = 64, 2, 64
+    sd = synth.make_state_dict(arch_param_spec(arch, dim), 0)
+    cond = synth.make_condition(b, size, seed=1)
+    x = synth.make_noise(3, f"var64.{arch}.x", b, 4, size)
+    t = torch.tensor([17, 803], dtype=torch.long)
+    net = getattr(nd, arch)(SimpleNamespace(dim=dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    with torch.inference_mode():
+        y = net(x.to(dev), t.to(dev), {k: v.to(dev) for k, v in cond.items()}).cpu()
+    with torch.no_grad():
+        ref = O.posemb_unet_forward(sd, arch, x, t, cond)
+    assert rel_err(y.numpy(), ref.numpy()) < 2e-4
