@@ -119,6 +119,14 @@ int nd_conv3x3_wino_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 
+/* EXPERIMENTAL (r1e): the same operator with Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (1.78x fewer multiplies than
+ * F(2x2,3x3); ~1e-5 relative difference to the direct form).  Not selected by the engine; takes plain / two-source inputs
+ * and the GroupNorm-affine + SiLU prologue, no upsample addressing, no statistics epilogue.  `weight` from
+ * nd_pack_conv3x3_wino4_weight (U = G g G^T in blocks [cin/8][coutP/16][18 position pairs][64 lanes][4]). */
+int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream);
+int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
+int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
+
 /* ------------------------------------------------------------------ pointwise GEMM */
 
 /* out[p, n] = epi( sum_k pro(in[p, k]) * W[k, n] + bias[n] ) per pixel: nn.Conv2d(k=1) and

@@ -570,3 +570,37 @@ def test_conv3x3_winograd_matches_direct_semantics(ctx, case, entry):
         c0 = 32
     out, *_ = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))
     assert rel_err(hu.nchw(out), ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", sorted(WINO_CASES))
+def test_conv3x3_winograd_f4x4_experimental_matches_direct_semantics(ctx, case):
+    """The experimental F(4x4,3x3) kernel (conv3x3_wino4.hip, not selected by the engine) == nn.Conv2d(3, padding=1).
+    Tolerance 5e-5: its fp32 transforms carry entries up to 8 and 1/24 (F(2x2,3x3): 1e-5)."""
+    import hiputil as hu
+    B, H, W, cin, cout = WINO_CASES[case]
+    x = U(case + ".wx", (B, cin, H, W), -1.5, 1.5)
+    w = U(case + ".ww", (cout, cin, 3, 3), -0.2, 0.2)
+    b = U(case + ".wb", (cout,))
+    ref = F.conv2d(x, w, b, padding=1)
+    wd, bd = hu.dev(w), hu.dev(b)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+
+    def run(s):
+        out = hu.full((B, H, W, cout))
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream)
+        ctx.sync()
+        return out
+
+    assert rel_err(hu.nchw(run(hu.src(hu.nhwc(x)))), ref) < 5e-5
+    M, A, D = U(case + ".wM", (B, cin)), U(case + ".wA", (B, cin), 0.5, 1.5), U(case + ".wD", (B, cin))
+    act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+    out = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
+    assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
+    c0 = cin // 2 // 4 * 4
+    out = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))          # virtual concat, any multiple-of-4 split
+    assert rel_err(hu.nchw(out), ref) < 5e-5
