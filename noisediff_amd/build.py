@@ -28,6 +28,8 @@ FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 # file on purpose (no VGPR-form switch) and its K loop must be unrolled completely (16 steps x 16 MFMA slices).
 SPECIAL = {
     "conv3x3_wino2": ("conv3x3_wino2", BASE_FLAGS + ["-mllvm", "-pragma-unroll-threshold=1000000"]),
+    # one wave per SIMD: 144 accumulator registers in the AGPR half, the rest of the pipeline state in the VGPR half
+    "conv3x3_wino4": ("conv3x3_wino4", BASE_FLAGS),
 }
 
 

@@ -32,7 +32,7 @@ constexpr int VD_FLOATS = (KC4 / 2) * NPOS * 16 * 2; // 9216 floats = 36 KB
 
 struct Wino4Args {
     nd_conv3x3 d;
-    int tiles_x, tiles_y, n_tiles, n_cg, total_wg;
+    int tiles_x, tiles_y, n_tiles, n_cg, n_c8, slots, total_wg;
 };
 
 // one row of B^T applied to six packed values (the same code serves the column pass)
@@ -56,125 +56,265 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
     y[3] = b + 8.0f * e + m[5];
 }
 
+// ---- the kernel.  One persistent workgroup per CU (one wave per SIMD, the whole register file):
+//   * items = (tile, 16-channel chunk); the halo of item i+1 is loaded from HBM/L2 during item i's first 8-channel
+//     stage (9 buffer loads per thread: the thread's tile and channel quad are fixed, the patch entry (a, b) of load `it`
+//     is wave-uniform, so the big part of every address sits in the scalar offset and nothing about it is recomputed)
+//     and written into the other LDS buffer at the end of that stage; the chunk's one barrier follows, and the second
+//     stage already reads the next item's first patch entries behind it;
+//   * a stage = 72 MFMAs (36 positions x the channel pair of this lane); the 18 weight fragments are refreshed in place
+//     for the NEXT stage right after their MFMAs (a whole stage of latency cover), the next stage's 36 patch entries are
+//     read from LDS at the top of the stage and transformed (B^T d B, packed float2) between the MFMA rows, each new
+//     operand row replacing the row whose MFMAs have just been issued.
+constexpr int W4_STAGE_LOADS = 9;                    // 576 (entry, tile) slots x 4 quads / 256 threads
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU;
-    __shared__ __attribute__((aligned(16))) float Vd[VD_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float Vd[];          // [2][VD_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = lane & 15, kq = lane >> 4;
 
-    int lid = blockIdx.x;
-    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
-    const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
-    const int ty = lid % a.tiles_y;
-    const int b = lid / a.tiles_y;
+    const int t_begin = (int)((long)blockIdx.x * a.total_wg / gridDim.x), t_end = (int)((long)(blockIdx.x + 1) * a.total_wg / gridDim.x);
+    if (t_begin >= t_end) return;
 
     const nd_src& s = a.d.src;
     const int H = a.d.H, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
     const int Ctot = s.c0 + s.c1;
-    const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;
-    const int cg = nt * 4 + wave;                              // this wave's 16-cout group
+    const int n_chunks = (Cin + KC4 - 1) / KC4;
+
+    auto decode = [&](int t, int& b_, int& ty_, int& tx_, int& nt_) {
+        int lid = t;
+        nt_ = lid % a.n_tiles;  lid /= a.n_tiles;
+        tx_ = lid % a.tiles_x;  lid /= a.tiles_x;
+        ty_ = lid % a.tiles_y;
+        b_ = lid / a.tiles_y;
+    };
+
+    // ---- staging: thread = (tile st, channel quad sq), load `it` = patch entry e = wave + 4 * it of that tile
+    const int st = (tid >> 2) & 15, sq = tid & 3;
+    const int sty = 4 * (st >> 2), stx = 4 * (st & 3);          // tile origin inside the 16x16 pixels (patch entry (0,0) is one up-left)
+    const long npx = (long)a.d.B * H * W;
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(npx * s.ld0 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(npx * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
+    const unsigned OOB = 0x7FFFFFF0u;                            // lane offset beyond any tensor: the load returns zeros (padding)
+    // LDS byte address of this thread's first write: pair 2*sq, entry `wave`, tile st
+    const unsigned st_lds = (unsigned)((((2 * sq) * NPOS + wave) * 16 + st) * 8);
+
+    f32x4 raw[W4_STAGE_LOADS];
+    f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
+    unsigned okmask = 0;
+    auto stage_issue = [&](int b_, int ty_, int tx_, int cb_) {
+        const bool sec = cb_ >= s.c0;                            // wave-uniform: a chunk never straddles the sources (host check)
+        const __amdgpu_buffer_rsrc_t rs = sec ? rsrc1 : rsrc0;
+        const int ld = sec ? s.ld1 : s.ld0;
+        const int cbase = sec ? cb_ - s.c0 : cb_;
+        const int c = cb_ + 4 * sq;
+        const bool cvalid = c < Cin;
+        if (AFF) {
+            const float* m = s.mad + (size_t)b_ * 3 * Ctot + (cvalid ? c : 0);
+            tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
+            tD = tD - tM * tA;
+        }
+        const int y0 = ty_ * 16 - 1, x0 = tx_ * 16 - 1;
+        okmask = 0;
+#pragma unroll
+        for (int it = 0; it < W4_STAGE_LOADS; ++it) {
+            const int e = wave + 4 * it;                         // wave-uniform patch entry
+            const int ay = (e * 43) >> 8, ax = e - 6 * ay;       // e / 6, e % 6 for e < 36
+            const int gy = y0 + sty + ay, gx = x0 + stx + ax;
+            const bool ok = cvalid && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            okmask |= (ok ? 1u : 0u) << it;
+            // scalar part: the patch entry's pixel for tile (0,0) of this 16x16 block, clamped into the image; lane part: the tile's origin
+            const int sy = min(max(y0 + ay, 0), H - 1), sx = min(max(x0 + ax, 0), W - 1);
+            const int soff = __builtin_amdgcn_readfirstlane((((b_ * H + sy) * W + sx) * ld + cbase) * 4);
+            const unsigned voff = ok ? (unsigned)((((gy - sy) * W + (gx - sx)) * ld + 4 * sq) * 4) : OOB;
+            raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+        }
+    };
+    auto stage_commit = [&](float* dst) {
+        char* base = reinterpret_cast<char*>(dst) + st_lds;
+#pragma unroll
+        for (int it = 0; it < W4_STAGE_LOADS; ++it) {
+            f32x4 v = raw[it];
+            if (AFF) {
+                v = nd_silu4(v * tA + tD);
+                const f32x4 zero = {0, 0, 0, 0};
+                v = ((okmask >> it) & 1u) ? v : zero;            // silu(affine(0)) != 0: padding is applied after the activation
+            }
+            *reinterpret_cast<f32x2*>(base + it * (4 * 16 * 8)) = f32x2{v.x, v.y};
+            *reinterpret_cast<f32x2*>(base + it * (4 * 16 * 8) + NPOS * 16 * 8) = f32x2{v.z, v.w};
+        }
+    };
+
+    // ---- MFMA side
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.d.weight), 0, (int)((long)a.n_c8 * a.n_cg * 18 * 256 * 4), 0x00020000);
+    const unsigned wvoff = (unsigned)(lane * 16);
+    auto wblock = [&](int c8_, int cg_) { return __builtin_amdgcn_readfirstlane(((c8_ * a.n_cg + cg_) * 18) * 1024); };
+    const unsigned d_lds = (unsigned)((kq * NPOS * 16 + tile) * 8);      // + stage * 4 pairs, + entry * 128
 
     f32x4 acc[NPOS];
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0, 0, 0, 0};
+    f32x4 U[18];
+    f32x2 V[6][6], T[6][6];
 
-    const int n_c8 = (Cin + 7) >> 3;
-    for (int cb = 0; cb < Cin; cb += KC4) {
-        __syncthreads();                                       // previous chunk consumed
-        // ---- stage: 18x18 halo pixels x 4 channel quads, each written to every (tile, patch entry) it belongs to
-        for (int i = tid; i < 324 * 4; i += 256) {
-            const int p = i >> 2, q = i & 3;
-            const int hy = p / 18, hx = p - hy * 18;
-            const int gy = y0 + hy, gx = x0 + hx;
-            const int c = cb + 4 * q;
-            f32x4 v = {0, 0, 0, 0};
-            const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin;
-            if (inside) {
-                const size_t pix = ((size_t)b * H + gy) * W + gx;
-                const bool sec = c >= s.c0;
-                v = sec ? nd_ld4(s.p1 + pix * s.ld1 + (c - s.c0)) : nd_ld4(s.p0 + pix * s.ld0 + c);
-                if (AFF) {
-                    const float* m = s.mad + (size_t)b * 3 * Ctot + c;
-                    v = nd_silu4((v - nd_ld4(m)) * nd_ld4(m + Ctot) + nd_ld4(m + 2 * Ctot));
-                }
-            }
-            const int kp = (q >> 1) * 4 + (q & 1) * 2;         // channel pair index of (v.x, v.y); (v.z, v.w) is kp + 1
+    auto load_u = [&](int pp, int wb) { U[pp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wb + pp * 1024, 0)); };
+    auto read_d = [&](const float* buf, int g2) {                // next stage's patch entries -> T (raw values for now)
+        const char* base = reinterpret_cast<const char*>(buf) + d_lds + g2 * (4 * NPOS * 16 * 8);
 #pragma unroll
-            for (int ey = 0; ey < 2; ++ey) {
-                const int tyi = (hy >> 2) - ey, ay = hy - 4 * tyi;
-                if (tyi < 0 || tyi > 3 || ay > 5) continue;
+        for (int e = 0; e < NPOS; ++e) T[e / 6][e % 6] = *reinterpret_cast<const f32x2*>(base + e * 128);
+    };
+    auto col_pass = [&]() {                                      // T <- B^T T (over the patch rows, every column)
 #pragma unroll
-                for (int ex = 0; ex < 2; ++ex) {
-                    const int txi = (hx >> 2) - ex, ax = hx - 4 * txi;
-                    if (txi < 0 || txi > 3 || ax > 5) continue;
-                    const int slot = (ay * 6 + ax) * 16 + tyi * 4 + txi;
-                    *reinterpret_cast<f32x2*>(&Vd[((kp * NPOS * 16) + slot) * 2]) = f32x2{v.x, v.y};
-                    *reinterpret_cast<f32x2*>(&Vd[(((kp + 1) * NPOS * 16) + slot) * 2]) = f32x2{v.z, v.w};
-                }
-            }
+        for (int bx = 0; bx < 6; ++bx) {
+            f32x2 col[6], t[6];
+#pragma unroll
+            for (int ay = 0; ay < 6; ++ay) col[ay] = T[ay][bx];
+            w4_bt(col, t);
+#pragma unroll
+            for (int xi = 0; xi < 6; ++xi) T[xi][bx] = t[xi];
         }
-        __syncthreads();
+    };
+    auto mfma_row = [&](int xi, int wb_next) {                   // 12 MFMAs of operand row xi; its weight fragments refreshed behind them
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const int pp = xi * 3 + h, p0 = 2 * pp, p1 = 2 * pp + 1;
+            acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].x, V[xi][2 * h].x, acc[p0], 0, 0, 0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].y, V[xi][2 * h].y, acc[p0], 0, 0, 0);
+            acc[p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].z, V[xi][2 * h + 1].x, acc[p1], 0, 0, 0);
+            acc[p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].w, V[xi][2 * h + 1].y, acc[p1], 0, 0, 0);
+            load_u(pp, wb_next);
+        }
+    };
+    // one 8-channel stage: MFMAs with (U, V) of this stage, operands of the next stage produced on the way
+    auto stage = [&](const float* next_buf, int next_g2, int wb_next, auto&& mid) {
+        read_d(next_buf, next_g2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(0, wb_next);
+        mfma_row(1, wb_next);
+        __builtin_amdgcn_sched_barrier(0);
+        col_pass();
+#pragma unroll
+        for (int xi = 2; xi < 6; ++xi) {
+            mfma_row(xi, wb_next);
+            w4_bt(T[xi - 2], V[xi - 2]);                         // rows whose MFMAs are issued take their next values
+        }
+        w4_bt(T[4], V[4]);
+        w4_bt(T[5], V[5]);
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+    };
 
-#pragma unroll 1
-        for (int g2 = 0; g2 < 2; ++g2) {                       // 8 channels: two MFMA k groups, packed side by side
-            const int c8 = (cb >> 3) + g2;
-            if (c8 >= n_c8) break;
-            const f32x2* dsrc = reinterpret_cast<const f32x2*>(Vd) + ((g2 * 4 + kq) * NPOS) * 16 + tile;
-            f32x2 V[6][6];
-            {   // B^T d B: rows (over a) for every column b, then columns
-                f32x2 T[6][6];
+    // ---- prologue: first item staged synchronously, first operands built
+    int b, ty, tx, nt;
+    decode(t_begin, b, ty, tx, nt);
+    int cur = 0;
+    stage_issue(b, ty, tx, 0);
+    stage_commit(Vd);
+    __syncthreads();
+    {
+        const int wb0 = wblock(0, nt * 4 + wave);
 #pragma unroll
-                for (int bx = 0; bx < 6; ++bx) {
-                    f32x2 col[6], t[6];
+        for (int pp = 0; pp < 18; ++pp) load_u(pp, wb0);
+        read_d(Vd, 0);
+        col_pass();
 #pragma unroll
-                    for (int ay = 0; ay < 6; ++ay) col[ay] = dsrc[(ay * 6 + bx) * 16];
-                    w4_bt(col, t);
-#pragma unroll
-                    for (int xi = 0; xi < 6; ++xi) T[xi][bx] = t[xi];
-                }
-#pragma unroll
-                for (int xi = 0; xi < 6; ++xi) w4_bt(T[xi], V[xi]);
-            }
-            const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.d.weight) + ((size_t)(c8 * a.n_cg + cg) * 18) * 64 + lane;
-#pragma unroll
-            for (int pp = 0; pp < 18; ++pp) {
-                const f32x4 u = wsrc[pp * 64];
-                const int p0 = 2 * pp, p1 = 2 * pp + 1;
-                acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, V[p0 / 6][p0 % 6].x, acc[p0], 0, 0, 0);
-                acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, V[p0 / 6][p0 % 6].y, acc[p0], 0, 0, 0);
-                acc[p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, V[p1 / 6][p1 % 6].x, acc[p1], 0, 0, 0);
-                acc[p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, V[p1 / 6][p1 % 6].y, acc[p1], 0, 0, 0);
-            }
-        }
+        for (int xi = 0; xi < 6; ++xi) w4_bt(T[xi], V[xi]);
     }
 
-    // ---- output transform Y = A^T M A on float4s (couts co .. co+3 of tile `tile`), bias, 16-byte stores
-    const int co = cg * 16 + 4 * kq;
-    f32x4 bias4 = {0, 0, 0, 0};
-    if (a.d.bias && co + 3 < Cout) bias4 = nd_ld4(a.d.bias + co);
-    f32x4 Z[4][6];
-#pragma unroll
-    for (int nu = 0; nu < 6; ++nu) {
-        f32x4 m[6], y[4];
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) m[xi] = acc[xi * 6 + nu];
-        w4_at(m, y);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Z[i][nu] = y[i];
-    }
-    const int py0 = ty * 16 + 4 * (tile >> 2), px0 = tx * 16 + 4 * (tile & 3);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f32x4 y[4];
-        w4_at(Z[i], y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int py = py0 + i, px = px0 + j;
-            if (py < H && px < W && co + 3 < Cout)
-                nd_st4(a.d.out + (((size_t)b * H + py) * W + px) * a.d.ldo + co, y[j] + bias4);
+    for (int t = t_begin; t < t_end; ++t) {
+        int b1 = b, ty1 = ty, tx1 = tx, nt1 = nt;
+        const bool more = t + 1 < t_end;
+        if (more) decode(t + 1, b1, ty1, tx1, nt1);
+        const int cg = nt * 4 + wave, cg1 = nt1 * 4 + wave;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const float* src = Vd + cur * VD_FLOATS;
+            float* dst = Vd + (cur ^ 1) * VD_FLOATS;
+            const bool last = ch + 1 == n_chunks;
+            // the item after this one (after the very last: a harmless re-stage of this tile's first chunk)
+            if (last) stage_issue(more ? b1 : b, more ? ty1 : ty, more ? tx1 : tx, 0);
+            else stage_issue(b, ty, tx, (ch + 1) * KC4);
+            const int c8 = 2 * ch;
+            // stage 0: channels 0-7 of the chunk; next operands = channels 8-15 of the same buffer
+            stage(src, 1, wblock(c8 + 1, cg), [&]() {
+                stage_commit(dst);
+                __syncthreads();                                 // next buffer complete; every read of this one has been issued
+            });
+            // stage 1: channels 8-15; next operands = first 8 channels of the next item (other buffer)
+            stage(dst, 0, last ? wblock(0, cg1) : wblock(c8 + 2, cg), [&]() {});
+            cur ^= 1;
         }
+
+        // ---- output transform Y = A^T M A on float4s (couts co .. co+3 of tile `tile`), bias, 16-byte stores, GN partials
+        {
+            const int co = cg * 16 + 4 * kq;
+            const bool cok = co + 3 < Cout;
+            f32x4 bias4 = {0, 0, 0, 0};
+            if (a.d.bias && cok) bias4 = nd_ld4(a.d.bias + co);
+            const int py0 = ty * 16 + 4 * (tile >> 2), px0 = tx * 16 + 4 * (tile & 3);
+            f32x4 sum4 = {0, 0, 0, 0}, sq4 = {0, 0, 0, 0}, pivot4 = {0, 0, 0, 0};
+            int cnt = 0;
+            f32x4 Z[4][6];
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                f32x4 m[6], y[4];
+#pragma unroll
+                for (int xi = 0; xi < 6; ++xi) m[xi] = acc[xi * 6 + nu];
+                w4_at(m, y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Z[i][nu] = y[i];
+            }
+#pragma unroll
+            for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 y[4];
+                w4_at(Z[i], y);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = y[j] + bias4;
+                    if (i == 0 && j == 0) {                      // one pivot per cout for the whole workgroup tile: tile 0's first pixel
+                        pivot4.x = __shfl(v.x, lane & 48); pivot4.y = __shfl(v.y, lane & 48);
+                        pivot4.z = __shfl(v.z, lane & 48); pivot4.w = __shfl(v.w, lane & 48);
+                    }
+                    const int py = py0 + i, px = px0 + j;
+                    if (py < H && px < W) {
+                        const f32x4 dv = v - pivot4;
+                        sum4 += dv;
+                        sq4 += dv * dv;
+                        ++cnt;
+                        if (cok) nd_st4(a.d.out + (((size_t)b * H + py) * W + px) * a.d.ldo + co, v);
+                    }
+                }
+            }
+            if (a.d.stats) {
+                // pool over the 16 tiles (the 16 lanes of a DPP row share their couts): sum = S + n p, M2 = Q - S^2 / n
+                float fc = nd_row16_sum((float)cnt);
+                f32x4 S, Q;
+                S.x = nd_row16_sum(sum4.x); S.y = nd_row16_sum(sum4.y); S.z = nd_row16_sum(sum4.z); S.w = nd_row16_sum(sum4.w);
+                Q.x = nd_row16_sum(sq4.x); Q.y = nd_row16_sum(sq4.y); Q.z = nd_row16_sum(sq4.z); Q.w = nd_row16_sum(sq4.w);
+                const int slot = (ty * a.tiles_x + tx) * 2;
+                if (tile == 0 && cok) {
+                    fc = fmaxf(fc, 1.0f);
+                    float* o = a.d.stats + (((size_t)b * a.slots + slot) * Cout + co) * 2;
+                    const f32x4 sm = S + fc * pivot4;
+                    const f32x4 m2 = Q - S * S / fc;
+                    nd_st4(o, f32x4{sm.x, fmaxf(m2.x, 0.0f), sm.y, fmaxf(m2.y, 0.0f)});
+                    nd_st4(o + 4, f32x4{sm.z, fmaxf(m2.z, 0.0f), sm.w, fmaxf(m2.w, 0.0f)});
+                    const f32x4 zero = {0, 0, 0, 0};             // the second slot of the tile (F(2x2) kernels: lower half) stays empty
+                    nd_st4(o + (size_t)Cout * 2, zero);
+                    nd_st4(o + (size_t)Cout * 2 + 4, zero);
+                }
+                if (b == 0 && nt == 0 && wave == 0 && lane == 0) {
+                    a.d.slot_count[slot] = (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
+                    a.d.slot_count[slot + 1] = 0.0f;
+                }
+            }
+        }
+        b = b1; ty = ty1; tx = tx1; nt = nt1;
     }
 }
 
@@ -205,22 +345,44 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+int w4_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 template <int MODE>
 int launch4(const Wino4Args& a, hipStream_t st) {
-    hipLaunchKernelGGL((wino4_kernel<MODE>), dim3((unsigned)a.total_wg), dim3(256), 0, st, a);
+    static bool configured = false;
+    const size_t lds = (size_t)2 * VD_FLOATS * sizeof(float);
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            nd_set_error("nd_conv3x3_wino4: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        configured = true;
+    }
+    const long resident = w4_cus();                       // one workgroup per CU (registers)
+    hipLaunchKernelGGL((wino4_kernel<MODE>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), lds, st, a);
     return 0;
 }
 
 }  // namespace
 
 extern "C" int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout) {
-    return (int64_t)nd_cdiv(cin, 8) * nd_cdiv(nd_round_up(cout, 64), 16) * 18 * 256;
+    return (int64_t)nd_round_up(nd_cdiv(cin, 8), 2) * nd_cdiv(nd_round_up(cout, 64), 16) * 18 * 256;     // whole 16-channel chunks
 }
 
 extern "C" int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
     ND_REQUIRE(oihw && packed, ND_E_BADARG, "nd_pack_conv3x3_wino4_weight: null pointer");
     ND_REQUIRE(cin > 0 && cout > 0, ND_E_BADARG, "nd_pack_conv3x3_wino4_weight: non-positive size");
-    const int n_c8 = nd_cdiv(cin, 8), n_cg = nd_round_up(cout, 64) / 16;
+    const int n_c8 = nd_round_up(nd_cdiv(cin, 8), 2), n_cg = nd_round_up(cout, 64) / 16;
     const size_t total = (size_t)n_c8 * n_cg * 18 * 256;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_wino4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cout, n_c8, n_cg);
@@ -245,7 +407,14 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
                "nd_conv3x3_wino4: unsupported prologue %d (use nd_conv3x3_wino2_nhwc_f32)", s.mode);
     ND_REQUIRE(s.mode != ND_PRO_AFFINE_SILU || s.mad, ND_E_BADARG, "nd_conv3x3_wino4: affine prologue needs mad");
     ND_REQUIRE(!s.upsample && !s.unshuffle, ND_E_BADARG, "nd_conv3x3_wino4: no upsample / unshuffle addressing (use nd_conv3x3_wino2_nhwc_f32)");
-    ND_REQUIRE(!d->stats && !d->slot_count, ND_E_BADARG, "nd_conv3x3_wino4: GroupNorm statistics are not produced by this kernel yet");
+    ND_REQUIRE((d->stats == nullptr) == (d->slot_count == nullptr), ND_E_BADARG, "nd_conv3x3_wino4: stats and slot_count go together");
+    ND_REQUIRE(!d->stats || d->cout % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: statistics need cout %% 4 == 0");
+    ND_REQUIRE(s.c1 == 0 || s.c0 % KC4 == 0, ND_E_SHAPE,
+               "nd_conv3x3_wino4: first concat source has %d channels; a 16-channel K chunk must not straddle the sources", s.c0);
+    {
+        const long px = (long)d->B * d->H * d->W;
+        ND_REQUIRE(px * s.ld0 * 4 < (1L << 31) && px * s.ld1 * 4 < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4: a source tensor of 2 GiB or more");
+    }
 
     Wino4Args a;
     a.d = *d;
@@ -253,11 +422,13 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     a.tiles_y = nd_cdiv(d->H, 16);
     a.n_tiles = nd_cdiv(d->cout, 64);
     a.n_cg = nd_round_up(d->cout, 64) / 16;
+    a.n_c8 = nd_round_up(nd_cdiv(d->cin, 8), 2);
+    a.slots = a.tiles_x * a.tiles_y * 2;
     const long wg = (long)d->B * a.tiles_x * a.tiles_y * a.n_tiles;
     ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4: grid too large");
     a.total_wg = (int)wg;
     hipStream_t st = (hipStream_t)stream;
-    if (s.mode == ND_PRO_AFFINE_SILU) launch4<ND_PRO_AFFINE_SILU>(a, st);
-    else launch4<ND_PRO_NONE>(a, st);
+    const int rc = s.mode == ND_PRO_AFFINE_SILU ? launch4<ND_PRO_AFFINE_SILU>(a, st) : launch4<ND_PRO_NONE>(a, st);
+    if (rc) return rc;
     return nd_launch_status("nd_conv3x3_wino4_nhwc_f32");
 }

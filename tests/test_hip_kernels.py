@@ -601,6 +601,10 @@ def test_conv3x3_winograd_f4x4_experimental_matches_direct_semantics(ctx, case):
     act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
     out = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
     assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
-    c0 = cin // 2 // 4 * 4
-    out = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))          # virtual concat, any multiple-of-4 split
-    assert rel_err(hu.nchw(out), ref) < 5e-5
+    c0 = cin // 2 // 16 * 16                                             # virtual concat: a 16-channel chunk must not straddle the sources
+    if c0:
+        out = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))
+        assert rel_err(hu.nchw(out), ref) < 5e-5
+    else:
+        with pytest.raises(L.HipError, match="straddle"):
+            run(hu.src(hu.nhwc(x[:, :8]), hu.nhwc(x[:, 8:])))
