@@ -66,6 +66,21 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
 //     for the NEXT stage right after their MFMAs (a whole stage of latency cover), the next stage's 36 patch entries are
 //     read from LDS at the top of the stage and transformed (B^T d B, packed float2) between the MFMA rows, each new
 //     operand row replacing the row whose MFMAs have just been issued.
+#ifndef W4_ABLATE
+#define W4_ABLATE 0          // diagnostic builds only (tools/w4_variants.sh): 1 no staging, 2 no weight refresh, 4 no transform, 8 no epilogue
+#endif
+#ifndef W4_URING
+#define W4_URING 18          // weight fragments in flight (18 = a whole stage ahead; 9 measured 15 % slower: L2 latency shows)
+#endif
+// MFMAs through inline asm (as in conv3x3_wino2.hip): "+a" keeps the 36 accumulators in place in the accumulator half of the
+// register file -- with the builtin, hipcc moved them between AGPR tuples and through VGPRs (s_nop 7 + 4 v_accvgpr_write per
+// move) several times per stage; operands are pinned to VGPRs.  The epilogue drains the pipe before reading them.
+#ifdef W4_NOP_TEST
+#define W4_MFMA(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#else
+#define W4_MFMA(acc, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#endif
+#define W4_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 constexpr int W4_STAGE_LOADS = 9;                    // 576 (entry, tile) slots x 4 quads / 256 threads
 
 template <int MODE>
@@ -93,19 +108,46 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     };
 
     // ---- staging: thread = (tile st, channel quad sq), load `it` = patch entry e = wave + 4 * it of that tile
-    const int st = (tid >> 2) & 15, sq = tid & 3;
+    const int st = tid & 15, sq = (tid >> 4) & 3;                  // == (lane & 15, lane >> 4): a wave's 64 lanes fill one 1-KB patch entry
     const int sty = 4 * (st >> 2), stx = 4 * (st & 3);          // tile origin inside the 16x16 pixels (patch entry (0,0) is one up-left)
     const long npx = (long)a.d.B * H * W;
     const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(npx * s.ld0 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(npx * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
     const unsigned OOB = 0x7FFFFFF0u;                            // lane offset beyond any tensor: the load returns zeros (padding)
     // LDS byte address of this thread's first write: pair 2*sq, entry `wave`, tile st
-    const unsigned st_lds = (unsigned)((((2 * sq) * NPOS + wave) * 16 + st) * 8);
+    const unsigned st_lds = (unsigned)(wave * 1024 + lane * 16);           // entry `wave`, then + 4 KB per load
 
-    f32x4 raw[W4_STAGE_LOADS];
+    f32x4 raw[AFF ? W4_STAGE_LOADS : 1];
     f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
-    unsigned okmask = 0;
-    auto stage_issue = [&](int b_, int ty_, int tx_, int cb_) {
+    // per staged tile: pixel offset of each of the 9 patch entries (lane part relative to a wave-uniform scalar pixel) and validity
+    int sbase[W4_STAGE_LOADS];
+    int* poff = reinterpret_cast<int*>(Vd + 2 * VD_FLOATS) + tid;          // [9][256], thread-private column
+    unsigned tilemask = 0, okmask = 0;
+    int sb_ = 0;
+    auto stage_tile = [&](int b_, int ty_, int tx_) {
+        sb_ = b_;
+        const int y0 = ty_ * 16 - 1, x0 = tx_ * 16 - 1;
+        const bool interior = ty_ > 0 && tx_ > 0 && y0 + 18 <= H && x0 + 18 <= W;      // wave-uniform
+        tilemask = 0;
+#pragma unroll
+        for (int it = 0; it < W4_STAGE_LOADS; ++it) {
+            const int e = wave + 4 * it;                         // wave-uniform patch entry
+            const int ay = (e * 43) >> 8, ax = e - 6 * ay;       // e / 6, e % 6 for e < 36
+            if (interior) {
+                sbase[it] = __builtin_amdgcn_readfirstlane((b_ * H + y0 + ay) * W + x0 + ax);
+                poff[it * 256] = sty * W + stx;
+                tilemask |= 1u << it;
+            } else {
+                const int gy = y0 + sty + ay, gx = x0 + stx + ax;
+                const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const int sy = min(max(y0 + ay, 0), H - 1), sx = min(max(x0 + ax, 0), W - 1);
+                sbase[it] = __builtin_amdgcn_readfirstlane((b_ * H + sy) * W + sx);
+                poff[it * 256] = ok ? (gy - sy) * W + (gx - sx) : 0;
+                tilemask |= (ok ? 1u : 0u) << it;
+            }
+        }
+    };
+    auto stage_issue = [&](int cb_, float* dma_dst) {
         const bool sec = cb_ >= s.c0;                            // wave-uniform: a chunk never straddles the sources (host check)
         const __amdgpu_buffer_rsrc_t rs = sec ? rsrc1 : rsrc0;
         const int ld = sec ? s.ld1 : s.ld0;
@@ -113,38 +155,33 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         const int c = cb_ + 4 * sq;
         const bool cvalid = c < Cin;
         if (AFF) {
-            const float* m = s.mad + (size_t)b_ * 3 * Ctot + (cvalid ? c : 0);
+            const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (cvalid ? c : 0);
             tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
             tD = tD - tM * tA;
         }
-        const int y0 = ty_ * 16 - 1, x0 = tx_ * 16 - 1;
-        okmask = 0;
+        okmask = cvalid ? tilemask : 0u;
+        const unsigned ld4 = (unsigned)ld * 4u;
 #pragma unroll
         for (int it = 0; it < W4_STAGE_LOADS; ++it) {
-            const int e = wave + 4 * it;                         // wave-uniform patch entry
-            const int ay = (e * 43) >> 8, ax = e - 6 * ay;       // e / 6, e % 6 for e < 36
-            const int gy = y0 + sty + ay, gx = x0 + stx + ax;
-            const bool ok = cvalid && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            okmask |= (ok ? 1u : 0u) << it;
-            // scalar part: the patch entry's pixel for tile (0,0) of this 16x16 block, clamped into the image; lane part: the tile's origin
-            const int sy = min(max(y0 + ay, 0), H - 1), sx = min(max(x0 + ax, 0), W - 1);
-            const int soff = __builtin_amdgcn_readfirstlane((((b_ * H + sy) * W + sx) * ld + cbase) * 4);
-            const unsigned voff = ok ? (unsigned)((((gy - sy) * W + (gx - sx)) * ld + 4 * sq) * 4) : OOB;
-            raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+            const int soff = __builtin_amdgcn_readfirstlane((sbase[it] * ld + cbase) * 4);
+            const unsigned voff = ((okmask >> it) & 1u) ? (unsigned)poff[it * 256] * ld4 + 16u * sq : OOB;
+#if !(W4_ABLATE & 1)
+            if (AFF) raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+            else     // LDS-DMA: 64 lanes x 16 bytes land as one contiguous patch entry, out-of-range lanes as zeros; no registers
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dma_dst + (wave + 4 * it) * 256),
+                                                         16, voff, soff, 0, 0);
+#endif
         }
     };
     auto stage_commit = [&](float* dst) {
+        if (!AFF) return;                                        // plain inputs went straight to LDS (LDS-DMA), nothing to commit
         char* base = reinterpret_cast<char*>(dst) + st_lds;
 #pragma unroll
         for (int it = 0; it < W4_STAGE_LOADS; ++it) {
-            f32x4 v = raw[it];
-            if (AFF) {
-                v = nd_silu4(v * tA + tD);
-                const f32x4 zero = {0, 0, 0, 0};
-                v = ((okmask >> it) & 1u) ? v : zero;            // silu(affine(0)) != 0: padding is applied after the activation
-            }
-            *reinterpret_cast<f32x2*>(base + it * (4 * 16 * 8)) = f32x2{v.x, v.y};
-            *reinterpret_cast<f32x2*>(base + it * (4 * 16 * 8) + NPOS * 16 * 8) = f32x2{v.z, v.w};
+            f32x4 v = nd_silu4(raw[it] * tA + tD);
+            const f32x4 zero = {0, 0, 0, 0};
+            v = ((okmask >> it) & 1u) ? v : zero;                // silu(affine(0)) != 0: padding is applied after the activation
+            *reinterpret_cast<f32x4*>(base + it * 4096) = v;
         }
     };
 
@@ -153,19 +190,19 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         const_cast<float*>(a.d.weight), 0, (int)((long)a.n_c8 * a.n_cg * 18 * 256 * 4), 0x00020000);
     const unsigned wvoff = (unsigned)(lane * 16);
     auto wblock = [&](int c8_, int cg_) { return __builtin_amdgcn_readfirstlane(((c8_ * a.n_cg + cg_) * 18) * 1024); };
-    const unsigned d_lds = (unsigned)((kq * NPOS * 16 + tile) * 8);      // + stage * 4 pairs, + entry * 128
+    const unsigned d_lds = (unsigned)((kq >> 1) * 256 + tile * 16 + (kq & 1) * 8);   // + stage * 512, + entry * 1024
 
     f32x4 acc[NPOS];
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0, 0, 0, 0};
-    f32x4 U[18];
+    f32x4 U[W4_URING];                                          // ring: fragment pp lives in U[pp % W4_URING], refreshed that far ahead
     f32x2 V[6][6], T[6][6];
 
-    auto load_u = [&](int pp, int wb) { U[pp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wb + pp * 1024, 0)); };
+    auto load_u = [&](int pp, int wb) { U[pp % W4_URING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wb + pp * 1024, 0)); };
     auto read_d = [&](const float* buf, int g2) {                // next stage's patch entries -> T (raw values for now)
-        const char* base = reinterpret_cast<const char*>(buf) + d_lds + g2 * (4 * NPOS * 16 * 8);
+        const char* base = reinterpret_cast<const char*>(buf) + d_lds + g2 * 512;
 #pragma unroll
-        for (int e = 0; e < NPOS; ++e) T[e / 6][e % 6] = *reinterpret_cast<const f32x2*>(base + e * 128);
+        for (int e = 0; e < NPOS; ++e) T[e / 6][e % 6] = *reinterpret_cast<const f32x2*>(base + e * 1024);
     };
     auto col_pass = [&]() {                                      // T <- B^T T (over the patch rows, every column)
 #pragma unroll
@@ -178,32 +215,53 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             for (int xi = 0; xi < 6; ++xi) T[xi][bx] = t[xi];
         }
     };
-    auto mfma_row = [&](int xi, int wb_next) {                   // 12 MFMAs of operand row xi; its weight fragments refreshed behind them
+    auto mfma_row = [&](int xi, int wb_cur, int wb_next) {       // 12 MFMAs of operand row xi; the ring refilled behind them
+        // first channel of the pair for all six positions, then the second: an accumulator is touched again six MFMAs later
+        // (the asm hides the instruction from hipcc's hazard recognizer, so the dependent-accumulate distance is kept long)
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
-            const int pp = xi * 3 + h, p0 = 2 * pp, p1 = 2 * pp + 1;
-            acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].x, V[xi][2 * h].x, acc[p0], 0, 0, 0);
-            acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].y, V[xi][2 * h].y, acc[p0], 0, 0, 0);
-            acc[p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].z, V[xi][2 * h + 1].x, acc[p1], 0, 0, 0);
-            acc[p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[pp].w, V[xi][2 * h + 1].y, acc[p1], 0, 0, 0);
-            load_u(pp, wb_next);
+            const int pp = xi * 3 + h;
+            const f32x4 u = U[pp % W4_URING];
+            W4_MFMA(acc[2 * pp], u.x, V[xi][2 * h].x);
+            W4_MFMA(acc[2 * pp + 1], u.z, V[xi][2 * h + 1].x);
+        }
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const int pp = xi * 3 + h;
+            const f32x4 u = U[pp % W4_URING];
+            W4_MFMA(acc[2 * pp], u.y, V[xi][2 * h].y);
+            W4_MFMA(acc[2 * pp + 1], u.w, V[xi][2 * h + 1].y);
+#if !(W4_ABLATE & 2)
+            if (pp + W4_URING < 18) load_u(pp + W4_URING, wb_cur);
+            else load_u(pp + W4_URING - 18, wb_next);
+#endif
         }
     };
     // one 8-channel stage: MFMAs with (U, V) of this stage, operands of the next stage produced on the way
-    auto stage = [&](const float* next_buf, int next_g2, int wb_next, auto&& mid) {
+    auto stage = [&](const float* next_buf, int next_g2, int wb_cur, int wb_next, auto&& mid) {
         read_d(next_buf, next_g2);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_row(0, wb_next);
-        mfma_row(1, wb_next);
+        mfma_row(0, wb_cur, wb_next);
+        mfma_row(1, wb_cur, wb_next);
         __builtin_amdgcn_sched_barrier(0);
+#if !(W4_ABLATE & 4)
         col_pass();
+#endif
 #pragma unroll
         for (int xi = 2; xi < 6; ++xi) {
-            mfma_row(xi, wb_next);
+            mfma_row(xi, wb_cur, wb_next);
+#if !(W4_ABLATE & 4)
             w4_bt(T[xi - 2], V[xi - 2]);                         // rows whose MFMAs are issued take their next values
+#else
+            for (int q = 0; q < 6; ++q) V[xi - 2][q] = T[xi - 2][q];
+#endif
         }
+#if !(W4_ABLATE & 4)
         w4_bt(T[4], V[4]);
         w4_bt(T[5], V[5]);
+#else
+        for (int q = 0; q < 6; ++q) { V[4][q] = T[4][q]; V[5][q] = T[5][q]; }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mid();
     };
@@ -212,13 +270,15 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     int b, ty, tx, nt;
     decode(t_begin, b, ty, tx, nt);
     int cur = 0;
-    stage_issue(b, ty, tx, 0);
+    stage_tile(b, ty, tx);
+    stage_issue(0, Vd);
     stage_commit(Vd);
-    __syncthreads();
+    __syncthreads();                                             // (plain inputs: the fence in front of it waits for the LDS-DMA)
+    if (!AFF) stage_issue(KC4, Vd + VD_FLOATS);                  // item 1 (n_chunks >= 2, host check) is on its way before chunk 0 starts
     {
         const int wb0 = wblock(0, nt * 4 + wave);
 #pragma unroll
-        for (int pp = 0; pp < 18; ++pp) load_u(pp, wb0);
+        for (int pp = 0; pp < W4_URING; ++pp) load_u(pp, wb0);
         read_d(Vd, 0);
         col_pass();
 #pragma unroll
@@ -234,21 +294,47 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             const float* src = Vd + cur * VD_FLOATS;
             float* dst = Vd + (cur ^ 1) * VD_FLOATS;
             const bool last = ch + 1 == n_chunks;
-            // the item after this one (after the very last: a harmless re-stage of this tile's first chunk)
-            if (last) stage_issue(more ? b1 : b, more ? ty1 : ty, more ? tx1 : tx, 0);
-            else stage_issue(b, ty, tx, (ch + 1) * KC4);
             const int c8 = 2 * ch;
+            if (AFF) {
+                // activation on the way in: the halo of the NEXT item goes through registers, loaded at the top of stage 0,
+                // transformed and written at its end (after the very last item: a harmless re-stage of this tile's first chunk)
+                if (last) {
+                    if (more) stage_tile(b1, ty1, tx1);
+                    stage_issue(0, dst);
+                } else {
+                    stage_issue((ch + 1) * KC4, dst);
+                }
+            }
             // stage 0: channels 0-7 of the chunk; next operands = channels 8-15 of the same buffer
-            stage(src, 1, wblock(c8 + 1, cg), [&]() {
+            stage(src, 1, wblock(c8, cg), wblock(c8 + 1, cg), [&]() {
                 stage_commit(dst);
-                __syncthreads();                                 // next buffer complete; every read of this one has been issued
+                if (AFF) {
+                    __syncthreads();                             // next buffer complete; every read of this one has been issued
+                } else {
+                    // plain inputs: the next item's 9 LDS-DMA loads were issued at the top of the PREVIOUS stage, before that
+                    // stage's and this stage's 18 + 18 weight-fragment loads, and memory operations retire in order: at most
+                    // 36 outstanding == the halo has landed.  No fence (it would drain the weight stream as well).
+                    asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
             });
+            if (!AFF) {
+                // the buffer this chunk read is free behind the barrier: the item after next goes into it, two stages ahead of
+                // its barrier (HBM latency under load is longer than one stage)
+                if (ch + 2 < n_chunks) {
+                    stage_issue((ch + 2) * KC4, const_cast<float*>(src));
+                } else {
+                    if (ch + 2 == n_chunks && more) stage_tile(b1, ty1, tx1);       // from here on the next tile is staged
+                    stage_issue((ch + 2 - n_chunks) * KC4, const_cast<float*>(src));
+                }
+            }
             // stage 1: channels 8-15; next operands = first 8 channels of the next item (other buffer)
-            stage(dst, 0, last ? wblock(0, cg1) : wblock(c8 + 2, cg), [&]() {});
+            stage(dst, 0, wblock(c8 + 1, cg), last ? wblock(0, cg1) : wblock(c8 + 2, cg), [&]() {});
             cur ^= 1;
         }
 
         // ---- output transform Y = A^T M A on float4s (couts co .. co+3 of tile `tile`), bias, 16-byte stores, GN partials
+        W4_MFMA_DRAIN();
         {
             const int co = cg * 16 + 4 * kq;
             const bool cok = co + 3 < Cout;
@@ -286,7 +372,9 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                         sum4 += dv;
                         sq4 += dv * dv;
                         ++cnt;
+#if !(W4_ABLATE & 8)
                         if (cok) nd_st4(a.d.out + (((size_t)b * H + py) * W + px) * a.d.ldo + co, v);
+#endif
                     }
                 }
             }
@@ -359,7 +447,7 @@ int w4_cus() {
 template <int MODE>
 int launch4(const Wino4Args& a, hipStream_t st) {
     static bool configured = false;
-    const size_t lds = (size_t)2 * VD_FLOATS * sizeof(float);
+    const size_t lds = ((size_t)2 * VD_FLOATS + W4_STAGE_LOADS * 256) * sizeof(float);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -394,7 +482,8 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3_wino4: null tensor pointer");
     ND_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->cin > 0 && d->cout > 0, ND_E_BADARG, "nd_conv3x3_wino4: non-positive size");
-    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4", d->cin, d->cout);
+    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->cin > KC4, ND_E_SHAPE,
+               "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4, cin > 16 (two K chunks in flight)", d->cin, d->cout);
     ND_REQUIRE(s.c0 + s.c1 == d->cin && s.c0 % 4 == 0 && s.c1 % 4 == 0 && s.c0 > 0, ND_E_SHAPE,
                "nd_conv3x3_wino4: source channels %d+%d do not match cin=%d (multiples of 4)", s.c0, s.c1, d->cin);
     ND_REQUIRE((s.c1 == 0) == (s.p1 == nullptr), ND_E_BADARG, "nd_conv3x3_wino4: p1/c1 mismatch");
