@@ -29,7 +29,7 @@ FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 SPECIAL = {
     "conv3x3_wino2": ("conv3x3_wino2", BASE_FLAGS + ["-mllvm", "-pragma-unroll-threshold=1000000"]),
     # one wave per SIMD: 144 accumulator registers in the AGPR half, the rest of the pipeline state in the VGPR half
-    "conv3x3_wino4": ("conv3x3_wino4", BASE_FLAGS + ["-DW4_NOP_TEST"]),  # s_nop 1 in front of every MFMA: see W4_MFMA
+    "conv3x3_wino4": ("conv3x3_wino4", BASE_FLAGS),
 }
 
 

@@ -75,11 +75,10 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
 // MFMAs through inline asm (as in conv3x3_wino2.hip): "+a" keeps the 36 accumulators in place in the accumulator half of the
 // register file -- with the builtin, hipcc moved them between AGPR tuples and through VGPRs (s_nop 7 + 4 v_accvgpr_write per
 // move) several times per stage; operands are pinned to VGPRs.  The epilogue drains the pipe before reading them.
-#ifdef W4_NOP_TEST
+// `s_nop 1` in front of every MFMA: without it results are wrong in every test shape (identical code otherwise), with it the
+// timing does not change -- the MFMA issue slot is not what bounds this kernel.  The hazard it covers is not one of the
+// register-proximity cases (no VALU or load writes an operand within 8 instructions of its MFMA); kept until identified.
 #define W4_MFMA(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-#else
-#define W4_MFMA(acc, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-#endif
 #define W4_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 constexpr int W4_STAGE_LOADS = 9;                    // 576 (entry, tile) slots x 4 quads / 256 threads
 
