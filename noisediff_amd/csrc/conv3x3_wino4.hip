@@ -20,6 +20,7 @@
 // its tile's patch entry (a, b); the two channels feed two MFMAs (k groups {0,2,4,6} and {1,3,5,7} of an 8-channel block)
 // and the whole transform runs on packed float2 math.
 #include <stdlib.h>
+#include <type_traits>
 #include "nd_common.h"
 
 namespace {
@@ -354,29 +355,39 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             }
 #pragma unroll
             for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0, 0, 0, 0};
+            const bool full = ty * 16 + 16 <= H && tx * 16 + 16 <= W && cg * 16 + 16 <= Cout;      // wave-uniform
+            const bool want_stats = a.d.stats != nullptr;
+            float* lane_out = a.d.out + (((size_t)b * H + py0) * W + px0) * a.d.ldo + co;
+            auto emit = [&](auto full_c, auto stats_c) {
+                constexpr bool FULL = decltype(full_c)::value, STATS = decltype(stats_c)::value;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 y[4];
-                w4_at(Z[i], y);
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 y[4];
+                    w4_at(Z[i], y);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = y[j] + bias4;
-                    if (i == 0 && j == 0) {                      // one pivot per cout for the whole workgroup tile: tile 0's first pixel
-                        pivot4.x = __shfl(v.x, lane & 48); pivot4.y = __shfl(v.y, lane & 48);
-                        pivot4.z = __shfl(v.z, lane & 48); pivot4.w = __shfl(v.w, lane & 48);
-                    }
-                    const int py = py0 + i, px = px0 + j;
-                    if (py < H && px < W) {
-                        const f32x4 dv = v - pivot4;
-                        sum4 += dv;
-                        sq4 += dv * dv;
-                        ++cnt;
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = y[j] + bias4;
+                        if (STATS && i == 0 && j == 0) {         // one pivot per cout for the whole workgroup tile: tile 0's first pixel
+                            pivot4.x = __shfl(v.x, lane & 48); pivot4.y = __shfl(v.y, lane & 48);
+                            pivot4.z = __shfl(v.z, lane & 48); pivot4.w = __shfl(v.w, lane & 48);
+                        }
+                        const bool inside = FULL || (py0 + i < H && px0 + j < W);
+                        if (inside) {
+                            if (STATS) {
+                                const f32x4 dv = v - pivot4;
+                                sum4 += dv;
+                                sq4 += dv * dv;
+                                ++cnt;
+                            }
 #if !(W4_ABLATE & 8)
-                        if (cok) nd_st4(a.d.out + (((size_t)b * H + py) * W + px) * a.d.ldo + co, v);
+                            if (FULL || cok) nd_st4(lane_out + (size_t)((i * W + j) * a.d.ldo), v);
 #endif
+                        }
                     }
                 }
-            }
+            };
+            if (full) { if (want_stats) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
+            else { if (want_stats) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
             if (a.d.stats) {
                 // pool over the 16 tiles (the 16 lanes of a DPP row share their couts): sum = S + n p, M2 = Q - S^2 / n
                 float fc = nd_row16_sum((float)cnt);
