@@ -25,6 +25,9 @@ constexpr int WBLOCK = 16 * 8 * 64 * 4;              // floats per packed weight
 constexpr int BUF = (2 * PLANE + 1) * LDA;          // floats per LDS buffer (+1 scratch pixel)
 constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 
+#ifndef W2_CLUMP
+#define W2_CLUMP 1           // all VALU of a step in one slice (0: spread over ten slices, the r1d arrangement; A/B builds)
+#endif
 #ifndef W2_ABLATE
 #define W2_ABLATE 0          // diagnostic builds only (tools/w2_variants.sh): drop parts of the loop to time the rest
 #endif
@@ -33,7 +36,13 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 // selection clumps them), which is what lets the source dictate the MFMA / VALU / LDS / VMEM interleave.  The compiler
 // cannot see that this is an MFMA, so the VALU->MFMA operand wait states ride along (hidden behind the matrix pipe's
 // 64-cycle cadence) and the epilogue drains the pipe before it reads the accumulators.
+#if W2_CLUMP
+// s_nop 1 in front: with pure MFMA-to-MFMA slices (no VALU between them any more) results are wrong without it, as in
+// conv3x3_wino4.hip; it is free (the matrix pipe holds the issue slot far longer than two wait states)
+#define W2_MFMA(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#else
 #define W2_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#endif
 #define W2_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 #define W2_PIN(x) asm volatile("" : "+v"(x))          // value is complete here: keeps pure VALU work in its slice
 
@@ -189,8 +198,11 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         if (MAP) imoff = cb_ * 4;
         okmask = cvalid ? tilemask : 0u;
     };
+    unsigned pix_r = 0, slot_r = 0;                        // table entries read one slice ahead of their use (W2_CLUMP)
+    auto issue_pre = [&](int it) { pix_r = itab[it * 256]; };
+    auto commit_pre = [&](int it) { slot_r = tab[it * 256] & 0xFFFFFu; };
     auto issue_one = [&](int it) {
-        const unsigned pix = itab[it * 256];
+        const unsigned pix = W2_CLUMP ? pix_r : itab[it * 256];
         // the scalar offsets are wave-uniform by construction; saying so keeps hipcc from wrapping each load in a waterfall loop
         raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, (unsigned)(__umul24(pix, ild4) + quad * 16),
                                                                                   __builtin_amdgcn_readfirstlane(isoff), 0));
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             const f32x4 zero = {0, 0, 0, 0};
             v = ((okmask >> it) & 1u) ? v : zero;
         }   // otherwise out-of-image pixels were loaded as zeros (px_oob) and channels beyond cin meet zero weights
-        const unsigned slot = tab[it * 256] & 0xFFFFFu;
+        const unsigned slot = W2_CLUMP ? slot_r : (tab[it * 256] & 0xFFFFFu);
         nd_st4(reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + slot), v);
     };
 
@@ -241,9 +253,9 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     if (t_begin + 1 < t_end) mask_next = tile_table(1, b1, ty1, tx1);
     issue_begin(b, 0, 0, mask_cur);
 #pragma unroll
-    for (int it = 0; it < STAGE_IT; ++it) issue_one(it);
+    for (int it = 0; it < STAGE_IT; ++it) { issue_pre(it); issue_one(it); }
 #pragma unroll
-    for (int it = 0; it < STAGE_IT; ++it) commit(it, As);
+    for (int it = 0; it < STAGE_IT; ++it) { commit_pre(it); commit(it, As); }
     __syncthreads();
     int cur = 0;
     const unsigned voff = (half * 64 + wn * 32 + col) * 16;                 // per-lane byte offset inside a weight block
@@ -327,6 +339,31 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #if !(W2_ABLATE & 4)
                     if (i < 8 && step + 2 < S) load_d1(src, step + 2, i >> 1, i & 1);
 #endif
+#if W2_CLUMP
+                    // Every switch between the fp32 MFMA and ordinary VALU work costs ~17-20 cycles on top of the instructions
+                    // themselves (tools/microbench/mfma_rate.hip: +20 for the first VALU instruction behind an MFMA, +4 for each
+                    // further one), so ALL of a step's VALU -- both transform passes, staging addresses, the prologue
+                    // activation -- sits in ONE slice; the other 15 carry only LDS reads and buffer loads.
+                    if (i == 2 && step + 1 < S) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) make_t(step + 1, c);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) make_v(q, Vn);
+                    }
+                    if (i >= 8 && i < 12) {
+#if !(W2_ABLATE & 2)
+                        if (step + WD < S) load_w1(wblock, step + WD, i - 8);
+                        else load_w1(wnext, step + WD - S, i - 8);
+#endif
+                    }
+#if !(W2_ABLATE & 1)
+#pragma unroll
+                    for (int it = 0; it < STAGE_IT; ++it) {
+                        if (it * (S - LAG) / STAGE_IT == step) { if (i == 0) issue_pre(it); if (i == 2) issue_one(it); }
+                        if (it * (S - LAG) / STAGE_IT + LAG == step) { if (i == 1) commit_pre(it); if (i == 2) commit(it, dst); }
+                    }
+#endif
+#else
                     if (i < 4) {
                         if (step + 1 < S) make_t(step + 1, i);
                     } else if (i < 8) {
@@ -343,6 +380,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
                         if (it * (S - LAG) / STAGE_IT == step && i == 12) issue_one(it);
                         if (it * (S - LAG) / STAGE_IT + LAG == step && i == 14) commit(it, dst);
                     }
+#endif
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
