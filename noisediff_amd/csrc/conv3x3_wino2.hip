@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     };
     unsigned pix_r = 0, slot_r = 0;                        // table entries read one slice ahead of their use (W2_CLUMP)
     auto issue_pre = [&](int it) { pix_r = itab[it * 256]; };
-    auto commit_pre = [&](int it) { slot_r = tab[it * 256] & 0xFFFFFu; };
+    auto commit_pre = [&](int it) { slot_r = tab[it * 256]; };      // (masked in commit: no lone VALU instruction in this slice)
     auto issue_one = [&](int it) {
         const unsigned pix = W2_CLUMP ? pix_r : itab[it * 256];
         // the scalar offsets are wave-uniform by construction; saying so keeps hipcc from wrapping each load in a waterfall loop
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             const f32x4 zero = {0, 0, 0, 0};
             v = ((okmask >> it) & 1u) ? v : zero;
         }   // otherwise out-of-image pixels were loaded as zeros (px_oob) and channels beyond cin meet zero weights
-        const unsigned slot = W2_CLUMP ? slot_r : (tab[it * 256] & 0xFFFFFu);
+        const unsigned slot = (W2_CLUMP ? slot_r : tab[it * 256]) & 0xFFFFFu;
         nd_st4(reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + slot), v);
     };
 
