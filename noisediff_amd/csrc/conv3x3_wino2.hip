@@ -28,6 +28,9 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 #ifndef W2_CLUMP
 #define W2_CLUMP 1           // all VALU of a step in one slice (0: spread over ten slices, the r1d arrangement; A/B builds)
 #endif
+#ifndef W2_ZERO_C
+#define W2_ZERO_C 1          // peeled first chunk whose first MFMAs take C = 0 (0: accumulators re-zeroed in the epilogue; A/B builds)
+#endif
 #ifndef W2_ABLATE
 #define W2_ABLATE 0          // diagnostic builds only (tools/w2_variants.sh): drop parts of the loop to time the rest
 #endif
@@ -43,6 +46,7 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 #else
 #define W2_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
 #endif
+#define W2_MFMA_Z(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv))
 #define W2_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 #define W2_PIN(x) asm volatile("" : "+v"(x))          // value is complete here: keeps pure VALU work in its slice
 
@@ -229,8 +233,10 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     };
 
     f32x16 M[16];                                         // position accumulators, resident across the K loop
+#if !W2_ZERO_C
 #pragma unroll
     for (int p = 0; p < 16; ++p) M[p] = nd_zero16();
+#endif
 
     // tile coordinates of this tile, the next one and the one after: decoded once, then advanced with carries
     // (the three integer divisions of decode() cost the in-order wave several hundred cycles per tile)
@@ -310,7 +316,8 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         const bool more_tiles = t + 1 < t_end;
         const int nb_ = more_tiles ? b1 : b, nnt = more_tiles ? nt1 : nt;   // the tile whose first chunk is staged during this tile's last one
 
-        for (int ch = 0; ch < n_chunks; ++ch) {
+        auto chunk = [&](int ch, auto first_c) {
+            constexpr bool FIRST = W2_ZERO_C && decltype(first_c)::value;     // first chunk of a tile: accumulators start from C = 0
             const float* src = As + cur * BUF;
             float* dst = As + (cur ^ 1) * BUF;
             const bool last_chunk = ch + 1 == n_chunks;
@@ -334,7 +341,8 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int nu = i & 3, k = i >> 2;
-                    W2_MFMA(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
+                    if (FIRST && (step & 3) == 0 && k == 0) W2_MFMA_Z(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
+                    else W2_MFMA(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
                     // the slice's share of the other work (<= ~40 issue cycles each)
 #if !(W2_ABLATE & 4)
                     if (i < 8 && step + 2 < S) load_d1(src, step + 2, i >> 1, i & 1);
@@ -390,7 +398,11 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             __syncthreads();                               // next buffer complete, current buffer free
             cur ^= 1;
             wblock = wnext;
-        }
+        };
+        // the first chunk is its own instance of the loop body (no branch inside the unrolled slices): its first MFMA on each
+        // accumulator takes the inline constant 0 as C, so the epilogue does not spend 256 v_accvgpr_write on re-zeroing
+        chunk(0, std::true_type{});
+        for (int ch = 1; ch < n_chunks; ++ch) chunk(ch, std::false_type{});
 
         // ------------------------------------------------------------ output transform + epilogue of tile (b, ty, tx, nt)
         W2_MFMA_DRAIN();
@@ -465,8 +477,10 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
             if (full) emit(std::true_type{});
             else emit(std::false_type{});
 #endif
+#if !W2_ZERO_C
 #pragma unroll
             for (int p = 0; p < 16; ++p) M[p] = nd_zero16();
+#endif
             if (a.d.stats) {
                 sS += sS2[0] + sS2[1];
                 sQ += sQ2[0] + sQ2[1];
