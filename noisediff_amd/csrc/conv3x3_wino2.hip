@@ -39,14 +39,20 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 // selection clumps them), which is what lets the source dictate the MFMA / VALU / LDS / VMEM interleave.  The compiler
 // cannot see that this is an MFMA, so the VALU->MFMA operand wait states ride along (hidden behind the matrix pipe's
 // 64-cycle cadence) and the epilogue drains the pipe before it reads the accumulators.
-#if W2_CLUMP
-// s_nop 1 in front: with pure MFMA-to-MFMA slices (no VALU between them any more) results are wrong without it, as in
-// conv3x3_wino4.hip; it is free (the matrix pipe holds the issue slot far longer than two wait states)
+#if W2_CLUMP && !defined(W2_NO_NOP)
+// s_nop 1 in front of every inline-asm MFMA: with slices that hold nothing but an MFMA (no VALU between consecutive MFMAs any
+// more) the results are wrong without it (-DW2_NO_NOP: relative error ~10 on every test shape, as in conv3x3_wino4.hip) although
+// no operand is written within 8 instructions of its MFMA; hipcc's hazard recognizer cannot see through the asm.  It costs
+// nothing: the matrix pipe holds the issue slot far longer than two wait states (tools/microbench/mfma_rate.hip).
 #define W2_MFMA(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
 #else
 #define W2_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
 #endif
+#ifdef W2_NO_NOP
+#define W2_MFMA_Z(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv))
+#else
 #define W2_MFMA_Z(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv))
+#endif
 #define W2_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 #define W2_PIN(x) asm volatile("" : "+v"(x))          // value is complete here: keeps pure VALU work in its slice
 
