@@ -34,6 +34,7 @@ from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, 
 GN_EPS = 1e-5
 WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
 PREACT = os.environ.get("ND_PREACT", "1") != "0"         # A-B knob: 0 = GroupNorm+SiLU always fused into block2's conv prologue
+PREACT_MIN = int(os.environ.get("ND_PREACT_MIN", "256"))  # A-B knob: narrowest block2 that gets the separate activation pass
 CHAIN = os.environ.get("ND_CHAIN", "1") != "0"           # A-B knob: 0 = one pointwise GEMM launch per Linear layer
 _CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that can open / continue a fused chain (pwchain.hip)
 _CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
@@ -360,7 +361,7 @@ class Plan:
         ss_off = None if posmap is not None else self.e.tproj_off.get(name)     # blocks built with time_emb_dim=None have no mlp
         mad1 = self.gn_finalize(st1, sc1, n1, name + ".block1.norm", cout, groups, ss_off)
         a1 = None
-        if PREACT and posmap is None and cout >= 128 and H >= 16 and W >= 16:
+        if PREACT and posmap is None and cout >= PREACT_MIN and H >= 16 and W >= 16:      # (same-box A/B at r1e: 128 -> 23.15, 256 -> 23.13, 512 -> 23.13, never -> 23.22 ms per step)
             # every 64-channel output slice of block2 would re-apply GroupNorm+SiLU to the same input tile (cout/64 times);
             # on these small, wide tensors one elementwise pass (tens of MB) is cheaper than that VALU work next to the MFMAs
             a1 = self._alloc(self.B, HW, cout)
