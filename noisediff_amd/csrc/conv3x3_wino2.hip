@@ -28,6 +28,12 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 #ifndef W2_CLUMP
 #define W2_CLUMP 1           // all VALU of a step in one slice (0: spread over ten slices, the r1d arrangement; A/B builds)
 #endif
+#ifndef W2_LAG
+#define W2_LAG 3             // steps between a staging load and its commit to LDS
+#endif
+#ifndef W2_WD
+#define W2_WD 3              // steps a weight fragment is loaded ahead of its MFMAs (2 -> 3: -0.5 % per step in a same-box A/B at r1e; bw[] holds four)
+#endif
 #ifndef W2_ZERO_C
 #define W2_ZERO_C 1          // peeled first chunk whose first MFMAs take C = 0 (0: accumulators re-zeroed in the epilogue; A/B builds)
 #endif
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     //      at step is(it) and committed LAG steps later.  Nothing in a step depends on that step's MFMAs; the source
     //      is written slice by slice (one MFMA + its share of the other work, pinned by sched_barrier) so that at
     //      most ~60 cycles of other instructions sit between two MFMAs and the matrix pipe never waits for the wave.
-    constexpr int S = 16, LAG = 3, WD = 2;
+    constexpr int S = 16, LAG = W2_LAG, WD = W2_WD;
     f32x4 bw[4][4], dr[2][8], Vc[4], Vn[4], T[4];
     auto load_w1 = [&](int wb, int step, int nu) {
         const int g = step & 3, xi = step >> 2;
