@@ -118,8 +118,11 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
 // matrix work instead of relying on a second resident workgroup to fill the gap; one barrier per chunk.
 constexpr int PKC = 32, PLDA = PKC + 4;
 
+#ifndef PW_PIPE_OCC
+#define PW_PIPE_OCC 3        // waves per SIMD the 64-pixel tiles are compiled for (168 registers; 2 -> 3: -0.2 % per step same-box, 4 spills)
+#endif
 template <int MB, int NB, int MODE>
-__global__ __launch_bounds__(256) void pointwise_pipe_kernel(const PwArgs a) {
+__global__ __launch_bounds__(256, (MB == 1 ? PW_PIPE_OCC : 2)) void pointwise_pipe_kernel(const PwArgs a) {
     constexpr int BM = 2 * MB * 32, BN = 2 * NB * 32;
     constexpr int SIT = BM / 32;                              // staging passes: BM rows x 8 channel quads / 256 threads
     constexpr int LDO = BN + 4;
