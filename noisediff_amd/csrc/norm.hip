@@ -181,7 +181,10 @@ extern "C" int nd_affine_silu_add_f32(const float* t, int ldt, const float* mad,
     ND_REQUIRE(nd_aligned16(t) && nd_aligned16(mad) && nd_aligned16(res0) && nd_aligned16(res1) && nd_aligned16(out), ND_E_ALIGN,
                "nd_affine_silu_add: pointers must be 16-byte aligned");
     const size_t total = (size_t)B * HW * (C / 4);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+#ifndef ASA_BLOCKS
+#define ASA_BLOCKS 16384     // grid cap of the streaming pass (4096 -> 16384: 5.3 -> 5.6 TB/s in the per-launch measurement, same-box)
+#endif
+    const int blocks = (int)((total + 255) / 256 < ASA_BLOCKS ? (total + 255) / 256 : ASA_BLOCKS);
     hipLaunchKernelGGL(affine_silu_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, ldt, mad, res0, ldr0, res1, ldr1,
                        out, ldo, B, HW, C);
     return nd_launch_status("nd_affine_silu_add_f32");
