@@ -28,6 +28,9 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 #ifndef W2_CLUMP
 #define W2_CLUMP 1           // all VALU of a step in one slice (0: spread over ten slices, the r1d arrangement; A/B builds)
 #endif
+#ifndef W2_LAZY_AFFINE
+#define W2_LAZY_AFFINE 1     // GroupNorm-affine constants folded at their first use instead of right behind their loads
+#endif
 #ifndef W2_LAG
 #define W2_LAG 3             // steps between a staging load and its commit to LDS
 #endif
@@ -209,7 +212,10 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
         if (AFF) {
             const float* m = s.mad + (size_t)b_ * 3 * Ctot + cs;
             tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
+#if !W2_LAZY_AFFINE
             tD = tD - tM * tA;                             // (v - M) * A + D = v * A + (D - M * A)
+#endif                                                     // (lazy: folded in the first commit, three steps later -- here the single
+                                                           //  in-order wave would sit out the whole L2 round trip of the three loads)
         }
         if (MAP) imoff = cb_ * 4;
         okmask = cvalid ? tilemask : 0u;
@@ -231,6 +237,9 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     auto commit = [&](int it, float* dst) {                // prologue transform + zero padding, registers -> LDS
         f32x4 v = raw[it];
         if (AFF) {
+#if W2_LAZY_AFFINE
+            if (it == 0) tD = tD - tM * tA;                // (v - M) * A + D = v * A + (D - M * A), once per staged item
+#endif
             v = v * tA + tD;
             if (MAP) v = v * (msc[it] + 1.0f) + msh[it];
             v = nd_silu4(v);
