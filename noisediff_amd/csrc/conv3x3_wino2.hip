@@ -28,6 +28,9 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 #ifndef W2_CLUMP
 #define W2_CLUMP 1           // all VALU of a step in one slice (0: spread over ten slices, the r1d arrangement; A/B builds)
 #endif
+#ifndef W2_XCD_REMAP
+#define W2_XCD_REMAP 1
+#endif
 #ifndef W2_LAZY_AFFINE
 #define W2_LAZY_AFFINE 1     // GroupNorm-affine constants folded at their first use instead of right behind their loads
 #endif
@@ -123,7 +126,10 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
     const int a_base = ((2 * by) * PW + bx) * LDA + 4 * half;
 
     // ---- (tile, chunk) items of this persistent workgroup
-    const int t_begin = (int)((long)blockIdx.x * a.total_wg / gridDim.x), t_end = (int)((long)(blockIdx.x + 1) * a.total_wg / gridDim.x);
+    // consecutive workgroup ids go round-robin over the 8 XCDs: give every XCD one contiguous run of tile ranges, so that
+    // neighbouring tiles (shared halo rows) and the weight blocks of one cout tile meet in the same L2
+    const int wgid = W2_XCD_REMAP ? nd_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int t_begin = (int)((long)wgid * a.total_wg / gridDim.x), t_end = (int)((long)(wgid + 1) * a.total_wg / gridDim.x);
     if (t_begin >= t_end) return;
 #ifdef W2_STAMP                 // diagnostic: shader-clock and 100 MHz wall stamps per workgroup -> clock under load
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
