@@ -12,24 +12,28 @@ namespace {
 // The per-item M2 was centred in fp32 registers; the pooling runs in fp64 (53 bits against fp32 inputs), so the
 // final subtraction loses nothing unless mean^2/var exceeds ~1e8.  Plain sums => independent loads, no serial
 // Welford chain, fixed reduction tree => bitwise reproducible.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ slot_count,
+#ifndef GNF_WAVES
+#define GNF_WAVES 4
+#endif
+constexpr int GNF_THREADS = 64 * GNF_WAVES;
+__global__ __launch_bounds__(GNF_THREADS) void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ slot_count,
                                                           int slots, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ ss, int ld_ss, float* __restrict__ mad,
                                                           int C, int G, float eps) {
-    __shared__ double part[4][3];
+    __shared__ double part[GNF_WAVES][3];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double N = 0.0, S = 0.0, Q = 0.0;
     const int items = slots * cpg;
     const float2* st2 = reinterpret_cast<const float2*>(stats) + (size_t)b * slots * C + g * cpg;
-    for (int i0 = tid; i0 < items; i0 += 256 * 8) {       // 8 independent loads in flight per thread, no branches
+    for (int i0 = tid; i0 < items; i0 += GNF_THREADS * 8) {   // 8 independent loads in flight per thread, no branches
         float ni[8];
         float2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u * 256, items - 1);
+            const int i = min(i0 + u * GNF_THREADS, items - 1);
             const int slot = i / cpg, j = i - slot * cpg;
-            ni[u] = (i0 + u * 256 < items) ? slot_count[slot] : 0.0f;
+            ni[u] = (i0 + u * GNF_THREADS < items) ? slot_count[slot] : 0.0f;
             v[u] = st2[(size_t)slot * C + j];
         }
 #pragma unroll
@@ -47,15 +51,25 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
     if (lane == 0) { part[wave][0] = N; part[wave][1] = S; part[wave][2] = Q; }
     __syncthreads();
-    N = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-    S = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
-    Q = (part[0][2] + part[1][2]) + (part[2][2] + part[3][2]);
+    double tot[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {                           // fixed pairwise tree over the waves: bitwise reproducible
+        double t[GNF_WAVES];
+#pragma unroll
+        for (int w = 0; w < GNF_WAVES; ++w) t[w] = part[w][q];
+#pragma unroll
+        for (int n = GNF_WAVES / 2; n > 0; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n; ++w) t[w] = t[2 * w] + t[2 * w + 1];
+        tot[q] = t[0];
+    }
+    N = tot[0]; S = tot[1]; Q = tot[2];
     const double mean = N > 0.0 ? S / N : 0.0;
     double var = N > 0.0 ? Q / N - mean * mean : 0.0;
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
-    for (int i = tid; i < cpg; i += 256) {
+    for (int i = tid; i < cpg; i += GNF_THREADS) {
         const int ch = g * cpg + i;
         const float sc = ss ? ss[(size_t)b * ld_ss + ch] : 0.0f;
         const float sh = ss ? ss[(size_t)b * ld_ss + C + ch] : 0.0f;
@@ -157,7 +171,7 @@ extern "C" int nd_groupnorm_finalize_f32(const float* stats, const float* slot_c
     ND_REQUIRE(stats && slot_count && gamma && beta && mad, ND_E_BADARG, "nd_groupnorm_finalize: null pointer");
     ND_REQUIRE(B > 0 && C > 0 && groups > 0 && slots > 0 && C % groups == 0, ND_E_SHAPE, "nd_groupnorm_finalize: C=%d groups=%d", C, groups);
     ND_REQUIRE(!scale_shift || ld_ss >= 2 * C, ND_E_SHAPE, "nd_groupnorm_finalize: ld_ss < 2C");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(GNF_THREADS), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
                        beta, scale_shift, ld_ss, mad, C, groups, eps);
     return nd_launch_status("nd_groupnorm_finalize_f32");
 }
