@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- sampled RAW patches / second on the NoiseDiff sampling hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          # N=1: one process
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N=1: one process; N>1: starts N rank processes itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts N fresh child processes -- one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1 -- BEFORE this process touches the GPU, relays rank 0's
+JSON line and exits non-zero if any rank fails: one command starts all GPUs, as the reference's nn.DataParallel entry
+does (models/modules.py:73-83).  Under torch.distributed.run the ranks already exist and nothing is spawned.
 
 Workload (BASELINE.json: "256x256x4, 1000-step DDPM", configs[2] per-GPU shard): NoiseDiffNet
 dim=64, sigmoid2 / pred_v, 16 patches of 256x256x4 per GPU.  A *step* is one reverse-diffusion
@@ -21,6 +26,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -31,9 +37,7 @@ sys.path.insert(0, REPO)
 
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 == FP32 vector peak.  `achieved` counts ALGORITHMIC
-                                   # conv FLOPs (18*Cin*Cout per pixel); the Winograd kernel issues 2.25x fewer MFMA FLOPs than that,
-                                   # so frac can approach / exceed 1 while the matrix pipe itself is ~45 % busy
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 == FP32 vector peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -57,6 +61,7 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for plumbing tests)")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0 (single-GPU box)")
+    ap.add_argument("--soak-s", type=float, default=3.0, help="seconds of untimed step replays before the W warm-up steps")
     return ap.parse_args()
 
 
@@ -78,7 +83,7 @@ def conv_bytes(m):
 def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
-    CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32")
+    CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32", "nd_conv3x3_wino4_nhwc_f32")
     STREAM = "nd_affine_silu_add_f32"           # the HBM-bound family: GroupNorm-apply + SiLU + residual adds, one pass
     convs = [op for op in plan.step_ops if op[2] in CONV or (op[2] == STREAM and op[3])]
     n_ev = 2 * len(convs)
@@ -137,59 +142,196 @@ def _oracle_step_fn(sd, size, timesteps, batch=1):
         _, x0 = O.predict_x0_eps(buf, "pred_v", img, t, out, clip=False)
         x0 = x0.clamp(-1, 1)
         mean = float(buf["posterior_mean_coef1"][t]) * x0 + float(buf["posterior_mean_coef2"][t]) * img
-        return mean + float(np_exp_half(buf["posterior_log_variance_clipped"][t])) * z
+        return mean + math.exp(0.5 * float(buf["posterior_log_variance_clipped"][t])) * z
 
     return one_step, synth.make_noise(2, "x_T", batch, 4, size)
 
 
-def cpu_baseline(sd, dim, size, timesteps):
-    """The CPU oracle's p_sample step (one U-Net forward + posterior update), batch 1, on this host's cores.
+def _time_steps(f, x, timesteps, n_min, budget_s, n_max):
+    """Seconds per step: one untimed step, then >= n_min timed steps until budget_s is spent (at most n_max)."""
+    x = f(x, timesteps - 1)
+    t0 = time.perf_counter()
+    n = 0
+    while n < n_min or (time.perf_counter() - t0 < budget_s and n < n_max):
+        x = f(x, timesteps - 2 - n)
+        n += 1
+    return (time.perf_counter() - t0) / n, n
 
-    The thread count is calibrated first (a cgroup-limited box thrashes with one thread per visible
-    core): candidates are timed on a 64x64 problem and the fastest is used for the real measurement,
-    which is bounded to <= 12 steps / ~20 s and extrapolated x T (steps are identical-cost)."""
-    from noisediff_amd import synth
-    from noisediff_amd.spec import noisediff_param_spec
+
+def cpu_baseline(sd, dim, size, timesteps, batch):
+    """The CPU oracle's p_sample step (one U-Net forward + posterior update) on this host's cores.
+
+    The thread count is calibrated AT THE REAL PROBLEM SIZE (a cgroup-limited box thrashes with one thread per visible
+    core, and the best count for a 64x64 toy is not the best one for 256x256): every candidate runs one untimed and two
+    timed batch-1 steps; the sweep stops early once a candidate is > 1.6x slower than the best so far.  The best count
+    is then timed for ~10 s at batch 1 and for >= 2 steps at batch min(B, 4); `value` is the better of the
+    two legs in patches/s, extrapolated x T (steps are identical-cost)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cands = sorted({c for c in (4, 8, 16, 32, 64, min(avail, 96)) if c <= avail})
-    sd_small = synth.make_state_dict(noisediff_param_spec(32), 0)
-    best, best_dt = cands[0], float("inf")
+    cands = sorted({c for c in (8, 16, 32, 48, 64, 96, 128, avail) if c <= avail})
+    sweep = {}
     with torch.no_grad():
+        f1, x1 = _oracle_step_fn(sd, size, timesteps, 1)
+        best, best_dt = cands[0], float("inf")
         for c in cands:
             torch.set_num_threads(c)
-            f, x = _oracle_step_fn(sd_small, 64, timesteps, batch=4)
-            x = f(x, timesteps - 1)
-            t0 = time.perf_counter()
-            for i in range(2):
-                x = f(x, timesteps - 2 - i)
-            dt = (time.perf_counter() - t0) / 2
+            dt, _ = _time_steps(f1, x1, timesteps, 2, 0.0, 2)
+            sweep[c] = round(dt, 4)
             if dt < best_dt:
                 best, best_dt = c, dt
-            if dt > 5.0:
+            elif dt > 1.6 * best_dt:
                 break
         torch.set_num_threads(best)
-        f, x = _oracle_step_fn(sd, size, timesteps)
-        x = f(x, timesteps - 1)                              # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 12):
-            x = f(x, timesteps - 2 - n)
-            n += 1
-            if time.perf_counter() - t0 > 40.0:
+        dt1, n1 = _time_steps(f1, x1, timesteps, 3, 10.0, 40)
+        b4 = min(batch, 4)
+        legs = {"batch1": {"s_per_step": dt1, "steps": n1, "patches_per_s": 1.0 / (timesteps * dt1)}}
+        if b4 > 1:
+            f4, x4 = _oracle_step_fn(sd, size, timesteps, b4)
+            dt4, n4 = _time_steps(f4, x4, timesteps, 2, 8.0, 10)
+            legs[f"batch{b4}"] = {"s_per_step": dt4, "steps": n4, "patches_per_s": b4 / (timesteps * dt4)}
+    top = max(legs, key=lambda k: legs[k]["patches_per_s"])
+    return {"value": legs[top]["patches_per_s"], "unit": "patches/s", "cores": best, "kind": "port", "legs": legs,
+            "thread_sweep_s_per_step_batch1": sweep,
+            "sample": f"CPU oracle p_sample steps (U-Net forward + posterior update) at dim {dim}, {size}x{size}x4 with {best} threads "
+                      f"(calibrated at this size over {list(sweep)}; {avail} cores visible): " +
+                      "; ".join(f"{k}: {v['steps']} steps, {v['s_per_step']:.3f} s/step" for k, v in legs.items()) +
+                      f"; value = best leg ({top}), extrapolated x{timesteps} steps per patch"}
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, nothing in THIS process
+    has touched the GPU), relay rank 0's JSON line, fail if any rank fails.  torch.cuda.device_count() does not
+    initialise the runtime on this image."""
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if not a.one_device and n_dev < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) are visible; refusing to report a smaller job as N={a.gpus}",
+              file=sys.stderr)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ND_BENCH_LAUNCHER="self")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    procs = []
+    for r in range(a.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(a.gpus))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, rc = "", 0
+    try:
+        pending = set(range(a.gpus))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if code != 0:
+                    rc = rc or code
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+            if rc:
                 break
-        dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / (timesteps * dt), "unit": "patches/s", "cores": best, "kind": "port",
-            "sample": f"{n} p_sample steps (U-Net forward + posterior update) of the CPU oracle at batch 1, dim {dim}, "
-                      f"{size}x{size}x4, {dt:.3f} s/step with {best} threads (best of {cands}; {avail} cores visible), "
-                      f"extrapolated x{timesteps} steps per patch"}
+            time.sleep(0.2)
+    finally:
+        for p in procs:                      # exact PIDs of the children started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if rc:
+        return rc
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 produced no JSON line", file=sys.stderr)
+        return 3
+    print(lines[-1], flush=True)
+    return 0
 
 
-def np_exp_half(v):
-    import math
-    return math.exp(0.5 * float(v))
+# MFMA multiplies actually issued per algorithmic multiply: Winograd F(2x2,3x3) does 16 per 2x2 outputs x 9 taps = 1/2.25,
+# F(4x4,3x3) 36 per 16 x 9 = 1/4; the direct kernel 1.  tiling ids: 9001 wino, 9002 wino2, 9004 wino4, else direct <TW,MB,NB>
+WINO_FACTOR = {9001: 2.25, 9002: 2.25, 9004: 4.0}
+UNIT_GFLOP = {(64, 128): 68.78, (64, 256): 275.12, (128, 256): 1077.65}     # SURVEY 8d: algorithmic GFLOP per patch.step (dim, size)
+
+
+def roofline(a, loop, plan, L, per_step):
+    n_inst = min(max(a.steps, 1), 3)
+    per = instrumented_pass(loop, plan, L, n_inst)
+    stream = per.pop(("stream", 0), None)
+    tot_ms = sum(d["ms"] for d in per.values())
+    tot_flop = sum(d["flop"] for d in per.values())
+    tot_exec = sum(d["flop"] / WINO_FACTOR.get(k[0], 1.0) for k, d in per.items())
+    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}>" if k[0] == 9004 else
+                       f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
+                       f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
+    tid, d = max(per.items(), key=lambda kv: kv[1]["ms"])
+    ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+    wf = WINO_FACTOR.get(tid[0], 1.0)
+    headline = (a.dim, a.size, a.batch) == (64, 256, 16)
+    traffic = tsrc = busy_pmc = bsrc = None
+    tfile = _latest_profile("traffic")                               # PMC passes cannot run inside this process
+    if os.path.exists(tfile) and headline:
+        tk = json.load(open(tfile))["kernels"].get(kname(tid))
+        if tk:
+            traffic = tk["hbm_bytes_per_launch"]
+            tsrc = (f"builder box, profiles/{os.path.basename(tfile)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same "
+                    "workload) -- NOT measured in this run")
+    bfile = _latest_profile("mfma_busy")                             # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), own PMC pass
+    if os.path.exists(bfile) and headline:
+        bk = json.load(open(bfile))["kernels"].get(kname(tid))
+        if bk:
+            busy_pmc = bk["matrix_pipe_busy_frac"]
+            bsrc = f"builder box, profiles/{os.path.basename(bfile)} -- NOT measured in this run"
+    unit = UNIT_GFLOP.get((a.dim, a.size))
+    out = {
+        "bound": "mfma", "kernel": kname(tid), "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS,
+        # `achieved` is priced in ALGORITHMIC conv FLOPs (18*Cin*Cout per output pixel, SURVEY 8d) over the event-timed launch
+        # duration of THIS run; a Winograd kernel issues `winograd_multiply_reduction` x fewer MFMA FLOPs than that, so the
+        # fraction of the fp32 matrix pipe that is actually busy -- the honest roofline fraction -- is `frac`:
+        "achieved": ach, "winograd_multiply_reduction": wf, "executed": ach / wf,
+        "frac": ach / wf / PEAK_FP32_MFMA_TFLOPS, "algorithmic_frac": ach / PEAK_FP32_MFMA_TFLOPS,
+        "frac_definition": "executed MFMA FLOP/s (= achieved / winograd_multiply_reduction) / peak; algorithmic_frac = achieved / peak "
+                           "may exceed 1 for Winograd kernels",
+        "traffic": traffic, "traffic_measured_on": tsrc,
+        "matrix_pipe_busy_pmc": busy_pmc, "matrix_pipe_busy_measured_on": bsrc,
+        "avg_launch_ms": d["ms"] / d["launches"], "launches_per_step": d["launches"] // n_inst,
+        "algorithmic_flop_per_launch": d["flop"] / d["launches"],
+        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+        "hbm_frac_at_algorithmic_bytes": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "all_conv3x3": {"algorithmic_tflops": tot_flop / (tot_ms * 1e-3) / 1e12, "executed_tflops": tot_exec / (tot_ms * 1e-3) / 1e12,
+                        "executed_frac": tot_exec / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                        "ms_per_step": tot_ms / n_inst, "share_of_step": (tot_ms / n_inst) / (per_step * 1e3) if not a.full else None},
+        "whole_step": None if (unit is None or a.full) else {
+            "algorithmic_gflop_per_patch_step": unit, "algorithmic_tflops": a.batch * unit / per_step / 1e3,
+            "algorithmic_frac_of_fp32_peak": a.batch * unit / per_step / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+            "note": "SURVEY 8d module-hook FLOPs of the reference forward (includes the layers the build eliminates algebraically)"},
+        "by_kernel": {kname(k): {"algorithmic_tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
+                                 "executed_frac": v["flop"] / WINO_FACTOR.get(k[0], 1.0) / (v["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                 "avg_ms": v["ms"] / v["launches"], "launches_per_step": v["launches"] // n_inst}
+                      for k, v in sorted(per.items())},
+    }
+    if stream:
+        # the step's HBM-bound family, judged on GB/s: algorithmic bytes (every operand read once, the result written
+        # once) over the summed launch time of the same instrumented pass
+        gbs = stream["bytes"] / (stream["ms"] * 1e-3) / 1e9
+        out["hbm_bound_family"] = {
+            "kernel": "affine_silu_add_kernel", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": gbs / PEAK_HBM_GBS, "launches_per_step": stream["launches"] // n_inst,
+            "ms_per_step": stream["ms"] / n_inst}
+    return out
 
 
 def main():
@@ -198,13 +340,15 @@ def main():
         a.dim, a.size, a.batch = 64, 128, 16
     elif a.config == "cfg4":
         a.dim, a.size, a.batch, a.sampling_timesteps, a.mid_attn = 128, 256, 8, 250, True
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))            # nothing above this line initialises the GPU
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        a.gpus = world
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: a line for a different job size than asked would be "
+              "misleading; start it as `python bench.py --gpus N` or with --nproc-per-node N", file=sys.stderr)
+        sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if a.one_device:
         local = 0
@@ -233,13 +377,33 @@ def main():
             sd.update(synth.make_state_dict(attention_param_spec("mid_attn", 8 * a.dim), 0))
         net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
+    bcast = None
     if world > 1:
         # the ONE collective of the data path: packed weight arena, rank 0 -> everyone, over xGMI
         eng = Engine(a.dim, dev, mid_attn=a.mid_attn)
         if rank == 0:
             eng.load_state_dict(sd)
-        eng.broadcast(src=0)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        eng.broadcast(src=0)                 # returns with the arena complete on this rank (device-synchronised)
+        bt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         net.adopt_engine(eng)
+        # evidence that every rank holds rank 0's weights: min and max over ranks of a checksum of the arena
+        cs = eng.arena.double().abs().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        nbytes = eng.arena.numel() * 4
+        bcast = {"ranks_in_broadcast": dist.get_world_size(), "backend": dist.get_backend() + (" (RCCL)" if a.backend == "nccl" else ""),
+                 "broadcast_bytes": nbytes, "broadcast_ms": float(bt.item()) * 1e3,
+                 "broadcast_GBps_per_rank": nbytes / float(bt.item()) / 1e9,
+                 "arena_checksum_equal_on_all_ranks": bool(lo.item() == hi.item() and hi.item() > 0),
+                 "per_step_collectives": 0, "devices": "all ranks on cuda:0 (--one-device rehearsal)" if a.one_device else
+                 f"one GPU per rank (cuda:0..{world - 1})",
+                 "launcher": "bench.py started the ranks itself" if os.environ.get("ND_BENCH_LAUNCHER") == "self" else
+                 "external (torch.distributed.run)"}
     gd = GaussianDiffusion(net, image_size=S, timesteps=T, sampling_timesteps=a.sampling_timesteps, beta_schedule="sigmoid2",
                            objective="pred_v").to(dev)
     n_sample_steps = a.sampling_timesteps or T
@@ -254,6 +418,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    soak_steps = 0
     if a.full:
         kw = dict(batch_size=B, condition={k: v.to(dev) for k, v in cond.items()})
         for _ in range(a.warmup):
@@ -272,6 +437,13 @@ def main():
         from noisediff_amd.diffusion import _Loop
         loop = _Loop(gd, plan)
         loop.start(None, None, seed=1, first_sample=rank * B, use_graph=not a.eager)
+        # untimed soak before the W warm-up steps: the chip reaches the clocks / temperature it holds over a 1000-step
+        # sample() (fp32 MFMA load throttles to ~2.1 GHz after the first second), and an outside utilisation probe sees the job
+        t_soak = time.perf_counter()
+        while a.soak_s > 0 and time.perf_counter() - t_soak < a.soak_s:
+            loop.advance(10)
+            plan.e.sync()
+            soak_steps += 10
         loop.advance(a.warmup)
         plan.e.sync()
         barrier()
@@ -288,69 +460,26 @@ def main():
         per_step = float(tt.item())
         value = world * B / per_step if a.full else world * B / (n_sample_steps * per_step)
 
+    sampler = f"{a.sampling_timesteps}-step DDIM of {T}" if a.sampling_timesteps else f"{T}-step DDPM"
     out = {
-        "metric": "sampled RAW patches/sec (256x256x4, 1000-step DDPM)", "value": value, "unit": "patches/s",
+        "metric": f"sampled RAW patches/sec ({S}x{S}x4, {sampler})", "value": value, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"NoiseDiffNet dim={a.dim}{' + mid Attention' if a.mid_attn else ''}, {S}x{S}x4 patches, " +
-                               (f"{a.sampling_timesteps}-step DDIM of {T}" if a.sampling_timesteps else f"{T}-step DDPM") + " (sigmoid2, pred_v), "
+                               sampler + " (sigmoid2, pred_v), "
                                f"{B} patches per GPU; a step = " +
-                               ("one full 1000-step sample() call" if a.full else
+                               ("one full sample() call" if a.full else
                                 "one reverse-diffusion step (U-Net forward + fused posterior/noise update) over the per-GPU batch; "
                                 f"patches/s = n_gpus*{B}/({n_sample_steps}*s_per_step)"),
                    "global_batch": world * B, "launch": "eager" if a.eager else "hipGraph replay",
-                   "noise": "device Philox4x32-10"},
+                   "noise": "device Philox4x32-10", "untimed_soak_steps": soak_steps},
     }
+    if bcast:
+        out["multi_gpu"] = bcast
     if rank == 0 and not a.no_roofline:
-        n_inst = min(max(a.steps, 1), 3)
-        per = instrumented_pass(loop, plan, L, n_inst)
-        stream = per.pop(("stream", 0), None)
-        tot_ms = sum(d["ms"] for d in per.values())
-        tot_flop = sum(d["flop"] for d in per.values())
-        kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
-                           f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
-        dom = max(per.items(), key=lambda kv: kv[1]["ms"])
-        tid, d = dom
-        ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
-        traffic, tsrc = None, None
-        tfile = _latest_profile("traffic")                               # PMC passes cannot run inside this process
-        if os.path.exists(tfile) and (a.dim, a.size, a.batch) == (64, 256, 16):
-            tk = json.load(open(tfile))["kernels"].get(kname(tid))
-            if tk:
-                traffic, tsrc = tk["hbm_bytes_per_launch"], f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
-        busy_pmc = None
-        bfile = _latest_profile("mfma_busy")                             # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), own PMC pass
-        if os.path.exists(bfile) and (a.dim, a.size, a.batch) == (64, 256, 16):
-            bk = json.load(open(bfile))["kernels"].get(kname(tid))
-            if bk:
-                busy_pmc = bk["matrix_pipe_busy_frac"]
-        out["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": traffic, "traffic_source": tsrc,
-            "kernel": kname(tid),
-            # Winograd F(2x2,3x3) kernels issue 2.25x fewer MFMA FLOPs than the algorithmic count `achieved` is priced in,
-            # so frac can exceed 1; matrix_pipe_frac = issued MFMA FLOP/s over the same peak
-            "matrix_pipe_frac": ach / (2.25 if tid[0] >= 9001 else 1.0) / PEAK_FP32_MFMA_TFLOPS,
-            "matrix_pipe_busy_pmc": busy_pmc,
-            "avg_launch_ms": d["ms"] / d["launches"], "launches_per_step": d["launches"] // n_inst,
-            "algorithmic_flop_per_launch": d["flop"] / d["launches"],
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-            "hbm_frac_at_algorithmic_bytes": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "all_conv3x3": {"tflops": tot_flop / (tot_ms * 1e-3) / 1e12, "ms_per_step": tot_ms / n_inst,
-                            "share_of_step": (tot_ms / n_inst) / (per_step * 1e3) if not a.full else None},
-            "by_kernel": {kname(k): {"tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12, "avg_ms": v["ms"] / v["launches"],
-                                     "launches_per_step": v["launches"] // n_inst} for k, v in sorted(per.items())},
-        }
-        if stream:
-            # the step's HBM-bound family, judged on GB/s: algorithmic bytes (every operand read once, the result written
-            # once) over the summed launch time of the same instrumented pass
-            gbs = stream["bytes"] / (stream["ms"] * 1e-3) / 1e9
-            out["roofline"]["hbm_bound_family"] = {
-                "kernel": "affine_silu_add_kernel", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": gbs / PEAK_HBM_GBS, "launches_per_step": stream["launches"] // n_inst,
-                "ms_per_step": stream["ms"] / n_inst}
+        out["roofline"] = roofline(a, loop, plan, L, per_step)
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items() if not k.startswith("mid_attn.")}, a.dim, S, n_sample_steps)
+        out["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items() if not k.startswith("mid_attn.")}, a.dim, S, n_sample_steps, B)
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -253,6 +253,9 @@ typedef struct nd_sampler_state {
     const int32_t* t_next;  /* [n_steps] DDIM: next timestep (-1 at the end); DDPM unused  */
     const float* coef;      /* [n_steps][8] per-step scalars, see sampler.hip              */
     int64_t* time_out;      /* [B] int64 buffer the network's time embedding reads         */
+    const int64_t* rng;     /* [2] device {seed, first_sample} or NULL.  When set it OVERRIDES the seed /
+                               first_sample arguments of nd_sampler_step_*: a captured step graph then
+                               serves every seed and every rank shard (no re-capture per sample() call) */
     int32_t n_steps, B;
 } nd_sampler_state;
 

@@ -56,7 +56,7 @@ CHAIN_RES_NONE, CHAIN_RES_INPUT, CHAIN_RES_INPUT_RAW = 0, 1, 2
 
 
 class SamplerState(C.Structure):
-    _fields_ = [("step", fptr), ("t_cur", fptr), ("t_next", fptr), ("coef", fptr), ("time_out", fptr),
+    _fields_ = [("step", fptr), ("t_cur", fptr), ("t_next", fptr), ("coef", fptr), ("time_out", fptr), ("rng", fptr),
                 ("n_steps", C.c_int32), ("B", C.c_int32)]
 
 

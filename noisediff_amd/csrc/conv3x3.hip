@@ -305,24 +305,17 @@ Tiling choose_tiling(int B, int H, int W, int cout) {
     return cand[best];
 }
 
-int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static inline int device_cus() { return nd_device_cus(); }
 
 template <int TW, int MB, int NB, int MODE>
 void launch_mode(const ConvArgs& a, hipStream_t st) {
-    static int per_cu = 0;   // resident workgroups per CU of this instantiation (occupancy query, once)
+    static std::atomic<int> per_cu_cache{0};   // resident workgroups per CU of this instantiation (same on every gfx950 device)
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (!per_cu) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_kernel<TW, MB, NB, MODE>, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
         static const int force = getenv("ND_CONV_WG_PER_CU") ? atoi(getenv("ND_CONV_WG_PER_CU")) : 0;   // tuning knob
         if (force > 0) per_cu = force;
+        per_cu_cache.store(per_cu, std::memory_order_relaxed);
     }
     const long resident = (long)device_cus() * per_cu;
     const dim3 grid((unsigned)(a.total_wg < resident ? a.total_wg : resident)), block(256);

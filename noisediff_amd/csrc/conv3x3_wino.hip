@@ -310,22 +310,15 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static inline int device_cus() { return nd_device_cus(); }
 
 template <int NB, int MODE, int KC>
 void launch_kc(const WinoArgs& a, hipStream_t st) {
-    static int per_cu = 0;
+    static std::atomic<int> per_cu_cache{0};
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (!per_cu) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wino_kernel<NB, MODE, KC>, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+        per_cu_cache.store(per_cu, std::memory_order_relaxed);
     }
     const long resident = (long)device_cus() * per_cu;
     const dim3 grid((unsigned)(a.total_wg < resident ? a.total_wg : resident)), block(256);

@@ -542,29 +542,13 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #endif
 }
 
-int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static inline int device_cus() { return nd_device_cus(); }
 
 template <int MODE>
 int launch_mode(const Wino2Args& a, hipStream_t st) {
-    static bool configured = false;
+    static nd_device_once configured;
     const size_t lds = ((size_t)2 * BUF + 3 * STAGE_IT * 256) * sizeof(float);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            nd_set_error("nd_conv3x3_wino2: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return (int)e;
-        }
-        configured = true;
-    }
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino2_kernel<MODE>), lds, "nd_conv3x3_wino2")) return e;
     const long resident = device_cus();                   // one workgroup per CU by construction (LDS + registers)
     const dim3 grid((unsigned)(a.total_wg < resident ? a.total_wg : resident)), block(256);
     hipLaunchKernelGGL((wino2_kernel<MODE>), grid, block, lds, st, a);

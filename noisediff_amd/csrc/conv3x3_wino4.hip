@@ -443,29 +443,13 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-int w4_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static inline int w4_cus() { return nd_device_cus(); }
 
 template <int MODE>
 int launch4(const Wino4Args& a, hipStream_t st) {
-    static bool configured = false;
+    static nd_device_once configured;
     const size_t lds = ((size_t)2 * VD_FLOATS + W4_STAGE_LOADS * 256) * sizeof(float);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            nd_set_error("nd_conv3x3_wino4: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return (int)e;
-        }
-        configured = true;
-    }
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE>), lds, "nd_conv3x3_wino4")) return e;
     const long resident = w4_cus();                       // one workgroup per CU (registers)
     hipLaunchKernelGGL((wino4_kernel<MODE>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), lds, st, a);
     return 0;

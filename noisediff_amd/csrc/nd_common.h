@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/noisediff_hip.h"
 
 #define ND_WAVE 64
@@ -27,6 +28,28 @@ static inline int nd_launch_status(const char* what) {
         nd_set_error("%s: %s", what, hipGetErrorString(e));
         return (int)e;
     }
+    return 0;
+}
+
+// Launch-time facts are cached PER DEVICE ORDINAL and race-free: the net may be driven from several host threads on
+// several devices at once (nn.DataParallel replicas, models/modules.py:81).
+int nd_device_cus();                       // CU count of the CURRENT device (runtime.hip)
+int nd_current_device();                   // hipGetDevice, 0 on failure
+struct nd_device_once {                    // one bit per device: "this kernel's function attribute is set on that device"
+    std::atomic<uint64_t> done{0};
+    bool is_done(int dev) const { return dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1u); }
+    void mark(int dev) { if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release); }
+};
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and idempotent: two racing threads both set it, harmlessly
+static inline int nd_reserve_lds(nd_device_once& once, const void* func, size_t lds, const char* who) {
+    const int dev = nd_current_device();
+    if (once.is_done(dev)) return 0;
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        nd_set_error("%s: cannot reserve %zu bytes of LDS: %s", who, lds, hipGetErrorString(e));
+        return (int)e;
+    }
+    once.mark(dev);
     return 0;
 }
 

@@ -237,31 +237,14 @@ __global__ void pack_chain_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+static inline int device_cus() { return nd_device_cus(); }
 
 template <int K0, int N1, int N2, int N3, int MODE>
 int launch(const ChainArgs& a, hipStream_t st) {
-    static bool configured = false;
+    static nd_device_once configured;
     constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
     const size_t lds = (size_t)(N1 * K0 + N2 * N1 + N3 * N2 + N1 + N2 + N3 + 2 * K0 + WAVES * K0) * sizeof(float);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            nd_set_error("nd_pointwise_chain: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return (int)e;
-        }
-        configured = true;
-    }
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE>), lds, "nd_pointwise_chain")) return e;
     const int wgs = nd_cdiv(a.n_tiles, WAVES);
     const int grid = wgs < device_cus() ? wgs : device_cus();
     hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE>), dim3(grid), dim3(THREADS), lds, st, a);

@@ -21,7 +21,23 @@ void nd_set_error(const char* fmt, ...) {
         }                                                                   \
     } while (0)
 
-extern "C" int nd_version(void) { return 1000 * 0 + 1; }
+int nd_current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+
+int nd_device_cus() {
+    static std::atomic<int> cache[64];                       // zero-initialised; 0 = not queried yet
+    const int dev = nd_current_device();
+    int cus = (dev >= 0 && dev < 64) ? cache[dev].load(std::memory_order_relaxed) : 0;
+    if (cus > 0) return cus;
+    hipDeviceProp_t prop;
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
+extern "C" int nd_version(void) { return 1000 * 0 + 2; }
 extern "C" const char* nd_last_error(void) { return g_err; }
 
 extern "C" int nd_device_arch(char* buf, int n) {

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void step_kernel(float* __restrict__ x, const 
     const float* cf = s.coef + (size_t)st * 8;
     const float* noise = noise_base ? noise_base + (size_t)st * noise_stride : nullptr;
     const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], c6 = cf[6], c7 = cf[7];
+    if (s.rng) { seed = (uint64_t)s.rng[0]; first_sample = s.rng[1]; }
     const size_t total = (size_t)B * per_sample_q;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 xt = nd_ld4(x + i * 4), o = nd_ld4(mo + i * 4);

@@ -286,12 +286,7 @@ extern "C" int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const flo
     ND_REQUIRE(cout <= 256 && ldo % 4 == 0 && nd_aligned16(out), ND_E_SHAPE, "nd_conv7x7_c4: cout <= 256, ldo %% 4 == 0, out 16-byte aligned");
     const long tiles = (long)B * nd_cdiv(H, C7_TH) * nd_cdiv(W, C7_TW);
     ND_REQUIRE(tiles < (1L << 31), ND_E_SHAPE, "nd_conv7x7_c4: grid too large");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = nd_device_cus();
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), block(512);
     const int ntiles = nd_cdiv(cout, 32);
 #define ND_C7_LAUNCH(NT) hipLaunchKernelGGL(conv7x7_kernel<NT>, grid, block, 0, (hipStream_t)stream, x, wpacked, bias, out, ldo, B, H, W, cout)

@@ -1,8 +1,9 @@
 """``GaussianDiffusion``: the reference's diffusion wrapper with the sampling loop on HIP.
 
-Same constructor, buffers, properties and ``.sample()`` signature as
-models/denoising_diffusion_pytorch.py:167-451, so ``Trainer.__init__`` / ``Trainer.test``
-(models/trainer_diffusion.py:77-86,286-294) work unchanged.  ``sample`` accepts two extra
+Same constructor, buffers, properties, ``.sample()`` and ``.forward()`` signatures as
+models/denoising_diffusion_pytorch.py:167-542, so ``Trainer.__init__`` / ``Trainer.test`` / ``Trainer.train``
+(models/trainer_diffusion.py:77-86,286-294,179-181) work unchanged.  The training entry points
+(``q_sample`` / ``p_losses`` / ``forward``) are plain differentiable PyTorch around ``self.model``.  ``sample`` accepts two extra
 keyword-only arguments for reproducibility (``noise=`` explicit draws for parity, ``seed=``
 for the device Philox stream); the reference call signature is a strict subset.
 
@@ -146,6 +147,18 @@ class GaussianDiffusion(nn.Module):
                 torch.stack(rows).to(torch.float32).contiguous())
 
     # ------------------------------------------------------------------ sampling
+    _MAX_LOOPS = 4       # captured step graphs kept per wrapper (one per (plan, sampler settings))
+
+    def _loop_for(self, plan) -> "_Loop":
+        key = (id(plan), self.is_ddim_sampling, self.objective, self.sampling_timesteps, float(self.ddim_sampling_eta))
+        loop = self._loop_cache.pop(key, None)
+        if loop is None:
+            loop = _Loop(self, plan)
+            while len(self._loop_cache) >= self._MAX_LOOPS:
+                self._loop_cache.pop(next(iter(self._loop_cache))).destroy()     # oldest first; frees its hipGraphExec
+        self._loop_cache[key] = loop                                            # most recently used last
+        return loop
+
     @torch.inference_mode()
     def sample(self, batch_size=16, condition=None, return_all_timesteps=False, preset_mean=None, *,
                noise: Optional[Dict[str, torch.Tensor]] = None, seed: Optional[int] = None):
@@ -154,20 +167,18 @@ class GaussianDiffusion(nn.Module):
         noise={'x_T': (B,C,H,W), 'steps': (n_draws,B,C,H,W)} injects the exact draws the reference would take
         from torch.randn / randn_like (parity mode).  Otherwise x_T and the per-step noise come from the
         device Philox stream keyed by (seed, global sample index, step); seed=None draws one from torch's
-        default generator, so torch.manual_seed() makes runs repeatable.
+        default generator, so torch.manual_seed() makes runs repeatable.  The seed lives in device memory, so
+        the captured step graph is reused by every call (no re-capture per seed).
         """
         net = _unwrap(self.model)
         if not hasattr(net, "hip_engine"):
-            raise TypeError("noisediff_amd.GaussianDiffusion drives noisediff_amd.NoiseDiffNet; got %s" % type(net).__name__)
+            raise TypeError("noisediff_amd.GaussianDiffusion.sample drives a noisediff_amd network (HIP engine); got "
+                            f"{type(net).__name__}.  Other nn.Modules are accepted for the training entry points only.")
         dev = self.device
         B, Cc, S = int(batch_size), self.channels, self.image_size
         plan = net.hip_engine(dev).plan(B, S, S)
         plan.set_condition(condition)
-        key = (id(plan), self.is_ddim_sampling, self.objective, self.sampling_timesteps, float(self.ddim_sampling_eta))
-        loop = self._loop_cache.get(key)
-        if loop is None:
-            loop = _Loop(self, plan)
-            self._loop_cache = {key: loop}
+        loop = self._loop_for(plan)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         ddim = self.is_ddim_sampling
@@ -180,11 +191,67 @@ class GaussianDiffusion(nn.Module):
                        first_sample=int(self.sample_offset), return_all=return_all_timesteps)
         return self.unnormalize(ret)
 
-    # ------------------------------------------------------------------ training entry points (not accelerated)
+    # copies (EMA's deepcopy of the trainer, pickling) never carry device loops: they hold ctypes handles
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_loop_cache"] = {}
+        return state
+
+    def release_graphs(self) -> None:
+        """Destroy every captured step graph of this wrapper (they are rebuilt on demand)."""
+        for loop in self._loop_cache.values():
+            loop.destroy()
+        self._loop_cache = {}
+
+    # ------------------------------------------------------------------ training entry points: plain differentiable PyTorch
+    # (models/denoising_diffusion_pytorch.py:473-542).  No HIP kernels here: `self.model` may be ANY differentiable
+    # nn.Module with the arch plug-in signature model(x, t, condition) -- e.g. the reference NoiseDiffNet while its
+    # weights are trained, which then load into noisediff_amd.NoiseDiffNet for sampling (same state dict).
+    @staticmethod
+    def _at(table: torch.Tensor, t: torch.Tensor, ndim: int) -> torch.Tensor:
+        """table[t] shaped (B, 1, ..., 1) for broadcasting against an ndim-dimensional batch (`extract`, :91-94)."""
+        return table.gather(-1, t).reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+    def predict_v(self, x_start, t, noise):                     # :310-314
+        return (self._at(self.sqrt_alphas_cumprod, t, x_start.ndim) * noise
+                - self._at(self.sqrt_one_minus_alphas_cumprod, t, x_start.ndim) * x_start)
+
+    def q_sample(self, x_start, t, noise=None):                 # :473-479: x_t = sqrt(ac) x_0 + sqrt(1 - ac) eps
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return (self._at(self.sqrt_alphas_cumprod, t, x_start.ndim) * x_start
+                + self._at(self.sqrt_one_minus_alphas_cumprod, t, x_start.ndim) * noise)
+
+    def p_losses(self, x_start, t, condition=None, noise=None, offset_noise_strength=None):
+        """Per-sample weighted MSE between the model output and the objective's target (:481-531)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        strength = self.offset_noise_strength if offset_noise_strength is None else offset_noise_strength
+        if strength > 0.:                                       # offset noise: one draw per (sample, channel), :490-492
+            offset = torch.randn(x_start.shape[:2], device=self.device)
+            noise = noise + strength * offset[:, :, None, None]
+        x_t = self.q_sample(x_start, t, noise)
+        model_out = self.model(x_t, t, condition)
+        if self.objective == "pred_noise":
+            target = noise
+        elif self.objective == "pred_x0":
+            target = x_start
+        elif self.objective == "pred_v":
+            target = self.predict_v(x_start, t, noise)
+        else:
+            raise ValueError(f"unknown objective {self.objective}")
+        per_sample = F.mse_loss(model_out, target, reduction="none").flatten(1).mean(dim=1)
+        loss = (per_sample * self.loss_weight.gather(-1, t)).mean()
+        if self.objective == "pred_x0":                         # the reference adds a mean-intensity term here (:521-525)
+            loss = loss + (model_out.mean(dim=(2, 3)) - target.mean(dim=(2, 3))).abs().mean()
+        return loss
+
     def forward(self, img, condition, *args, **kwargs):
-        raise NotImplementedError(
-            "noisediff_amd accelerates the sampling path (GaussianDiffusion.sample) only; train with the reference's "
-            "GaussianDiffusion.forward / p_losses (models/denoising_diffusion_pytorch.py:481-542) and load the weights here.")
+        """Training loss for a batch: uniform random timesteps, then p_losses (:534-542)."""
+        b, _c, h, w = img.shape
+        assert h == self.image_size and w == self.image_size, f"height and width of image must be {self.image_size}"
+        t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
+        return self.p_losses(self.normalize(img), t, condition, *args, **kwargs)
 
 
 class _Loop:
@@ -198,53 +265,75 @@ class _Loop:
         with torch.cuda.device(dev), torch.inference_mode(False):
             self.t_cur, self.t_next, self.coef = t_cur.to(dev), t_next.to(dev), coef.to(dev)
             self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.rng = torch.zeros(2, dtype=torch.int64, device=dev)      # {seed, first_sample}: read by the step kernel
             torch.cuda.synchronize(dev)
         st = L.SamplerState()
         st.step, st.t_cur, st.t_next, st.coef = self.step.data_ptr(), self.t_cur.data_ptr(), self.t_next.data_ptr(), self.coef.data_ptr()
-        st.time_out, st.n_steps, st.B = plan.time.data_ptr(), self.n_steps, plan.B
+        st.time_out, st.rng, st.n_steps, st.B = plan.time.data_ptr(), self.rng.data_ptr(), self.n_steps, plan.B
         self.state = st
         self.graph = C.c_void_p()
         self.graph_key = None
         self.noise_nhwc = None
 
-    def _step_eager(self, noise_ptr, stride, seed, first):
+    def destroy(self) -> None:
+        if getattr(self, "graph", None):
+            try:
+                self.plan.e.sync()
+                L.call("nd_graph_destroy", self.graph)
+            finally:
+                self.graph, self.graph_key = C.c_void_p(), None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:        # interpreter shutdown: the library or the device may already be gone
+            pass
+
+    def _step_eager(self, noise_ptr, stride):
         p, e, st = self.plan, self.plan.e, self.plan.e.stream
         L.call("nd_sampler_begin_step", C.byref(self.state), st)
         p.run(p.step_ops)
         fn = "nd_sampler_step_ddim_f32" if self.gd.is_ddim_sampling else "nd_sampler_step_ddpm_f32"
+        # seed / first_sample arguments are overridden by state.rng (device memory): nothing call-specific is baked in
         L.call(fn, p.x.data_ptr(), p.model_out.data_ptr(), noise_ptr, stride, C.byref(self.state),
-               L.OBJECTIVES[self.gd.objective], C.c_uint64(seed), first, p.B, p.H * p.W, e.inp_dim, st)
+               L.OBJECTIVES[self.gd.objective], C.c_uint64(0), 0, p.B, p.H * p.W, e.inp_dim, st)
         L.call("nd_sampler_advance", C.byref(self.state), st)
 
-    def _ensure_graph(self, noise_ptr, stride, seed, first):
-        key = (noise_ptr, stride, seed, first)
+    def _ensure_graph(self, noise_ptr, stride):
+        key = (noise_ptr, stride)
         if self.graph_key == key:
             return
         st = self.plan.e.stream
-        if self.graph:
-            L.call("nd_graph_destroy", self.graph)
-            self.graph = C.c_void_p()
+        self.destroy()
         L.call("nd_graph_begin", st)
         try:
-            self._step_eager(noise_ptr, stride, seed, first)
+            self._step_eager(noise_ptr, stride)
         finally:
             L.call("nd_graph_end", st, C.byref(self.graph))
         self.graph_key = key
 
     def start(self, x_T, step_noise, seed, first_sample, use_graph=True):
-        """Reset the device loop state, load or draw x_T and (re)capture the step graph."""
+        """Reset the device loop state, load or draw x_T and capture the step graph if there is none yet."""
         p, e = self.plan, self.plan.e
         B, Cc, H, W = p.B, e.inp_dim, p.H, p.W
         st = e.stream
         self.use_graph = use_graph
         with torch.cuda.device(p.dev):
+            e.sync()                                           # a previous run may still read step / rng
             self.step.zero_()
+            self.rng.copy_(torch.tensor([int(seed), int(first_sample)], dtype=torch.int64))
             noise_ptr, stride = None, 0
             if step_noise is not None:
                 need = self.n_steps - 1
                 if step_noise.shape[0] < need or tuple(step_noise.shape[1:]) != (B, Cc, H, W):
                     raise ValueError(f"noise['steps'] must be (>={need}, {B}, {Cc}, {H}, {W}); got {tuple(step_noise.shape)}")
-                self.noise_nhwc = step_noise.to(p.dev, torch.float32).permute(0, 1, 3, 4, 2).contiguous()
+                nh = step_noise.to(p.dev, torch.float32).permute(0, 1, 3, 4, 2)
+                if self.noise_nhwc is not None and self.noise_nhwc.shape == nh.shape:
+                    self.noise_nhwc.copy_(nh)                  # same buffer -> same captured graph
+                else:
+                    with torch.inference_mode(False):
+                        self.noise_nhwc = torch.empty(nh.shape, dtype=torch.float32, device=p.dev)
+                    self.noise_nhwc.copy_(nh)
                 noise_ptr, stride = self.noise_nhwc.data_ptr(), B * Cc * H * W
             torch.cuda.synchronize(p.dev)
             if x_T is not None:
@@ -253,7 +342,7 @@ class _Loop:
                 p.load_x(x_T)
             else:
                 L.call("nd_philox_normal_f32", p.x.data_ptr(), C.c_uint64(seed), first_sample, -1, B, H * W, Cc, st)
-            self._args = (noise_ptr, stride, seed, first_sample)
+            self._args = (noise_ptr, stride)
             if use_graph:
                 self._ensure_graph(*self._args)
 

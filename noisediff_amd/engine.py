@@ -95,6 +95,15 @@ class Engine:
         self.plans: Dict[Tuple[int, int, int], "Plan"] = {}
         self.loaded = False
 
+    def __del__(self):                      # the engine owns its HIP stream (plans and loops only borrow it)
+        s, self.stream = getattr(self, "stream", None), None
+        if s:
+            try:
+                L.call("nd_stream_sync", s)
+                L.call("nd_stream_destroy", s)
+            except Exception:               # interpreter shutdown: the library or the device may already be gone
+                pass
+
     # ------------------------------------------------------------------ arena layout
     def _layout(self) -> None:
         self.slots: Dict[str, Slot] = {}
@@ -187,7 +196,12 @@ class Engine:
     def broadcast(self, src: int = 0, group=None) -> None:
         """The ONE collective of the sampling path: packed weights root -> all ranks (RCCL over xGMI)."""
         import torch.distributed as dist
-        dist.broadcast(self.arena, src=src, group=group)
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)          # rank src: the packing kernels ran on the library's stream
+            dist.broadcast(self.arena, src=src, group=group)
+            # the collective is asynchronous to the host and ordered only against torch's stream; the kernels that read the
+            # arena run on the library's own non-blocking stream, so the arena must be complete before this returns
+            torch.cuda.synchronize(self.device)
         self.loaded = True
 
     # ------------------------------------------------------------------ plans

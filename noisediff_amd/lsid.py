@@ -54,6 +54,15 @@ class LSID(nn.Module):
 class _LsidPlan:
     """Packed weights + workspace + recorded launches for one input shape."""
 
+    def __del__(self):                      # the plan owns its HIP stream
+        s, self.stream = getattr(self, "stream", None), None
+        if s:
+            try:
+                L.call("nd_stream_sync", s)
+                L.call("nd_stream_destroy", s)
+            except Exception:               # interpreter shutdown: the library or the device may already be gone
+                pass
+
     def __init__(self, net: LSID, dev: torch.device, B: int, H: int, W: int):
         self.lib = L.load()
         self.dev, self.B, self.H, self.W = dev, B, H, W

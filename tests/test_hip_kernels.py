@@ -609,3 +609,96 @@ def test_conv3x3_winograd_f4x4_experimental_matches_direct_semantics(ctx, case):
     else:
         with pytest.raises(L.HipError, match="straddle"):
             run(hu.src(hu.nhwc(x[:, :8]), hu.nhwc(x[:, 8:])))
+
+
+# The shapes that carry the bench workload (SURVEY Appendix A at d=64, 256x256: H/8 = 32x32 with 256..768 input channels and
+# 8 output tiles, 16..24 K chunks; H/4 concat; the full-resolution upsample conv; the 64 -> 64 layer at 256x256).
+# (B, H, W, cin, cout, first-source channels of a virtual concat or 0, nearest-x2 upsample addressing)
+HEADLINE_CASES = {
+    "h8_512_512": (2, 32, 32, 512, 512, 0, 0),
+    "h8_768cat_512": (2, 32, 32, 768, 512, 512, 0),
+    "h8_256_512": (1, 32, 32, 256, 512, 0, 0),
+    "h4_384cat_256": (2, 64, 64, 384, 256, 256, 0),
+    "h1_up_128_64": (2, 128, 128, 128, 64, 0, 1),
+    "h1_64_64": (1, 256, 256, 64, 64, 0, 0),
+}
+
+
+def _headline_inputs(case):
+    B, H, W, cin, cout, c0, up = HEADLINE_CASES[case]
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    bound = 1.0 / np.sqrt(9 * cin)                                   # PyTorch default init: outputs stay O(1)
+    x = U(case + ".x", (B, cin, hs, ws), -1.5, 1.5)
+    w = U(case + ".w", (cout, cin, 3, 3), -bound, bound)
+    b = U(case + ".b", (cout,), -bound, bound)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    return x, xin, w, b
+
+
+@pytest.mark.parametrize("case", sorted(HEADLINE_CASES))
+def test_conv3x3_wino2_headline_shapes(ctx, case):
+    """wino2 at the bench workload's own layer shapes: output, GroupNorm partials, affine + SiLU prologue, bitwise repeat."""
+    import hiputil as hu
+    B, H, W, cin, cout, c0, up = HEADLINE_CASES[case]
+    x, xin, w, b = _headline_inputs(case)
+    ref = F.conv2d(xin, w, b, padding=1)
+    wd, bd = hu.dev(w), hu.dev(b)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    slots = ctx.lib.nd_conv3x3_wino_stat_slots(H, W)
+
+    def run(s):
+        out, st, sc = hu.full((B, H, W, cout)), hu.full((B, slots, cout, 2)), hu.full((slots,))
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out, d.stats, d.slot_count = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st.data_ptr(), sc.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        L.call("nd_conv3x3_wino2_nhwc_f32", C.byref(d), ctx.stream)
+        ctx.sync()
+        return out, st, sc
+
+    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
+    out, st, sc = run(s)
+    assert rel_err(hu.nchw(out), ref) < 1e-5
+    gamma, beta = U(case + ".g", (cout,), 0.5, 1.5), U(case + ".be", (cout,))
+    mad = hu.gn_finalize(ctx, st, sc, slots, hu.dev(gamma), hu.dev(beta), None, B, cout, 8).cpu()
+    mine = (ref - mad[:, 0, :, None, None]) * mad[:, 1, :, None, None] + mad[:, 2, :, None, None]
+    assert rel_err(mine, F.group_norm(ref, 8, gamma, beta, eps=1e-5)) < 1e-5
+    out2, st2, _ = run(s)                                               # inline-asm MFMAs: a missed wait state shows as run-to-run noise
+    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
+    if not up:
+        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
+        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+        out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
+        assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 1e-5
+
+
+@pytest.mark.parametrize("case", sorted(k for k, v in HEADLINE_CASES.items() if not v[6]))
+def test_conv3x3_wino4_headline_shapes(ctx, case):
+    """F(4x4,3x3) at the same shapes (5e-5: its transforms carry entries up to 8 and 1/24)."""
+    import hiputil as hu
+    B, H, W, cin, cout, c0, up = HEADLINE_CASES[case]
+    x, xin, w, b = _headline_inputs(case)
+    ref = F.conv2d(xin, w, b, padding=1)
+    wd, bd = hu.dev(w), hu.dev(b)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+
+    def run(s):
+        out = hu.full((B, H, W, cout))
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream)
+        ctx.sync()
+        return out
+
+    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x))
+    out = run(s)
+    assert rel_err(hu.nchw(out), ref) < 5e-5
+    assert torch.equal(out.cpu(), run(s).cpu())
+    M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
+    act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+    out = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
+    assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5

@@ -304,3 +304,142 @@ def test_condition_batch_mismatch_and_bad_iso_are_rejected():
         net.hip_engine(DEV).plan(1, 20, 32)
     out = gd.sample(batch_size=3, condition=to_dev(cond), seed=1)
     assert out.shape == (3, 4, 32, 32)
+
+
+# --------------------------------------------------------------------------- the bench workload's own sizes, against the oracle
+
+def _oracle_threads():
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    torch.set_num_threads(max(1, min(n, 32)))
+
+
+@pytest.mark.parametrize("dim,H,B,mid", [(64, 256, 1, False), (64, 128, 2, False), (128, 64, 1, True)])
+def test_net_forward_headline_sizes_match_oracle(dim, H, B, mid):
+    """One NoiseDiffNet.forward at the sizes the bench runs: d=64 at 256x256 (cfg3: every conv on the Winograd
+    kernel, 512/768-channel layers on 32x32 images, the separate activation pass for cout >= 256), d=64 at 128x128 (cfg2) and the
+    cfg4 width d=128 with the mid Attention (channel counts 1024 / 1536 / 2048)."""
+    _oracle_threads()
+    net = make_net(dim, mid_attn=mid)
+    sd = state_dict(dim, mid_attn=mid)
+    cond = synth.make_condition(B, H, seed=3)
+    x = synth.make_noise(4, "net.x", B, 4, H)
+    t = torch.tensor([640, 17][:B])
+    with torch.inference_mode():
+        y = net(x.to(DEV), t.to(DEV), to_dev(cond)).cpu()
+        ref = O.noisediff_forward(sd, x, t, cond, mid_attention="mid_attn" if mid else None)
+    assert float(ref.abs().max()) > 0.1
+    assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
+
+
+def test_sampler_25_step_ddpm_at_256_matches_oracle_along_the_trajectory():
+    """The headline configuration (d=64, 256x256x4, pred_v, sigmoid2) through a complete 25-step DDPM chain -- x_T to x_0 with the
+    reference's noise draws injected -- compared with the oracle at EVERY step (tools/parity_full_length.py runs all 1000)."""
+    _oracle_threads()
+    dim, B, H, T = 64, 1, 256, 25
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(B, H, seed=1)
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(T - 1)])
+    traj = gd.sample(batch_size=B, condition=to_dev(cond), return_all_timesteps=True, noise={"x_T": x_T, "steps": steps}).cpu()
+    ref = O.sample(state_dict(dim), cond, image_size=H, batch_size=B, timesteps=T, x_T=x_T, noise=lambda i, s: steps[i], return_all=True)
+    assert traj.shape == ref.shape == (B, T + 1, 4, H, H)
+    worst = max(rel_err(traj[:, k].numpy(), ref[:, k].numpy()) for k in range(T + 1))
+    assert worst < SAMPLE_TOL / 10, worst                                   # measured ~4e-6 over 1000 steps (profiles/)
+
+
+def test_config3_batch16_at_256_matches_oracle_on_one_row():
+    """BASELINE config 3 per-GPU shard at its size (d=64, 256x256x4, batch 16): a 3-step DDIM of the whole batch; row 5 must equal
+    the oracle run on that sample alone (per-sample independence + parity at B=16), rows [6, 8) the same rows run as a shard."""
+    _oracle_threads()
+    dim, B, H, S = 64, 16, 256, 3
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=1000, sampling_timesteps=S, ddim_sampling_eta=0.5, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(B, H, seed=1)
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(S - 1)])
+    full = gd.sample(batch_size=B, condition=to_dev(cond), noise={"x_T": x_T, "steps": steps}).cpu()
+    one = {k: v[5:6] for k, v in cond.items()}
+    ref = O.sample(state_dict(dim), one, image_size=H, batch_size=1, timesteps=1000, sampling_timesteps=S, eta=0.5, x_T=x_T[5:6],
+                   noise=lambda i, s: steps[i][5:6])
+    assert rel_err(full[5:6].numpy(), ref.numpy()) < SAMPLE_TOL / 10
+    part = gd.sample(batch_size=2, condition=to_dev({k: v[6:8] for k, v in cond.items()}), noise={"x_T": x_T[6:8], "steps": steps[:, 6:8]}).cpu()
+    assert rel_err(part.numpy(), full[6:8].numpy()) < 1e-5
+
+
+# --------------------------------------------------------------------------- multi-rank product path (SURVEY 8e)
+
+def _rank_worker(rank, world, port, q, mode):
+    """One rank of the sharded HIP sampler: broadcast_weights (the one collective) + sample_sharded, everything on cuda:0
+    (the GPU box has one card, so the process group is gloo; on an 8-GPU node the same code runs with backend nccl = RCCL)."""
+    import os
+    import torch.distributed as dist
+    from noisediff_amd.shard import broadcast_weights, sample_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dim, H, T, total = 16, 32, 6, 5
+    args = SimpleNamespace(dim=dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False)
+    net = NoiseDiffNet(args)                                       # every rank starts from its own random init ...
+    if rank == 0:
+        net.load_state_dict(state_dict(dim), strict=True)          # ... only rank 0 holds the checkpoint
+    net = net.to(DEV).eval()
+    eng = broadcast_weights(net, DEV, src=0)
+    assert net.hip_engine(DEV) is eng                              # the broadcast arena is the one the forward uses
+    gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+
+    def make_cond(lo, hi):
+        return to_dev(synth.make_condition(hi - lo, H, seed=1, first_sample=lo, total=total))
+
+    if mode == "philox":
+        out = sample_sharded(gd.sample, total, make_cond, seed=21, set_offset=lambda lo: setattr(gd, "sample_offset", lo), gather=True)
+    else:
+        state = {}
+
+        def fn(batch_size, condition, seed):
+            lo = state["lo"]
+            noise = {"x_T": synth.make_noise(seed, "x_T", batch_size, 4, H, lo),
+                     "steps": torch.stack([synth.make_noise(seed, f"noise.{i}", batch_size, 4, H, lo) for i in range(T - 1)])}
+            return gd.sample(batch_size=batch_size, condition=condition, noise=noise)
+
+        out = sample_sharded(fn, total, make_cond, seed=2, set_offset=lambda lo: state.update(lo=lo), gather=True)
+    if rank == 0:
+        q.put(out.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["explicit", "philox"])
+def test_two_rank_hip_sampler_equals_single_rank(mode):
+    """2 ranks (ragged 3 + 2 split of 5 patches): Engine.broadcast -> adopt_engine -> sharded HIP sampling -> all-gather
+    == the same 5 patches sampled by one process; explicit-noise mode is also checked against the oracle."""
+    import os
+    import torch.multiprocessing as mp
+    dim, H, T, total = 16, 32, 6, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + (0 if mode == "explicit" else 1)) % 2000
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(total, H, seed=1)
+    if mode == "philox":
+        one = gd.sample(batch_size=total, condition=to_dev(cond), seed=21).cpu().numpy()
+        assert np.isfinite(got).all() and rel_err(got, one) < 1e-5
+        return
+    x_T = synth.make_noise(2, "x_T", total, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", total, 4, H) for i in range(T - 1)])
+    one = gd.sample(batch_size=total, condition=to_dev(cond), noise={"x_T": x_T, "steps": steps}).cpu().numpy()
+    assert rel_err(got, one) < 1e-5
+    ref = O.sample(state_dict(dim), cond, image_size=H, batch_size=total, timesteps=T, x_T=x_T, noise=lambda i, s: steps[i])
+    assert rel_err(got, ref.numpy()) < SAMPLE_TOL / 10
