@@ -368,8 +368,21 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int nu = i & 3, k = i >> 2;
+#ifdef W2_NOP_MASK          // diagnostic builds (tools/w2_nop_probe.sh): wait states only in front of the MFMAs of slices in the mask
+                    if (FIRST && (step & 3) == 0 && k == 0) {
+#ifdef W2_ZNOP_MASK         // ... and in front of the zero-C MFMAs (step / 4) * 4 + i in this mask
+                        if ((W2_ZNOP_MASK >> (step + i)) & 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
+                        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
+#else
+                        W2_MFMA_Z(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
+#endif
+                    }
+                    else if ((W2_NOP_MASK >> i) & 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
+                    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
+#else
                     if (FIRST && (step & 3) == 0 && k == 0) W2_MFMA_Z(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
                     else W2_MFMA(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
+#endif
                     // the slice's share of the other work (<= ~40 issue cycles each)
 #if !(W2_ABLATE & 4)
                     if (i < 8 && step + 2 < S) load_d1(src, step + 2, i >> 1, i & 1);

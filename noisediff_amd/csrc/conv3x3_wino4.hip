@@ -1,24 +1,35 @@
-// conv3x3_wino4.hip -- Winograd F(4x4,3x3) 3x3 convolution on v_mfma_f32_16x16x4_f32 (EXPERIMENTAL, r1e).
+// conv3x3_wino4.hip -- Winograd F(4x4,3x3) 3x3 convolution on v_mfma_f32_16x16x4_f32.
 //
 // F(4x4,3x3) needs 36 multiplies per 16 outputs (2.25 per output) against 4 for F(2x2,3x3): 1.78x fewer MFMAs than
-// conv3x3_wino2.hip.  Its 36 position accumulators do not fit a 32x32 MFMA tile (36 x 16 registers), so the product is
-// laid out on the 16x16x4 instruction instead: one wave = 16 tiles of 4x4 pixels (the workgroup's 16x16 pixels) x 16
-// output channels = 36 x 4 accumulator registers; the four waves of a workgroup take four cout groups (64 couts, the
-// workgroup tile of wino2).  Operand roles are swapped (A = transformed weights U, B = transformed input V) so that a
-// lane ends up with FOUR CONSECUTIVE COUTS of one tile: the output transform runs on float4s and stores 16 bytes.
+// conv3x3_wino2.hip, 4x fewer than the direct form.  On this chip the fp32 MFMA and ordinary VALU work share issue
+// cycles (tools/microbench/mfma_issue.hip: every VALU instruction next to an fp32 MFMA costs ~4.5 cycles of matrix time,
+// every MFMA<->VALU switch ~18 more), so the structure is built around ONE rule: no VALU instruction inside the MFMA
+// loop, and every transform computed once per workgroup.
+//
+//   * workgroup = 4 waves, one per SIMD, the whole register file each; its tile = a 16 x 32 pixel region (two "tile
+//     groups" of 16 tiles of 4x4 pixels) x 64 output channels.  Wave (tg, ch) owns tile group tg and the 32 couts
+//     [32 ch, 32 ch + 32): 36 positions x 2 cout groups of 16 = 72 accumulators of 4 registers (288: the first 64 live
+//     in the accumulator half of the file, the last 8 in ordinary registers).  Operand roles are swapped (A = transformed
+//     weights U, B = transformed input V) so that a lane ends up with FOUR CONSECUTIVE COUTS of one tile: the output
+//     transform runs on float4s and stores 16 bytes.  Each V operand serves the wave's two cout groups.
+//   * K is processed in chunks of 16 channels.  The halo of a chunk lives in LDS as [patch entry 36][channel quad 4]
+//     [tile 16] float4 per tile group: a halo pixel is stored once per (tile, entry) it belongs to (2.25x duplication),
+//     which makes every access a conflict-free row and lets the halo arrive by LDS-DMA (buffer_load ... lds: 1 KB per
+//     wave instruction, no registers, zero padding from out-of-range lanes).
+//   * the input transform V = B^T d B runs IN PLACE on that image, once per workgroup: lane (tile, channel pair) reads
+//     its 36 patch entries, transforms them with packed float2 math and writes the 36 positions back to the same
+//     addresses.  The two waves of a tile group take one 8-channel half each -- the waves that consume a V image are
+//     the ones that produced it.  GroupNorm-affine + SiLU prologues are applied here too (on the raw values).
+//   * the MFMA loop of a wave is then nothing but: 2 ds_read_b64 (V of two positions) + 2 buffer_load_b128 (U of two
+//     positions x two cout groups, a ring of fragments deep) per 8 MFMAs.  Per 16-channel chunk: stage 0, stage 1
+//     (8 channels each, 144 MFMAs), then [wait for the next chunk's LDS-DMA, barrier, transform it in place, barrier].
+//     The DMA of chunk c+1 is issued early in chunk c into the buffer chunk c-1 was read from.
 //
 // Transform matrices (Lavin & Gray, interpolation points 0, +-1, +-2, inf):
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-// fp32 rounding of these transforms is ~10x that of F(2x2,3x3) (~1e-5 relative); the sampler's measured full-length
-// error with F(2x2,3x3) is 3.8e-6 against a 1e-3 budget.
-//
-// LDS image of a K chunk (16 channels): [channel pair 8][patch position (a,b) 36][tile 16] float2 -- a halo pixel is
-// stored once per (tile, patch position) it belongs to (1.78x duplication), which makes every operand read of the
-// transform a conflict-free 128-byte row: lane (tile = l & 15, k = l >> 4) reads the pair of channels (2k, 2k+1) of
-// its tile's patch entry (a, b); the two channels feed two MFMAs (k groups {0,2,4,6} and {1,3,5,7} of an 8-channel block)
-// and the whole transform runs on packed float2 math.
+// fp32 rounding of these transforms is ~10x that of F(2x2,3x3) (~1e-5 relative; parity tests at 5e-5).
 #include <stdlib.h>
 #include <type_traits>
 #include "nd_common.h"
@@ -26,15 +37,46 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((address_space(3))) short* lds_short_ptr;
+typedef __attribute__((address_space(3))) unsigned* lds_u32_ptr;
 
 constexpr int KC4 = 16;                              // channels per K chunk
 constexpr int NPOS = 36;                             // positions (xi, nu) == patch entries (a, b)
-constexpr int VD_FLOATS = (KC4 / 2) * NPOS * 16 * 2; // 9216 floats = 36 KB
+constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk image: 36 entries x 1 KB = 36 KB
+constexpr int W4_LOADS = 18;                         // staging loads per thread and chunk (2 x 36 entries x 64 lanes / 256)
+constexpr int LDS_BYTES = 4 * VD_FLOATS * 4 + W4_LOADS * 256 * 2 + 2 * 256 * 4;      // [tg 2][buf 2] images + int16 border table + padding masks
+
+#ifndef W4_UR
+#define W4_UR 8              // weight fragments in flight per wave (x 4 registers); a stage consumes 36
+#endif
+#ifndef W4_VR
+#define W4_VR 3              // V operand pairs read ahead
+#endif
+#ifndef W4_DMA_AT
+#define W4_DMA_AT 6          // position pair of stage 0 behind which the next chunk's LDS-DMA is issued
+#endif
+#ifndef W4_ABLATE
+#define W4_ABLATE 0          // diagnostic builds only: 1 no staging, 2 no weight loads, 4 no transform, 8 no epilogue stores
+#endif
 
 struct Wino4Args {
     nd_conv3x3 d;
-    int tiles_x, tiles_y, n_tiles, n_cg, n_c8, slots, total_wg;
+    int tiles_x, tiles_y, regions_x, n_tiles, n_cg, n_c8, slots, total_wg;
 };
+
+// MFMAs through inline asm: the constraint pins each accumulator to its half of the register file for the whole kernel
+// (with the builtin, hipcc moved accumulators between AGPR tuples and through VGPRs several times per stage) and a
+// volatile asm keeps its place between the sched_barriers.  W4_NOP: see the hazard note in conv3x3_wino2.hip.
+#ifndef W4_NOP
+#define W4_NOP "s_nop 1\n\t"
+#endif
+#define W4_MFMA_A(acc, av, bv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#define W4_MFMA_V(acc, av, bv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define W4_MFMA_AZ(acc, av, bv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "v"(bv))
+#define W4_MFMA_VZ(acc, av, bv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(av), "v"(bv))
+#define W4_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+constexpr int ACC_AGPR = 64;                         // accumulators [0, 64) in a[0:255], [64, 72) in VGPRs
 
 // one row of B^T applied to six packed values (the same code serves the column pass)
 __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
@@ -57,156 +99,152 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
     y[3] = b + 8.0f * e + m[5];
 }
 
-// ---- the kernel.  One persistent workgroup per CU (one wave per SIMD, the whole register file):
-//   * items = (tile, 16-channel chunk); the halo of item i+1 is loaded from HBM/L2 during item i's first 8-channel
-//     stage (9 buffer loads per thread: the thread's tile and channel quad are fixed, the patch entry (a, b) of load `it`
-//     is wave-uniform, so the big part of every address sits in the scalar offset and nothing about it is recomputed)
-//     and written into the other LDS buffer at the end of that stage; the chunk's one barrier follows, and the second
-//     stage already reads the next item's first patch entries behind it;
-//   * a stage = 72 MFMAs (36 positions x the channel pair of this lane); the 18 weight fragments are refreshed in place
-//     for the NEXT stage right after their MFMAs (a whole stage of latency cover), the next stage's 36 patch entries are
-//     read from LDS at the top of the stage and transformed (B^T d B, packed float2) between the MFMA rows, each new
-//     operand row replacing the row whose MFMAs have just been issued.
-#ifndef W4_ABLATE
-#define W4_ABLATE 0          // diagnostic builds only (tools/w4_variants.sh): 1 no staging, 2 no weight refresh, 4 no transform, 8 no epilogue
-#endif
-#ifndef W4_URING
-#define W4_URING 18          // weight fragments in flight (18 = a whole stage ahead; 9 measured 15 % slower: L2 latency shows)
-#endif
-// MFMAs through inline asm (as in conv3x3_wino2.hip): "+a" keeps the 36 accumulators in place in the accumulator half of the
-// register file -- with the builtin, hipcc moved them between AGPR tuples and through VGPRs (s_nop 7 + 4 v_accvgpr_write per
-// move) several times per stage; operands are pinned to VGPRs.  The epilogue drains the pipe before reading them.
-// `s_nop 1` in front of every MFMA: without it results are wrong in every test shape (identical code otherwise), with it the
-// timing does not change -- the MFMA issue slot is not what bounds this kernel.  The hazard it covers is not one of the
-// register-proximity cases (no VALU or load writes an operand within 8 instructions of its MFMA); kept until identified.
-#define W4_MFMA(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-#define W4_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
-constexpr int W4_STAGE_LOADS = 9;                    // 576 (entry, tile) slots x 4 quads / 256 threads
-
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU;
-    extern __shared__ __attribute__((aligned(16))) float Vd[];          // [2][VD_FLOATS]
+    extern __shared__ __attribute__((aligned(16))) float Vd[];          // [tg 2][buf 2][VD_FLOATS], then the border table
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave >> 1, ch2 = wave & 1;                            // tile group; cout half (and transform half) of this wave
     const int tile = lane & 15, kq = lane >> 4;
 
-    const int t_begin = (int)((long)blockIdx.x * a.total_wg / gridDim.x), t_end = (int)((long)(blockIdx.x + 1) * a.total_wg / gridDim.x);
+    const int wgid = nd_xcd_remap(blockIdx.x, gridDim.x);
+    const int t_begin = (int)((long)wgid * a.total_wg / gridDim.x), t_end = (int)((long)(wgid + 1) * a.total_wg / gridDim.x);
     if (t_begin >= t_end) return;
 
     const nd_src& s = a.d.src;
     const int H = a.d.H, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
+    const int up = s.upsample ? 1 : 0;
+    const int sH = H >> up, sW = W >> up;
     const int Ctot = s.c0 + s.c1;
     const int n_chunks = (Cin + KC4 - 1) / KC4;
 
-    auto decode = [&](int t, int& b_, int& ty_, int& tx_, int& nt_) {
+    auto decode = [&](int t, int& b_, int& ty_, int& rx_, int& nt_) {
         int lid = t;
         nt_ = lid % a.n_tiles;  lid /= a.n_tiles;
-        tx_ = lid % a.tiles_x;  lid /= a.tiles_x;
+        rx_ = lid % a.regions_x;  lid /= a.regions_x;
         ty_ = lid % a.tiles_y;
         b_ = lid / a.tiles_y;
     };
 
-    // ---- staging: thread = (tile st, channel quad sq), load `it` = patch entry e = wave + 4 * it of that tile
-    const int st = tid & 15, sq = (tid >> 4) & 3;                  // == (lane & 15, lane >> 4): a wave's 64 lanes fill one 1-KB patch entry
-    const int sty = 4 * (st >> 2), stx = 4 * (st & 3);          // tile origin inside the 16x16 pixels (patch entry (0,0) is one up-left)
-    const long npx = (long)a.d.B * H * W;
+    // ---- staging: thread = (tile st, channel quad kq) of tile group tg; load `it` fetches patch entry e = 18 * ch2 + it, i.e.
+    //      patch row 3 * ch2 + it / 6, column it % 6 (the sibling wave takes the other three rows).  A wave instruction lands
+    //      as one contiguous 1-KB patch entry.  Addresses: a wave-uniform source pixel per entry (scalar registers: three row
+    //      bases and six column offsets per tile, clamped into the image) + this lane's pixel relative to it -- a constant
+    //      for tiles whose halo lies inside the image, a 16-bit LDS table entry (-1 = outside: zero padding) for the others.
+    const int sty = 4 * (tile >> 2), stx = 4 * (tile & 3);              // tile origin inside the 16x16 pixels (entry (0,0) is one up-left)
+    const long npx = (long)a.d.B * sH * sW;
     const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(npx * s.ld0 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(npx * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
-    const unsigned OOB = 0x7FFFFFF0u;                            // lane offset beyond any tensor: the load returns zeros (padding)
-    // LDS byte address of this thread's first write: pair 2*sq, entry `wave`, tile st
-    const unsigned st_lds = (unsigned)(wave * 1024 + lane * 16);           // entry `wave`, then + 4 KB per load
+    const unsigned OOB = 0x7FFFFFF0u;                                    // lane offset beyond any tensor: the load returns zeros (padding)
+    float* const vd_tg = Vd + tg * 2 * VD_FLOATS;                        // this tile group's two chunk images
+    lds_short_ptr const ptab = (lds_short_ptr)(Vd + 4 * VD_FLOATS) + tid;        // [18][256] int16, thread-private column (border tiles only)
+    const int lane_px = (sty >> up) * sW + (stx >> up);                  // interior tiles: this lane's pixel relative to the entry's pixel
 
-    f32x4 raw[AFF ? W4_STAGE_LOADS : 1];
-    f32x4 tM = {0, 0, 0, 0}, tA = {1, 1, 1, 1}, tD = {0, 0, 0, 0};
-    // per staged tile: pixel offset of each of the 9 patch entries (lane part relative to a wave-uniform scalar pixel) and validity
-    int sbase[W4_STAGE_LOADS];
-    int* poff = reinterpret_cast<int*>(Vd + 2 * VD_FLOATS) + tid;          // [9][256], thread-private column
-    unsigned tilemask = 0, okmask = 0;
+    int s_row[3], s_col[6];                                              // wave-uniform: (b * sH + source row) * sW of the wave's three patch rows; source columns
+    bool s_interior = false;                                             // wave-uniform: the staged tile's halo lies inside the image
     int sb_ = 0;
-    auto stage_tile = [&](int b_, int ty_, int tx_) {
+    // AFF, border tiles: bit e of the per-thread LDS word pair = patch entry e of this lane's tile is inside the image
+    lds_u32_ptr const pmask = (lds_u32_ptr)(Vd + 4 * VD_FLOATS + W4_LOADS * 128) + tid;        // [2][256] behind the int16 table
+    auto stage_tile = [&](int b_, int ty_, int rx_) {
         sb_ = b_;
-        const int y0 = ty_ * 16 - 1, x0 = tx_ * 16 - 1;
-        const bool interior = ty_ > 0 && tx_ > 0 && y0 + 18 <= H && x0 + 18 <= W;      // wave-uniform
-        tilemask = 0;
+        const int y0 = ty_ * 16 - 1 + 3 * ch2, x0 = (2 * rx_ + tg) * 16 - 1;        // first patch row of this wave, first patch column
+        s_interior = ty_ > 0 && x0 >= 0 && ty_ * 16 + 17 <= H && x0 + 18 <= W;
 #pragma unroll
-        for (int it = 0; it < W4_STAGE_LOADS; ++it) {
-            const int e = wave + 4 * it;                         // wave-uniform patch entry
-            const int ay = (e * 43) >> 8, ax = e - 6 * ay;       // e / 6, e % 6 for e < 36
-            if (interior) {
-                sbase[it] = __builtin_amdgcn_readfirstlane((b_ * H + y0 + ay) * W + x0 + ax);
-                poff[it * 256] = sty * W + stx;
-                tilemask |= 1u << it;
-            } else {
-                const int gy = y0 + sty + ay, gx = x0 + stx + ax;
-                const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                const int sy = min(max(y0 + ay, 0), H - 1), sx = min(max(x0 + ax, 0), W - 1);
-                sbase[it] = __builtin_amdgcn_readfirstlane((b_ * H + sy) * W + sx);
-                poff[it * 256] = ok ? (gy - sy) * W + (gx - sx) : 0;
-                tilemask |= (ok ? 1u : 0u) << it;
+        for (int r = 0; r < 3; ++r) s_row[r] = (b_ * sH + (min(max(y0 + r, 0), H - 1) >> up)) * sW;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s_col[c] = min(max(x0 + c, 0), W - 1) >> up;
+        if (s_interior) return;
+#pragma unroll
+        for (int it = 0; it < W4_LOADS; ++it) {
+            const int r = it / 6, c = it % 6;
+            const int gy = y0 + sty + r, gx = x0 + stx + c;
+            const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const int sy = min(max(y0 + r, 0), H - 1), sx = min(max(x0 + c, 0), W - 1);
+            ptab[it * 256] = (short)(ok ? ((gy >> up) - (sy >> up)) * sW + ((gx >> up) - (sx >> up)) : -1);
+        }
+        if (AFF) {                                                       // all 36 entries of this lane's tile (the transform needs them)
+            const int ya = ty_ * 16 - 1 + sty;
+            unsigned long long m = 0;
+#pragma unroll
+            for (int e = 0; e < NPOS; ++e) {
+                const int gy = ya + e / 6, gx = x0 + stx + e % 6;
+                m |= (unsigned long long)(((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? 1 : 0) << e;
             }
+            pmask[0] = (unsigned)m;
+            pmask[256] = (unsigned)(m >> 32);
         }
     };
-    auto stage_issue = [&](int cb_, float* dma_dst) {
-        const bool sec = cb_ >= s.c0;                            // wave-uniform: a chunk never straddles the sources (host check)
+    // the chunk being staged: source, channel base, affine constants of the transform lane
+    f32x2 tA2 = {1, 1}, tD2 = {0, 0};                                    // loaded by stage_issue, used by the transform of the same item
+    auto stage_issue = [&](int cb_, float* dst) {
+        const bool sec = cb_ >= s.c0;                                    // wave-uniform: a chunk never straddles the sources (host check)
         const __amdgpu_buffer_rsrc_t rs = sec ? rsrc1 : rsrc0;
         const int ld = sec ? s.ld1 : s.ld0;
         const int cbase = sec ? cb_ - s.c0 : cb_;
-        const int c = cb_ + 4 * sq;
-        const bool cvalid = c < Cin;
-        if (AFF) {
-            const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (cvalid ? c : 0);
-            tM = nd_ld4(m); tA = nd_ld4(m + Ctot); tD = nd_ld4(m + 2 * Ctot);
-            tD = tD - tM * tA;
-        }
-        okmask = cvalid ? tilemask : 0u;
+        const bool cvalid = cb_ + 4 * kq < Cin;
         const unsigned ld4 = (unsigned)ld * 4u;
-#pragma unroll
-        for (int it = 0; it < W4_STAGE_LOADS; ++it) {
-            const int soff = __builtin_amdgcn_readfirstlane((sbase[it] * ld + cbase) * 4);
-            const unsigned voff = ((okmask >> it) & 1u) ? (unsigned)poff[it * 256] * ld4 + 16u * sq : OOB;
+        if (AFF) {                                                       // transform lane: channels cb + 8 ch2 + 2 kq + {0, 1}
+            const int c = cb_ + 8 * ch2 + 2 * kq;
+            const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (c < Cin ? c : 0);
+            const f32x2 M = *reinterpret_cast<const f32x2*>(m), A = *reinterpret_cast<const f32x2*>(m + Ctot), D = *reinterpret_cast<const f32x2*>(m + 2 * Ctot);
+            tA2 = A;
+            tD2 = D - M * A;                                             // (v - M) * A + D = v * A + (D - M * A)
+        }
 #if !(W4_ABLATE & 1)
-            if (AFF) raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
-            else     // LDS-DMA: 64 lanes x 16 bytes land as one contiguous patch entry, out-of-range lanes as zeros; no registers
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dma_dst + (wave + 4 * it) * 256),
-                                                         16, voff, soff, 0, 0);
+        float* const dst_w = dst + 18 * ch2 * 256;
+        const unsigned q16 = 16u * kq;
+        if (s_interior) {
+            const unsigned voff = cvalid ? (unsigned)lane_px * ld4 + q16 : OOB;
+#pragma unroll
+            for (int it = 0; it < W4_LOADS; ++it) {
+                const int soff = ((s_row[it / 6] + s_col[it % 6]) * ld + cbase) * 4;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst_w + it * 256), 16, voff, soff, 0, 0);
+            }
+        } else {
+            const unsigned cmask = cvalid ? 0u : 0xFFFFFFu;              // invalid channel quad: every entry out of range
+#pragma unroll
+            for (int it = 0; it < W4_LOADS; ++it) {
+                const int soff = ((s_row[it / 6] + s_col[it % 6]) * ld + cbase) * 4;
+                // -1 (outside the image) becomes pixel 0xFFFFFF: x ld4 >= 1 GiB, beyond every source tensor (host check)
+                const unsigned px = ((unsigned)(int)ptab[it * 256] | cmask) & 0xFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst_w + it * 256), 16, __umul24(px, ld4) + q16, soff, 0, 0);
+            }
+        }
 #endif
-        }
-    };
-    auto stage_commit = [&](float* dst) {
-        if (!AFF) return;                                        // plain inputs went straight to LDS (LDS-DMA), nothing to commit
-        char* base = reinterpret_cast<char*>(dst) + st_lds;
-#pragma unroll
-        for (int it = 0; it < W4_STAGE_LOADS; ++it) {
-            f32x4 v = nd_silu4(raw[it] * tA + tD);
-            const f32x4 zero = {0, 0, 0, 0};
-            v = ((okmask >> it) & 1u) ? v : zero;                // silu(affine(0)) != 0: padding is applied after the activation
-            *reinterpret_cast<f32x4*>(base + it * 4096) = v;
-        }
     };
 
-    // ---- MFMA side
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.d.weight), 0, (int)((long)a.n_c8 * a.n_cg * 18 * 256 * 4), 0x00020000);
-    const unsigned wvoff = (unsigned)(lane * 16);
-    auto wblock = [&](int c8_, int cg_) { return __builtin_amdgcn_readfirstlane(((c8_ * a.n_cg + cg_) * 18) * 1024); };
-    const unsigned d_lds = (unsigned)((kq >> 1) * 256 + tile * 16 + (kq & 1) * 8);   // + stage * 512, + entry * 1024
+    // ---- LDS addresses of the MFMA / transform lane: channel pair (2 kq, 2 kq + 1) of 8-channel half g2, tile `tile`:
+    //      + g2 * 512 + entry * 1024 bytes
+    const unsigned d_lds = (unsigned)((kq >> 1) * 256 + tile * 16 + (kq & 1) * 8);
 
-    f32x4 acc[NPOS];
-#pragma unroll
-    for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0, 0, 0, 0};
-    f32x4 U[W4_URING];                                          // ring: fragment pp lives in U[pp % W4_URING], refreshed that far ahead
-    f32x2 V[6][6], T[6][6];
-
-    auto load_u = [&](int pp, int wb) { U[pp % W4_URING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wb + pp * 1024, 0)); };
-    auto read_d = [&](const float* buf, int g2) {                // next stage's patch entries -> T (raw values for now)
-        const char* base = reinterpret_cast<const char*>(buf) + d_lds + g2 * 512;
+    // in-place input transform of one chunk image (this wave: half ch2 of tile group tg)
+    auto transform = [&](float* buf) {
+#if !(W4_ABLATE & 4)
+        char* base = reinterpret_cast<char*>(buf) + d_lds + ch2 * 512;
+        f32x2 T[6][6];
 #pragma unroll
         for (int e = 0; e < NPOS; ++e) T[e / 6][e % 6] = *reinterpret_cast<const f32x2*>(base + e * 1024);
-    };
-    auto col_pass = [&]() {                                      // T <- B^T T (over the patch rows, every column)
+        if (AFF) {
+            // silu(x) = x / (1 + 2^(-x log2 e)); one patch row at a time (sched_barrier: left alone, hipcc interleaves all 72 chains
+            // and spills); the padding of border tiles is applied after the activation (silu(affine(0)) != 0)
+            unsigned long long padmask = ~0ull;
+            if (!s_interior) padmask = (unsigned long long)pmask[0] | ((unsigned long long)pmask[256] << 32);      // wave-uniform branch
 #pragma unroll
-        for (int bx = 0; bx < 6; ++bx) {
+            for (int ay = 0; ay < 6; ++ay) {
+#pragma unroll
+                for (int bx = 0; bx < 6; ++bx) {
+                    f32x2 v = T[ay][bx] * tA2 + tD2;
+                    v.x = nd_silu(v.x); v.y = nd_silu(v.y);
+                    const f32x2 zero = {0, 0};
+                    T[ay][bx] = ((padmask >> (ay * 6 + bx)) & 1ull) ? v : zero;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int bx = 0; bx < 6; ++bx) {                                 // T <- B^T T (over the patch rows, every column)
             f32x2 col[6], t[6];
 #pragma unroll
             for (int ay = 0; ay < 6; ++ay) col[ay] = T[ay][bx];
@@ -214,205 +252,237 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #pragma unroll
             for (int xi = 0; xi < 6; ++xi) T[xi][bx] = t[xi];
         }
-    };
-    auto mfma_row = [&](int xi, int wb_cur, int wb_next) {       // 12 MFMAs of operand row xi; the ring refilled behind them
-        // first channel of the pair for all six positions, then the second: an accumulator is touched again six MFMAs later
-        // (the asm hides the instruction from hipcc's hazard recognizer, so the dependent-accumulate distance is kept long)
 #pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            const int pp = xi * 3 + h;
-            const f32x4 u = U[pp % W4_URING];
-            W4_MFMA(acc[2 * pp], u.x, V[xi][2 * h].x);
-            W4_MFMA(acc[2 * pp + 1], u.z, V[xi][2 * h + 1].x);
-        }
+        for (int xi = 0; xi < 6; ++xi) {                                 // V[xi] = T[xi] B, written back to its position's slot
+            f32x2 v[6];
+            w4_bt(T[xi], v);
 #pragma unroll
-        for (int h = 0; h < 3; ++h) {
-            const int pp = xi * 3 + h;
-            const f32x4 u = U[pp % W4_URING];
-            W4_MFMA(acc[2 * pp], u.y, V[xi][2 * h].y);
-            W4_MFMA(acc[2 * pp + 1], u.w, V[xi][2 * h + 1].y);
-#if !(W4_ABLATE & 2)
-            if (pp + W4_URING < 18) load_u(pp + W4_URING, wb_cur);
-            else load_u(pp + W4_URING - 18, wb_next);
-#endif
+            for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2*>(base + (xi * 6 + nu) * 1024) = v[nu];
         }
-    };
-    // one 8-channel stage: MFMAs with (U, V) of this stage, operands of the next stage produced on the way
-    auto stage = [&](const float* next_buf, int next_g2, int wb_cur, int wb_next, auto&& mid) {
-        read_d(next_buf, next_g2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(0, wb_cur, wb_next);
-        mfma_row(1, wb_cur, wb_next);
-        __builtin_amdgcn_sched_barrier(0);
-#if !(W4_ABLATE & 4)
-        col_pass();
 #endif
-#pragma unroll
-        for (int xi = 2; xi < 6; ++xi) {
-            mfma_row(xi, wb_cur, wb_next);
-#if !(W4_ABLATE & 4)
-            w4_bt(T[xi - 2], V[xi - 2]);                         // rows whose MFMAs are issued take their next values
-#else
-            for (int q = 0; q < 6; ++q) V[xi - 2][q] = T[xi - 2][q];
-#endif
-        }
-#if !(W4_ABLATE & 4)
-        w4_bt(T[4], V[4]);
-        w4_bt(T[5], V[5]);
-#else
-        for (int q = 0; q < 6; ++q) { V[4][q] = T[4][q]; V[5][q] = T[5][q]; }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        mid();
     };
 
-    // ---- prologue: first item staged synchronously, first operands built
-    int b, ty, tx, nt;
-    decode(t_begin, b, ty, tx, nt);
+    // ---- MFMA side
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.d.weight), 0, (int)((long)a.n_c8 * a.n_cg * 18 * 256 * 4), 0x00020000);
+    const unsigned wvoff = (unsigned)(lane * 16);
+    auto wblock = [&](int c8_, int cg_) { return __builtin_amdgcn_readfirstlane(((c8_ * a.n_cg + cg_) * 18) * 1024); };
+
+    f32x4 acc[2 * NPOS];                                                 // [position][cout group j]: 2 * pos + j
+    f32x4 U[W4_UR];                                                      // ring: fragment q = 2 * pp + j of a stage lives in U[q % W4_UR]
+    f32x2 Vr[W4_VR][2];                                                  // ring: the two V operands of position pair pp in Vr[pp % W4_VR]
+    static_assert(72 % W4_UR == 0 && W4_UR % 2 == 0, "the ring must close over a chunk's two stages of 36 fragments");
+    auto load_u = [&](int slot, int q, int wb0, int wb1) {               // q in [0, 36): (pp = q >> 1, j = q & 1)
+#if !(W4_ABLATE & 2)
+        U[slot % W4_UR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((q & 1) ? wb1 : wb0) + (q >> 1) * 1024, 0));
+#endif
+    };
+    auto read_v = [&](const char* vbase, int pp) {
+        Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x2*>(vbase + (2 * pp) * 1024);
+        Vr[pp % W4_VR][1] = *reinterpret_cast<const f32x2*>(vbase + (2 * pp + 1) * 1024);
+    };
+    auto mfma = [&](auto first_c, int idx, float av, float bv) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        if (idx < ACC_AGPR) { if (FIRST) W4_MFMA_AZ(acc[idx], av, bv); else W4_MFMA_A(acc[idx], av, bv); }
+        else                { if (FIRST) W4_MFMA_VZ(acc[idx], av, bv); else W4_MFMA_V(acc[idx], av, bv); }
+    };
+    // one 8-channel stage: 18 position pairs x 8 MFMAs.  V operands of the stage come from `vbase` (this tile group's current
+    // image + half g2); weight fragments of this stage from (wb0, wb1), the ring is refilled from the next stage's (nb0, nb1)
+    // once this stage's 36 are in flight.  `mid(pp)` runs behind position pair pp (the LDS-DMA issue of stage 0).
+    // `off_c`: ring slot of the stage's fragment 0 (stage 0 of a chunk: 0, stage 1: 36 % W4_UR; a chunk's 72 fragments close the ring)
+    auto stage = [&](auto first_c, auto off_c, const char* vbase, int wb0, int wb1, int nb0, int nb1, auto&& mid) {
+        constexpr int OFF = decltype(off_c)::value;
+#pragma unroll
+        for (int pp = 0; pp < W4_VR - 1; ++pp) read_v(vbase, pp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pp = 0; pp < 18; ++pp) {
+            if (pp + W4_VR - 1 < 18) read_v(vbase, pp + W4_VR - 1);
+            const f32x4 u0 = U[(OFF + 2 * pp) % W4_UR], u1 = U[(OFF + 2 * pp + 1) % W4_UR];
+            const f32x2 v0 = Vr[pp % W4_VR][0], v1 = Vr[pp % W4_VR][1];
+            __builtin_amdgcn_sched_barrier(0);
+            // even channels of the pair first (the first touch of every accumulator in a tile's first stage), then the odd ones:
+            // an accumulator is used again four MFMAs later (dependent latency 40 cycles, issue 32)
+            mfma(first_c, 4 * pp + 0, u0.x, v0.x);
+            mfma(first_c, 4 * pp + 1, u1.x, v0.x);
+            mfma(first_c, 4 * pp + 2, u0.z, v1.x);
+            mfma(first_c, 4 * pp + 3, u1.z, v1.x);
+            mfma(std::false_type{}, 4 * pp + 0, u0.y, v0.y);
+            mfma(std::false_type{}, 4 * pp + 1, u1.y, v0.y);
+            mfma(std::false_type{}, 4 * pp + 2, u0.w, v1.y);
+            mfma(std::false_type{}, 4 * pp + 3, u1.w, v1.y);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 2 * pp + j + W4_UR;                         // the slot just consumed takes the fragment W4_UR ahead
+                if (q < 36) load_u(OFF + q, q, wb0, wb1);
+                else load_u(OFF + q, q - 36, nb0, nb1);
+            }
+            mid(pp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // accumulators are read in program order through volatile asm: left to itself hipcc hoists ~200 v_accvgpr_read to the top of
+    // the epilogue and spills what they produce
+    auto read_acc = [&](int idx) -> f32x4 {
+        if (idx >= ACC_AGPR) {
+            // an accumulator in ordinary registers: the empty volatile asm keeps hipcc from scheduling its (plain VALU) readers above
+            // W4_MFMA_DRAIN -- it does not know the asm statements that produced it are MFMAs still in flight
+            asm volatile("" : "+v"(acc[idx]));
+            return acc[idx];
+        }
+        f32x4 r;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.x) : "a"(acc[idx].x));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.y) : "a"(acc[idx].y));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.z) : "a"(acc[idx].z));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.w) : "a"(acc[idx].w));
+        return r;
+    };
+
+    // ---- prologue: first item staged and transformed synchronously, weight ring primed
+    int b, ty, rx, nt;
+    decode(t_begin, b, ty, rx, nt);
+    int b1 = b, ty1 = ty, rx1 = rx, nt1 = nt;
     int cur = 0;
-    stage_tile(b, ty, tx);
-    stage_issue(0, Vd);
-    stage_commit(Vd);
-    __syncthreads();                                             // (plain inputs: the fence in front of it waits for the LDS-DMA)
-    if (!AFF) stage_issue(KC4, Vd + VD_FLOATS);                  // item 1 (n_chunks >= 2, host check) is on its way before chunk 0 starts
+    stage_tile(b, ty, rx);
+    stage_issue(0, vd_tg);
     {
-        const int wb0 = wblock(0, nt * 4 + wave);
+        const int cg0 = nt * 4 + ch2 * 2;
+        const int wb0 = wblock(0, cg0), wb1 = wblock(0, cg0 + 1);
 #pragma unroll
-        for (int pp = 0; pp < W4_URING; ++pp) load_u(pp, wb0);
-        read_d(Vd, 0);
-        col_pass();
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) w4_bt(T[xi], V[xi]);
+        for (int q = 0; q < W4_UR; ++q) load_u(q, q, wb0, wb1);
     }
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_UR) : "memory");        // the W4_LOADS LDS-DMA loads are older than the ring's
+    __builtin_amdgcn_s_barrier();
+    transform(vd_tg);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     for (int t = t_begin; t < t_end; ++t) {
-        int b1 = b, ty1 = ty, tx1 = tx, nt1 = nt;
         const bool more = t + 1 < t_end;
-        if (more) decode(t + 1, b1, ty1, tx1, nt1);
-        const int cg = nt * 4 + wave, cg1 = nt1 * 4 + wave;
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const float* src = Vd + cur * VD_FLOATS;
-            float* dst = Vd + (cur ^ 1) * VD_FLOATS;
+        if (more) decode(t + 1, b1, ty1, rx1, nt1);
+        const int cg0 = nt * 4 + ch2 * 2, cg1 = (more ? nt1 : nt) * 4 + ch2 * 2;
+
+        auto chunk = [&](int ch, auto first_c) {
+            const char* vcur = reinterpret_cast<const char*>(vd_tg + cur * VD_FLOATS) + d_lds;
+            float* nxt = vd_tg + (cur ^ 1) * VD_FLOATS;
             const bool last = ch + 1 == n_chunks;
+            const bool have_next = !last || more;                        // wave-uniform: is there a next (tile, chunk) item
             const int c8 = 2 * ch;
-            if (AFF) {
-                // activation on the way in: the halo of the NEXT item goes through registers, loaded at the top of stage 0,
-                // transformed and written at its end (after the very last item: a harmless re-stage of this tile's first chunk)
-                if (last) {
-                    if (more) stage_tile(b1, ty1, tx1);
-                    stage_issue(0, dst);
-                } else {
-                    stage_issue((ch + 1) * KC4, dst);
-                }
-            }
-            // stage 0: channels 0-7 of the chunk; next operands = channels 8-15 of the same buffer
-            stage(src, 1, wblock(c8, cg), wblock(c8 + 1, cg), [&]() {
-                stage_commit(dst);
-                if (AFF) {
-                    __syncthreads();                             // next buffer complete; every read of this one has been issued
-                } else {
-                    // plain inputs: the next item's 9 LDS-DMA loads were issued at the top of the PREVIOUS stage, before that
-                    // stage's and this stage's 18 + 18 weight-fragment loads, and memory operations retire in order: at most
-                    // 36 outstanding == the halo has landed.  No fence (it would drain the weight stream as well).
-                    asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
+            // weight blocks: this chunk's two stages, then the next item's first stage (after the very last item: a harmless reload)
+            const int w00 = wblock(c8, cg0), w01 = wblock(c8, cg0 + 1), w10 = wblock(c8 + 1, cg0), w11 = wblock(c8 + 1, cg0 + 1);
+            const int n0 = last ? wblock(0, cg1) : wblock(c8 + 2, cg0), n1 = last ? wblock(0, cg1 + 1) : wblock(c8 + 2, cg0 + 1);
+            if (last && more) stage_tile(b1, ty1, rx1);                  // from here on the next tile is staged
+            stage(first_c, std::integral_constant<int, 0>{}, vcur, w00, w01, w10, w11, [&](int pp) {
+                if (pp == W4_DMA_AT && have_next) stage_issue(last ? 0 : (ch + 1) * KC4, nxt);
             });
-            if (!AFF) {
-                // the buffer this chunk read is free behind the barrier: the item after next goes into it, two stages ahead of
-                // its barrier (HBM latency under load is longer than one stage)
-                if (ch + 2 < n_chunks) {
-                    stage_issue((ch + 2) * KC4, const_cast<float*>(src));
-                } else {
-                    if (ch + 2 == n_chunks && more) stage_tile(b1, ty1, tx1);       // from here on the next tile is staged
-                    stage_issue((ch + 2 - n_chunks) * KC4, const_cast<float*>(src));
-                }
+            stage(std::false_type{}, std::integral_constant<int, 36 % W4_UR>{}, vcur + 512, w10, w11, n0, n1, [&](int) {});
+            // the next item's image: its 18 LDS-DMA loads per thread were issued behind position pair W4_DMA_AT of stage 0; memory
+            // operations retire in order and 2 * (17 - W4_DMA_AT) + 36 weight loads were issued after them
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (17 - W4_DMA_AT) + 36) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (have_next) {
+                transform(nxt);
             }
-            // stage 1: channels 8-15; next operands = first 8 channels of the next item (other buffer)
-            stage(dst, 0, wblock(c8 + 1, cg), last ? wblock(0, cg1) : wblock(c8 + 2, cg), [&]() {});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                // next image complete for both consumers; the current one is free
             cur ^= 1;
-        }
+        };
+        chunk(0, std::true_type{});
+        for (int ch = 1; ch < n_chunks; ++ch) chunk(ch, std::false_type{});
 
         // ---- output transform Y = A^T M A on float4s (couts co .. co+3 of tile `tile`), bias, 16-byte stores, GN partials
         W4_MFMA_DRAIN();
-        {
-            const int co = cg * 16 + 4 * kq;
-            const bool cok = co + 3 < Cout;
-            f32x4 bias4 = {0, 0, 0, 0};
-            if (a.d.bias && cok) bias4 = nd_ld4(a.d.bias + co);
-            const int py0 = ty * 16 + 4 * (tile >> 2), px0 = tx * 16 + 4 * (tile & 3);
-            f32x4 sum4 = {0, 0, 0, 0}, sq4 = {0, 0, 0, 0}, pivot4 = {0, 0, 0, 0};
-            int cnt = 0;
-            f32x4 Z[4][6];
+        const int tx = 2 * rx + tg;                                      // this wave's 16x16-pixel tile
+        int Wt = __builtin_amdgcn_readfirstlane(W), ldot = __builtin_amdgcn_readfirstlane(a.d.ldo);
+        asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the 16 store offsets from being hoisted into (spilled) SGPRs
+        if (tx < a.tiles_x) {
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) {
-                f32x4 m[6], y[4];
+            for (int j = 0; j < 2; ++j) {
+                const int cg = cg0 + j;
+                const int co = cg * 16 + 4 * kq;
+                const bool cok = co + 3 < Cout;
+                f32x4 bias4 = {0, 0, 0, 0};
+                if (a.d.bias && cok) bias4 = nd_ld4(a.d.bias + co);
+                const int py0 = ty * 16 + sty, px0 = tx * 16 + stx;
+                f32x4 sum4 = {0, 0, 0, 0}, sq4 = {0, 0, 0, 0}, pivot4 = {0, 0, 0, 0};
+                int cnt = 0;
+                const bool full = ty * 16 + 16 <= H && tx * 16 + 16 <= W && cg * 16 + 16 <= Cout;      // wave-uniform
+                const bool want_stats = a.d.stats != nullptr;
+                float* lane_out = a.d.out + (((size_t)b * H + py0) * Wt + px0) * ldot + co;
+                // two output rows at a time (Z[2][6]: the full Z[4][6] next to the live weight ring and the accumulators that sit in
+                // ordinary registers does not fit the 256 registers VALU instructions can address)
+                auto emit = [&](auto full_c, auto stats_c) {
+                    constexpr bool FULL = decltype(full_c)::value, STATS = decltype(stats_c)::value;
 #pragma unroll
-                for (int xi = 0; xi < 6; ++xi) m[xi] = acc[xi * 6 + nu];
-                w4_at(m, y);
+                    for (int ih = 0; ih < 2; ++ih) {
+                        f32x4 Z[2][6];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Z[i][nu] = y[i];
-            }
+                        for (int nu = 0; nu < 6; ++nu) {
+                            f32x4 m[6];
 #pragma unroll
-            for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0, 0, 0, 0};
-            const bool full = ty * 16 + 16 <= H && tx * 16 + 16 <= W && cg * 16 + 16 <= Cout;      // wave-uniform
-            const bool want_stats = a.d.stats != nullptr;
-            float* lane_out = a.d.out + (((size_t)b * H + py0) * W + px0) * a.d.ldo + co;
-            auto emit = [&](auto full_c, auto stats_c) {
-                constexpr bool FULL = decltype(full_c)::value, STATS = decltype(stats_c)::value;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 y[4];
-                    w4_at(Z[i], y);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 v = y[j] + bias4;
-                        if (STATS && i == 0 && j == 0) {         // one pivot per cout for the whole workgroup tile: tile 0's first pixel
-                            pivot4.x = __shfl(v.x, lane & 48); pivot4.y = __shfl(v.y, lane & 48);
-                            pivot4.z = __shfl(v.z, lane & 48); pivot4.w = __shfl(v.w, lane & 48);
+                            for (int xi = 0; xi < 6; ++xi) m[xi] = read_acc(2 * (xi * 6 + nu) + j);
+                            const f32x4 p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], u = m[3] - m[4];
+                            if (ih == 0) { Z[0][nu] = m[0] + p + r;  Z[1][nu] = q + 2.0f * u; }
+                            else         { Z[0][nu] = p + 4.0f * r;  Z[1][nu] = q + 8.0f * u + m[5]; }
                         }
-                        const bool inside = FULL || (py0 + i < H && px0 + j < W);
-                        if (inside) {
-                            if (STATS) {
-                                const f32x4 dv = v - pivot4;
-                                sum4 += dv;
-                                sq4 += dv * dv;
-                                ++cnt;
-                            }
+#pragma unroll
+                        for (int i2 = 0; i2 < 2; ++i2) {
+                            const int i = 2 * ih + i2;
+                            f32x4 y[4];
+                            w4_at(Z[i2], y);
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const f32x4 v = y[jj] + bias4;
+                                if (STATS && i == 0 && jj == 0) {        // one pivot per cout for the whole 16x16 tile: tile 0's first pixel
+                                    pivot4.x = __shfl(v.x, lane & 48); pivot4.y = __shfl(v.y, lane & 48);
+                                    pivot4.z = __shfl(v.z, lane & 48); pivot4.w = __shfl(v.w, lane & 48);
+                                }
+                                const bool inside = FULL || (py0 + i < H && px0 + jj < W);
+                                if (inside) {
+                                    if (STATS) {
+                                        const f32x4 dv = v - pivot4;
+                                        sum4 += dv;
+                                        sq4 += dv * dv;
+                                        ++cnt;
+                                    }
 #if !(W4_ABLATE & 8)
-                            if (FULL || cok) nd_st4(lane_out + (size_t)((i * W + j) * a.d.ldo), v);
+                                    if (FULL || cok) nd_st4(lane_out + (size_t)((i * Wt + jj) * ldot), v);
 #endif
+                                }
+                            }
                         }
                     }
-                }
-            };
-            if (full) { if (want_stats) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
-            else { if (want_stats) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
-            if (a.d.stats) {
-                // pool over the 16 tiles (the 16 lanes of a DPP row share their couts): sum = S + n p, M2 = Q - S^2 / n
-                float fc = nd_row16_sum((float)cnt);
-                f32x4 S, Q;
-                S.x = nd_row16_sum(sum4.x); S.y = nd_row16_sum(sum4.y); S.z = nd_row16_sum(sum4.z); S.w = nd_row16_sum(sum4.w);
-                Q.x = nd_row16_sum(sq4.x); Q.y = nd_row16_sum(sq4.y); Q.z = nd_row16_sum(sq4.z); Q.w = nd_row16_sum(sq4.w);
-                const int slot = (ty * a.tiles_x + tx) * 2;
-                if (tile == 0 && cok) {
-                    fc = fmaxf(fc, 1.0f);
-                    float* o = a.d.stats + (((size_t)b * a.slots + slot) * Cout + co) * 2;
-                    const f32x4 sm = S + fc * pivot4;
-                    const f32x4 m2 = Q - S * S / fc;
-                    nd_st4(o, f32x4{sm.x, fmaxf(m2.x, 0.0f), sm.y, fmaxf(m2.y, 0.0f)});
-                    nd_st4(o + 4, f32x4{sm.z, fmaxf(m2.z, 0.0f), sm.w, fmaxf(m2.w, 0.0f)});
-                    const f32x4 zero = {0, 0, 0, 0};             // the second slot of the tile (F(2x2) kernels: lower half) stays empty
-                    nd_st4(o + (size_t)Cout * 2, zero);
-                    nd_st4(o + (size_t)Cout * 2 + 4, zero);
-                }
-                if (b == 0 && nt == 0 && wave == 0 && lane == 0) {
-                    a.d.slot_count[slot] = (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
-                    a.d.slot_count[slot + 1] = 0.0f;
+                };
+                if (full) { if (want_stats) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
+                else { if (want_stats) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
+                if (a.d.stats) {
+                    // pool over the 16 tiles (the 16 lanes of a DPP row share their couts): sum = S + n p, M2 = Q - S^2 / n
+                    float fc = nd_row16_sum((float)cnt);
+                    f32x4 S, Q;
+                    S.x = nd_row16_sum(sum4.x); S.y = nd_row16_sum(sum4.y); S.z = nd_row16_sum(sum4.z); S.w = nd_row16_sum(sum4.w);
+                    Q.x = nd_row16_sum(sq4.x); Q.y = nd_row16_sum(sq4.y); Q.z = nd_row16_sum(sq4.z); Q.w = nd_row16_sum(sq4.w);
+                    const int slot = (ty * a.tiles_x + tx) * 2;
+                    if (tile == 0 && cok) {
+                        fc = fmaxf(fc, 1.0f);
+                        float* o = a.d.stats + (((size_t)b * a.slots + slot) * Cout + co) * 2;
+                        const f32x4 sm = S + fc * pivot4;
+                        const f32x4 m2 = Q - S * S / fc;
+                        nd_st4(o, f32x4{sm.x, fmaxf(m2.x, 0.0f), sm.y, fmaxf(m2.y, 0.0f)});
+                        nd_st4(o + 4, f32x4{sm.z, fmaxf(m2.z, 0.0f), sm.w, fmaxf(m2.w, 0.0f)});
+                        const f32x4 zero = {0, 0, 0, 0};             // the second slot of the tile (F(2x2) kernels: lower half) stays empty
+                        nd_st4(o + (size_t)Cout * 2, zero);
+                        nd_st4(o + (size_t)Cout * 2 + 4, zero);
+                    }
+                    if (b == 0 && nt == 0 && ch2 == 0 && j == 0 && lane == 0) {
+                        a.d.slot_count[slot] = (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
+                        a.d.slot_count[slot + 1] = 0.0f;
+                    }
                 }
             }
         }
-        b = b1; ty = ty1; tx = tx1; nt = nt1;
+        b = b1; ty = ty1; rx = rx1; nt = nt1;
     }
 }
 
@@ -443,15 +513,12 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-static inline int w4_cus() { return nd_device_cus(); }
-
 template <int MODE>
 int launch4(const Wino4Args& a, hipStream_t st) {
     static nd_device_once configured;
-    const size_t lds = ((size_t)2 * VD_FLOATS + W4_STAGE_LOADS * 256) * sizeof(float);
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE>), lds, "nd_conv3x3_wino4")) return e;
-    const long resident = w4_cus();                       // one workgroup per CU (registers)
-    hipLaunchKernelGGL((wino4_kernel<MODE>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), lds, st, a);
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE>), LDS_BYTES, "nd_conv3x3_wino4")) return e;
+    const long resident = nd_device_cus();                // one workgroup per CU (registers, LDS)
+    hipLaunchKernelGGL((wino4_kernel<MODE>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
     return 0;
 }
 
@@ -476,8 +543,7 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3_wino4: null tensor pointer");
     ND_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->cin > 0 && d->cout > 0, ND_E_BADARG, "nd_conv3x3_wino4: non-positive size");
-    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->cin > KC4, ND_E_SHAPE,
-               "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4, cin > 16 (two K chunks in flight)", d->cin, d->cout);
+    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4", d->cin, d->cout);
     ND_REQUIRE(s.c0 + s.c1 == d->cin && s.c0 % 4 == 0 && s.c1 % 4 == 0 && s.c0 > 0, ND_E_SHAPE,
                "nd_conv3x3_wino4: source channels %d+%d do not match cin=%d (multiples of 4)", s.c0, s.c1, d->cin);
     ND_REQUIRE((s.c1 == 0) == (s.p1 == nullptr), ND_E_BADARG, "nd_conv3x3_wino4: p1/c1 mismatch");
@@ -488,26 +554,30 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(d->ldo >= d->cout && d->ldo % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: ldo must be >= cout and a multiple of 4");
     ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
                "nd_conv3x3_wino4: unsupported prologue %d (use nd_conv3x3_wino2_nhwc_f32)", s.mode);
-    ND_REQUIRE(s.mode != ND_PRO_AFFINE_SILU || s.mad, ND_E_BADARG, "nd_conv3x3_wino4: affine prologue needs mad");
-    ND_REQUIRE(!s.upsample && !s.unshuffle, ND_E_BADARG, "nd_conv3x3_wino4: no upsample / unshuffle addressing (use nd_conv3x3_wino2_nhwc_f32)");
+    ND_REQUIRE(s.mode != ND_PRO_AFFINE_SILU || (s.mad && (s.c0 + s.c1) % 2 == 0), ND_E_BADARG, "nd_conv3x3_wino4: affine prologue needs mad");
+    ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3_wino4: no unshuffle addressing");
+    ND_REQUIRE(!s.upsample || (d->H % 2 == 0 && d->W % 2 == 0 && s.c1 == 0), ND_E_SHAPE,
+               "nd_conv3x3_wino4: nearest-x2 upsample addressing needs even H, W and a single source");
     ND_REQUIRE((d->stats == nullptr) == (d->slot_count == nullptr), ND_E_BADARG, "nd_conv3x3_wino4: stats and slot_count go together");
-    ND_REQUIRE(!d->stats || d->cout % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: statistics need cout %% 4 == 0");
     ND_REQUIRE(s.c1 == 0 || s.c0 % KC4 == 0, ND_E_SHAPE,
                "nd_conv3x3_wino4: first concat source has %d channels; a 16-channel K chunk must not straddle the sources", s.c0);
+    ND_REQUIRE(d->W <= 2048 && d->H <= 32768, ND_E_SHAPE, "nd_conv3x3_wino4: image wider than 2048 (16-bit border table)");
     {
-        const long px = (long)d->B * d->H * d->W;
-        ND_REQUIRE(px * s.ld0 * 4 < (1L << 31) && px * s.ld1 * 4 < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4: a source tensor of 2 GiB or more");
+        const long px = (long)(d->B) * (d->H >> (s.upsample ? 1 : 0)) * (d->W >> (s.upsample ? 1 : 0));
+        ND_REQUIRE(px * s.ld0 * 4 < (1L << 30) - 65536 && px * s.ld1 * 4 < (1L << 30) - 65536, ND_E_SHAPE, "nd_conv3x3_wino4: a source tensor of 1 GiB or more");
+        ND_REQUIRE(s.ld0 >= 16 && (s.c1 == 0 || s.ld1 >= 16), ND_E_SHAPE, "nd_conv3x3_wino4: pixel stride below 16 floats");
     }
 
     Wino4Args a;
     a.d = *d;
     a.tiles_x = nd_cdiv(d->W, 16);
     a.tiles_y = nd_cdiv(d->H, 16);
+    a.regions_x = nd_cdiv(d->W, 32);
     a.n_tiles = nd_cdiv(d->cout, 64);
     a.n_cg = nd_round_up(d->cout, 64) / 16;
     a.n_c8 = nd_round_up(nd_cdiv(d->cin, 8), 2);
     a.slots = a.tiles_x * a.tiles_y * 2;
-    const long wg = (long)d->B * a.tiles_x * a.tiles_y * a.n_tiles;
+    const long wg = (long)d->B * a.regions_x * a.tiles_y * a.n_tiles;
     ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4: grid too large");
     a.total_wg = (int)wg;
     hipStream_t st = (hipStream_t)stream;

@@ -572,13 +572,37 @@ def test_conv3x3_winograd_matches_direct_semantics(ctx, case, entry):
     assert rel_err(hu.nchw(out), ref) < 1e-5
 
 
+def _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats=True):
+    import hiputil as hu
+    out = hu.full((B, H, W, cout))
+    d = L.Conv3x3()
+    d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
+    d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+    st = sc = None
+    slots = ctx.lib.nd_conv3x3_wino_stat_slots(H, W)
+    if stats:
+        st, sc = hu.full((B, slots, cout, 2)), hu.full((slots,))
+        d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
+    L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream)
+    ctx.sync()
+    return out, st, sc, slots
+
+
+def _check_gn(ctx, case, ref, st, sc, slots, B, cout, tol):
+    import hiputil as hu
+    groups = 8 if cout % 8 == 0 else 2
+    gamma, beta = U(case + ".wg", (cout,), 0.5, 1.5), U(case + ".wbe", (cout,))
+    mad = hu.gn_finalize(ctx, st, sc, slots, hu.dev(gamma), hu.dev(beta), None, B, cout, groups).cpu()
+    mine = (ref - mad[:, 0, :, None, None]) * mad[:, 1, :, None, None] + mad[:, 2, :, None, None]
+    assert rel_err(mine, F.group_norm(ref, groups, gamma, beta, eps=1e-5)) < tol
+
+
 @pytest.mark.parametrize("case", sorted(WINO_CASES))
-def test_conv3x3_winograd_f4x4_experimental_matches_direct_semantics(ctx, case):
-    """The experimental F(4x4,3x3) kernel (conv3x3_wino4.hip, not selected by the engine) == nn.Conv2d(3, padding=1).
+def test_conv3x3_winograd_f4x4_matches_direct_semantics(ctx, case):
+    """The F(4x4,3x3) kernel (conv3x3_wino4.hip) == nn.Conv2d(3, padding=1), GroupNorm partials included.
     Tolerance 5e-5: its fp32 transforms carry entries up to 8 and 1/24 (F(2x2,3x3): 1e-5)."""
     import hiputil as hu
     B, H, W, cin, cout = WINO_CASES[case]
-    cin = max(cin, 24)                                  # two 16-channel K chunks are always in flight (ragged_edges: 16 -> 24)
     x = U(case + ".wx", (B, cin, H, W), -1.5, 1.5)
     w = U(case + ".ww", (cout, cin, 3, 3), -0.2, 0.2)
     b = U(case + ".wb", (cout,))
@@ -587,28 +611,26 @@ def test_conv3x3_winograd_f4x4_experimental_matches_direct_semantics(ctx, case):
     wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
     L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
     ctx.sync()
+    run = lambda s, stats=True: _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats)
 
-    def run(s):
-        out = hu.full((B, H, W, cout))
-        d = L.Conv3x3()
-        d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
-        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
-        L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream)
-        ctx.sync()
-        return out
-
-    assert rel_err(hu.nchw(run(hu.src(hu.nhwc(x)))), ref) < 5e-5
+    out, st, sc, slots = run(hu.src(hu.nhwc(x)))
+    assert rel_err(hu.nchw(out), ref) < 5e-5
+    _check_gn(ctx, case, ref, st, sc, slots, B, cout, 5e-5)
     M, A, D = U(case + ".wM", (B, cin)), U(case + ".wA", (B, cin), 0.5, 1.5), U(case + ".wD", (B, cin))
     act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
-    out = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
+    out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))), stats=False)
     assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
     c0 = cin // 2 // 16 * 16                                             # virtual concat: a 16-channel chunk must not straddle the sources
     if c0:
-        out = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))
+        out, *_ = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])))
         assert rel_err(hu.nchw(out), ref) < 5e-5
     else:
         with pytest.raises(L.HipError, match="straddle"):
             run(hu.src(hu.nhwc(x[:, :8]), hu.nhwc(x[:, 8:])))
+    if H % 2 == 0 and W % 2 == 0:                                        # nearest-x2 upsample addressing (Upsample's conv, Diffusion_arch.py:74-75)
+        xs = x[:, :, : H // 2, : W // 2].contiguous()
+        out, *_ = run(hu.src(hu.nhwc(xs), upsample=1), stats=False)
+        assert rel_err(hu.nchw(out), F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)) < 5e-5
 
 
 # The shapes that carry the bench workload (SURVEY Appendix A at d=64, 256x256: H/8 = 32x32 with 256..768 input channels and
@@ -673,9 +695,10 @@ def test_conv3x3_wino2_headline_shapes(ctx, case):
         assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 1e-5
 
 
-@pytest.mark.parametrize("case", sorted(k for k, v in HEADLINE_CASES.items() if not v[6]))
+@pytest.mark.parametrize("case", sorted(HEADLINE_CASES))
 def test_conv3x3_wino4_headline_shapes(ctx, case):
-    """F(4x4,3x3) at the same shapes (5e-5: its transforms carry entries up to 8 and 1/24)."""
+    """F(4x4,3x3) at the same shapes (5e-5: its transforms carry entries up to 8 and 1/24): output, GroupNorm partials, bitwise repeat,
+    affine + SiLU prologue."""
     import hiputil as hu
     B, H, W, cin, cout, c0, up = HEADLINE_CASES[case]
     x, xin, w, b = _headline_inputs(case)
@@ -684,21 +707,15 @@ def test_conv3x3_wino4_headline_shapes(ctx, case):
     wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
     L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
     ctx.sync()
-
-    def run(s):
-        out = hu.full((B, H, W, cout))
-        d = L.Conv3x3()
-        d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
-        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
-        L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream)
-        ctx.sync()
-        return out
-
-    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x))
-    out = run(s)
+    run = lambda s: _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout)
+    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
+    out, st, sc, slots = run(s)
     assert rel_err(hu.nchw(out), ref) < 5e-5
-    assert torch.equal(out.cpu(), run(s).cpu())
-    M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
-    act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
-    out = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
-    assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
+    _check_gn(ctx, case, ref, st, sc, slots, B, cout, 5e-5)
+    out2, st2, *_ = run(s)
+    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
+    if not up:
+        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
+        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+        out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
+        assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
