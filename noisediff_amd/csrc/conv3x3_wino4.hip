@@ -44,20 +44,36 @@ typedef __attribute__((address_space(3))) unsigned* lds_u32_ptr;
 constexpr int KC4 = 16;                              // channels per K chunk
 constexpr int NPOS = 36;                             // positions (xi, nu) == patch entries (a, b)
 constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk image: 36 entries x 1 KB = 36 KB
-constexpr int W4_LOADS = 18;                         // staging loads per thread and chunk (2 x 36 entries x 64 lanes / 256)
-constexpr int LDS_BYTES = 4 * VD_FLOATS * 4 + W4_LOADS * 256 * 2 + 2 * 256 * 4;      // [tg 2][buf 2] images + int16 border table + padding masks
+
+constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + NPOS * 256 * 2 + 2 * 256 * 4;          // [tg 2] V images + int16 border table + padding masks
 
 #ifndef W4_UR
-#define W4_UR 8              // weight fragments in flight per wave (x 4 registers); a stage consumes 36
+#define W4_UR 18             // weight fragments in flight per wave in the K loop (x 4 registers); a stage consumes 18
 #endif
+#ifndef W4_UR_AFF
+#define W4_UR_AFF 9          // ... of the GroupNorm-affine + SiLU variant (its transform needs more registers)
+#endif
+#ifndef W4_UR_EPI
+#define W4_UR_EPI 6          // ... across a tile's epilogue (its output transform needs the registers): the ring runs down in the
+#endif                       // last stage of a tile and is refilled in one burst at the start of the next tile's first stage
 #ifndef W4_VR
 #define W4_VR 3              // V operand pairs read ahead
 #endif
-#ifndef W4_DMA_AT
-#define W4_DMA_AT 6          // position pair of stage 0 behind which the next chunk's LDS-DMA is issued
+#ifndef W4_ISSUE
+#define W4_ISSUE 2           // halo patch entries requested per position pair of stage 0 (36 in all)
+#endif
+#ifndef W4_ISSUE_ORDER
+#define W4_ISSUE_ORDER 1
+#endif
+#ifndef W4_STAGGER
+#define W4_STAGGER 12        // s_sleep units (64 cycles) between the 16 start phases of the workgroups; 0 = all start together
+#endif
+#ifndef W4_COMMIT_AT
+#define W4_COMMIT_AT 9       // position pair of stage 1 behind which they are written to LDS (~5000 cycles later)
 #endif
 #ifndef W4_ABLATE
-#define W4_ABLATE 0          // diagnostic builds only: 1 no staging, 2 no weight loads, 4 no transform, 8 no epilogue stores
+#define W4_ABLATE 0          // diagnostic builds only: 1 no staging, 2 no weight loads, 4 no transform, 8 no epilogue stores,
+                             // 16 halo loaded but not written to LDS, 32 written but not loaded, 64 every halo load from the same pixels
 #endif
 
 struct Wino4Args {
@@ -99,9 +115,22 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
     y[3] = b + 8.0f * e + m[5];
 }
 
+// Order in which a lane requests its 36 patch entries.  A halo pixel is patch entry (a, b) of one tile and (a +- 4, b +- 4) of its
+// neighbours, i.e. it is requested up to four times per tile group: rows and columns in the order 0, 4, 1, 5, 2, 3 put those
+// requests a few instructions apart, so that all but the first hit in the CU's L1 instead of going to L2 as separate requests.
+__device__ __forceinline__ constexpr int issue_order(int i) {
+#if W4_ISSUE_ORDER
+    constexpr int ord[6] = {0, 4, 1, 5, 2, 3};
+    return ord[i / 6] * 6 + ord[i % 6];
+#else
+    return i;
+#endif
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU;
+    constexpr int UR = AFF ? W4_UR_AFF : W4_UR, UR_EPI = W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
     extern __shared__ __attribute__((aligned(16))) float Vd[];          // [tg 2][buf 2][VD_FLOATS], then the border table
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,6 +142,20 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     const int t_begin = (int)((long)wgid * a.total_wg / gridDim.x), t_end = (int)((long)(wgid + 1) * a.total_wg / gridDim.x);
     if (t_begin >= t_end) return;
 
+#ifdef W4_STAMP                  // diagnostic (tools/w4_clock.py): shader-clock and 100 MHz wall stamps per workgroup -> clock under load, phase split
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_epi = 0, stamp_xf = 0, stamp_wait = 0, stamp_t = 0;
+#define W4_T0() (stamp_t = __builtin_amdgcn_s_memtime())
+#define W4_ACC(x) (x += __builtin_amdgcn_s_memtime() - stamp_t)
+#else
+#define W4_T0()
+#define W4_ACC(x)
+#endif
+#if W4_STAGGER
+    // persistent workgroups with equal work run in lockstep: their halo requests and output stores would hit memory as chip-wide
+    // bursts.  Spread the start over ~one chunk period (16 phases x W4_STAGGER x 64 cycles).
+    for (int k = (int)(blockIdx.x >> 3) & 15; k > 0; --k) __builtin_amdgcn_s_sleep(W4_STAGGER);
+#endif
     const nd_src& s = a.d.src;
     const int H = a.d.H, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
     const int up = s.upsample ? 1 : 0;
@@ -128,90 +171,89 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         b_ = lid / a.tiles_y;
     };
 
-    // ---- staging: thread = (tile st, channel quad kq) of tile group tg; load `it` fetches patch entry e = 18 * ch2 + it, i.e.
-    //      patch row 3 * ch2 + it / 6, column it % 6 (the sibling wave takes the other three rows).  A wave instruction lands
-    //      as one contiguous 1-KB patch entry.  Addresses: a wave-uniform source pixel per entry (scalar registers: three row
-    //      bases and six column offsets per tile, clamped into the image) + this lane's pixel relative to it -- a constant
-    //      for tiles whose halo lies inside the image, a 16-bit LDS table entry (-1 = outside: zero padding) for the others.
+    // ---- staging.  The lane that transforms (tile, channel pair) loads that pair's 36 patch entries itself, 8 bytes each, straight
+    //      into the registers the transform works on: no raw image in LDS, no staging writes, one V image per tile group.
+    //      Addresses: a wave-uniform source pixel per entry (scalar registers: six row bases and six column offsets per tile,
+    //      clamped into the image) + this lane's pixel relative to it -- a constant for tiles whose halo lies inside the image, a
+    //      16-bit LDS table entry (-1 = outside: zero padding) for the others.
     const int sty = 4 * (tile >> 2), stx = 4 * (tile & 3);              // tile origin inside the 16x16 pixels (entry (0,0) is one up-left)
     const long npx = (long)a.d.B * sH * sW;
     const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(npx * s.ld0 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(npx * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
     const unsigned OOB = 0x7FFFFFF0u;                                    // lane offset beyond any tensor: the load returns zeros (padding)
-    float* const vd_tg = Vd + tg * 2 * VD_FLOATS;                        // this tile group's two chunk images
-    lds_short_ptr const ptab = (lds_short_ptr)(Vd + 4 * VD_FLOATS) + tid;        // [18][256] int16, thread-private column (border tiles only)
+    float* const vd_tg = Vd + tg * VD_FLOATS;                            // this tile group's V image
+    lds_short_ptr const ptab = (lds_short_ptr)(Vd + 2 * VD_FLOATS) + tid;        // [36][256] int16, thread-private column (border tiles only)
     const int lane_px = (sty >> up) * sW + (stx >> up);                  // interior tiles: this lane's pixel relative to the entry's pixel
+    const unsigned lane_ch = (unsigned)(8 * ch2 + 2 * kq) * 4u;          // byte offset of this lane's channel pair inside a 16-channel chunk
 
-    int s_row[3], s_col[6];                                              // wave-uniform: (b * sH + source row) * sW of the wave's three patch rows; source columns
+    int s_row[6], s_col[6];                                              // wave-uniform: (b * sH + source row) * sW of the six patch rows; source columns
     bool s_interior = false;                                             // wave-uniform: the staged tile's halo lies inside the image
     int sb_ = 0;
+    f32x2 tA2 = {1, 1}, tD2 = {0, 0};                                    // AFF: loaded with a chunk's halo, used by the transform of the same item
     // AFF, border tiles: bit e of the per-thread LDS word pair = patch entry e of this lane's tile is inside the image
-    lds_u32_ptr const pmask = (lds_u32_ptr)(Vd + 4 * VD_FLOATS + W4_LOADS * 128) + tid;        // [2][256] behind the int16 table
+    lds_u32_ptr const pmask = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + NPOS * 128) + tid;            // [2][256] behind the int16 table
     auto stage_tile = [&](int b_, int ty_, int rx_) {
         sb_ = b_;
-        const int y0 = ty_ * 16 - 1 + 3 * ch2, x0 = (2 * rx_ + tg) * 16 - 1;        // first patch row of this wave, first patch column
-        s_interior = ty_ > 0 && x0 >= 0 && ty_ * 16 + 17 <= H && x0 + 18 <= W;
+        const int y0 = ty_ * 16 - 1, x0 = (2 * rx_ + tg) * 16 - 1;       // first patch row / column of the tile group
+        s_interior = ty_ > 0 && x0 >= 0 && y0 + 18 <= H && x0 + 18 <= W;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) s_row[r] = (b_ * sH + (min(max(y0 + r, 0), H - 1) >> up)) * sW;
+        for (int r = 0; r < 6; ++r) s_row[r] = (b_ * sH + (min(max(y0 + r, 0), H - 1) >> up)) * sW;
 #pragma unroll
         for (int c = 0; c < 6; ++c) s_col[c] = min(max(x0 + c, 0), W - 1) >> up;
         if (s_interior) return;
+        unsigned long long m = 0;
 #pragma unroll
-        for (int it = 0; it < W4_LOADS; ++it) {
-            const int r = it / 6, c = it % 6;
+        for (int e = 0; e < NPOS; ++e) {
+            const int r = e / 6, c = e % 6;
             const int gy = y0 + sty + r, gx = x0 + stx + c;
             const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             const int sy = min(max(y0 + r, 0), H - 1), sx = min(max(x0 + c, 0), W - 1);
-            ptab[it * 256] = (short)(ok ? ((gy >> up) - (sy >> up)) * sW + ((gx >> up) - (sx >> up)) : -1);
+            ptab[e * 256] = (short)(ok ? ((gy >> up) - (sy >> up)) * sW + ((gx >> up) - (sx >> up)) : -1);
+            m |= (unsigned long long)(ok ? 1 : 0) << e;
         }
-        if (AFF) {                                                       // all 36 entries of this lane's tile (the transform needs them)
-            const int ya = ty_ * 16 - 1 + sty;
-            unsigned long long m = 0;
-#pragma unroll
-            for (int e = 0; e < NPOS; ++e) {
-                const int gy = ya + e / 6, gx = x0 + stx + e % 6;
-                m |= (unsigned long long)(((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? 1 : 0) << e;
-            }
+        if (AFF) {
             pmask[0] = (unsigned)m;
             pmask[256] = (unsigned)(m >> 32);
         }
     };
     // the chunk being staged: source, channel base, affine constants of the transform lane
-    f32x2 tA2 = {1, 1}, tD2 = {0, 0};                                    // loaded by stage_issue, used by the transform of the same item
-    auto stage_issue = [&](int cb_, float* dst) {
+    f32x2 T[6][6];                                                       // the halo in flight: loaded during a chunk's stage 0 (two entries per position
+                                                                         // pair), transformed at the chunk's end
+    __amdgpu_buffer_rsrc_t i_rs = rsrc0;
+    int i_ld = 0, i_cbase = 0;
+    unsigned i_voff = 0, i_ld4 = 0, i_cmask = 0;
+    auto stage_issue_begin = [&](int cb_) {
         const bool sec = cb_ >= s.c0;                                    // wave-uniform: a chunk never straddles the sources (host check)
-        const __amdgpu_buffer_rsrc_t rs = sec ? rsrc1 : rsrc0;
-        const int ld = sec ? s.ld1 : s.ld0;
-        const int cbase = sec ? cb_ - s.c0 : cb_;
-        const bool cvalid = cb_ + 4 * kq < Cin;
-        const unsigned ld4 = (unsigned)ld * 4u;
-        if (AFF) {                                                       // transform lane: channels cb + 8 ch2 + 2 kq + {0, 1}
-            const int c = cb_ + 8 * ch2 + 2 * kq;
-            const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (c < Cin ? c : 0);
+        i_rs = sec ? rsrc1 : rsrc0;
+        i_ld = sec ? s.ld1 : s.ld0;
+        i_cbase = sec ? cb_ - s.c0 : cb_;
+        const int c = cb_ + 8 * ch2 + 2 * kq;                            // this lane's channel pair
+        const bool cvalid = c < Cin;
+        i_ld4 = (unsigned)i_ld * 4u;
+        i_voff = cvalid ? (unsigned)lane_px * i_ld4 + lane_ch : OOB;     // interior tiles: the same lane offset for every entry
+        i_cmask = cvalid ? 0u : 0xFFFFFFu;                               // invalid channel pair: every entry out of range
+        if (AFF) {
+            const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (cvalid ? c : 0);
             const f32x2 M = *reinterpret_cast<const f32x2*>(m), A = *reinterpret_cast<const f32x2*>(m + Ctot), D = *reinterpret_cast<const f32x2*>(m + 2 * Ctot);
             tA2 = A;
             tD2 = D - M * A;                                             // (v - M) * A + D = v * A + (D - M * A)
         }
+    };
+    auto stage_issue_one = [&](int e) {
 #if !(W4_ABLATE & 1)
-        float* const dst_w = dst + 18 * ch2 * 256;
-        const unsigned q16 = 16u * kq;
-        if (s_interior) {
-            const unsigned voff = cvalid ? (unsigned)lane_px * ld4 + q16 : OOB;
-#pragma unroll
-            for (int it = 0; it < W4_LOADS; ++it) {
-                const int soff = ((s_row[it / 6] + s_col[it % 6]) * ld + cbase) * 4;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst_w + it * 256), 16, voff, soff, 0, 0);
-            }
-        } else {
-            const unsigned cmask = cvalid ? 0u : 0xFFFFFFu;              // invalid channel quad: every entry out of range
-#pragma unroll
-            for (int it = 0; it < W4_LOADS; ++it) {
-                const int soff = ((s_row[it / 6] + s_col[it % 6]) * ld + cbase) * 4;
-                // -1 (outside the image) becomes pixel 0xFFFFFF: x ld4 >= 1 GiB, beyond every source tensor (host check)
-                const unsigned px = ((unsigned)(int)ptab[it * 256] | cmask) & 0xFFFFFFu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst_w + it * 256), 16, __umul24(px, ld4) + q16, soff, 0, 0);
-            }
+        const int soff = ((s_row[e / 6] + s_col[e % 6]) * i_ld + i_cbase) * 4;
+        unsigned voff = i_voff;
+        if (!s_interior) {      // wave-uniform.  -1 (outside the image) becomes pixel 0xFFFFFF: x ld4 >= 1 GiB, beyond every source tensor (host check)
+            const unsigned px = ((unsigned)(int)ptab[e * 256] | i_cmask) & 0xFFFFFFu;
+            voff = __umul24(px, i_ld4) + lane_ch;
         }
+#if W4_ABLATE & 64
+        T[e / 6][e % 6] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(i_rs, i_voff, i_cbase * 4, 0));
+#else
+        T[e / 6][e % 6] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(i_rs, voff, soff, 0));
+#endif
+#else
+        T[e / 6][e % 6] = f32x2{(float)e, 1.0f};
 #endif
     };
 
@@ -219,13 +261,10 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     //      + g2 * 512 + entry * 1024 bytes
     const unsigned d_lds = (unsigned)((kq >> 1) * 256 + tile * 16 + (kq & 1) * 8);
 
-    // in-place input transform of one chunk image (this wave: half ch2 of tile group tg)
+    // input transform of the staged halo (registers) into this tile group's V image (this wave: half ch2)
     auto transform = [&](float* buf) {
 #if !(W4_ABLATE & 4)
         char* base = reinterpret_cast<char*>(buf) + d_lds + ch2 * 512;
-        f32x2 T[6][6];
-#pragma unroll
-        for (int e = 0; e < NPOS; ++e) T[e / 6][e % 6] = *reinterpret_cast<const f32x2*>(base + e * 1024);
         if (AFF) {
             // silu(x) = x / (1 + 2^(-x log2 e)); one patch row at a time (sched_barrier: left alone, hipcc interleaves all 72 chains
             // and spills); the padding of border tiles is applied after the activation (silu(affine(0)) != 0)
@@ -269,54 +308,63 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     auto wblock = [&](int c8_, int cg_) { return __builtin_amdgcn_readfirstlane(((c8_ * a.n_cg + cg_) * 18) * 1024); };
 
     f32x4 acc[2 * NPOS];                                                 // [position][cout group j]: 2 * pos + j
-    f32x4 U[W4_UR];                                                      // ring: fragment q = 2 * pp + j of a stage lives in U[q % W4_UR]
-    f32x2 Vr[W4_VR][2];                                                  // ring: the two V operands of position pair pp in Vr[pp % W4_VR]
-    static_assert(72 % W4_UR == 0 && W4_UR % 2 == 0, "the ring must close over a chunk's two stages of 36 fragments");
-    auto load_u = [&](int slot, int q, int wb0, int wb1) {               // q in [0, 36): (pp = q >> 1, j = q & 1)
+    f32x4 U[UR];                                                         // ring: fragment pp of a stage (positions 2pp, 2pp+1) lives in U[(OFF + pp) % UR]
+    f32x2 Vr[W4_VR][4];                                                  // ring: V of position pair pp, [tile group][position] in Vr[pp % W4_VR]
+    static_assert(36 % UR == 0, "the ring must close over a chunk's two stages of 18 fragments");
+    auto load_u = [&](int slot, int q, int wb) {                         // q in [0, 18): position pair
 #if !(W4_ABLATE & 2)
-        U[slot % W4_UR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((q & 1) ? wb1 : wb0) + (q >> 1) * 1024, 0));
+        U[slot % UR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wb + q * 1024, 0));
 #endif
     };
-    auto read_v = [&](const char* vbase, int pp) {
-        Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x2*>(vbase + (2 * pp) * 1024);
-        Vr[pp % W4_VR][1] = *reinterpret_cast<const f32x2*>(vbase + (2 * pp + 1) * 1024);
+    auto read_v = [&](const char* v0base, const char* v1base, int pp) {
+        Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x2*>(v0base + (2 * pp) * 1024);
+        Vr[pp % W4_VR][1] = *reinterpret_cast<const f32x2*>(v0base + (2 * pp + 1) * 1024);
+        Vr[pp % W4_VR][2] = *reinterpret_cast<const f32x2*>(v1base + (2 * pp) * 1024);
+        Vr[pp % W4_VR][3] = *reinterpret_cast<const f32x2*>(v1base + (2 * pp + 1) * 1024);
     };
     auto mfma = [&](auto first_c, int idx, float av, float bv) {
         constexpr bool FIRST = decltype(first_c)::value;
         if (idx < ACC_AGPR) { if (FIRST) W4_MFMA_AZ(acc[idx], av, bv); else W4_MFMA_A(acc[idx], av, bv); }
         else                { if (FIRST) W4_MFMA_VZ(acc[idx], av, bv); else W4_MFMA_V(acc[idx], av, bv); }
     };
-    // one 8-channel stage: 18 position pairs x 8 MFMAs.  V operands of the stage come from `vbase` (this tile group's current
-    // image + half g2); weight fragments of this stage from (wb0, wb1), the ring is refilled from the next stage's (nb0, nb1)
-    // once this stage's 36 are in flight.  `mid(pp)` runs behind position pair pp (the LDS-DMA issue of stage 0).
-    // `off_c`: ring slot of the stage's fragment 0 (stage 0 of a chunk: 0, stage 1: 36 % W4_UR; a chunk's 72 fragments close the ring)
-    auto stage = [&](auto first_c, auto off_c, const char* vbase, int wb0, int wb1, int nb0, int nb1, auto&& mid) {
-        constexpr int OFF = decltype(off_c)::value;
+    // one 8-channel stage: 18 position pairs x 8 MFMAs.  V operands come from the two tile groups' current images (+ half g2);
+    // weight fragments of this stage from block `wb`, the ring is refilled from the next stage's `nb` once this stage's 18 are
+    // requested.  `mid(pp)` runs behind position pair pp (halo loads of stage 0, their LDS writes in stage 1).
+    // `off_c`: ring slot of the stage's fragment 0 (stage 0 of a chunk: 0, stage 1: 18 % UR; a chunk's 36 fragments close the ring).
+    // `din_c` fragments of this stage are in flight on entry, `dout_c` of the next stage on exit (UR in the steady state).
+    auto stage = [&](auto first_c, auto off_c, auto din_c, auto dout_c, const char* v0base, const char* v1base, int wb, int nb, auto&& mid) {
+        constexpr int OFF = decltype(off_c)::value, DIN = decltype(din_c)::value, DOUT = decltype(dout_c)::value;
+        auto hi = [](int pp) { const int h = pp + UR; return h < 18 + DOUT ? h : 18 + DOUT; };   // fragments requested before position pair pp
 #pragma unroll
-        for (int pp = 0; pp < W4_VR - 1; ++pp) read_v(vbase, pp);
+        for (int pp = 0; pp < W4_VR - 1; ++pp) read_v(v0base, v1base, pp);
+#pragma unroll
+        for (int q = DIN; q < hi(0); ++q) {                              // (only behind an epilogue: the burst that refills the ring)
+            if (q < 18) load_u(OFF + q, q, wb);
+            else load_u(OFF + q, q - 18, nb);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pp = 0; pp < 18; ++pp) {
-            if (pp + W4_VR - 1 < 18) read_v(vbase, pp + W4_VR - 1);
-            const f32x4 u0 = U[(OFF + 2 * pp) % W4_UR], u1 = U[(OFF + 2 * pp + 1) % W4_UR];
-            const f32x2 v0 = Vr[pp % W4_VR][0], v1 = Vr[pp % W4_VR][1];
+            if (pp + W4_VR - 1 < 18) read_v(v0base, v1base, pp + W4_VR - 1);
+            const f32x4 u = U[(OFF + pp) % UR];
+            const f32x2 va0 = Vr[pp % W4_VR][0], va1 = Vr[pp % W4_VR][1], vb0 = Vr[pp % W4_VR][2], vb1 = Vr[pp % W4_VR][3];
             __builtin_amdgcn_sched_barrier(0);
             // even channels of the pair first (the first touch of every accumulator in a tile's first stage), then the odd ones:
-            // an accumulator is used again four MFMAs later (dependent latency 40 cycles, issue 32)
-            mfma(first_c, 4 * pp + 0, u0.x, v0.x);
-            mfma(first_c, 4 * pp + 1, u1.x, v0.x);
-            mfma(first_c, 4 * pp + 2, u0.z, v1.x);
-            mfma(first_c, 4 * pp + 3, u1.z, v1.x);
-            mfma(std::false_type{}, 4 * pp + 0, u0.y, v0.y);
-            mfma(std::false_type{}, 4 * pp + 1, u1.y, v0.y);
-            mfma(std::false_type{}, 4 * pp + 2, u0.w, v1.y);
-            mfma(std::false_type{}, 4 * pp + 3, u1.w, v1.y);
+            // an accumulator is used again four MFMAs later (dependent latency 40 cycles, issue 32).  Each weight fragment serves
+            // both tile groups: it is loaded once per workgroup.
+            mfma(first_c, 4 * pp + 0, u.x, va0.x);
+            mfma(first_c, 4 * pp + 1, u.x, vb0.x);
+            mfma(first_c, 4 * pp + 2, u.z, va1.x);
+            mfma(first_c, 4 * pp + 3, u.z, vb1.x);
+            mfma(std::false_type{}, 4 * pp + 0, u.y, va0.y);
+            mfma(std::false_type{}, 4 * pp + 1, u.y, vb0.y);
+            mfma(std::false_type{}, 4 * pp + 2, u.w, va1.y);
+            mfma(std::false_type{}, 4 * pp + 3, u.w, vb1.y);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int q = 2 * pp + j + W4_UR;                         // the slot just consumed takes the fragment W4_UR ahead
-                if (q < 36) load_u(OFF + q, q, wb0, wb1);
-                else load_u(OFF + q, q - 36, nb0, nb1);
+            for (int q = (hi(pp) > DIN ? hi(pp) : DIN); q < hi(pp + 1); ++q) {     // the slot just consumed takes the fragment UR ahead
+                if (q < 18) load_u(OFF + q, q, wb);
+                else load_u(OFF + q, q - 18, nb);
             }
             mid(pp);
             __builtin_amdgcn_sched_barrier(0);
@@ -344,17 +392,15 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     int b, ty, rx, nt;
     decode(t_begin, b, ty, rx, nt);
     int b1 = b, ty1 = ty, rx1 = rx, nt1 = nt;
-    int cur = 0;
     stage_tile(b, ty, rx);
-    stage_issue(0, vd_tg);
-    {
-        const int cg0 = nt * 4 + ch2 * 2;
-        const int wb0 = wblock(0, cg0), wb1 = wblock(0, cg0 + 1);
+    stage_issue_begin(0);
 #pragma unroll
-        for (int q = 0; q < W4_UR; ++q) load_u(q, q, wb0, wb1);
+    for (int e = 0; e < NPOS; ++e) stage_issue_one(e);
+    {
+        const int wb = wblock(0, nt * 4 + wave);
+#pragma unroll
+        for (int q = 0; q < UR_EPI; ++q) load_u(q, q, wb);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_UR) : "memory");        // the W4_LOADS LDS-DMA loads are older than the ring's
-    __builtin_amdgcn_s_barrier();
     transform(vd_tg);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -362,51 +408,63 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     for (int t = t_begin; t < t_end; ++t) {
         const bool more = t + 1 < t_end;
         if (more) decode(t + 1, b1, ty1, rx1, nt1);
-        const int cg0 = nt * 4 + ch2 * 2, cg1 = (more ? nt1 : nt) * 4 + ch2 * 2;
+        const int cg = nt * 4 + wave, cg_next = (more ? nt1 : nt) * 4 + wave;          // this wave's 16 output channels
 
-        auto chunk = [&](int ch, auto first_c) {
-            const char* vcur = reinterpret_cast<const char*>(vd_tg + cur * VD_FLOATS) + d_lds;
-            float* nxt = vd_tg + (cur ^ 1) * VD_FLOATS;
-            const bool last = ch + 1 == n_chunks;
-            const bool have_next = !last || more;                        // wave-uniform: is there a next (tile, chunk) item
+        auto chunk = [&](int ch, auto first_c, auto last_c) {
+            const char* v0cur = reinterpret_cast<const char*>(Vd) + d_lds;                                       // tile group 0 / 1: V images
+            const char* v1cur = reinterpret_cast<const char*>(Vd + VD_FLOATS) + d_lds;
+            constexpr bool last = decltype(last_c)::value;               // last chunk of the tile (n_chunks >= 2: never also the first)
             const int c8 = 2 * ch;
             // weight blocks: this chunk's two stages, then the next item's first stage (after the very last item: a harmless reload)
-            const int w00 = wblock(c8, cg0), w01 = wblock(c8, cg0 + 1), w10 = wblock(c8 + 1, cg0), w11 = wblock(c8 + 1, cg0 + 1);
-            const int n0 = last ? wblock(0, cg1) : wblock(c8 + 2, cg0), n1 = last ? wblock(0, cg1 + 1) : wblock(c8 + 2, cg0 + 1);
+            const int w0 = wblock(c8, cg), w1 = wblock(c8 + 1, cg), wn = last ? wblock(0, cg_next) : wblock(c8 + 2, cg);
             if (last && more) stage_tile(b1, ty1, rx1);                  // from here on the next tile is staged
-            stage(first_c, std::integral_constant<int, 0>{}, vcur, w00, w01, w10, w11, [&](int pp) {
-                if (pp == W4_DMA_AT && have_next) stage_issue(last ? 0 : (ch + 1) * KC4, nxt);
-            });
-            stage(std::false_type{}, std::integral_constant<int, 36 % W4_UR>{}, vcur + 512, w10, w11, n0, n1, [&](int) {});
-            // the next item's image: its 18 LDS-DMA loads per thread were issued behind position pair W4_DMA_AT of stage 0; memory
-            // operations retire in order and 2 * (17 - W4_DMA_AT) + 36 weight loads were issued after them
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (17 - W4_DMA_AT) + 36) : "memory");
-            __builtin_amdgcn_s_barrier();
-            if (have_next) {
-                transform(nxt);
-            }
+            using I0 = std::integral_constant<int, 0>;
+            using IOFF1 = std::integral_constant<int, 18 % UR>;
+            using IUR = std::integral_constant<int, UR>;
+            using IEPI = std::integral_constant<int, UR_EPI>;
+            constexpr bool FIRST = decltype(first_c)::value;              // first chunk of a tile: the ring comes out of an epilogue
+            // the next item's halo: two patch entries per position pair of stage 0 (unconditional: behind the very last item this is a
+            // harmless re-stage of the tile's first chunk -- a conditional load would keep the 72 staging registers alive everywhere)
+            auto issue = [&](int pp) {
+                if (pp == 0) stage_issue_begin(last ? 0 : (ch + 1) * KC4);
+#pragma unroll
+                for (int i = pp * W4_ISSUE; i < (pp + 1) * W4_ISSUE && i < NPOS; ++i) stage_issue_one(issue_order(i));
+            };
+            stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IUR>{}, IUR{}, v0cur, v1cur, w0, w1, issue);
+            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 512, v1cur + 512, w1, wn, [&](int) {});
+            W4_T0();
+            __builtin_amdgcn_s_barrier();                                // every wave has read its last V operands of this chunk
+            W4_ACC(stamp_wait);
+            W4_T0();
+            transform(vd_tg);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                // next image complete for both consumers; the current one is free
-            cur ^= 1;
+            __builtin_amdgcn_s_barrier();                                // the next item's V images are complete
+            W4_ACC(stamp_xf);
         };
-        chunk(0, std::true_type{});
-        for (int ch = 1; ch < n_chunks; ++ch) chunk(ch, std::false_type{});
+        // three instances of the chunk body, no branch between alternatives (accumulators pinned by asm constraints do not survive an
+        // if / else of two instances without copies): first (ring refilled behind the epilogue), middle, last (ring runs down)
+        chunk(0, std::true_type{}, std::false_type{});
+        for (int ch = 1; ch + 1 < n_chunks; ++ch) chunk(ch, std::false_type{}, std::false_type{});
+        chunk(n_chunks - 1, std::false_type{}, std::true_type{});
 
         // ---- output transform Y = A^T M A on float4s (couts co .. co+3 of tile `tile`), bias, 16-byte stores, GN partials
+        W4_T0();
         W4_MFMA_DRAIN();
-        const int tx = 2 * rx + tg;                                      // this wave's 16x16-pixel tile
+
         int Wt = __builtin_amdgcn_readfirstlane(W), ldot = __builtin_amdgcn_readfirstlane(a.d.ldo);
         asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the 16 store offsets from being hoisted into (spilled) SGPRs
-        if (tx < a.tiles_x) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int cg = cg0 + j;
+        for (int j = 0; j < 2; ++j) {                                    // the two 16x16-pixel tiles (tile groups) of the region
+            const int tx = 2 * rx + j;
+            if (tx < a.tiles_x) {
                 const int co = cg * 16 + 4 * kq;
                 const bool cok = co + 3 < Cout;
-                f32x4 bias4 = {0, 0, 0, 0};
+                float z0 = 0.0f;
+                asm volatile("" : "+v"(z0));                               // a fresh zero per tile: hipcc otherwise keeps one zero float4 alive (and spilled) for the whole kernel
+                f32x4 bias4 = {z0, z0, z0, z0};
                 if (a.d.bias && cok) bias4 = nd_ld4(a.d.bias + co);
                 const int py0 = ty * 16 + sty, px0 = tx * 16 + stx;
-                f32x4 sum4 = {0, 0, 0, 0}, sq4 = {0, 0, 0, 0}, pivot4 = {0, 0, 0, 0};
+                f32x4 sum4 = {z0, z0, z0, z0}, sq4 = {z0, z0, z0, z0}, pivot4 = {z0, z0, z0, z0};
                 int cnt = 0;
                 const bool full = ty * 16 + 16 <= H && tx * 16 + 16 <= W && cg * 16 + 16 <= Cout;      // wave-uniform
                 const bool want_stats = a.d.stats != nullptr;
@@ -420,12 +478,14 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                         f32x4 Z[2][6];
 #pragma unroll
                         for (int nu = 0; nu < 6; ++nu) {
-                            f32x4 m[6];
-#pragma unroll
-                            for (int xi = 0; xi < 6; ++xi) m[xi] = read_acc(2 * (xi * 6 + nu) + j);
-                            const f32x4 p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], u = m[3] - m[4];
-                            if (ih == 0) { Z[0][nu] = m[0] + p + r;  Z[1][nu] = q + 2.0f * u; }
-                            else         { Z[0][nu] = p + 4.0f * r;  Z[1][nu] = q + 8.0f * u + m[5]; }
+                            auto M = [&](int xi) { return read_acc(2 * (xi * 6 + nu) + j); };
+                            const f32x4 m1 = M(1), m2 = M(2);
+                            const f32x4 p = m1 + m2, q = m1 - m2;
+                            const f32x4 m3 = M(3), m4 = M(4);
+                            const f32x4 r = m3 + m4, u = m3 - m4;
+                            if (ih == 0) { Z[0][nu] = M(0) + p + r;  Z[1][nu] = q + 2.0f * u; }
+                            else         { Z[0][nu] = p + 4.0f * r;  Z[1][nu] = q + 8.0f * u + M(5); }
+                            __builtin_amdgcn_sched_barrier(0);            // one column at a time: short live ranges
                         }
 #pragma unroll
                         for (int i2 = 0; i2 < 2; ++i2) {
@@ -475,15 +535,29 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                         nd_st4(o + (size_t)Cout * 2, zero);
                         nd_st4(o + (size_t)Cout * 2 + 4, zero);
                     }
-                    if (b == 0 && nt == 0 && ch2 == 0 && j == 0 && lane == 0) {
+#ifndef W4_STAMP
+                    if (b == 0 && nt == 0 && wave == 0 && lane == 0) {
                         a.d.slot_count[slot] = (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
                         a.d.slot_count[slot + 1] = 0.0f;
                     }
+#endif
                 }
             }
         }
+        W4_ACC(stamp_epi);
         b = b1; ty = ty1; rx = rx1; nt = nt1;
     }
+#ifdef W4_STAMP
+    if (tid == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.d.slot_count) + 8 * blockIdx.x;
+        dbg[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        dbg[2] = (unsigned long long)(t_end - t_begin) * n_chunks;
+        dbg[3] = stamp_epi;
+        dbg[4] = stamp_xf;
+        dbg[5] = stamp_wait;
+    }
+#endif
 }
 
 // OIHW (cout, cin, 3, 3) -> U = G g G^T in blocks [cin/8][cout/16][18 position pairs][64 lanes][4]:
@@ -543,7 +617,8 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3_wino4: null tensor pointer");
     ND_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->cin > 0 && d->cout > 0, ND_E_BADARG, "nd_conv3x3_wino4: non-positive size");
-    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4", d->cin, d->cout);
+    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->cin > KC4, ND_E_SHAPE,
+               "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4, cin > 16 (at least two K chunks)", d->cin, d->cout);
     ND_REQUIRE(s.c0 + s.c1 == d->cin && s.c0 % 4 == 0 && s.c1 % 4 == 0 && s.c0 > 0, ND_E_SHAPE,
                "nd_conv3x3_wino4: source channels %d+%d do not match cin=%d (multiples of 4)", s.c0, s.c1, d->cin);
     ND_REQUIRE((s.c1 == 0) == (s.p1 == nullptr), ND_E_BADARG, "nd_conv3x3_wino4: p1/c1 mismatch");
