@@ -45,13 +45,13 @@ constexpr int KC4 = 16;                              // channels per K chunk
 constexpr int NPOS = 36;                             // positions (xi, nu) == patch entries (a, b)
 constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk image: 36 entries x 1 KB = 36 KB
 
-constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + NPOS * 256 * 2 + 2 * 256 * 4;          // [tg 2] V images + int16 border table + padding masks
+constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 12) * 256 * 4;   // [tg 2] V images + raw halo + per-thread tables
 
 #ifndef W4_UR
 #define W4_UR 18             // weight fragments in flight per wave in the K loop (x 4 registers); a stage consumes 18
 #endif
 #ifndef W4_UR_AFF
-#define W4_UR_AFF 9          // ... of the GroupNorm-affine + SiLU variant (its transform needs more registers)
+#define W4_UR_AFF 18         // ... of the GroupNorm-affine + SiLU variant (its transform needs more registers)
 #endif
 #ifndef W4_UR_EPI
 #define W4_UR_EPI 6          // ... across a tile's epilogue (its output transform needs the registers): the ring runs down in the
@@ -59,17 +59,11 @@ constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + NPOS * 256 * 2 + 2 * 256 * 4;     
 #ifndef W4_VR
 #define W4_VR 3              // V operand pairs read ahead
 #endif
-#ifndef W4_ISSUE
-#define W4_ISSUE 2           // halo patch entries requested per position pair of stage 0 (36 in all)
-#endif
-#ifndef W4_ISSUE_ORDER
-#define W4_ISSUE_ORDER 1
+#ifndef W4_COMMIT_AT
+#define W4_COMMIT_AT 6       // position pair of stage 1 behind which the first of the 10 staged halo items is written to LDS
 #endif
 #ifndef W4_STAGGER
 #define W4_STAGGER 12        // s_sleep units (64 cycles) between the 16 start phases of the workgroups; 0 = all start together
-#endif
-#ifndef W4_COMMIT_AT
-#define W4_COMMIT_AT 9       // position pair of stage 1 behind which they are written to LDS (~5000 cycles later)
 #endif
 #ifndef W4_ABLATE
 #define W4_ABLATE 0          // diagnostic builds only: 1 no staging, 2 no weight loads, 4 no transform, 8 no epilogue stores,
@@ -115,18 +109,6 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
     y[3] = b + 8.0f * e + m[5];
 }
 
-// Order in which a lane requests its 36 patch entries.  A halo pixel is patch entry (a, b) of one tile and (a +- 4, b +- 4) of its
-// neighbours, i.e. it is requested up to four times per tile group: rows and columns in the order 0, 4, 1, 5, 2, 3 put those
-// requests a few instructions apart, so that all but the first hit in the CU's L1 instead of going to L2 as separate requests.
-__device__ __forceinline__ constexpr int issue_order(int i) {
-#if W4_ISSUE_ORDER
-    constexpr int ord[6] = {0, 4, 1, 5, 2, 3};
-    return ord[i / 6] * 6 + ord[i % 6];
-#else
-    return i;
-#endif
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU;
@@ -144,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 
 #ifdef W4_STAMP                  // diagnostic (tools/w4_clock.py): shader-clock and 100 MHz wall stamps per workgroup -> clock under load, phase split
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long stamp_epi = 0, stamp_xf = 0, stamp_wait = 0, stamp_t = 0;
+    unsigned long long stamp_epi = 0, stamp_xf = 0, stamp_wait = 0, stamp_t = 0, stamp_drain = 0;
 #define W4_T0() (stamp_t = __builtin_amdgcn_s_memtime())
 #define W4_ACC(x) (x += __builtin_amdgcn_s_memtime() - stamp_t)
 #else
@@ -171,117 +153,117 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         b_ = lid / a.tiles_y;
     };
 
-    // ---- staging.  The lane that transforms (tile, channel pair) loads that pair's 36 patch entries itself, 8 bytes each, straight
-    //      into the registers the transform works on: no raw image in LDS, no staging writes, one V image per tile group.
-    //      Addresses: a wave-uniform source pixel per entry (scalar registers: six row bases and six column offsets per tile,
-    //      clamped into the image) + this lane's pixel relative to it -- a constant for tiles whose halo lies inside the image, a
-    //      16-bit LDS table entry (-1 = outside: zero padding) for the others.
+    // ---- staging.  The 18 x 34 pixel halo of the region (both tile groups) x 16 channels is fetched ONCE per chunk: item
+    //      (pixel, channel quad) = 16 bytes, 2448 items over 256 threads (10 per thread), a wave instruction covers 16 pixels
+    //      x 64 contiguous bytes.  (Fetching per (tile, patch entry) instead asks for every pixel 2.25 times in 32-byte pieces:
+    //      4 x the cache-line fills, and the L1 fill path -- one 128-byte line per two cycles -- then bounds the kernel.)
+    //      The raw image in LDS: record (row r, column c) of 64 bytes at index r * 40 + cperm(c), cperm swapping column bits
+    //      0-1 with bits 2-3, and the channel pair P of a pixel in 8-byte slot P ^ 2 ((r >> 2) & 3): a transform read -- 32
+    //      lanes = 16 tiles x 2 pairs, the tiles 4 pixels apart in x and y -- then touches 32 different 8-byte banks.
+    constexpr int RAW_ROWP = 40, RAW_ITEMS = 18 * 34 * 4, RAW_IT = (RAW_ITEMS + 255) / 256;      // 10
     const int sty = 4 * (tile >> 2), stx = 4 * (tile & 3);              // tile origin inside the 16x16 pixels (entry (0,0) is one up-left)
     const long npx = (long)a.d.B * sH * sW;
     const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(npx * s.ld0 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(npx * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
-    const unsigned OOB = 0x7FFFFFF0u;                                    // lane offset beyond any tensor: the load returns zeros (padding)
     float* const vd_tg = Vd + tg * VD_FLOATS;                            // this tile group's V image
-    lds_short_ptr const ptab = (lds_short_ptr)(Vd + 2 * VD_FLOATS) + tid;        // [36][256] int16, thread-private column (border tiles only)
-    const int lane_px = (sty >> up) * sW + (stx >> up);                  // interior tiles: this lane's pixel relative to the entry's pixel
-    const unsigned lane_ch = (unsigned)(8 * ch2 + 2 * kq) * 4u;          // byte offset of this lane's channel pair inside a 16-channel chunk
+    char* const rawbuf = reinterpret_cast<char*>(Vd + 2 * VD_FLOATS);    // [18][40] records of 64 bytes
+    lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + 18 * RAW_ROWP * 16) + tid;      // [10][256] source pixel of this thread's items
+    auto cperm = [](int c) { return ((c >> 2) & 3) | ((c & 3) << 2) | (c & 48); };
+    const int sq = tid & 3;                                              // channel quad of this thread's items
+    // per-thread constants live in LDS tables (thread-private columns), not in registers: [10] LDS address of staged item k,
+    // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
+    // patch crosses a multiple-of-4 row): entry (a, b) is at ttab[(a >> 2) * 6 + b] + a * RAW_ROWP * 64
+    lds_u32_ptr const dtab = ptab + RAW_IT * 256;
+    lds_u32_ptr const ttab = dtab + RAW_IT * 256;
+#pragma unroll
+    for (int k = 0; k < RAW_IT; ++k) {
+        const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
+        dtab[k * 256] = (unsigned)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ (2 * ((r >> 2) & 3))) * 8));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int bx = 0; bx < 6; ++bx) {
+            const int r0 = 4 * (tile >> 2) + 4 * h, c = 16 * tg + 4 * (tile & 3) + bx;
+            ttab[(h * 6 + bx) * 256] = (unsigned)((4 * (tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + kq) ^ (2 * ((r0 >> 2) & 3))) * 8));
+        }
 
-    int s_row[6], s_col[6];                                              // wave-uniform: (b * sH + source row) * sW of the six patch rows; source columns
-    bool s_interior = false;                                             // wave-uniform: the staged tile's halo lies inside the image
     int sb_ = 0;
-    f32x2 tA2 = {1, 1}, tD2 = {0, 0};                                    // AFF: loaded with a chunk's halo, used by the transform of the same item
-    // AFF, border tiles: bit e of the per-thread LDS word pair = patch entry e of this lane's tile is inside the image
-    lds_u32_ptr const pmask = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + NPOS * 128) + tid;            // [2][256] behind the int16 table
+    f32x4 tA4 = {1, 1, 1, 1}, tD4 = {0, 0, 0, 0};                        // AFF: loaded with a chunk's halo, applied when it is written to LDS
     auto stage_tile = [&](int b_, int ty_, int rx_) {
         sb_ = b_;
-        const int y0 = ty_ * 16 - 1, x0 = (2 * rx_ + tg) * 16 - 1;       // first patch row / column of the tile group
-        s_interior = ty_ > 0 && x0 >= 0 && y0 + 18 <= H && x0 + 18 <= W;
+        const int y0 = ty_ * 16 - 1, x0 = rx_ * 32 - 1;                  // first halo row / column of the region
 #pragma unroll
-        for (int r = 0; r < 6; ++r) s_row[r] = (b_ * sH + (min(max(y0 + r, 0), H - 1) >> up)) * sW;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s_col[c] = min(max(x0 + c, 0), W - 1) >> up;
-        if (s_interior) return;
-        unsigned long long m = 0;
-#pragma unroll
-        for (int e = 0; e < NPOS; ++e) {
-            const int r = e / 6, c = e % 6;
-            const int gy = y0 + sty + r, gx = x0 + stx + c;
-            const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const int sy = min(max(y0 + r, 0), H - 1), sx = min(max(x0 + c, 0), W - 1);
-            ptab[e * 256] = (short)(ok ? ((gy >> up) - (sy >> up)) * sW + ((gx >> up) - (sx >> up)) : -1);
-            m |= (unsigned long long)(ok ? 1 : 0) << e;
-        }
-        if (AFF) {
-            pmask[0] = (unsigned)m;
-            pmask[256] = (unsigned)(m >> 32);
+        for (int k = 0; k < RAW_IT; ++k) {
+            const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
+            const int gy = y0 + r, gx = x0 + c;
+            const bool ok = pix < 18 * 34 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            // outside the image: pixel 0xFFFFFF -- x ld4 >= 1 GiB, beyond every source tensor (host check): the load returns the zero padding
+            ptab[k * 256] = ok ? (unsigned)((b_ * sH + (gy >> up)) * sW + (gx >> up)) : 0xFFFFFFu;
         }
     };
     // the chunk being staged: source, channel base, affine constants of the transform lane
-    f32x2 T[6][6];                                                       // the halo in flight: loaded during a chunk's stage 0 (two entries per position
-                                                                         // pair), transformed at the chunk's end
+    f32x4 raw[RAW_IT];                                                   // the halo in flight: loaded during a chunk's stage 0, written to LDS during its stage 1
     __amdgpu_buffer_rsrc_t i_rs = rsrc0;
-    int i_ld = 0, i_cbase = 0;
-    unsigned i_voff = 0, i_ld4 = 0, i_cmask = 0;
+    int i_soff = 0;
+    unsigned i_ld4 = 0, i_cmask = 0;
     auto stage_issue_begin = [&](int cb_) {
         const bool sec = cb_ >= s.c0;                                    // wave-uniform: a chunk never straddles the sources (host check)
         i_rs = sec ? rsrc1 : rsrc0;
-        i_ld = sec ? s.ld1 : s.ld0;
-        i_cbase = sec ? cb_ - s.c0 : cb_;
-        const int c = cb_ + 8 * ch2 + 2 * kq;                            // this lane's channel pair
-        const bool cvalid = c < Cin;
-        i_ld4 = (unsigned)i_ld * 4u;
-        i_voff = cvalid ? (unsigned)lane_px * i_ld4 + lane_ch : OOB;     // interior tiles: the same lane offset for every entry
-        i_cmask = cvalid ? 0u : 0xFFFFFFu;                               // invalid channel pair: every entry out of range
-        if (AFF) {
-            const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (cvalid ? c : 0);
-            const f32x2 M = *reinterpret_cast<const f32x2*>(m), A = *reinterpret_cast<const f32x2*>(m + Ctot), D = *reinterpret_cast<const f32x2*>(m + 2 * Ctot);
-            tA2 = A;
-            tD2 = D - M * A;                                             // (v - M) * A + D = v * A + (D - M * A)
+        i_ld4 = (unsigned)(sec ? s.ld1 : s.ld0) * 4u;
+        i_soff = (sec ? cb_ - s.c0 : cb_) * 4;
+        i_cmask = cb_ + 4 * sq < Cin ? 0u : 0xFFFFFFu;                   // invalid channel quad: every item out of range
+        if (AFF) {                                                       // this thread's channel quad: cb + 4 sq .. + 3
+            const int c = cb_ + 4 * sq;
+            const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (c < Cin ? c : 0);
+            const f32x4 M = nd_ld4(m), A = nd_ld4(m + Ctot), D = nd_ld4(m + 2 * Ctot);
+            tA4 = A;
+            tD4 = D - M * A;                                             // (v - M) * A + D = v * A + (D - M * A)
         }
     };
-    auto stage_issue_one = [&](int e) {
+    auto stage_issue_one = [&](int k) {
 #if !(W4_ABLATE & 1)
-        const int soff = ((s_row[e / 6] + s_col[e % 6]) * i_ld + i_cbase) * 4;
-        unsigned voff = i_voff;
-        if (!s_interior) {      // wave-uniform.  -1 (outside the image) becomes pixel 0xFFFFFF: x ld4 >= 1 GiB, beyond every source tensor (host check)
-            const unsigned px = ((unsigned)(int)ptab[e * 256] | i_cmask) & 0xFFFFFFu;
-            voff = __umul24(px, i_ld4) + lane_ch;
+        const unsigned px = (ptab[k * 256] | i_cmask) & 0xFFFFFFu;
+        raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i_rs, __umul24(px, i_ld4) + 16u * sq, i_soff, 0));
+#else
+        raw[k] = f32x4{(float)k, 1.0f, 0.5f, 0.25f};
+#endif
+    };
+    auto stage_commit_one = [&](int k) {
+        if (k == RAW_IT - 1 && (tid >> 2) + 64 * k >= 18 * 34) return;   // the last round covers 36 pixels only
+        f32x4 v = raw[k];
+        if (AFF) {
+            // GroupNorm-affine + SiLU on the raw halo (each pixel once: 40 values per thread and chunk); silu(x) = x / (1 + 2^(-x log2 e)).
+            // The zero padding is applied after the activation (silu(affine(0)) != 0): items outside the image carry the 0xFFFFFF mark
+            const f32x4 x = v * tA4 + tD4;
+            const f32x4 t = x * -1.44269504088896340736f;
+            f32x4 e;
+            e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y); e.z = __builtin_amdgcn_exp2f(t.z); e.w = __builtin_amdgcn_exp2f(t.w);
+            e = e + 1.0f;
+            f32x4 r;
+            r.x = __builtin_amdgcn_rcpf(e.x); r.y = __builtin_amdgcn_rcpf(e.y); r.z = __builtin_amdgcn_rcpf(e.z); r.w = __builtin_amdgcn_rcpf(e.w);
+            const bool inside = ((ptab[k * 256] | i_cmask) & 0xFFFFFFu) != 0xFFFFFFu;
+            const f32x4 zero = {0, 0, 0, 0};
+            v = inside ? x * r : zero;
         }
-#if W4_ABLATE & 64
-        T[e / 6][e % 6] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(i_rs, i_voff, i_cbase * 4, 0));
-#else
-        T[e / 6][e % 6] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(i_rs, voff, soff, 0));
-#endif
-#else
-        T[e / 6][e % 6] = f32x2{(float)e, 1.0f};
-#endif
+        *reinterpret_cast<f32x4*>(rawbuf + dtab[k * 256]) = v;
     };
 
     // ---- LDS addresses of the MFMA / transform lane: channel pair (2 kq, 2 kq + 1) of 8-channel half g2, tile `tile`:
     //      + g2 * 512 + entry * 1024 bytes
     const unsigned d_lds = (unsigned)((kq >> 1) * 256 + tile * 16 + (kq & 1) * 8);
 
-    // input transform of the staged halo (registers) into this tile group's V image (this wave: half ch2)
+    // input transform of the staged halo (raw image) into this tile group's V image (this wave: half ch2)
     auto transform = [&](float* buf) {
 #if !(W4_ABLATE & 4)
         char* base = reinterpret_cast<char*>(buf) + d_lds + ch2 * 512;
-        if (AFF) {
-            // silu(x) = x / (1 + 2^(-x log2 e)); one patch row at a time (sched_barrier: left alone, hipcc interleaves all 72 chains
-            // and spills); the padding of border tiles is applied after the activation (silu(affine(0)) != 0)
-            unsigned long long padmask = ~0ull;
-            if (!s_interior) padmask = (unsigned long long)pmask[0] | ((unsigned long long)pmask[256] << 32);      // wave-uniform branch
+        f32x2 T[6][6];
+        unsigned t_addr[12];
 #pragma unroll
-            for (int ay = 0; ay < 6; ++ay) {
+        for (int i = 0; i < 12; ++i) t_addr[i] = ttab[i * 256];
 #pragma unroll
-                for (int bx = 0; bx < 6; ++bx) {
-                    f32x2 v = T[ay][bx] * tA2 + tD2;
-                    v.x = nd_silu(v.x); v.y = nd_silu(v.y);
-                    const f32x2 zero = {0, 0};
-                    T[ay][bx] = ((padmask >> (ay * 6 + bx)) & 1ull) ? v : zero;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        for (int e = 0; e < NPOS; ++e)
+            T[e / 6][e % 6] = *reinterpret_cast<const f32x2*>(rawbuf + t_addr[((e / 6) >> 2) * 6 + e % 6] + (e / 6) * (RAW_ROWP * 64));
 #pragma unroll
         for (int bx = 0; bx < 6; ++bx) {                                 // T <- B^T T (over the patch rows, every column)
             f32x2 col[6], t[6];
@@ -395,12 +377,16 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     stage_tile(b, ty, rx);
     stage_issue_begin(0);
 #pragma unroll
-    for (int e = 0; e < NPOS; ++e) stage_issue_one(e);
+    for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k);
     {
         const int wb = wblock(0, nt * 4 + wave);
 #pragma unroll
         for (int q = 0; q < UR_EPI; ++q) load_u(q, q, wb);
     }
+#pragma unroll
+    for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     transform(vd_tg);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -423,17 +409,26 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             using IUR = std::integral_constant<int, UR>;
             using IEPI = std::integral_constant<int, UR_EPI>;
             constexpr bool FIRST = decltype(first_c)::value;              // first chunk of a tile: the ring comes out of an epilogue
-            // the next item's halo: two patch entries per position pair of stage 0 (unconditional: behind the very last item this is a
-            // harmless re-stage of the tile's first chunk -- a conditional load would keep the 72 staging registers alive everywhere)
+            // the next item's halo: requested over the first position pairs of stage 0, written to the raw image over stage 1
+            // (unconditional: behind the very last item this is a harmless re-stage of the tile's first chunk -- a conditional load /
+            // store pair would keep the staging registers alive everywhere)
             auto issue = [&](int pp) {
                 if (pp == 0) stage_issue_begin(last ? 0 : (ch + 1) * KC4);
+                if (pp < RAW_IT) stage_issue_one(pp);
+            };
+            auto commit = [&](int pp) {
+                if (AFF) {      // the activation is VALU work: one clump behind the stage's last MFMAs (every MFMA <-> VALU switch costs ~18 cycles)
+                    if (pp == 17) {
 #pragma unroll
-                for (int i = pp * W4_ISSUE; i < (pp + 1) * W4_ISSUE && i < NPOS; ++i) stage_issue_one(issue_order(i));
+                        for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k);
+                    }
+                } else if (pp >= W4_COMMIT_AT && pp < W4_COMMIT_AT + RAW_IT) stage_commit_one(pp - W4_COMMIT_AT);
             };
             stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IUR>{}, IUR{}, v0cur, v1cur, w0, w1, issue);
-            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 512, v1cur + 512, w1, wn, [&](int) {});
+            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 512, v1cur + 512, w1, wn, commit);
             W4_T0();
-            __builtin_amdgcn_s_barrier();                                // every wave has read its last V operands of this chunk
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this thread's share of the raw image is written
+            __builtin_amdgcn_s_barrier();                                // ... and every wave has read its last V operands of this chunk
             W4_ACC(stamp_wait);
             W4_T0();
             transform(vd_tg);
@@ -545,6 +540,11 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             }
         }
         W4_ACC(stamp_epi);
+#ifdef W4_STAMP_DRAIN          // diagnostic: how long do the epilogue's stores (and the weight fragments in flight) take to complete
+        W4_T0();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4_ACC(stamp_drain);
+#endif
         b = b1; ty = ty1; rx = rx1; nt = nt1;
     }
 #ifdef W4_STAMP
@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         dbg[3] = stamp_epi;
         dbg[4] = stamp_xf;
         dbg[5] = stamp_wait;
+        dbg[6] = stamp_drain;
     }
 #endif
 }

@@ -39,7 +39,13 @@ CHAIN = os.environ.get("ND_CHAIN", "1") != "0"           # A-B knob: 0 = one poi
 _CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that can open / continue a fused chain (pwchain.hip)
 _CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
 WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two-waves-per-SIMD Winograd kernel (conv3x3_wino.hip)
+WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel (conv3x3_wino4.hip)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
+
+
+def _wino4_layer(cin: int, cout: int) -> bool:
+    """Layers whose weights are also packed for the F(4x4,3x3) kernel: at least two 16-channel K chunks (conv3x3_wino4.hip)."""
+    return cin > 16 and cin % 4 == 0 and cout % 4 == 0
 
 
 def _classify(name: str, shape: Sequence[int]) -> str:
@@ -121,6 +127,8 @@ class Engine:
             if kind == "conv3":
                 n = self.lib.nd_pack_conv3x3_weight_floats(p.shape[1], p.shape[0])
                 add(p.name + ".wino", self.lib.nd_pack_conv3x3_wino_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
+                if WINO4 and _wino4_layer(p.shape[1], p.shape[0]):
+                    add(p.name + ".wino4", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind in ("pw", "pw_unshuffle"):
                 n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
                 if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
@@ -172,6 +180,8 @@ class Engine:
                 if kind == "conv3":
                     L.call("nd_pack_conv3x3_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], st)
                     L.call("nd_pack_conv3x3_wino_weight", t.data_ptr(), self.p(p.name + ".wino"), p.shape[1], p.shape[0], st)
+                    if p.name + ".wino4" in self.slots:
+                        L.call("nd_pack_conv3x3_wino4_weight", t.data_ptr(), self.p(p.name + ".wino4"), p.shape[1], p.shape[0], st)
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
                     if p.name + ".chain" in self.slots:
@@ -323,10 +333,21 @@ class Plan:
         wino2 = (wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
                  and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
                  and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
-        entry = "nd_conv3x3_wino2_nhwc_f32" if wino2 else "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32"
+        # F(4x4,3x3) (1.78x fewer MFMAs again; 16 x 32-pixel regions, 16-channel K chunks) wherever its kernel takes the layer:
+        # plain / GroupNorm-affine + SiLU inputs, concat on a chunk boundary, images that fill its regions, sources below 1 GiB
+        up = 1 if src.upsample else 0
+        src_bytes = self.B * (H >> up) * (W >> up) * 4 * max(src.ld0, src.ld1)
+        wino4 = (wino and WINO4 and (name + ".weight.wino4") in e.slots and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)
+                 and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (src.c1 == 0 or (src.c0 % 16 == 0 and not up))
+                 and src.ld0 >= 16 and (src.c1 == 0 or src.ld1 >= 16) and src_bytes < (1 << 30) - (1 << 16)
+                 and (not up or (H % 2 == 0 and W % 2 == 0)))
+        if wino4:
+            d.weight = e.p(name + ".weight.wino4")
+        entry = ("nd_conv3x3_wino4_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
+                 "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32")
         self._add(entry, C.byref(d), e.stream,
                   meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
-                        "tiling": 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
+                        "tiling": 9004 if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
         self._keep.append(d)
         return out, st, sc, slots
 

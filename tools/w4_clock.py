@@ -22,10 +22,10 @@ for (B, H, W, cin, cout) in [(16, 256, 256, 64, 64), (16, 32, 32, 512, 512)]:
     for _ in range(3):
         L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream); ctx.sync()
     v = dbg.cpu().view(256, 8).double()
-    cyc, real, chunks, epi, xf, wait = (v[:, i] for i in range(6))
+    cyc, real, chunks, epi, xf, wait, drain = (v[:, i] for i in range(7))
     n_chunks = (cin + 15) // 16
     mhz = cyc / (real / 100.0)
     per = lambda t: float((t / chunks).mean())
     print((B, H, W, cin, cout), f"clock {mhz.mean():.0f} MHz (min {mhz.min():.0f} max {mhz.max():.0f}); cycles/chunk {per(cyc):.0f} (MFMA 9216):",
           f"stages {per(cyc - epi - xf - wait):.0f}, wait+barrier {per(wait):.0f}, transform+barrier {per(xf):.0f}, epilogue {per(epi):.0f}"
-          f" (= {float((epi / (chunks / n_chunks)).mean()):.0f} per tile); wall/WG {float(real.mean()) / 100:.1f} us", flush=True)
+          f" (= {float((epi / (chunks / n_chunks)).mean()):.0f} per tile), drain {float((drain / (chunks / n_chunks)).mean()):.0f} per tile; wall/WG {float(real.mean()) / 100:.1f} us", flush=True)
