@@ -62,6 +62,9 @@ constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 12) * 25
 #ifndef W4_COMMIT_AT
 #define W4_COMMIT_AT 6       // position pair of stage 1 behind which the first of the 10 staged halo items is written to LDS
 #endif
+#ifndef W4_NT_STORE
+#define W4_NT_STORE 0
+#endif
 #ifndef W4_STAGGER
 #define W4_STAGGER 12        // s_sleep units (64 cycles) between the 16 start phases of the workgroups; 0 = all start together
 #endif
@@ -158,8 +161,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     //      x 64 contiguous bytes.  (Fetching per (tile, patch entry) instead asks for every pixel 2.25 times in 32-byte pieces:
     //      4 x the cache-line fills, and the L1 fill path -- one 128-byte line per two cycles -- then bounds the kernel.)
     //      The raw image in LDS: record (row r, column c) of 64 bytes at index r * 40 + cperm(c), cperm swapping column bits
-    //      0-1 with bits 2-3, and the channel pair P of a pixel in 8-byte slot P ^ 2 ((r >> 2) & 3): a transform read -- 32
-    //      lanes = 16 tiles x 2 pairs, the tiles 4 pixels apart in x and y -- then touches 32 different 8-byte banks.
+    //      0-1 with bits 2-3, and the channel pair P of a pixel in 8-byte slot P ^ swz(r, c): the transform's reads -- tiles 4 pixels
+    //      apart in x and y -- then fall on different banks.
     constexpr int RAW_ROWP = 40, RAW_ITEMS = 18 * 34 * 4, RAW_IT = (RAW_ITEMS + 255) / 256;      // 10
     const int sty = 4 * (tile >> 2), stx = 4 * (tile & 3);              // tile origin inside the 16x16 pixels (entry (0,0) is one up-left)
     const long npx = (long)a.d.B * sH * sW;
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     char* const rawbuf = reinterpret_cast<char*>(Vd + 2 * VD_FLOATS);    // [18][40] records of 64 bytes
     lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + 18 * RAW_ROWP * 16) + tid;      // [10][256] source pixel of this thread's items
     auto cperm = [](int c) { return ((c >> 2) & 3) | ((c & 3) << 2) | (c & 48); };
+    auto swz = [](int r, int c) { return (2 * ((r >> 2) & 3)) ^ (4 * ((c >> 3) & 1)); };       // slot swizzle of a pixel's 8 channel pairs (even: quads stay 16 contiguous bytes)
     const int sq = tid & 3;                                              // channel quad of this thread's items
     // per-thread constants live in LDS tables (thread-private columns), not in registers: [10] LDS address of staged item k,
     // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
@@ -178,15 +182,20 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) {
         const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
-        dtab[k * 256] = (unsigned)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ (2 * ((r >> 2) & 3))) * 8));
+        dtab[k * 256] = (unsigned)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));
     }
+    // the transform's own lane mapping (any lane may produce any V element): 16 consecutive lanes = 8 tiles x the two channel
+    // pairs of a quad, so that the compiler's paired LDS accesses (ds_read2 / ds_write2: 16-lane groups, 32 banks) are conflict-free
+    // on the raw image (with the swizzle above) and on the V image (8 tiles x 16 contiguous bytes)
+    const int t_tile = ((lane >> 1) & 7) | ((lane >> 4) & 1) << 3, t_kq = (lane & 1) | ((lane >> 5) << 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int bx = 0; bx < 6; ++bx) {
-            const int r0 = 4 * (tile >> 2) + 4 * h, c = 16 * tg + 4 * (tile & 3) + bx;
-            ttab[(h * 6 + bx) * 256] = (unsigned)((4 * (tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + kq) ^ (2 * ((r0 >> 2) & 3))) * 8));
+            const int r0 = 4 * (t_tile >> 2) + 4 * h, c = 16 * tg + 4 * (t_tile & 3) + bx;
+            ttab[(h * 6 + bx) * 256] = (unsigned)((4 * (t_tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + t_kq) ^ swz(r0, c)) * 8));
         }
+    const unsigned t_lds = (unsigned)(ch2 * 1024 + (t_kq >> 1) * 512 + t_tile * 32 + (t_kq & 1) * 16);  // V image address of the transform lane
 
     int sb_ = 0;
     f32x4 tA4 = {1, 1, 1, 1}, tD4 = {0, 0, 0, 0};                        // AFF: loaded with a chunk's halo, applied when it is written to LDS
@@ -249,14 +258,15 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         *reinterpret_cast<f32x4*>(rawbuf + dtab[k * 256]) = v;
     };
 
-    // ---- LDS addresses of the MFMA / transform lane: channel pair (2 kq, 2 kq + 1) of 8-channel half g2, tile `tile`:
-    //      + g2 * 512 + entry * 1024 bytes
-    const unsigned d_lds = (unsigned)((kq >> 1) * 256 + tile * 16 + (kq & 1) * 8);
+    // ---- V image of a tile group (36 KB): [position pair 18][8-channel half g2][kq >> 1][tile 16][kq & 1] x 16 bytes, the 16 bytes
+    //      being positions (2pp, 2pp+1) x channels (2kq, 2kq+1) -- what one MFMA lane needs for a position pair, one conflict-free
+    //      ds_read_b128 (twice the bytes per LDS cycle of the 8-byte forms).  MFMA lane: + g2 * 1024 + pp * 2048 bytes
+    const unsigned d_lds = (unsigned)((kq >> 1) * 512 + tile * 32 + (kq & 1) * 16);
 
     // input transform of the staged halo (raw image) into this tile group's V image (this wave: half ch2)
     auto transform = [&](float* buf) {
 #if !(W4_ABLATE & 4)
-        char* base = reinterpret_cast<char*>(buf) + d_lds + ch2 * 512;
+        char* base = reinterpret_cast<char*>(buf) + t_lds;
         f32x2 T[6][6];
         unsigned t_addr[12];
 #pragma unroll
@@ -278,7 +288,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             f32x2 v[6];
             w4_bt(T[xi], v);
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2*>(base + (xi * 6 + nu) * 1024) = v[nu];
+            for (int h = 0; h < 3; ++h)                                  // 16 bytes = positions (xi, 2h), (xi, 2h + 1) of this lane's channel pair
+                *reinterpret_cast<f32x4*>(base + (xi * 3 + h) * 2048) = f32x4{v[2 * h].x, v[2 * h].y, v[2 * h + 1].x, v[2 * h + 1].y};
         }
 #endif
     };
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 
     f32x4 acc[2 * NPOS];                                                 // [position][cout group j]: 2 * pos + j
     f32x4 U[UR];                                                         // ring: fragment pp of a stage (positions 2pp, 2pp+1) lives in U[(OFF + pp) % UR]
-    f32x2 Vr[W4_VR][4];                                                  // ring: V of position pair pp, [tile group][position] in Vr[pp % W4_VR]
+    f32x4 Vr[W4_VR][2];                                                  // ring: V of position pair pp, one per tile group, in Vr[pp % W4_VR]
     static_assert(36 % UR == 0, "the ring must close over a chunk's two stages of 18 fragments");
     auto load_u = [&](int slot, int q, int wb) {                         // q in [0, 18): position pair
 #if !(W4_ABLATE & 2)
@@ -299,10 +310,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #endif
     };
     auto read_v = [&](const char* v0base, const char* v1base, int pp) {
-        Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x2*>(v0base + (2 * pp) * 1024);
-        Vr[pp % W4_VR][1] = *reinterpret_cast<const f32x2*>(v0base + (2 * pp + 1) * 1024);
-        Vr[pp % W4_VR][2] = *reinterpret_cast<const f32x2*>(v1base + (2 * pp) * 1024);
-        Vr[pp % W4_VR][3] = *reinterpret_cast<const f32x2*>(v1base + (2 * pp + 1) * 1024);
+        Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x4*>(v0base + pp * 2048);
+        Vr[pp % W4_VR][1] = *reinterpret_cast<const f32x4*>(v1base + pp * 2048);
     };
     auto mfma = [&](auto first_c, int idx, float av, float bv) {
         constexpr bool FIRST = decltype(first_c)::value;
@@ -329,19 +338,19 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         for (int pp = 0; pp < 18; ++pp) {
             if (pp + W4_VR - 1 < 18) read_v(v0base, v1base, pp + W4_VR - 1);
             const f32x4 u = U[(OFF + pp) % UR];
-            const f32x2 va0 = Vr[pp % W4_VR][0], va1 = Vr[pp % W4_VR][1], vb0 = Vr[pp % W4_VR][2], vb1 = Vr[pp % W4_VR][3];
+            const f32x4 va = Vr[pp % W4_VR][0], vb = Vr[pp % W4_VR][1];     // {pos 2pp: ch even, odd; pos 2pp+1: ch even, odd}
             __builtin_amdgcn_sched_barrier(0);
             // even channels of the pair first (the first touch of every accumulator in a tile's first stage), then the odd ones:
             // an accumulator is used again four MFMAs later (dependent latency 40 cycles, issue 32).  Each weight fragment serves
             // both tile groups: it is loaded once per workgroup.
-            mfma(first_c, 4 * pp + 0, u.x, va0.x);
-            mfma(first_c, 4 * pp + 1, u.x, vb0.x);
-            mfma(first_c, 4 * pp + 2, u.z, va1.x);
-            mfma(first_c, 4 * pp + 3, u.z, vb1.x);
-            mfma(std::false_type{}, 4 * pp + 0, u.y, va0.y);
-            mfma(std::false_type{}, 4 * pp + 1, u.y, vb0.y);
-            mfma(std::false_type{}, 4 * pp + 2, u.w, va1.y);
-            mfma(std::false_type{}, 4 * pp + 3, u.w, vb1.y);
+            mfma(first_c, 4 * pp + 0, u.x, va.x);
+            mfma(first_c, 4 * pp + 1, u.x, vb.x);
+            mfma(first_c, 4 * pp + 2, u.z, va.z);
+            mfma(first_c, 4 * pp + 3, u.z, vb.z);
+            mfma(std::false_type{}, 4 * pp + 0, u.y, va.y);
+            mfma(std::false_type{}, 4 * pp + 1, u.y, vb.y);
+            mfma(std::false_type{}, 4 * pp + 2, u.w, va.w);
+            mfma(std::false_type{}, 4 * pp + 3, u.w, vb.w);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = (hi(pp) > DIN ? hi(pp) : DIN); q < hi(pp + 1); ++q) {     // the slot just consumed takes the fragment UR ahead
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 } else if (pp >= W4_COMMIT_AT && pp < W4_COMMIT_AT + RAW_IT) stage_commit_one(pp - W4_COMMIT_AT);
             };
             stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IUR>{}, IUR{}, v0cur, v1cur, w0, w1, issue);
-            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 512, v1cur + 512, w1, wn, commit);
+            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit);
             W4_T0();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this thread's share of the raw image is written
             __builtin_amdgcn_s_barrier();                                // ... and every wave has read its last V operands of this chunk
@@ -503,7 +512,11 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                                         ++cnt;
                                     }
 #if !(W4_ABLATE & 8)
+#if W4_NT_STORE
+                                    if (FULL || cok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(lane_out + (size_t)((i * Wt + jj) * ldot)));
+#else
                                     if (FULL || cok) nd_st4(lane_out + (size_t)((i * Wt + jj) * ldot), v);
+#endif
 #endif
                                 }
                             }
