@@ -221,6 +221,13 @@ int nd_linear_rows_f32(const float* in, int ld_in, const float* W, const float* 
  * freqs[half] = exp(arange(half) * -(ln(theta)/(half-1))) is a constant of the model, computed
  * once on the host so that the angle t*f is bit-identical to the reference's. */
 int nd_sinusoidal_time_emb_f32(const int64_t* time, const float* freqs, float* emb, int B, int half, void* stream);
+/* The whole time conditioning of one diffusion step in one launch (SURVEY 8b minimum symbol set):
+ * out[b, j] = (Wp . silu(W2 . gelu(W1 . emb(time[b]) + b1) + b2) + bp)[j] with emb = SinusoidalPosEmb (:100-107), W1/W2 =
+ * time_mlp[1]/[3] (:502-507), Wp/bp = every ResnetBlock.mlp[1] Linear stacked into one (J, 4 dim) matrix (:149-152; the SiLU
+ * is ResnetBlock.mlp[0]).  Weights in torch (N, K) layout.  Dynamic LDS: nd_cond_step_lds_bytes(B, dim) <= 160 KB. */
+int64_t nd_cond_step_lds_bytes(int B, int dim);
+int nd_cond_step_f32(const int64_t* time, const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2,
+                     const float* Wp, const float* bp, float* out, int ld_out, int B, int dim, int J, void* stream);
 /* nn.Embedding lookup (:591): out[b] = table[idx[b]], idx int64. */
 int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, int B, int rows, int dim, void* stream);
 

@@ -92,6 +92,8 @@ SIGNATURES = {
     "nd_affine_silu_add_f32": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "nd_linear_rows_f32": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "nd_sinusoidal_time_emb_f32": (i32, [vp, vp, vp, i32, i32, vp]),
+    "nd_cond_step_lds_bytes": (i64, [i32, i32]),
+    "nd_cond_step_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_embedding_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_pack_conv7x7_weight": (i32, [vp, vp, i32, vp]),
@@ -124,7 +126,7 @@ SIGNATURES = {
 
 _UNCHECKED = {"nd_version", "nd_last_error", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
               "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats", "nd_conv3x3_wino_stat_slots",
-              "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats"}
+              "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_cond_step_lds_bytes"}
 
 _lib: Optional[C.CDLL] = None
 

@@ -39,6 +39,7 @@ CHAIN = os.environ.get("ND_CHAIN", "1") != "0"           # A-B knob: 0 = one poi
 _CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that can open / continue a fused chain (pwchain.hip)
 _CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
 WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two-waves-per-SIMD Winograd kernel (conv3x3_wino.hip)
+COND_STEP = os.environ.get("ND_COND_STEP", "1") != "0"   # A-B knob: 0 = time embedding / time_mlp / projections as four launches
 WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel (conv3x3_wino4.hip)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 
@@ -513,6 +514,12 @@ class Plan:
 
     def _record_time(self) -> None:
         e, d = self.e, self.e.dim
+        if COND_STEP and e.lib.nd_cond_step_lds_bytes(self.B, d) <= 160 * 1024:
+            # one launch: time embedding, time_mlp, SiLU and every ResnetBlock.mlp projection (tproj)
+            self._add("nd_cond_step_f32", self.time.data_ptr(), e.p("time_freqs"), e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"),
+                      e.p("time_mlp.3.weight"), e.p("time_mlp.3.bias"), e.p("tproj.weight"), e.p("tproj.bias"), self.tproj.data_ptr(),
+                      e.tproj_rows, self.B, d, e.tproj_rows, e.stream)
+            return
         self._add("nd_sinusoidal_time_emb_f32", self.time.data_ptr(), e.p("time_freqs"), self.emb.data_ptr(), self.B, d // 2, e.stream)
         self.linear_rows(self.emb, e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"), self.t1, d, 4 * d, act_out=L.ACT_GELU)
         # every consumer applies SiLU first (ResnetBlock.mlp[0]), so it is applied once here

@@ -720,3 +720,41 @@ def test_conv3x3_wino4_headline_shapes(ctx, case):
         act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
         out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
         assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
+
+
+@pytest.mark.parametrize("dim,B", [(64, 16), (16, 2), (128, 8), (48, 3)])
+def test_cond_step_single_launch_matches_torch(ctx, dim, B):
+    """nd_cond_step_f32 == SinusoidalPosEmb -> Linear -> GELU -> Linear -> SiLU -> stacked ResnetBlock.mlp Linears
+    (Diffusion_arch.py:100-107, 502-507, 149-152), and equals the four separate launches it replaces."""
+    import math
+    import hiputil as hu
+    J = 2 * (3 * dim + 40)                                               # any row count; not a multiple of the grid stride
+    t = torch.tensor([(997 * i + 3) % 1000 for i in range(B)], dtype=torch.long)
+    half = dim // 2
+    freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(torch.float32)
+    W1, b1 = U(f"cs.W1.{dim}", (4 * dim, dim), -0.2, 0.2), U(f"cs.b1.{dim}", (4 * dim,))
+    W2, b2 = U(f"cs.W2.{dim}", (4 * dim, 4 * dim), -0.1, 0.1), U(f"cs.b2.{dim}", (4 * dim,))
+    Wp, bp = U(f"cs.Wp.{dim}", (J, 4 * dim), -0.1, 0.1), U(f"cs.bp.{dim}", (J,))
+    ang = t[:, None].float() * freqs[None]
+    emb = torch.cat((ang.sin(), ang.cos()), -1)
+    ref = F.linear(F.silu(F.linear(F.gelu(F.linear(emb, W1, b1)), W2, b2)), Wp, bp)
+    td, fd = hu.dev(t), hu.dev(freqs)
+    dW1, db1, dW2, db2, dWp, dbp = (hu.dev(v) for v in (W1, b1, W2, b2, Wp, bp))
+    out = hu.full((B, J + 3))
+    assert ctx.lib.nd_cond_step_lds_bytes(B, dim) == B * dim * 9 * 4
+    L.call("nd_cond_step_f32", td.data_ptr(), fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+           dWp.data_ptr(), dbp.data_ptr(), out.data_ptr(), J + 3, B, dim, J, ctx.stream)
+    ctx.sync()
+    assert rel_err(out[:, :J].cpu(), ref) < TOL
+    assert torch.isnan(out[:, J:]).all()                                 # nothing written beyond the J columns
+    # the launches it replaces
+    e, t1, st, o2 = hu.full((B, dim)), hu.full((B, 4 * dim)), hu.full((B, 4 * dim)), hu.full((B, J))
+    L.call("nd_sinusoidal_time_emb_f32", td.data_ptr(), fd.data_ptr(), e.data_ptr(), B, half, ctx.stream)
+    L.call("nd_linear_rows_f32", e.data_ptr(), dim, dW1.data_ptr(), db1.data_ptr(), t1.data_ptr(), 4 * dim, B, dim, 4 * dim, 0, L.ACT_GELU, ctx.stream)
+    L.call("nd_linear_rows_f32", t1.data_ptr(), 4 * dim, dW2.data_ptr(), db2.data_ptr(), st.data_ptr(), 4 * dim, B, 4 * dim, 4 * dim, 0, L.ACT_SILU, ctx.stream)
+    L.call("nd_linear_rows_f32", st.data_ptr(), 4 * dim, dWp.data_ptr(), dbp.data_ptr(), o2.data_ptr(), J, B, 4 * dim, J, 0, 0, ctx.stream)
+    ctx.sync()
+    assert rel_err(out[:, :J].cpu(), o2.cpu()) < 1e-5
+    with pytest.raises(L.HipError, match="LDS"):
+        L.call("nd_cond_step_f32", td.data_ptr(), fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+               dWp.data_ptr(), dbp.data_ptr(), out.data_ptr(), J + 3, 64, 128, J, ctx.stream)
