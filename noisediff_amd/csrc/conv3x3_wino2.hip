@@ -51,20 +51,24 @@ constexpr int STAGE_IT = (NPIX * 8 + 255) / 256;    // 11
 // selection clumps them), which is what lets the source dictate the MFMA / VALU / LDS / VMEM interleave.  The compiler
 // cannot see that this is an MFMA, so the VALU->MFMA operand wait states ride along (hidden behind the matrix pipe's
 // 64-cycle cadence) and the epilogue drains the pipe before it reads the accumulators.
-#if W2_CLUMP && !defined(W2_NO_NOP)
-// s_nop 1 in front of every inline-asm MFMA: with slices that hold nothing but an MFMA (no VALU between consecutive MFMAs any
-// more) the results are wrong without it (-DW2_NO_NOP: relative error ~10 on every test shape, as in conv3x3_wino4.hip) although
-// no operand is written within 8 instructions of its MFMA; hipcc's hazard recognizer cannot see through the asm.  It costs
-// nothing: the matrix pipe holds the issue slot far longer than two wait states (tools/microbench/mfma_rate.hip).
-#define W2_MFMA(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-#else
-#define W2_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+// Wait states in front of the asm MFMAs.  The ISA rule at stake: a VGPR written by a VALU instruction may be read as an MFMA
+// A/B operand only two wait states later, and hipcc's hazard recognizer pads nothing inside (or on behalf of) an asm string.
+// r1 carried a blanket `s_nop 1` in front of every MFMA ("wrong without it").  r2 probed it with eleven side builds that keep
+// the pad only for one class of MFMA at a time -- behind LDS reads, behind the VALU clump, behind buffer loads, behind another
+// MFMA, for the zero-C MFMAs of a tile's first chunk, or nowhere (tools/w2_nop_probe.sh, profiles/r2_wino2_nop_probe.txt): every
+// build is bit-identical to the padded one.  That is what the schedule implies: every B operand is loaded (hipcc counts and waits
+// for its own loads in front of the asm), every A operand (Vc, packed adds) is written a whole step -- sixteen MFMAs -- before its
+// first use, except at a chunk's start where six more packed adds stand between the last write of Vc[nu] and MFMA nu.  The pad is
+// therefore kept only where VALU work directly precedes an MFMA, as insurance against a reordering of that work: the MFMA behind
+// the VALU slice (i == 3) and the first MFMA of a step (i == 0; step 0 follows the chunk prologue's transforms).  It is free there
+// (the matrix pipe holds the issue slot far longer than two wait states, tools/microbench/mfma_rate.hip).
+#ifndef W2_NOP_MASK
+#define W2_NOP_MASK 0x0009       // bit i: MFMA i of a step is padded (0xFFFF: the r1 blanket pad; tools/w2_nop_probe.sh builds others)
 #endif
-#ifdef W2_NO_NOP
-#define W2_MFMA_Z(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv))
-#else
-#define W2_MFMA_Z(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv))
-#endif
+#define W2_MFMA_P(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#define W2_MFMA_N(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#define W2_MFMA_ZP(acc, av, bv) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv))
+#define W2_MFMA_ZN(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv))
 #define W2_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 #define W2_PIN(x) asm volatile("" : "+v"(x))          // value is complete here: keeps pure VALU work in its slice
 
@@ -368,21 +372,14 @@ __global__ __launch_bounds__(256, 1) void wino2_kernel(const Wino2Args a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int nu = i & 3, k = i >> 2;
-#ifdef W2_NOP_MASK          // diagnostic builds (tools/w2_nop_probe.sh): wait states only in front of the MFMAs of slices in the mask
-                    if (FIRST && (step & 3) == 0 && k == 0) {
-#ifdef W2_ZNOP_MASK         // ... and in front of the zero-C MFMAs (step / 4) * 4 + i in this mask
-                        if ((W2_ZNOP_MASK >> (step + i)) & 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
-                        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
-#else
-                        W2_MFMA_Z(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
-#endif
+                    {
+                        const bool pad = (W2_NOP_MASK >> i) & 1;
+                        if (FIRST && (step & 3) == 0 && k == 0) {         // first touch of the accumulator in this tile: C = 0
+                            if (pad) W2_MFMA_ZP(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
+                            else W2_MFMA_ZN(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
+                        } else if (pad) W2_MFMA_P(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
+                        else W2_MFMA_N(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
                     }
-                    else if ((W2_NOP_MASK >> i) & 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
-                    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(M[xi * 4 + nu]) : "v"(Vc[nu][k]), "v"(bw[step & 3][nu][k]));
-#else
-                    if (FIRST && (step & 3) == 0 && k == 0) W2_MFMA_Z(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
-                    else W2_MFMA(M[xi * 4 + nu], Vc[nu][k], bw[step & 3][nu][k]);
-#endif
                     // the slice's share of the other work (<= ~40 issue cycles each)
 #if !(W2_ABLATE & 4)
                     if (i < 8 && step + 2 < S) load_d1(src, step + 2, i >> 1, i & 1);

@@ -80,9 +80,13 @@ struct Wino4Args {
 
 // MFMAs through inline asm: the constraint pins each accumulator to its half of the register file for the whole kernel
 // (with the builtin, hipcc moved accumulators between AGPR tuples and through VGPRs several times per stage) and a
-// volatile asm keeps its place between the sched_barriers.  W4_NOP: see the hazard note in conv3x3_wino2.hip.
+// volatile asm keeps its place between the sched_barriers.  No wait states are needed in front of them: the ISA's
+// VALU-write -> MFMA-operand rule cannot apply here, because no MFMA operand of this kernel is ever written by a VALU
+// instruction -- A comes from buffer loads, B from LDS reads (hipcc waits for both in front of the asm), C from the
+// previous MFMA on the accumulator or the inline constant 0.  (-DW4_NOP='"s_nop 1\n\t"' restores r1's pad: same
+// bits, same time.)
 #ifndef W4_NOP
-#define W4_NOP "s_nop 1\n\t"
+#define W4_NOP ""
 #endif
 #define W4_MFMA_A(acc, av, bv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
 #define W4_MFMA_V(acc, av, bv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
