@@ -127,6 +127,19 @@ int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 
+/* ------------------------------------------------------------------ conv 3x3, training */
+
+/* Weight gradient of nn.Conv2d(cin, cout, 3, padding=1): dw[co][ci][r][s] = sum_{b,y,x} dy[b][y][x][co] * x[b][y+r-1][x+s-1][ci]
+ * (zero padding), x and dy NHWC fp32, dw in the torch OIHW layout.  The backward of Block.proj and the resampling convs under
+ * GaussianDiffusion.p_losses (models/denoising_diffusion_pytorch.py:481-531; loss.backward() at models/trainer_diffusion.py:187).
+ * Exact-fp32 MFMA; the split over pixel tiles depends on the shape only and the partial sums are added in a fixed order, so the
+ * result is bitwise repeatable.  `workspace`: nd_conv3x3_wgrad_workspace_floats(...) floats.
+ * The DATA gradient of the same layer is the forward operator itself: nd_conv3x3_*_nhwc_f32 on weights packed from
+ * w.flip(2, 3).transpose(0, 1) (taps flipped, channel roles swapped) -- see noisediff_amd/train.py. */
+int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout);
+int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* workspace,
+                              int B, int H, int W, int cin, int cout, void* stream);
+
 /* ------------------------------------------------------------------ pointwise GEMM */
 
 /* out[p, n] = epi( sum_k pro(in[p, k]) * W[k, n] + bias[n] ) per pixel: nn.Conv2d(k=1) and

@@ -1,0 +1,154 @@
+// conv3x3_wgrad.hip -- weight gradient of nn.Conv2d(cin, cout, 3, padding=1) on NHWC fp32 (first training kernel).
+//
+//   dW[co][ci][r][s] = sum over (b, y, x) of dY[b][y][x][co] * X[b][y + r - 1][x + s - 1][ci]          (zero padding)
+//
+// the backward of Block.proj / the up- and down-sampling convs under GaussianDiffusion.p_losses
+// (models/denoising_diffusion_pytorch.py:481-531 -> loss.backward(), models/trainer_diffusion.py:187).  The data gradient of
+// the same layer needs no kernel of its own: it is the forward convolution with the taps flipped and the channel roles
+// swapped, i.e. nd_conv3x3_*_nhwc_f32 on weights packed from w.flip(2, 3).transpose(0, 1) (noisediff_amd/train.py).
+//
+// Structure: nine 64 x 64 GEMMs (one per tap) that share their A operand, K = pixels, on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: D(co, ci) += dY(pixel pair, co)^T X(pixel pair, ci)).  A workgroup owns a (64 couts x 64 cins) block
+// of all nine taps -- 4 waves x 9 accumulators of 32 x 32 -- and walks its share of the 16 x 16-pixel tiles: per tile the dY tile
+// and the 18 x 18 X halo (zero padded) are staged in LDS (145 KB), then 128 pixel pairs x 9 MFMAs per wave with both operands
+// read as one conflict-free ds_read_b32 each.  The split over pixel tiles is fixed by the shape alone, partial sums go to a
+// workspace and a second kernel adds them in a fixed order: bitwise repeatable, no atomics.
+#include "nd_common.h"
+
+namespace {
+
+constexpr int WG_TILE = 16, HALO = 18, CB = 64;                        // pixels per tile side, halo side, channel block
+constexpr int WGRAD_TARGET_WGS = 512;
+
+struct WgradArgs {
+    const float* x; const float* dy; float* ws;
+    int ldx, ldy, B, H, W, cin, cout;
+    int n_co, n_ci, S, tiles_x, tiles_y, n_tiles;
+};
+
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dYs = sm;                                                 // [256 pixels][64 couts]
+    float* Xs = sm + WG_TILE * WG_TILE * CB;                         // [324 halo pixels][64 cins]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int co_w = 32 * (wave >> 1), ci_w = 32 * (wave & 1);       // this wave's 32 x 32 block of the 64 x 64
+    int bid = blockIdx.x;
+    const int s = bid % a.S;  bid /= a.S;
+    const int cib = bid % a.n_ci, cob = bid / a.n_ci;
+    const int co0 = cob * CB, ci0 = cib * CB;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = nd_zero16();
+
+    for (int tile = s; tile < a.n_tiles; tile += a.S) {
+        int lid = tile;
+        const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
+        const int ty = lid % a.tiles_y;
+        const int b = lid / a.tiles_y;
+        const int y0 = ty * WG_TILE, x0 = tx * WG_TILE;
+        __syncthreads();                                             // the previous tile's operands have been consumed
+        // ---- stage dY (16 x 16 x 64 couts) and X (18 x 18 x 64 cins); outside the image / beyond the channels: zeros
+        for (int i = tid; i < WG_TILE * WG_TILE * (CB / 4); i += 256) {
+            const int q = i & 15, p = i >> 4, py = p >> 4, px = p & 15;
+            const int gy = y0 + py, gx = x0 + px, c = co0 + 4 * q;
+            f32x4 v = {0, 0, 0, 0};
+            if (gy < a.H && gx < a.W && c < a.cout) v = nd_ld4(a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldy + c);
+            nd_st4(dYs + p * CB + 4 * q, v);
+        }
+        for (int i = tid; i < HALO * HALO * (CB / 4); i += 256) {
+            const int q = i & 15, p = i >> 4, py = p / HALO, px = p - py * HALO;
+            const int gy = y0 + py - 1, gx = x0 + px - 1, c = ci0 + 4 * q;
+            f32x4 v = {0, 0, 0, 0};
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c < a.cin)
+                v = nd_ld4(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx + c);
+            nd_st4(Xs + p * CB + 4 * q, v);
+        }
+        __syncthreads();
+        // ---- 128 pixel pairs x 9 taps: lane (col, half) feeds dY[pixel + half][co_w + col] and X[pixel + half + tap][ci_w + col]
+        const float* ap = dYs + half * CB + co_w + col;
+        const float* bp = Xs + half * CB + ci_w + col;
+#pragma unroll 2
+        for (int py = 0; py < WG_TILE; ++py) {
+#pragma unroll
+            for (int px = 0; px < WG_TILE; px += 2) {
+                const float av = ap[(py * WG_TILE + px) * CB];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float bv = bp[((py + t / 3) * HALO + px + t % 3) * CB];
+                    acc[t] = nd_mfma(av, bv, acc[t]);
+                }
+            }
+        }
+    }
+    // ---- this workgroup's partial sums: ws[s][tap][co][ci], rows of 32 consecutive cins per lane group
+    const int coP = a.n_co * CB, ciP = a.n_ci * CB;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + co_w + nd_acc_row(r, lane), ci = ci0 + ci_w + col;
+            a.ws[(((size_t)s * 9 + t) * coP + co) * ciP + ci] = acc[t][r];
+        }
+}
+
+// dW (OIHW, torch layout) = sum over the S partials in a fixed order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int cin, int cout, int coP, int ciP) {
+    const size_t total = (size_t)cout * cin * 9;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % 9);
+        const size_t oc = i / 9;
+        const int ci = (int)(oc % cin), co = (int)(oc / cin);
+        float sum = 0.0f;
+        for (int s = 0; s < S; ++s) sum += ws[(((size_t)s * 9 + t) * coP + co) * ciP + ci];
+        dw[i] = sum;
+    }
+}
+
+void plan(int B, int H, int W, int cin, int cout, WgradArgs& a) {
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
+    a.n_co = nd_cdiv(cout, CB);
+    a.n_ci = nd_cdiv(cin, CB);
+    a.tiles_x = nd_cdiv(W, WG_TILE);
+    a.tiles_y = nd_cdiv(H, WG_TILE);
+    a.n_tiles = B * a.tiles_x * a.tiles_y;
+    const int blocks = a.n_co * a.n_ci;
+    int S = WGRAD_TARGET_WGS / blocks;                               // fixed by the shape: the summation order never depends on the device
+    if (S < 1) S = 1;
+    if (S > a.n_tiles) S = a.n_tiles;
+    a.S = S;
+}
+
+}  // namespace
+
+extern "C" int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return -1;
+    WgradArgs a;
+    plan(B, H, W, cin, cout, a);
+    return (int64_t)a.S * 9 * a.n_co * CB * a.n_ci * CB;
+}
+
+extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* workspace,
+                                         int B, int H, int W, int cin, int cout, void* stream) {
+    ND_REQUIRE(x && dy && dw_oihw && workspace, ND_E_BADARG, "nd_conv3x3_wgrad: null pointer");
+    ND_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, ND_E_BADARG, "nd_conv3x3_wgrad: non-positive size");
+    ND_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx >= cin && ldy >= cout && ldx % 4 == 0 && ldy % 4 == 0, ND_E_SHAPE,
+               "nd_conv3x3_wgrad: cin=%d, cout=%d and the pixel strides must be multiples of 4", cin, cout);
+    ND_REQUIRE(nd_aligned16(x) && nd_aligned16(dy), ND_E_ALIGN, "nd_conv3x3_wgrad: x and dy must be 16-byte aligned");
+    WgradArgs a;
+    plan(B, H, W, cin, cout, a);
+    a.x = x; a.dy = dy; a.ws = workspace; a.ldx = ldx; a.ldy = ldy;
+    const long wgs = (long)a.n_co * a.n_ci * a.S;
+    ND_REQUIRE(wgs < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wgrad: grid too large");
+    const size_t lds = (size_t)(WG_TILE * WG_TILE + HALO * HALO) * CB * sizeof(float);
+    static nd_device_once configured;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wgrad_kernel), lds, "nd_conv3x3_wgrad")) return e;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wgs), dim3(256), lds, st, a);
+    if (int e = nd_launch_status("nd_conv3x3_wgrad_nhwc_f32")) return e;
+    const size_t total = (size_t)cout * cin * 9;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw_oihw, a.S, cin, cout, a.n_co * CB, a.n_ci * CB);
+    return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (reduce)");
+}

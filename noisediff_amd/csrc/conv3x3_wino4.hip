@@ -516,7 +516,9 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                                         ++cnt;
                                     }
 #if !(W4_ABLATE & 8)
-#if W4_NT_STORE
+#if W4_ABLATE & 128                 // timing experiment only (results land in the wrong pixels): every wave store covers eight whole 128-byte lines
+                                    if (FULL || cok) nd_st4(a.d.out + (((size_t)b * H + ty * 16 + (i * 4 + jj)) * Wt + tx * 16) * ldot + wave * 256 + lane * 4, v);
+#elif W4_NT_STORE
                                     if (FULL || cok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(lane_out + (size_t)((i * Wt + jj) * ldot)));
 #else
                                     if (FULL || cok) nd_st4(lane_out + (size_t)((i * Wt + jj) * ldot), v);

@@ -10,8 +10,9 @@ The reference binds its two plug-in interfaces by *import name* (SURVEY 8b):
     (the reference file is not executed, so its unused torchvision / ema_pytorch imports are not needed for it), and
   * lets ``models.archs.Diffusion_arch`` / ``others_arch`` load normally, then rebinds the class names this package
     implements (``NoiseDiffNet``, ``UNet_PosEmbV2*``) to a constructor that returns the HIP network for inference
-    (``args.phase != 'train'``) and the reference's own differentiable class for training -- whose checkpoints load into
-    the HIP network unchanged (same state dict).
+    (``args.phase != 'train'``) and the reference's own differentiable class for training -- its 3x3 convolutions routed
+    through the HIP library forward and backward (noisediff_amd/train.py; ND_TRAIN_ACCEL=0 keeps them on PyTorch) -- whose
+    checkpoints load into the HIP network unchanged (same state dict).
 ``main()`` then runs the script with ``runpy`` as ``__main__`` (same ``sys.argv``, script directory first on ``sys.path``),
 which is what ``python test_diffusion.py ...`` does.  Nothing is written to the reference tree.
 """
@@ -34,7 +35,11 @@ def _hip_or_reference(name: str, reference_cls):
     """Constructor with the registry's calling convention ``cls(args)`` (models/modules.py:41)."""
     def construct(args):
         if getattr(args, "phase", "test") == "train":
-            return reference_cls(args)               # autograd path: the reference's own nn.Module
+            net = reference_cls(args)                # autograd path: the reference's own nn.Module ...
+            if os.environ.get("ND_TRAIN_ACCEL", "1") != "0":
+                from noisediff_amd import train
+                train.accelerate(net)                # ... with its 3x3 convolutions (85 % of the FLOPs) forward and backward on the HIP library
+            return net
         import noisediff_amd
         return getattr(noisediff_amd, name)(args)
     construct.__name__ = construct.__qualname__ = name

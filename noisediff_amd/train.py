@@ -1,0 +1,141 @@
+"""Training on MI355X, first slice: the 3x3 convolutions of a differentiable network -- 85 % of the FLOPs of
+``GaussianDiffusion.p_losses`` (models/denoising_diffusion_pytorch.py:481-531) -- forward AND backward on the HIP library.
+
+    model = <the reference NoiseDiffNet, or any nn.Module>            # differentiable PyTorch
+    noisediff_amd.train.accelerate(model)                             # every nn.Conv2d(3x3, padding 1, stride 1) -> HIP
+    loss = noisediff_amd.GaussianDiffusion(model, ...)(img, condition); loss.backward()
+
+``Conv3x3Function`` is a ``torch.autograd.Function`` over the C ABI:
+  * forward      nd_conv3x3_{wino4, wino2, direct}_nhwc_f32 (the sampling path's kernels, same selection rule as the engine)
+  * grad input   the SAME forward kernels on weights packed from ``w.flip(2, 3).transpose(0, 1)`` -- the data gradient of a
+                 stride-1 "same" convolution is that convolution with the taps flipped and the channel roles swapped
+  * grad weight  nd_conv3x3_wgrad_nhwc_f32 (conv3x3_wgrad.hip: nine tap GEMMs over the pixels on the fp32 MFMA, fixed
+                 summation order, no atomics)
+  * grad bias    a sum over pixels (torch)
+Tensors stay what PyTorch hands over: NCHW-shaped, ``channels_last`` in memory (= the library's NHWC; other layouts are
+converted once per call), fp32, on the caller's CUDA stream -- so autograd's stream ordering holds without synchronisation.
+Everything else in the network (norms, activations, 1x1 convolutions, attention) stays on PyTorch's own ROCm kernels for now.
+
+There is no fallback: a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+
+
+def _nhwc(t: torch.Tensor) -> torch.Tensor:
+    """NCHW-shaped tensor whose memory is NHWC (channels_last), fp32, contiguous in that format."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """y = conv2d(x, w, bias, padding=1) on the HIP library; x (B, cin, H, W) channels_last, returns (B, cout, H, W) channels_last."""
+    lib = L.load()
+    B, cin, H, W = x.shape
+    cout = w_oihw.shape[0]
+    if x.device.type != "cuda":
+        raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {x.device} and there is no CPU path")
+    if cin % 4 or cout % 4:
+        raise L.HipError(f"conv3x3 on the HIP library needs channel counts that are multiples of 4 (cin={cin}, cout={cout})")
+    st = _stream()
+    w_oihw = w_oihw.detach().to(torch.float32).contiguous()
+    with torch.cuda.device(x.device):
+        out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        src_bytes = B * H * W * cin * 4
+        wino = H >= 16 and W >= 16 and cin % 8 == 0
+        wino4 = wino and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and cin > 16 and src_bytes < (1 << 30) - (1 << 16)
+        wino2 = wino and B * H * W < (1 << 24) and src_bytes < (1 << 31)
+        if wino4:
+            pack, entry = "nd_pack_conv3x3_wino4_weight", "nd_conv3x3_wino4_nhwc_f32"
+        elif wino2:
+            pack, entry = "nd_pack_conv3x3_wino_weight", "nd_conv3x3_wino2_nhwc_f32"
+        else:
+            pack, entry = "nd_pack_conv3x3_weight", "nd_conv3x3_nhwc_f32"
+            if cin % 8:
+                raise L.HipError(f"conv3x3 on the HIP library needs cin % 8 == 0 (cin={cin})")
+        wp = torch.empty(int(getattr(lib, pack + "_floats")(cin, cout)), dtype=torch.float32, device=x.device)
+        L.call(pack, w_oihw.data_ptr(), wp.data_ptr(), cin, cout, st)
+        d = L.Conv3x3()
+        d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x.data_ptr(), cin, cin, L.PRO_NONE
+        d.weight, d.out = wp.data_ptr(), out.data_ptr()
+        if bias is not None:
+            b = bias.detach().to(torch.float32).contiguous()
+            d.bias = b.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        L.call(entry, C.byref(d), st)
+        # wp / b are dropped on return: safe, because the kernels were enqueued on torch's CURRENT stream and the caching
+        # allocator reuses a block only for work that is enqueued later on that same stream
+    return out
+
+
+class Conv3x3Function(torch.autograd.Function):
+    """nn.Conv2d(cin, cout, 3, padding=1) forward and backward on libnoisediff_hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xn = _nhwc(x)
+        ctx.save_for_backward(xn, weight)
+        ctx.has_bias = bias is not None
+        return _conv3x3_nhwc(xn, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xn, weight = ctx.saved_tensors
+        lib = L.load()
+        g = _nhwc(grad_out)
+        B, cin, H, W = xn.shape
+        cout = weight.shape[0]
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            # dL/dx = conv(dL/dy, flip(w)^T): the forward operator itself
+            grad_x = _conv3x3_nhwc(g, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None)
+        if ctx.needs_input_grad[1]:
+            with torch.cuda.device(xn.device):
+                grad_w = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xn.device)
+                ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, cin, cout)), dtype=torch.float32, device=xn.device)
+                L.call("nd_conv3x3_wgrad_nhwc_f32", xn.data_ptr(), cin, g.data_ptr(), cout, grad_w.data_ptr(), ws.data_ptr(),
+                       B, H, W, cin, cout, _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = g.sum(dim=(0, 2, 3))
+        return grad_x, grad_w, grad_b
+
+
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable F.conv2d(x, weight, bias, padding=1) for 3x3 kernels on the HIP library."""
+    if tuple(weight.shape[2:]) != (3, 3) or x.dim() != 4 or x.shape[1] != weight.shape[1]:
+        raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)} is not a 3x3 convolution")
+    return Conv3x3Function.apply(x, weight, bias)
+
+
+def _eligible(m: nn.Module) -> bool:
+    return (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
+            and m.groups == 1 and m.padding_mode == "zeros" and m.in_channels % 8 == 0 and m.out_channels % 8 == 0)
+
+
+def _hip_conv_forward(self: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    return conv3x3(x, self.weight, self.bias)
+
+
+def accelerate(model: nn.Module) -> int:
+    """Route every eligible 3x3 convolution of ``model`` (stride 1, padding 1, channel counts multiples of 8) through the HIP
+    library, forward and backward.  Parameters, module tree and state dict are untouched; the replacement is a bound method, so
+    ``copy.deepcopy`` (the trainer's EMA) rebinds it to the copy.  Returns the number of layers taken."""
+    import types
+    n = 0
+    for m in model.modules():
+        if _eligible(m) and getattr(m.forward, "__func__", None) is not _hip_conv_forward:
+            m.forward = types.MethodType(_hip_conv_forward, m)
+            n += 1
+    return n

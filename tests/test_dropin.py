@@ -66,7 +66,8 @@ def test_overlay_on_the_real_reference_registry():
         import sys, types
         sys.dont_write_bytecode = True
         from types import SimpleNamespace
-        from noisediff_amd import dropin
+        import torch
+        from noisediff_amd import dropin, train
         dropin.install()
         sys.path.insert(0, %r)
         import models.modules as M
@@ -78,6 +79,9 @@ def test_overlay_on_the_real_reference_registry():
             ref = M.define_network(a)
             assert [(k, tuple(v.shape)) for k, v in hip.state_dict().items()] == [(k, tuple(v.shape)) for k, v in ref.state_dict().items()], name
             hip.load_state_dict(ref.state_dict(), strict=True)        # a checkpoint trained on the reference class loads unchanged
+            n3 = sum(1 for m in ref.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3))
+            acc = sum(1 for m in ref.modules() if getattr(getattr(m, 'forward', None), '__func__', None) is train._hip_conv_forward)
+            assert acc == n3 > 20, (name, acc, n3)                    # training: every 3x3 conv of the reference class goes through the HIP library
             print('RESULT', name, type(hip).__module__, type(ref).__module__)
         import torch
         gd = GaussianDiffusion(torch.nn.DataParallel(ref), image_size=32, timesteps=20, beta_schedule='sigmoid2')

@@ -1,0 +1,103 @@
+"""Training slice on the GPU: conv3x3 forward / data gradient / weight gradient on the HIP library, as a
+torch.autograd.Function, against PyTorch's own fp32 convolution autograd on the same tensors."""
+import copy
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+from noisediff_amd import _lib as L, synth, train
+from util import rel_err
+
+DEV = torch.device("cuda", 0)
+# (B, H, W, cin, cout): F(4x4) forward + dgrad; F(2x2) (narrow image); direct kernel (8x8); uneven channel blocks, ragged tiles
+CASES = {"wino4": (2, 32, 64, 64, 64), "wino4_wide": (1, 32, 32, 128, 192), "wino2": (2, 24, 20, 32, 48), "direct": (3, 8, 8, 16, 24),
+         "ragged": (2, 40, 36, 24, 72)}
+
+
+def U(name, shape, lo=-1.0, hi=1.0):
+    return synth.uniform(11, name, shape, lo, hi)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_conv3x3_autograd_matches_torch(case):
+    B, H, W, cin, cout = CASES[case]
+    x = U(case + ".x", (B, cin, H, W), -1.5, 1.5).to(DEV)
+    w = (U(case + ".w", (cout, cin, 3, 3)) / (9 * cin) ** 0.5).to(DEV)
+    b = U(case + ".b", (cout,)).to(DEV)
+    gy = U(case + ".gy", (B, cout, H, W)).to(DEV)
+    outs = []
+    for fn in (lambda a, ww, bb: F.conv2d(a, ww, bb, padding=1), train.conv3x3):
+        xa, wa, ba = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        y = fn(xa, wa, ba)
+        y.backward(gy)
+        outs.append([t.detach().float().cpu() for t in (y, xa.grad, wa.grad, ba.grad)])
+    for name, ref, got in zip(("y", "grad_x", "grad_w", "grad_b"), *outs):
+        assert got.shape == ref.shape
+        assert rel_err(got.numpy(), ref.numpy()) < 1e-4, (case, name)     # F(4x4) transforms: ~1e-5; MIOpen's own summation order differs too
+    # no bias, input that needs no gradient
+    xa, wa = x.clone(), w.clone().requires_grad_()
+    train.conv3x3(xa, wa).backward(gy)
+    assert rel_err(wa.grad.cpu().numpy(), outs[0][2].numpy()) < 1e-4
+
+
+def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum():
+    lib = L.load()
+    B, H, W, cin, cout = 2, 48, 32, 64, 128
+    x = U("wg.x", (B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = U("wg.gy", (B, cout, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
+    ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, cin, cout)), device=DEV)
+    outs = []
+    for _ in range(3):
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        torch.cuda.synchronize()
+        L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), ws.data_ptr(), B, H, W, cin, cout,
+               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (cout, cin, 3, 3), gy.double().cpu(), padding=1)
+    assert rel_err(outs[0].numpy(), ref.numpy()) < 2e-5
+    assert lib.nd_conv3x3_wgrad_workspace_floats(0, 8, 8, 8, 8) == -1
+    with pytest.raises(L.HipError):
+        L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), ws.data_ptr(), B, H, W, 6, cout, None)
+
+
+class _Block(nn.Module):
+    """Conv3x3 -> GroupNorm -> SiLU -> Conv3x3 + 1x1 shortcut: the shape of the reference's ResnetBlock (Diffusion_arch.py:146-170)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.c1, self.n1 = nn.Conv2d(cin, cout, 3, padding=1), nn.GroupNorm(8, cout)
+        self.c2, self.n2 = nn.Conv2d(cout, cout, 3, padding=1), nn.GroupNorm(8, cout)
+        self.res = nn.Conv2d(cin, cout, 1)
+
+    def forward(self, x):
+        h = F.silu(self.n1(self.c1(x)))
+        return F.silu(self.n2(self.c2(h))) + self.res(x)
+
+
+def test_accelerate_keeps_losses_and_gradients_of_a_resnet_block():
+    torch.manual_seed(0)
+    ref = nn.Sequential(_Block(32, 64), _Block(64, 64), nn.Conv2d(64, 4, 1)).to(DEV)
+    hip = copy.deepcopy(ref)
+    assert train.accelerate(hip) == 4 and train.accelerate(hip) == 0           # four 3x3 convs taken, idempotent
+    assert list(hip.state_dict()) == list(ref.state_dict())
+    ema = copy.deepcopy(hip)                                                     # the trainer's EMA deep-copies the net
+    assert ema[0].c1.forward.__self__ is ema[0].c1
+    x = U("blk.x", (2, 32, 32, 64)).to(DEV)
+    target = U("blk.t", (2, 4, 32, 64)).to(DEV)
+    losses = []
+    for net in (ref, hip):
+        loss = F.mse_loss(net(x), target)
+        loss.backward()
+        losses.append(float(loss))
+    assert losses[1] == pytest.approx(losses[0], rel=2e-5)
+    for (k, p), q in zip(ref.named_parameters(), hip.parameters()):
+        assert rel_err(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 2e-4, k
+    with pytest.raises(L.HipError, match="no CPU path"):
+        train.conv3x3(torch.zeros(1, 8, 8, 8), torch.zeros(8, 8, 3, 3))
