@@ -53,6 +53,9 @@ constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 12) * 25
 #ifndef W4_UR_AFF
 #define W4_UR_AFF 18         // ... of the GroupNorm-affine + SiLU variant (its transform needs more registers)
 #endif
+#ifndef W4_UR_MAP
+#define W4_UR_MAP 9          // ... of the map variant (20 more staging registers per in-flight halo item)
+#endif
 #ifndef W4_UR_EPI
 #define W4_UR_EPI 6          // ... across a tile's epilogue (its output transform needs the registers): the ring runs down in the
 #endif                       // last stage of a tile and is refilled in one burst at the start of the next tile's first stage
@@ -118,8 +121,10 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
 
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
-    constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU;
-    constexpr int UR = AFF ? W4_UR_AFF : W4_UR, UR_EPI = W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
+    constexpr bool MAP = MODE == ND_PRO_AFFINE_MAP_SILU;                  // + per-pixel scale / shift maps (ResnetBlock2)
+    constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAP;               // GroupNorm-affine + SiLU applied while the halo is written to LDS
+    constexpr bool LEAKY = MODE == ND_PRO_LEAKY || MODE == ND_PRO_LEAKY_SECOND;      // LSID: LeakyReLU(0.2) of the producer, applied by the consumer
+    constexpr int UR = MAP ? W4_UR_MAP : AFF ? W4_UR_AFF : W4_UR, UR_EPI = W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
     extern __shared__ __attribute__((aligned(16))) float Vd[];          // [tg 2][buf 2][VD_FLOATS], then the border table
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     const long npx = (long)a.d.B * sH * sW;
     const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(npx * s.ld0 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(npx * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MAP ? s.map : s.p0), 0, MAP ? (int)(npx * 2 * Ctot * 4) : 0, 0x00020000);
     float* const vd_tg = Vd + tg * VD_FLOATS;                            // this tile group's V image
     char* const rawbuf = reinterpret_cast<char*>(Vd + 2 * VD_FLOATS);    // [18][40] records of 64 bytes
     lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + 18 * RAW_ROWP * 16) + tid;      // [10][256] source pixel of this thread's items
@@ -186,7 +192,9 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) {
         const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
-        dtab[k * 256] = (unsigned)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));
+        // (+ the item's halo row and column in the upper bits: stage_tile needs them once per tile, and kept in registers
+        //  they get spilled -- a scratch reload in the K loop drains the weight ring)
+        dtab[k * 256] = (unsigned)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8)) | ((unsigned)r << 20) | ((unsigned)c << 25);
     }
     // the transform's own lane mapping (any lane may produce any V element): 16 consecutive lanes = 8 tiles x the two channel
     // pairs of a quad, so that the compiler's paired LDS accesses (ds_read2 / ds_write2: 16-lane groups, 32 banks) are conflict-free
@@ -208,20 +216,25 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         const int y0 = ty_ * 16 - 1, x0 = rx_ * 32 - 1;                  // first halo row / column of the region
 #pragma unroll
         for (int k = 0; k < RAW_IT; ++k) {
-            const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
+            const unsigned dk = dtab[k * 256];
+            const int r = (int)((dk >> 20) & 31u), c = (int)(dk >> 25);
             const int gy = y0 + r, gx = x0 + c;
-            const bool ok = pix < 18 * 34 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const bool ok = r < 18 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;   // (the last round's items beyond pixel 611 have r >= 18)
             // outside the image: pixel 0xFFFFFF -- x ld4 >= 1 GiB, beyond every source tensor (host check): the load returns the zero padding
             ptab[k * 256] = ok ? (unsigned)((b_ * sH + (gy >> up)) * sW + (gx >> up)) : 0xFFFFFFu;
         }
     };
     // the chunk being staged: source, channel base, affine constants of the transform lane
     f32x4 raw[RAW_IT];                                                   // the halo in flight: loaded during a chunk's stage 0, written to LDS during its stage 1
+    f32x4 msc[MAP ? RAW_IT : 1], msh[MAP ? RAW_IT : 1];                  // MAP: the items' scale / shift map values
+    bool i_second = false;                                               // wave-uniform: the chunk comes from the second concat source
     __amdgpu_buffer_rsrc_t i_rs = rsrc0;
-    int i_soff = 0;
+    int i_soff = 0, i_mapoff = 0;
     unsigned i_ld4 = 0, i_cmask = 0;
     auto stage_issue_begin = [&](int cb_) {
         const bool sec = cb_ >= s.c0;                                    // wave-uniform: a chunk never straddles the sources (host check)
+        i_second = sec;
+        i_mapoff = cb_ * 4;
         i_rs = sec ? rsrc1 : rsrc0;
         i_ld4 = (unsigned)(sec ? s.ld1 : s.ld0) * 4u;
         i_soff = (sec ? cb_ - s.c0 : cb_) * 4;
@@ -238,6 +251,11 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #if !(W4_ABLATE & 1)
         const unsigned px = (ptab[k * 256] | i_cmask) & 0xFFFFFFu;
         raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i_rs, __umul24(px, i_ld4) + 16u * sq, i_soff, 0));
+        if (MAP) {                                                       // the maps have the conv's resolution (host: no upsample with MAP): [pixel][scale C | shift C]
+            const unsigned mo = __umul24(px, (unsigned)(2 * Ctot * 4)) + 16u * sq;
+            msc[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff, 0));
+            msh[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff + Ctot * 4, 0));
+        }
 #else
         raw[k] = f32x4{(float)k, 1.0f, 0.5f, 0.25f};
 #endif
@@ -248,7 +266,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         if (AFF) {
             // GroupNorm-affine + SiLU on the raw halo (each pixel once: 40 values per thread and chunk); silu(x) = x / (1 + 2^(-x log2 e)).
             // The zero padding is applied after the activation (silu(affine(0)) != 0): items outside the image carry the 0xFFFFFF mark
-            const f32x4 x = v * tA4 + tD4;
+            f32x4 x = v * tA4 + tD4;
+            if (MAP) x = x * (msc[k] + 1.0f) + msh[k];                   // ResnetBlock2: x * (scale + 1) + shift per pixel (Diffusion_arch.py:188-192)
             const f32x4 t = x * -1.44269504088896340736f;
             f32x4 e;
             e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y); e.z = __builtin_amdgcn_exp2f(t.z); e.w = __builtin_amdgcn_exp2f(t.w);
@@ -259,7 +278,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             const f32x4 zero = {0, 0, 0, 0};
             v = inside ? x * r : zero;
         }
-        *reinterpret_cast<f32x4*>(rawbuf + dtab[k * 256]) = v;
+        if (MODE == ND_PRO_LEAKY || (MODE == ND_PRO_LEAKY_SECOND && i_second)) v = nd_leaky4(v);      // keeps zeros: the padding needs no mask
+        *reinterpret_cast<f32x4*>(rawbuf + (dtab[k * 256] & 0xFFFFFu)) = v;
     };
 
     // ---- V image of a tile group (36 KB): [position pair 18][8-channel half g2][kq >> 1][tile 16][kq & 1] x 16 bytes, the 16 bytes
@@ -430,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 if (pp < RAW_IT) stage_issue_one(pp);
             };
             auto commit = [&](int pp) {
-                if (AFF) {      // the activation is VALU work: one clump behind the stage's last MFMAs (every MFMA <-> VALU switch costs ~18 cycles)
+                if (AFF || LEAKY) {     // the activation is VALU work: one clump behind the stage's last MFMAs (every MFMA <-> VALU switch costs ~18 cycles)
                     if (pp == 17) {
 #pragma unroll
                         for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k);
@@ -647,9 +667,15 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(nd_aligned16(s.p0) && nd_aligned16(s.p1) && nd_aligned16(d->weight) && nd_aligned16(s.mad) && nd_aligned16(d->out) &&
                nd_aligned16(d->bias), ND_E_ALIGN, "nd_conv3x3_wino4: pointers must be 16-byte aligned");
     ND_REQUIRE(d->ldo >= d->cout && d->ldo % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: ldo must be >= cout and a multiple of 4");
-    ND_REQUIRE(s.mode == ND_PRO_NONE || s.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
-               "nd_conv3x3_wino4: unsupported prologue %d (use nd_conv3x3_wino2_nhwc_f32)", s.mode);
-    ND_REQUIRE(s.mode != ND_PRO_AFFINE_SILU || (s.mad && (s.c0 + s.c1) % 2 == 0), ND_E_BADARG, "nd_conv3x3_wino4: affine prologue needs mad");
+    const bool aff = s.mode == ND_PRO_AFFINE_SILU || s.mode == ND_PRO_AFFINE_MAP_SILU;
+    ND_REQUIRE(s.mode == ND_PRO_NONE || aff || s.mode == ND_PRO_LEAKY || s.mode == ND_PRO_LEAKY_SECOND, ND_E_BADARG,
+               "nd_conv3x3_wino4: unsupported prologue %d", s.mode);
+    ND_REQUIRE(!aff || s.mad, ND_E_BADARG, "nd_conv3x3_wino4: affine prologue needs mad");
+    ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || (s.map && !s.upsample && nd_aligned16(s.map)), ND_E_BADARG,
+               "nd_conv3x3_wino4: the map prologue needs a 16-byte aligned map and no upsample addressing");
+    ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || (long)d->B * d->H * d->W * 2 * (s.c0 + s.c1) * 4 < (1L << 30) - 65536, ND_E_SHAPE,
+               "nd_conv3x3_wino4: a scale / shift map of 1 GiB or more");
+    ND_REQUIRE(s.mode != ND_PRO_LEAKY_SECOND || s.p1, ND_E_BADARG, "nd_conv3x3_wino4: LEAKY_SECOND needs a second source");
     ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3_wino4: no unshuffle addressing");
     ND_REQUIRE(!s.upsample || (d->H % 2 == 0 && d->W % 2 == 0 && s.c1 == 0), ND_E_SHAPE,
                "nd_conv3x3_wino4: nearest-x2 upsample addressing needs even H, W and a single source");
@@ -676,7 +702,14 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4: grid too large");
     a.total_wg = (int)wg;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = s.mode == ND_PRO_AFFINE_SILU ? launch4<ND_PRO_AFFINE_SILU>(a, st) : launch4<ND_PRO_NONE>(a, st);
+    int rc;
+    switch (s.mode) {
+        case ND_PRO_AFFINE_SILU: rc = launch4<ND_PRO_AFFINE_SILU>(a, st); break;
+        case ND_PRO_AFFINE_MAP_SILU: rc = launch4<ND_PRO_AFFINE_MAP_SILU>(a, st); break;
+        case ND_PRO_LEAKY: rc = launch4<ND_PRO_LEAKY>(a, st); break;
+        case ND_PRO_LEAKY_SECOND: rc = launch4<ND_PRO_LEAKY_SECOND>(a, st); break;
+        default: rc = launch4<ND_PRO_NONE>(a, st); break;
+    }
     if (rc) return rc;
     return nd_launch_status("nd_conv3x3_wino4_nhwc_f32");
 }

@@ -335,10 +335,11 @@ class Plan:
                  and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
                  and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
         # F(4x4,3x3) (1.78x fewer MFMAs again; 16 x 32-pixel regions, 16-channel K chunks) wherever its kernel takes the layer:
-        # plain / GroupNorm-affine + SiLU inputs, concat on a chunk boundary, images that fill its regions, sources below 1 GiB
+        # plain / GroupNorm-affine (+ per-pixel map) + SiLU inputs, concat on a chunk boundary, images that fill its regions, sources below 1 GiB
         up = 1 if src.upsample else 0
         src_bytes = self.B * (H >> up) * (W >> up) * 4 * max(src.ld0, src.ld1)
-        wino4 = (wino and WINO4 and (name + ".weight.wino4") in e.slots and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)
+        wino4 = (wino and WINO4 and (name + ".weight.wino4") in e.slots and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU)
+                 and not (src.mode == L.PRO_AFFINE_MAP_SILU and (up or self.B * H * W * 8 * cin >= (1 << 30) - (1 << 16)))
                  and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (src.c1 == 0 or (src.c0 % 16 == 0 and not up))
                  and src.ld0 >= 16 and (src.c1 == 0 or src.ld1 >= 16) and src_bytes < (1 << 30) - (1 << 16)
                  and (not up or (H % 2 == 0 and W % 2 == 0)))

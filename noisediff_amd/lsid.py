@@ -21,6 +21,9 @@ from . import _lib as L
 from .net import _attach, _init
 from .spec import LSID_STAGES, lsid_param_spec
 
+import os
+WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel
+
 
 class LSID(nn.Module):
     def __init__(self, args=None):
@@ -108,14 +111,19 @@ class _LsidPlan:
         L.call("nd_pack_pointwise_weight", m.data_ptr(), out.data_ptr(), cin, cout, 0, self.stream)
         return out
 
-    def _pack_conv(self, t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _pack_conv(self, t: torch.Tensor):
+        """(direct, F(2x2,3x3), F(4x4,3x3) or None) packings of one 3x3 weight."""
         cout, cin = t.shape[:2]
         d = self._f(self.lib.nd_pack_conv3x3_weight_floats(cin, cout))
         w = self._f(self.lib.nd_pack_conv3x3_wino_weight_floats(cin, cout))
         self.keep.append(t)
         L.call("nd_pack_conv3x3_weight", t.data_ptr(), d.data_ptr(), cin, cout, self.stream)
         L.call("nd_pack_conv3x3_wino_weight", t.data_ptr(), w.data_ptr(), cin, cout, self.stream)
-        return d, w
+        w4 = None
+        if WINO4 and cin > 16 and cin % 4 == 0 and cout % 4 == 0:
+            w4 = self._f(self.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout))
+            L.call("nd_pack_conv3x3_wino4_weight", t.data_ptr(), w4.data_ptr(), cin, cout, self.stream)
+        return d, w, w4
 
     def _add(self, name: str, *args) -> None:
         self.keep.append(args)
@@ -136,7 +144,14 @@ class _LsidPlan:
         d.src, d.weight, d.bias, d.out = src, self.w[name + ".weight"][1 if wino else 0].data_ptr(), self.w[name + ".bias"].data_ptr(), out.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, h, w, cin, cout, cout
         wino2 = wino and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * h * w < (1 << 24) and self.B * h * w * 4 * max(src.ld0, src.ld1) < (1 << 31)
-        self._add("nd_conv3x3_wino2_nhwc_f32" if wino2 else "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), self.stream)
+        # F(4x4,3x3) where its kernel takes the layer (same rule as the engine's): the LeakyReLU prologues are applied while the halo is staged
+        wino4 = (wino and self.w[name + ".weight"][2] is not None and w >= 32 and (w % 32 == 0 or w >= 96) and w <= 2048
+                 and (src.c1 == 0 or src.c0 % 16 == 0) and src.ld0 >= 16 and (src.c1 == 0 or src.ld1 >= 16)
+                 and self.B * h * w * 4 * max(src.ld0, src.ld1) < (1 << 30) - (1 << 16))
+        if wino4:
+            d.weight = self.w[name + ".weight"][2].data_ptr()
+        self._add("nd_conv3x3_wino4_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
+                  "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32", C.byref(d), self.stream)
         self.keep.append(d)
         return out
 

@@ -628,6 +628,17 @@ def test_conv3x3_winograd_f4x4_matches_direct_semantics(ctx, case):
     else:
         with pytest.raises(L.HipError, match="straddle"):
             run(hu.src(hu.nhwc(x[:, :8]), hu.nhwc(x[:, 8:])))
+    # the per-pixel scale / shift map of ResnetBlock2 and LSID's LeakyReLU prologues (whole input / second concat source only)
+    sc, sh = U(case + ".sc", (B, cin, H, W), -0.5, 0.5), U(case + ".sh", (B, cin, H, W), -0.5, 0.5)
+    actm = F.silu(((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None]) * (sc + 1) + sh)
+    sm = hu.src(hu.nhwc(x), None, L.PRO_AFFINE_MAP_SILU, mad=hu.dev(torch.stack((M, A, D), 1)), map=hu.nhwc(torch.cat((sc, sh), 1)))
+    out, *_ = run(sm, stats=False)
+    assert rel_err(hu.nchw(out), F.conv2d(actm, w, b, padding=1)) < 5e-5
+    out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_LEAKY), stats=False)
+    assert rel_err(hu.nchw(out), F.conv2d(F.leaky_relu(x, 0.2), w, b, padding=1)) < 5e-5
+    if c0:
+        out, *_ = run(hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:]), L.PRO_LEAKY_SECOND), stats=False)
+        assert rel_err(hu.nchw(out), F.conv2d(torch.cat((x[:, :c0], F.leaky_relu(x[:, c0:], 0.2)), 1), w, b, padding=1)) < 5e-5
     if H % 2 == 0 and W % 2 == 0:                                        # nearest-x2 upsample addressing (Upsample's conv, Diffusion_arch.py:74-75)
         xs = x[:, :, : H // 2, : W // 2].contiguous()
         out, *_ = run(hu.src(hu.nhwc(xs), upsample=1), stats=False)
