@@ -40,12 +40,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(3))) short* lds_short_ptr;
 typedef __attribute__((address_space(3))) unsigned* lds_u32_ptr;
+typedef __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
 
 constexpr int KC4 = 16;                              // channels per K chunk
 constexpr int NPOS = 36;                             // positions (xi, nu) == patch entries (a, b)
 constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk image: 36 entries x 1 KB = 36 KB
 
-constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 12) * 256 * 4;   // [tg 2] V images + raw halo + per-thread tables
+constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 10 + 12) * 256 * 4;   // [tg 2] V images + raw halo + per-thread tables
 
 #ifndef W4_UR
 #define W4_UR 18             // weight fragments in flight per wave in the K loop (x 4 registers); a stage consumes 18
@@ -188,13 +189,15 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
     // patch crosses a multiple-of-4 row): entry (a, b) is at ttab[(a >> 2) * 6 + b] + a * RAW_ROWP * 64
     lds_u32_ptr const dtab = ptab + RAW_IT * 256;
-    lds_u32_ptr const ttab = dtab + RAW_IT * 256;
+    lds_u32_ptr const rtab = dtab + RAW_IT * 256;                       // [10] halo row | column << 8 of item k (stage_tile needs them once per tile)
+    lds_u32_ptr const ttab = rtab + RAW_IT * 256;
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) {
         const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
-        // (+ the item's halo row and column in the upper bits: stage_tile needs them once per tile, and kept in registers
-        //  they get spilled -- a scratch reload in the K loop drains the weight ring)
-        dtab[k * 256] = (unsigned)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8)) | ((unsigned)r << 20) | ((unsigned)c << 25);
+        // (the per-item values are tables, not registers: kept in registers they get spilled, and a scratch reload in the K loop
+        //  drains the weight ring; any per-item VALU arithmetic in the stage loops costs an MFMA <-> VALU switch)
+        dtab[k * 256] = (unsigned)(2 * VD_FLOATS * 4 + (r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS
+        rtab[k * 256] = (unsigned)r | ((unsigned)c << 8);
     }
     // the transform's own lane mapping (any lane may produce any V element): 16 consecutive lanes = 8 tiles x the two channel
     // pairs of a quad, so that the compiler's paired LDS accesses (ds_read2 / ds_write2: 16-lane groups, 32 banks) are conflict-free
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         }
     const unsigned t_lds = (unsigned)(ch2 * 1024 + (t_kq >> 1) * 512 + t_tile * 32 + (t_kq & 1) * 16);  // V image address of the transform lane
 
+    const unsigned OOB = 0x7FFFFFF0u;                                    // byte offset beyond any tensor: the load returns zeros (padding)
     int sb_ = 0;
     f32x4 tA4 = {1, 1, 1, 1}, tD4 = {0, 0, 0, 0};                        // AFF: loaded with a chunk's halo, applied when it is written to LDS
     auto stage_tile = [&](int b_, int ty_, int rx_) {
@@ -216,10 +220,11 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         const int y0 = ty_ * 16 - 1, x0 = rx_ * 32 - 1;                  // first halo row / column of the region
 #pragma unroll
         for (int k = 0; k < RAW_IT; ++k) {
-            const unsigned dk = dtab[k * 256];
-            const int r = (int)((dk >> 20) & 31u), c = (int)(dk >> 25);
+            const unsigned rc = rtab[k * 256];
+            const int r = (int)(rc & 255u), c = (int)(rc >> 8);
             const int gy = y0 + r, gx = x0 + c;
             const bool ok = r < 18 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;   // (the last round's items beyond pixel 611 have r >= 18)
+            // outside the image: pixel 0xFFFFFF -- x ld4 >= 1 GiB, beyond every source tensor (host check): the load returns the zero padding
             // outside the image: pixel 0xFFFFFF -- x ld4 >= 1 GiB, beyond every source tensor (host check): the load returns the zero padding
             ptab[k * 256] = ok ? (unsigned)((b_ * sH + (gy >> up)) * sW + (gx >> up)) : 0xFFFFFFu;
         }
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     bool i_second = false;                                               // wave-uniform: the chunk comes from the second concat source
     __amdgpu_buffer_rsrc_t i_rs = rsrc0;
     int i_soff = 0, i_mapoff = 0;
-    unsigned i_ld4 = 0, i_cmask = 0;
+    unsigned i_ld4 = 0, i_bias = 0;
     auto stage_issue_begin = [&](int cb_) {
         const bool sec = cb_ >= s.c0;                                    // wave-uniform: a chunk never straddles the sources (host check)
         i_second = sec;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         i_rs = sec ? rsrc1 : rsrc0;
         i_ld4 = (unsigned)(sec ? s.ld1 : s.ld0) * 4u;
         i_soff = (sec ? cb_ - s.c0 : cb_) * 4;
-        i_cmask = cb_ + 4 * sq < Cin ? 0u : 0xFFFFFFu;                   // invalid channel quad: every item out of range
+        i_bias = cb_ + 4 * sq < Cin ? 16u * sq : OOB;                    // invalid channel quad: every item out of range (pixel offsets stay below 2^30)
         if (AFF) {                                                       // this thread's channel quad: cb + 4 sq .. + 3
             const int c = cb_ + 4 * sq;
             const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (c < Cin ? c : 0);
@@ -249,8 +254,11 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     };
     auto stage_issue_one = [&](int k) {
 #if !(W4_ABLATE & 1)
-        const unsigned px = (ptab[k * 256] | i_cmask) & 0xFFFFFFu;
-        raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i_rs, __umul24(px, i_ld4) + 16u * sq, i_soff, 0));
+        // ONE VALU instruction per item (no branch, no masking: every per-item instruction in a stage loop costs an MFMA <-> VALU
+        // switch): pixel x stride + this lane's channel-quad offset, the latter out of range for a quad beyond cin
+        const unsigned px = ptab[k * 256];
+        const unsigned voff = __umul24(px, i_ld4) + i_bias;
+        raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i_rs, voff, i_soff, 0));
         if (MAP) {                                                       // the maps have the conv's resolution (host: no upsample with MAP): [pixel][scale C | shift C]
             const unsigned mo = __umul24(px, (unsigned)(2 * Ctot * 4)) + 16u * sq;
             msc[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff, 0));
@@ -274,12 +282,12 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             e = e + 1.0f;
             f32x4 r;
             r.x = __builtin_amdgcn_rcpf(e.x); r.y = __builtin_amdgcn_rcpf(e.y); r.z = __builtin_amdgcn_rcpf(e.z); r.w = __builtin_amdgcn_rcpf(e.w);
-            const bool inside = ((ptab[k * 256] | i_cmask) & 0xFFFFFFu) != 0xFFFFFFu;
+            const bool inside = ptab[k * 256] != 0xFFFFFFu && i_bias != OOB;
             const f32x4 zero = {0, 0, 0, 0};
             v = inside ? x * r : zero;
         }
         if (MODE == ND_PRO_LEAKY || (MODE == ND_PRO_LEAKY_SECOND && i_second)) v = nd_leaky4(v);      // keeps zeros: the padding needs no mask
-        *reinterpret_cast<f32x4*>(rawbuf + (dtab[k * 256] & 0xFFFFFu)) = v;
+        *reinterpret_cast<lds_f32x4_ptr>(dtab[k * 256]) = v;
     };
 
     // ---- V image of a tile group (36 KB): [position pair 18][8-channel half g2][kq >> 1][tile 16][kq & 1] x 16 bytes, the 16 bytes
