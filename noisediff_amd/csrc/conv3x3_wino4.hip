@@ -64,8 +64,11 @@ constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 10 + 12)
 #define W4_VR 3              // V operand pairs read ahead
 #endif
 #ifndef W4_COMMIT_AT
-#define W4_COMMIT_AT 6       // position pair of stage 1 behind which the first of the 10 staged halo items is written to LDS
-#endif
+#define W4_COMMIT_AT 8       // AFF / LEAKY: position pair of stage 1 behind which the 10 staged halo items are activated and written to LDS
+#endif                       // (plain sources: item pp behind position pair pp, no VALU work)
+#ifndef W4_XF_AT
+#define W4_XF_AT 10          // position pair of stage 1 behind which the raw image is complete (barrier); the transform's 36 raw reads follow,
+#endif                       // six per position pair, under the MFMAs of the stage's tail
 #ifndef W4_NT_STORE
 #define W4_NT_STORE 0
 #endif
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 
 #ifdef W4_STAMP                  // diagnostic (tools/w4_clock.py): shader-clock and 100 MHz wall stamps per workgroup -> clock under load, phase split
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long stamp_epi = 0, stamp_xf = 0, stamp_wait = 0, stamp_t = 0, stamp_drain = 0;
+    unsigned long long stamp_epi = 0, stamp_xf = 0, stamp_wait = 0, stamp_t = 0, stamp_drain = 0, stamp_first = 0, stamp_last = 0, stamp_second = 0, stamp_third = 0, stamp_pro = 0, stamp_top = 0, stamp_tile = 0;
 #define W4_T0() (stamp_t = __builtin_amdgcn_s_memtime())
 #define W4_ACC(x) (x += __builtin_amdgcn_s_memtime() - stamp_t)
 #else
@@ -175,10 +178,21 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     //      apart in x and y -- then fall on different banks.
     constexpr int RAW_ROWP = 40, RAW_ITEMS = 18 * 34 * 4, RAW_IT = (RAW_ITEMS + 255) / 256;      // 10
     const int sty = 4 * (tile >> 2), stx = 4 * (tile & 3);              // tile origin inside the 16x16 pixels (entry (0,0) is one up-left)
+    // Source addressing: byte address = resource base + soffset (SGPR: the region's base pixel and the chunk's channel base) +
+    // voffset (VGPR: item pixel relative to the region x pixel stride + channel quad).  The resources start one row + one pixel in
+    // front of the tensors, so that soffset is never negative, and end with the tensors.  Halo entries outside the image carry
+    // the relative pixel PX_MARK = one past the last pixel: x any source's stride that is beyond its resource whatever the region
+    // (gfx950 range-checks soffset + voffset; voffset alone is already out of range), and the load returns the zero padding -- as
+    // does every item of an invalid channel quad (bias 0x7FFFFFF0).  No product or sum wraps: tensors stay below 1 GiB (host check).
     const long npx = (long)a.d.B * sH * sW;
-    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)(npx * s.ld0 * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0, (int)(npx * (s.p1 ? s.ld1 : s.ld0) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MAP ? s.map : s.p0), 0, MAP ? (int)(npx * 2 * Ctot * 4) : 0, 0x00020000);
+    const unsigned PX_MARK = (unsigned)(npx + sW + 2);
+    auto src_rsrc = [&](const float* p, long px_stride_floats) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p) - (long)(sW + 1) * px_stride_floats, 0,
+                                                 (int)((npx + sW + 1) * px_stride_floats * 4), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc0 = src_rsrc(s.p0, s.ld0);
+    const __amdgpu_buffer_rsrc_t rsrc1 = s.p1 ? src_rsrc(s.p1, s.ld1) : rsrc0;
+    const __amdgpu_buffer_rsrc_t rsrcm = MAP ? src_rsrc(s.map, 2 * Ctot) : rsrc0;
     float* const vd_tg = Vd + tg * VD_FLOATS;                            // this tile group's V image
     char* const rawbuf = reinterpret_cast<char*>(Vd + 2 * VD_FLOATS);    // [18][40] records of 64 bytes
     lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + 18 * RAW_ROWP * 16) + tid;      // [10][256] source pixel of this thread's items
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
     // patch crosses a multiple-of-4 row): entry (a, b) is at ttab[(a >> 2) * 6 + b] + a * RAW_ROWP * 64
     lds_u32_ptr const dtab = ptab + RAW_IT * 256;
-    lds_u32_ptr const rtab = dtab + RAW_IT * 256;                       // [10] halo row | column << 8 of item k (stage_tile needs them once per tile)
+    lds_u32_ptr const rtab = dtab + RAW_IT * 256;                       // [10] item k: pixel relative to the region | halo row << 16 | column << 24 (stage_tile, once per tile)
     lds_u32_ptr const ttab = rtab + RAW_IT * 256;
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) {
@@ -197,7 +211,10 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         // (the per-item values are tables, not registers: kept in registers they get spilled, and a scratch reload in the K loop
         //  drains the weight ring; any per-item VALU arithmetic in the stage loops costs an MFMA <-> VALU switch)
         dtab[k * 256] = (unsigned)(2 * VD_FLOATS * 4 + (r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS
-        rtab[k * 256] = (unsigned)r | ((unsigned)c << 8);
+        // pixel of halo entry (r, c) relative to the region's base pixel (one source row above, one pixel left of the halo origin):
+        // nearest-x2 upsample addressing halves the coordinates -- (16 ty - 1 + r) >> 1 = 8 ty - 1 + ((r + 1) >> 1)
+        const int dy = up ? (r + 1) >> 1 : r, dx = up ? (c + 1) >> 1 : c;
+        rtab[k * 256] = (unsigned)(dy * sW + dx) | ((unsigned)r << 16) | ((unsigned)c << 24);
     }
     // the transform's own lane mapping (any lane may produce any V element): 16 consecutive lanes = 8 tiles x the two channel
     // pairs of a quad, so that the compiler's paired LDS accesses (ds_read2 / ds_write2: 16-lane groups, 32 banks) are conflict-free
@@ -214,20 +231,26 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 
     const unsigned OOB = 0x7FFFFFF0u;                                    // byte offset beyond any tensor: the load returns zeros (padding)
     int sb_ = 0;
+    unsigned spx_ = 0;                                                   // the staged region's base pixel (scalar)
+    bool tab_clean = false;                                              // ptab holds the unmasked table of an interior region
     f32x4 tA4 = {1, 1, 1, 1}, tD4 = {0, 0, 0, 0};                        // AFF: loaded with a chunk's halo, applied when it is written to LDS
     auto stage_tile = [&](int b_, int ty_, int rx_) {
         sb_ = b_;
-        const int y0 = ty_ * 16 - 1, x0 = rx_ * 32 - 1;                  // first halo row / column of the region
+        spx_ = (unsigned)((b_ * sH + ((ty_ * 16) >> up)) * sW + ((rx_ * 32) >> up));
+        // halo rows / columns inside the image (scalars); a region away from the border keeps the table of the one before it
+        const int r_lo = ty_ == 0 ? 1 : 0, r_n = min(17, H - ty_ * 16) - r_lo;
+        const int c_lo = rx_ == 0 ? 1 : 0, c_n = min(33, W - rx_ * 32) - c_lo;
+        const bool interior = r_lo == 0 && r_n == 17 && c_lo == 0 && c_n == 33;
+        if (!(interior && tab_clean)) {
 #pragma unroll
-        for (int k = 0; k < RAW_IT; ++k) {
-            const unsigned rc = rtab[k * 256];
-            const int r = (int)(rc & 255u), c = (int)(rc >> 8);
-            const int gy = y0 + r, gx = x0 + c;
-            const bool ok = r < 18 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;   // (the last round's items beyond pixel 611 have r >= 18)
-            // outside the image: pixel 0xFFFFFF -- x ld4 >= 1 GiB, beyond every source tensor (host check): the load returns the zero padding
-            // outside the image: pixel 0xFFFFFF -- x ld4 >= 1 GiB, beyond every source tensor (host check): the load returns the zero padding
-            ptab[k * 256] = ok ? (unsigned)((b_ * sH + (gy >> up)) * sW + (gx >> up)) : 0xFFFFFFu;
+            for (int k = 0; k < RAW_IT; ++k) {
+                const unsigned rc = rtab[k * 256];
+                const unsigned r = (rc >> 16) & 255u, c = rc >> 24;
+                const bool ok = r - (unsigned)r_lo <= (unsigned)r_n && c - (unsigned)c_lo <= (unsigned)c_n;   // (items beyond pixel 611 have r >= 18)
+                ptab[k * 256] = ok ? (rc & 0xFFFFu) : PX_MARK;            // outside the image: beyond the resource, the load returns the zero padding
+            }
         }
+        tab_clean = interior;
     };
     // the chunk being staged: source, channel base, affine constants of the transform lane
     f32x4 raw[RAW_IT];                                                   // the halo in flight: loaded during a chunk's stage 0, written to LDS during its stage 1
@@ -239,11 +262,11 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     auto stage_issue_begin = [&](int cb_) {
         const bool sec = cb_ >= s.c0;                                    // wave-uniform: a chunk never straddles the sources (host check)
         i_second = sec;
-        i_mapoff = cb_ * 4;
+        i_mapoff = (int)(cb_ * 4u + spx_ * (unsigned)(2 * Ctot * 4));
         i_rs = sec ? rsrc1 : rsrc0;
         i_ld4 = (unsigned)(sec ? s.ld1 : s.ld0) * 4u;
-        i_soff = (sec ? cb_ - s.c0 : cb_) * 4;
-        i_bias = cb_ + 4 * sq < Cin ? 16u * sq : OOB;                    // invalid channel quad: every item out of range (pixel offsets stay below 2^30)
+        i_soff = (int)((sec ? cb_ - s.c0 : cb_) * 4u + spx_ * i_ld4);
+        i_bias = cb_ + 4 * sq < Cin ? 16u * sq : OOB;                    // invalid channel quad: every item out of range
         if (AFF) {                                                       // this thread's channel quad: cb + 4 sq .. + 3
             const int c = cb_ + 4 * sq;
             const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (c < Cin ? c : 0);
@@ -260,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         const unsigned voff = __umul24(px, i_ld4) + i_bias;
         raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i_rs, voff, i_soff, 0));
         if (MAP) {                                                       // the maps have the conv's resolution (host: no upsample with MAP): [pixel][scale C | shift C]
-            const unsigned mo = __umul24(px, (unsigned)(2 * Ctot * 4)) + 16u * sq;
+            const unsigned mo = __umul24(px, (unsigned)(2 * Ctot * 4)) + i_bias;
             msc[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff, 0));
             msh[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff + Ctot * 4, 0));
         }
@@ -273,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         f32x4 v = raw[k];
         if (AFF) {
             // GroupNorm-affine + SiLU on the raw halo (each pixel once: 40 values per thread and chunk); silu(x) = x / (1 + 2^(-x log2 e)).
-            // The zero padding is applied after the activation (silu(affine(0)) != 0): items outside the image carry the 0xFFFFFF mark
+            // The zero padding is applied after the activation (silu(affine(0)) != 0): items outside the image carry PX_MARK
             f32x4 x = v * tA4 + tD4;
             if (MAP) x = x * (msc[k] + 1.0f) + msh[k];                   // ResnetBlock2: x * (scale + 1) + shift per pixel (Diffusion_arch.py:188-192)
             const f32x4 t = x * -1.44269504088896340736f;
@@ -282,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             e = e + 1.0f;
             f32x4 r;
             r.x = __builtin_amdgcn_rcpf(e.x); r.y = __builtin_amdgcn_rcpf(e.y); r.z = __builtin_amdgcn_rcpf(e.z); r.w = __builtin_amdgcn_rcpf(e.w);
-            const bool inside = ptab[k * 256] != 0xFFFFFFu && i_bias != OOB;
+            const bool inside = ptab[k * 256] != PX_MARK && i_bias != OOB;
             const f32x4 zero = {0, 0, 0, 0};
             v = inside ? x * r : zero;
         }
@@ -295,17 +318,23 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     //      ds_read_b128 (twice the bytes per LDS cycle of the 8-byte forms).  MFMA lane: + g2 * 1024 + pp * 2048 bytes
     const unsigned d_lds = (unsigned)((kq >> 1) * 512 + tile * 32 + (kq & 1) * 16);
 
-    // input transform of the staged halo (raw image) into this tile group's V image (this wave: half ch2)
-    auto transform = [&](float* buf) {
-#if !(W4_ABLATE & 4)
-        char* base = reinterpret_cast<char*>(buf) + t_lds;
-        f32x2 T[6][6];
-        unsigned t_addr[12];
+    // input transform of the staged halo (raw image) into this tile group's V image (this wave: half ch2), in three steps so that
+    // the raw reads can run under the tail of a stage: xf_addr (the lane's 12 raw addresses), xf_read (patch row `ay`), xf_finish
+    // (B^T d B in registers, then -- behind the caller's barrier: every wave has read its last V operands -- the V image)
+    auto xf_addr = [&](unsigned (&t_addr)[12]) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) t_addr[i] = ttab[i * 256];
+    };
+    auto xf_read = [&](f32x2 (&T)[6][6], const unsigned (&t_addr)[12], int ay) {
+#if !(W4_ABLATE & 4)
 #pragma unroll
-        for (int e = 0; e < NPOS; ++e)
-            T[e / 6][e % 6] = *reinterpret_cast<const f32x2*>(rawbuf + t_addr[((e / 6) >> 2) * 6 + e % 6] + (e / 6) * (RAW_ROWP * 64));
+        for (int bx = 0; bx < 6; ++bx)
+            T[ay][bx] = *reinterpret_cast<const f32x2*>(rawbuf + t_addr[(ay >> 2) * 6 + bx] + ay * (RAW_ROWP * 64));
+#endif
+    };
+    auto xf_finish = [&](f32x2 (&T)[6][6], float* buf, auto&& before_write) {
+#if !(W4_ABLATE & 4)
+        char* base = reinterpret_cast<char*>(buf) + t_lds;
 #pragma unroll
         for (int bx = 0; bx < 6; ++bx) {                                 // T <- B^T T (over the patch rows, every column)
             f32x2 col[6], t[6];
@@ -316,13 +345,20 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             for (int xi = 0; xi < 6; ++xi) T[xi][bx] = t[xi];
         }
 #pragma unroll
-        for (int xi = 0; xi < 6; ++xi) {                                 // V[xi] = T[xi] B, written back to its position's slot
+        for (int xi = 0; xi < 6; ++xi) {                                 // V[xi] = T[xi] B
             f32x2 v[6];
             w4_bt(T[xi], v);
 #pragma unroll
-            for (int h = 0; h < 3; ++h)                                  // 16 bytes = positions (xi, 2h), (xi, 2h + 1) of this lane's channel pair
-                *reinterpret_cast<f32x4*>(base + (xi * 3 + h) * 2048) = f32x4{v[2 * h].x, v[2 * h].y, v[2 * h + 1].x, v[2 * h + 1].y};
+            for (int bx = 0; bx < 6; ++bx) T[xi][bx] = v[bx];
         }
+        before_write();
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+            for (int h = 0; h < 3; ++h)                                  // 16 bytes = positions (xi, 2h), (xi, 2h + 1) of this lane's channel pair
+                *reinterpret_cast<f32x4*>(base + (xi * 3 + h) * 2048) = f32x4{T[xi][2 * h].x, T[xi][2 * h].y, T[xi][2 * h + 1].x, T[xi][2 * h + 1].y};
+#else
+        before_write();
 #endif
     };
 
@@ -428,13 +464,27 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    transform(vd_tg);
+    {
+        f32x2 T[6][6];
+        unsigned t_addr[12];
+        xf_addr(t_addr);
+#pragma unroll
+        for (int ay = 0; ay < 6; ++ay) xf_read(T, t_addr, ay);
+        xf_finish(T, vd_tg, [] {});
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+#ifdef W4_STAMP
+    stamp_pro = __builtin_amdgcn_s_memtime() - stamp_c0;
+#endif
     for (int t = t_begin; t < t_end; ++t) {
         const bool more = t + 1 < t_end;
-        if (more) decode(t + 1, b1, ty1, rx1, nt1);
+        W4_T0();
+        if (more) {                                                      // the next item: decode(t + 1) without the divisions
+            nt1 = nt + 1;  rx1 = rx;  ty1 = ty;  b1 = b;
+            if (nt1 == a.n_tiles) { nt1 = 0;  if (++rx1 == a.regions_x) { rx1 = 0;  if (++ty1 == a.tiles_y) { ty1 = 0;  ++b1; } } }
+        }
         const int cg = nt * 4 + wave, cg_next = (more ? nt1 : nt) * 4 + wave;          // this wave's 16 output channels
 
         auto chunk = [&](int ch, auto first_c, auto last_c) {
@@ -444,7 +494,14 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             const int c8 = 2 * ch;
             // weight blocks: this chunk's two stages, then the next item's first stage (after the very last item: a harmless reload)
             const int w0 = wblock(c8, cg), w1 = wblock(c8 + 1, cg), wn = last ? wblock(0, cg_next) : wblock(c8 + 2, cg);
+#ifdef W4_STAMP
+            if (decltype(first_c)::value) W4_ACC(stamp_top);
+            W4_T0();
+#endif
             if (last && more) stage_tile(b1, ty1, rx1);                  // from here on the next tile is staged
+#ifdef W4_STAMP
+            if (last) W4_ACC(stamp_tile);
+#endif
             using I0 = std::integral_constant<int, 0>;
             using IOFF1 = std::integral_constant<int, 18 % UR>;
             using IUR = std::integral_constant<int, UR>;
@@ -457,22 +514,39 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 if (pp == 0) stage_issue_begin(last ? 0 : (ch + 1) * KC4);
                 if (pp < RAW_IT) stage_issue_one(pp);
             };
+            f32x2 T[6][6];                                                // the next item's patch of this transform lane: read under the tail of stage 1
+            unsigned t_addr[12];
             auto commit = [&](int pp) {
-                if (AFF || LEAKY) {     // the activation is VALU work: one clump behind the stage's last MFMAs (every MFMA <-> VALU switch costs ~18 cycles)
-                    if (pp == 17) {
+                if (AFF || LEAKY) {     // the activation is VALU work: one clump (every MFMA <-> VALU switch costs ~18 cycles)
+                    if (pp == W4_COMMIT_AT) {
 #pragma unroll
                         for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k);
                     }
-                } else if (pp >= W4_COMMIT_AT && pp < W4_COMMIT_AT + RAW_IT) stage_commit_one(pp - W4_COMMIT_AT);
+                } else if (pp < RAW_IT) stage_commit_one(pp);
+                if (pp == W4_XF_AT) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this thread's share of the raw image is written ...
+                    __builtin_amdgcn_s_barrier();                        // ... and so is every other wave's
+                    xf_addr(t_addr);
+                }
+                if (pp > W4_XF_AT && pp <= W4_XF_AT + 6) xf_read(T, t_addr, pp - W4_XF_AT - 1);
             };
+            W4_T0();
             stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IUR>{}, IUR{}, v0cur, v1cur, w0, w1, issue);
             stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit);
+#ifdef W4_STAMP
+            if (FIRST) W4_ACC(stamp_first);
+            if (last) W4_ACC(stamp_last);
+            if (!FIRST && !last && ch == 1) W4_ACC(stamp_second);
+            if (!FIRST && !last && ch == 2) W4_ACC(stamp_third);
+#endif
             W4_T0();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this thread's share of the raw image is written
-            __builtin_amdgcn_s_barrier();                                // ... and every wave has read its last V operands of this chunk
-            W4_ACC(stamp_wait);
-            W4_T0();
-            transform(vd_tg);
+            xf_finish(T, vd_tg, [&] {
+                W4_ACC(stamp_xf);
+                W4_T0();
+                __builtin_amdgcn_s_barrier();                            // every wave has read its last V operands of this chunk
+                W4_ACC(stamp_wait);
+                W4_T0();
+            });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                // the next item's V images are complete
             W4_ACC(stamp_xf);
@@ -551,6 +625,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #else
                                     if (FULL || cok) nd_st4(lane_out + (size_t)((i * Wt + jj) * ldot), v);
 #endif
+#else
+                                    asm volatile("" :: "v"(v));          // (the output transform stays: only the store is gone)
 #endif
                                 }
                             }
@@ -596,14 +672,20 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     }
 #ifdef W4_STAMP
     if (tid == 0) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.d.slot_count) + 8 * blockIdx.x;
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.d.slot_count) + 16 * blockIdx.x;
         dbg[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
         dbg[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
         dbg[2] = (unsigned long long)(t_end - t_begin) * n_chunks;
         dbg[3] = stamp_epi;
         dbg[4] = stamp_xf;
-        dbg[5] = stamp_wait;
-        dbg[6] = stamp_drain;
+        dbg[5] = stamp_second;      // ... second chunks
+        dbg[6] = stamp_first;       // stage time of the tiles' first chunks (behind an epilogue) ...
+        dbg[7] = stamp_last;        // ... and of their last chunks
+        dbg[8] = stamp_third;
+        dbg[9] = stamp_wait;        // barrier in front of the transform
+        dbg[10] = stamp_pro;        // stagger + prologue
+        dbg[11] = stamp_top;        // loop top: decode of the next tile
+        dbg[12] = stamp_tile;       // stage_tile
     }
 #endif
 }
@@ -681,7 +763,7 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(!aff || s.mad, ND_E_BADARG, "nd_conv3x3_wino4: affine prologue needs mad");
     ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || (s.map && !s.upsample && nd_aligned16(s.map)), ND_E_BADARG,
                "nd_conv3x3_wino4: the map prologue needs a 16-byte aligned map and no upsample addressing");
-    ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || (long)d->B * d->H * d->W * 2 * (s.c0 + s.c1) * 4 < (1L << 30) - 65536, ND_E_SHAPE,
+    ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || (long)(d->B * (long)d->H + 2) * d->W * 2 * (s.c0 + s.c1) * 4 < (1L << 30) - 65536, ND_E_SHAPE,
                "nd_conv3x3_wino4: a scale / shift map of 1 GiB or more");
     ND_REQUIRE(s.mode != ND_PRO_LEAKY_SECOND || s.p1, ND_E_BADARG, "nd_conv3x3_wino4: LEAKY_SECOND needs a second source");
     ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3_wino4: no unshuffle addressing");
@@ -693,8 +775,10 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(d->W <= 2048 && d->H <= 32768, ND_E_SHAPE, "nd_conv3x3_wino4: image wider than 2048 (16-bit border table)");
     {
         const long px = (long)(d->B) * (d->H >> (s.upsample ? 1 : 0)) * (d->W >> (s.upsample ? 1 : 0));
-        ND_REQUIRE(px * s.ld0 * 4 < (1L << 30) - 65536 && px * s.ld1 * 4 < (1L << 30) - 65536, ND_E_SHAPE, "nd_conv3x3_wino4: a source tensor of 1 GiB or more");
-        ND_REQUIRE(s.ld0 >= 16 && (s.c1 == 0 || s.ld1 >= 16), ND_E_SHAPE, "nd_conv3x3_wino4: pixel stride below 16 floats");
+        // byte offsets (region base + relative pixel x stride + the out-of-range bias 0x7FFFFFF0) stay below 2^32, pixels below 2^24
+        const long ext = px + (d->W >> (s.upsample ? 1 : 0)) + 2;
+        ND_REQUIRE(ext * s.ld0 * 4 < (1L << 30) - 65536 && ext * s.ld1 * 4 < (1L << 30) - 65536 && ext < (1L << 24), ND_E_SHAPE,
+                   "nd_conv3x3_wino4: a source tensor of 1 GiB or 16 M pixels or more");
     }
 
     Wino4Args a;

@@ -337,11 +337,12 @@ class Plan:
         # F(4x4,3x3) (1.78x fewer MFMAs again; 16 x 32-pixel regions, 16-channel K chunks) wherever its kernel takes the layer:
         # plain / GroupNorm-affine (+ per-pixel map) + SiLU inputs, concat on a chunk boundary, images that fill its regions, sources below 1 GiB
         up = 1 if src.upsample else 0
-        src_bytes = self.B * (H >> up) * (W >> up) * 4 * max(src.ld0, src.ld1)
+        src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
+        src_bytes = src_px * 4 * max(src.ld0, src.ld1)
         wino4 = (wino and WINO4 and (name + ".weight.wino4") in e.slots and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU)
-                 and not (src.mode == L.PRO_AFFINE_MAP_SILU and (up or self.B * H * W * 8 * cin >= (1 << 30) - (1 << 16)))
+                 and not (src.mode == L.PRO_AFFINE_MAP_SILU and (up or (self.B * H + 2) * W * 8 * cin >= (1 << 30) - (1 << 16)))
                  and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (src.c1 == 0 or (src.c0 % 16 == 0 and not up))
-                 and src.ld0 >= 16 and (src.c1 == 0 or src.ld1 >= 16) and src_bytes < (1 << 30) - (1 << 16)
+                 and src_bytes < (1 << 30) - (1 << 16) and src_px < (1 << 24)
                  and (not up or (H % 2 == 0 and W % 2 == 0)))
         if wino4:
             d.weight = e.p(name + ".weight.wino4")

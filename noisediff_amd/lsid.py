@@ -146,8 +146,8 @@ class _LsidPlan:
         wino2 = wino and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * h * w < (1 << 24) and self.B * h * w * 4 * max(src.ld0, src.ld1) < (1 << 31)
         # F(4x4,3x3) where its kernel takes the layer (same rule as the engine's): the LeakyReLU prologues are applied while the halo is staged
         wino4 = (wino and self.w[name + ".weight"][2] is not None and w >= 32 and (w % 32 == 0 or w >= 96) and w <= 2048
-                 and (src.c1 == 0 or src.c0 % 16 == 0) and src.ld0 >= 16 and (src.c1 == 0 or src.ld1 >= 16)
-                 and self.B * h * w * 4 * max(src.ld0, src.ld1) < (1 << 30) - (1 << 16))
+                 and (src.c1 == 0 or src.c0 % 16 == 0) and self.B * h * w + w + 2 < (1 << 24)
+                 and (self.B * h * w + w + 2) * 4 * max(src.ld0, src.ld1) < (1 << 30) - (1 << 16))
         if wino4:
             d.weight = self.w[name + ".weight"][2].data_ptr()
         self._add("nd_conv3x3_wino4_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else

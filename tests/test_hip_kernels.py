@@ -645,6 +645,28 @@ def test_conv3x3_winograd_f4x4_matches_direct_semantics(ctx, case):
         assert rel_err(hu.nchw(out), F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)) < 5e-5
 
 
+def test_conv3x3_winograd_f4x4_channel_slice_of_a_wider_tensor(ctx):
+    """Sources with a pixel stride above their channel count (a channel slice of a wider NHWC tensor; stride 68 floats: the
+    border padding must not depend on the stride), images with every kind of border region, second region row / batch offsets."""
+    import hiputil as hu
+    B, H, W, cin, cout, ld = 2, 48, 96, 32, 64, 68
+    x = U("slice.x", (B, cin, H, W), -1.5, 1.5)
+    w = U("slice.w", (cout, cin, 3, 3), -0.2, 0.2)
+    b = U("slice.b", (cout,))
+    wide = torch.full((B, H, W, ld), float("nan"))
+    wide[..., 20:20 + cin] = x.permute(0, 2, 3, 1)
+    wide_d = hu.dev(wide)
+    wd, bd = hu.dev(w), hu.dev(b)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    s = L.Src()
+    s.p0, s.c0, s.ld0, s.mode = wide_d.data_ptr() + 20 * 4, cin, ld, L.PRO_NONE
+    s._refs = [wide_d]
+    out, *_ = _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats=False)
+    assert rel_err(hu.nchw(out), F.conv2d(x, w, b, padding=1)) < 5e-5
+
+
 # The shapes that carry the bench workload (SURVEY Appendix A at d=64, 256x256: H/8 = 32x32 with 256..768 input channels and
 # 8 output tiles, 16..24 K chunks; H/4 concat; the full-resolution upsample conv; the 64 -> 64 layer at 256x256).
 # (B, H, W, cin, cout, first-source channels of a virtual concat or 0, nearest-x2 upsample addressing)

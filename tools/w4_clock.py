@@ -13,7 +13,7 @@ for (B, H, W, cin, cout) in [(16, 256, 256, 64, 64), (16, 32, 32, 512, 512)]:
     wd = hu.dev(w); wp = torch.empty(ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout), device=hu.DEV)
     L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream); ctx.sync()
     out = torch.empty(B, H, W, cout, device=hu.DEV)
-    dbg = torch.zeros(8 * 256, dtype=torch.int64, device=hu.DEV)
+    dbg = torch.zeros(16 * 256, dtype=torch.int64, device=hu.DEV)
     st = torch.zeros(B * ctx.lib.nd_conv3x3_wino_stat_slots(H, W) * cout * 2, device=hu.DEV)
     torch.cuda.synchronize()
     d = L.Conv3x3(); d.src, d.weight, d.out = hu.src(x), wp.data_ptr(), out.data_ptr()
@@ -21,11 +21,13 @@ for (B, H, W, cin, cout) in [(16, 256, 256, 64, 64), (16, 32, 32, 512, 512)]:
     d.slot_count = dbg.data_ptr(); d.stats = st.data_ptr()
     for _ in range(3):
         L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream); ctx.sync()
-    v = dbg.cpu().view(256, 8).double()
-    cyc, real, chunks, epi, xf, wait, drain = (v[:, i] for i in range(7))
+    v = dbg.cpu().view(256, 16).double()
+    cyc, real, chunks, epi, xf, second, first, last, third, wait, pro, top, stile = (v[:, i] for i in range(13))
     n_chunks = (cin + 15) // 16
     mhz = cyc / (real / 100.0)
     per = lambda t: float((t / chunks).mean())
-    print((B, H, W, cin, cout), f"clock {mhz.mean():.0f} MHz (min {mhz.min():.0f} max {mhz.max():.0f}); cycles/chunk {per(cyc):.0f} (MFMA 9216):",
-          f"stages {per(cyc - epi - xf - wait):.0f}, wait+barrier {per(wait):.0f}, transform+barrier {per(xf):.0f}, epilogue {per(epi):.0f}"
-          f" (= {float((epi / (chunks / n_chunks)).mean()):.0f} per tile), drain {float((drain / (chunks / n_chunks)).mean()):.0f} per tile; wall/WG {float(real.mean()) / 100:.1f} us", flush=True)
+    tiles = chunks / n_chunks
+    pt = lambda t: float((t / tiles).mean())
+    print((B, H, W, cin, cout), f"clock {mhz.mean():.0f} MHz (min {mhz.min():.0f} max {mhz.max():.0f}); wall/WG {float(real.mean()) / 100:.1f} us, {float(tiles.mean()):.0f} tiles x {n_chunks} chunks;",
+          f"per tile: {pt(cyc):.0f} cycles (MFMA {9216 * n_chunks}) = stages of chunk 0 {pt(first):.0f}, chunk 1 {pt(second):.0f}, chunk 2 {pt(third):.0f}, last {pt(last):.0f},",
+          f"all chunks {pt(cyc - epi - xf - wait - pro):.0f}; barrier waits {pt(wait):.0f}, transforms {pt(xf):.0f}, epilogue {pt(epi):.0f}; loop top {pt(top):.0f}, stage_tile {pt(stile):.0f}; per WG: stagger + prologue {float(pro.mean()):.0f}", flush=True)
