@@ -37,6 +37,7 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(3))) short* lds_short_ptr;
 typedef __attribute__((address_space(3))) unsigned* lds_u32_ptr;
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         W4_T0();
         W4_MFMA_DRAIN();
 
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d.out, 0, (int)((unsigned)a.d.B * H * W * a.d.ldo * 4u), 0x00020000);
         int Wt = __builtin_amdgcn_readfirstlane(W), ldot = __builtin_amdgcn_readfirstlane(a.d.ldo);
         asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the 16 store offsets from being hoisted into (spilled) SGPRs
 #pragma unroll
@@ -578,7 +580,9 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 int cnt = 0;
                 const bool full = ty * 16 + 16 <= H && tx * 16 + 16 <= W && cg * 16 + 16 <= Cout;      // wave-uniform
                 const bool want_stats = a.d.stats != nullptr;
-                float* lane_out = a.d.out + (((size_t)b * H + py0) * Wt + px0) * ldot + co;
+                // stores: buffer addressing -- one 32-bit lane offset per tile + one 32-bit add per output pixel instead of 64-bit
+                // address arithmetic on scalar pairs (the output stays below 4 GiB, host check)
+                const unsigned lane_off = (unsigned)((((unsigned)b * H + py0) * Wt + px0) * ldot + co) * 4u;
                 // two output rows at a time (Z[2][6]: the full Z[4][6] next to the live weight ring and the accumulators that sit in
                 // ordinary registers does not fit the 256 registers VALU instructions can address)
                 auto emit = [&](auto full_c, auto stats_c) {
@@ -620,10 +624,11 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #if !(W4_ABLATE & 8)
 #if W4_ABLATE & 128                 // timing experiment only (results land in the wrong pixels): every wave store covers eight whole 128-byte lines
                                     if (FULL || cok) nd_st4(a.d.out + (((size_t)b * H + ty * 16 + (i * 4 + jj)) * Wt + tx * 16) * ldot + wave * 256 + lane * 4, v);
-#elif W4_NT_STORE
-                                    if (FULL || cok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(lane_out + (size_t)((i * Wt + jj) * ldot)));
 #else
-                                    if (FULL || cok) nd_st4(lane_out + (size_t)((i * Wt + jj) * ldot), v);
+                                    if (FULL || cok)
+                                        // (the pixel offset goes through the vector offset: with it in the scalar offset field the
+                                        //  kernel stored wrong values for one lane quad -- not understood, measured)
+                                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), orsrc, lane_off + (unsigned)((i * Wt + jj) * ldot * 4), 0, W4_NT_STORE ? 2 : 0);
 #endif
 #else
                                     asm volatile("" :: "v"(v));          // (the output transform stays: only the store is gone)
@@ -780,6 +785,8 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
         ND_REQUIRE(ext * s.ld0 * 4 < (1L << 30) - 65536 && ext * s.ld1 * 4 < (1L << 30) - 65536 && ext < (1L << 24), ND_E_SHAPE,
                    "nd_conv3x3_wino4: a source tensor of 1 GiB or 16 M pixels or more");
     }
+
+    ND_REQUIRE((long)d->B * d->H * d->W * d->ldo * 4 < (1L << 32) - 65536, ND_E_SHAPE, "nd_conv3x3_wino4: an output tensor of 4 GiB or more");
 
     Wino4Args a;
     a.d = *d;
