@@ -26,7 +26,7 @@ struct PwArgs {
 };
 
 // Epilogue shared by both kernels: accumulators -> LDS -> (bias, activation, residuals, fused ResnetBlock tail) -> global.
-template <int MB, int NB>
+template <int MB, int NB, int JB = 0>
 __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][NB], float* As, int b, int p0, int n0) {
     constexpr int BM = 2 * MB * 32, BN = 2 * NB * 32;
     constexpr int LDO = BN + 4;                               // output tile row stride in LDS (floats)
@@ -67,29 +67,34 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
         }
         float* out = a.d.out;
         if (vec_ok) {
-            f32x4 r0[BM / RPI], r1[BM / RPI], rt[BM / RPI];
+            constexpr int NJ = BM / RPI, JBLK = JB > 0 ? JB : NJ;  // residual reads in flight together: a block of JBLK rows per thread
+            static_assert(NJ % JBLK == 0, "row block");
+#pragma unroll 1
+            for (int j0 = 0; j0 < NJ; j0 += JBLK) {
+                f32x4 r0[JBLK], r1[JBLK], rt[JBLK];
 #pragma unroll
-            for (int j = 0; j < BM / RPI; ++j) {              // all residual reads in flight together
-                const size_t pix = (size_t)b * HW + min(p0 + rbase + j * RPI, HW - 1);
-                r0[j] = a.d.res0 ? nd_ld4(a.d.res0 + pix * a.d.ldr0 + ns) : zero;
-                r1[j] = a.d.res1 ? nd_ld4(a.d.res1 + pix * a.d.ldr1 + ns) : zero;
-                rt[j] = a.d.gn_t ? nd_ld4(a.d.gn_t + pix * a.d.ldt + ns) : zero;
-            }
+                for (int j = 0; j < JBLK; ++j) {
+                    const size_t pix = (size_t)b * HW + min(p0 + rbase + (j0 + j) * RPI, HW - 1);
+                    r0[j] = a.d.res0 ? nd_ld4(a.d.res0 + pix * a.d.ldr0 + ns) : zero;
+                    r1[j] = a.d.res1 ? nd_ld4(a.d.res1 + pix * a.d.ldr1 + ns) : zero;
+                    rt[j] = a.d.gn_t ? nd_ld4(a.d.gn_t + pix * a.d.ldt + ns) : zero;
+                }
 #pragma unroll
-            for (int j = 0; j < BM / RPI; ++j) {
-                const int r = rbase + j * RPI;
-                f32x4 v = nd_ld4(&As[r * LDO + q * 4]) + bias4;
-                if (a.d.act == ND_ACT_GELU) { v.x = nd_gelu(v.x); v.y = nd_gelu(v.y); v.z = nd_gelu(v.z); v.w = nd_gelu(v.w); }
-                else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
-                v += r0[j] + r1[j] + vadd4;
-                if (a.d.gn_t) v += nd_silu4((rt[j] - gM) * gA + gD);
-                if (a.d.shuffle_c > 0) {       // ConvTranspose2d(2, stride 2): scatter to pixel (2y+p1, 2x+p2), channel c
-                    const int p = p0 + r, y = p / W, x = p - y * W;
-                    const int sub = n / a.d.shuffle_c, cch = n - sub * a.d.shuffle_c;
-                    const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
-                    if (p < HW && oy < a.d.shuffle_h && ox < a.d.shuffle_w)
-                        nd_st4(out + ((size_t)(b * a.d.shuffle_h + oy) * a.d.shuffle_w + ox) * a.d.ldo + cch, v);
-                } else if (p0 + r < HW) nd_st4(out + ((size_t)b * HW + p0 + r) * a.d.ldo + n, v);
+                for (int j = 0; j < JBLK; ++j) {
+                    const int r = rbase + (j0 + j) * RPI;
+                    f32x4 v = nd_ld4(&As[r * LDO + q * 4]) + bias4;
+                    if (a.d.act == ND_ACT_GELU) { v.x = nd_gelu(v.x); v.y = nd_gelu(v.y); v.z = nd_gelu(v.z); v.w = nd_gelu(v.w); }
+                    else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
+                    v += r0[j] + r1[j] + vadd4;
+                    if (a.d.gn_t) v += nd_silu4((rt[j] - gM) * gA + gD);
+                    if (a.d.shuffle_c > 0) {       // ConvTranspose2d(2, stride 2): scatter to pixel (2y+p1, 2x+p2), channel c
+                        const int p = p0 + r, y = p / W, x = p - y * W;
+                        const int sub = n / a.d.shuffle_c, cch = n - sub * a.d.shuffle_c;
+                        const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
+                        if (p < HW && oy < a.d.shuffle_h && ox < a.d.shuffle_w)
+                            nd_st4(out + ((size_t)(b * a.d.shuffle_h + oy) * a.d.shuffle_w + ox) * a.d.ldo + cch, v);
+                    } else if (p0 + r < HW) nd_st4(out + ((size_t)b * HW + p0 + r) * a.d.ldo + n, v);
+                }
             }
         } else if (nvalid) {                                  // ragged channel tail (cout % 4 != 0): scalar path
             for (int j = 0; j < BM / RPI; ++j) {
@@ -259,6 +264,155 @@ __global__ __launch_bounds__(256, (MB == 1 ? PW_PIPE_OCC : 2)) void pointwise_pi
 #undef PW_STEP
 
     pw_epilogue<MB, NB>(a, acc, As, b, p0, n0);
+}
+
+// ---- large-tile variant for the wide layers (cin % 64 == 0, cout % 128 == 0): one workgroup per CU, ONE WAVE PER SIMD with the
+// whole register file -- the design that carries conv3x3_wino2 / wino4.  Tile = 128 pixels x 128 or 256 couts, a wave owns 64 x 64
+// or 64 x 128 of it: 4 or 8 accumulators of 32 x 32 pinned in the AGPR half by inline-asm MFMAs, so one A fragment serves NB and one
+// B fragment two MFMAs (6 operand registers per 8 MFMAs; the 64 x 128 tiles of the kernel above move 3 per 2).  K in chunks of 64:
+// a barrier every 16 k MFMA cycles instead of every 2 k; the next chunk's activations are requested at the start of a chunk and
+// written (prologue applied) to the other LDS buffer in its middle; weight fragments run three 8-channel groups ahead in a register
+// ring that crosses chunk boundaries.  Everything between two MFMA groups is loads -- the fp32 MFMA and the VALU share issue cycles.
+#define PWB_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+constexpr int BKC = 64, BLDA = BKC + 4;
+
+#ifndef PWB_OCC2
+#define PWB_OCC2 1           // workgroups per CU of the 128-cout form (2: both fit, but they run in phase -- epilogues do not overlap MFMAs; measured slower)
+#endif
+template <int NB, int MODE>
+__global__ __launch_bounds__(256, (NB == 2 ? PWB_OCC2 : 1)) void pointwise_big_kernel(const PwArgs a) {
+    constexpr int MB = 2, BM = 2 * MB * 32;                   // 128 pixels
+    constexpr int SIT = BM / 16;                              // staging passes: 128 rows x 16 channel quads / 256 threads
+    constexpr int ABUF = BM * BLDA;
+    extern __shared__ __attribute__((aligned(16))) float Ab[]; // two A buffers during the K loop, the output tile in the epilogue
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, col = lane & 31;
+
+    int lid = nd_xcd_remap(blockIdx.x, a.total_wg);
+    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
+    const int mt = lid % a.m_tiles;
+    const int b = lid / a.m_tiles;
+
+    const nd_src& s = a.d.src;
+    const int HW = a.d.HW, Cin = a.d.cin;
+    const int p0 = mt * BM, n0 = nt * (2 * NB * 32);
+
+    int a_off[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_off[mb] = ((wm * MB + mb) * 32 + col) * BLDA + 4 * half;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d.weight), 0, a.cinP * a.coutP * 4, 0x00020000);
+    const unsigned wvoff = (unsigned)((half * a.coutP + n0 + wn * NB * 32 + col) * 16);
+    // activations through buffer resources: 32-bit row offsets (the host checks that the sources stay below 4 GiB)
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)((unsigned)a.d.B * HW * s.ld0 * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0,
+                                                                          (int)((unsigned)a.d.B * HW * (s.p1 ? s.ld1 : s.ld0) * 4u), 0x00020000);
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = nd_zero16();
+
+    const int quad = tid & 15, prow = tid >> 4;
+    unsigned rowoff0[SIT], rowoff1[SIT];                      // byte offset of this thread's rows (+ its channel quad)
+    float rmean[SIT], rrstd[SIT];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const unsigned pix = (unsigned)b * HW + min(p0 + prow + it * 16, HW - 1);
+        rowoff0[it] = pix * (unsigned)s.ld0 * 4u + quad * 16u;
+        rowoff1[it] = pix * (unsigned)s.ld1 * 4u + quad * 16u;
+        rmean[it] = 0.0f; rrstd[it] = 1.0f;
+        if (MODE == ND_PRO_LAYERNORM) {                       // host: rowstats present
+            rmean[it] = s.rowstats[2 * (size_t)pix];
+            rrstd[it] = s.rowstats[2 * (size_t)pix + 1];
+        }
+    }
+
+    f32x4 bq[4][NB], av[2][MB], raw[SIT];
+    f32x4 pA, pB, pC;                                          // per-chunk channel constants of the prologue
+    auto load_b = [&](int slot, int cb, int g) {               // weight fragments of channels cb + 8g .. + 7
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            bq[slot & 3][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wrsrc, wvoff, __builtin_amdgcn_readfirstlane((((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 16), 0));
+    };
+    auto load_a = [&](int slot, const float* src, int g) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[slot & 1][mb] = nd_ld4(&src[a_off[mb] + g * 8]);
+    };
+    auto stage_load = [&](int cb) {
+        const bool sec = cb >= s.c0;                          // wave-uniform: a 64-channel chunk never straddles the sources (host check)
+        const int soff = __builtin_amdgcn_readfirstlane((sec ? cb - s.c0 : cb) * 4);
+        if (sec) {
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, rowoff1[it], soff, 0));
+        } else {
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) raw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, rowoff0[it], soff, 0));
+        }
+        const int c = cb + quad * 4;
+        if (MODE == ND_PRO_LAYERNORM) {
+            const f32x4 zero = {0, 0, 0, 0};
+            pA = nd_ld4(s.gamma + c); pB = nd_ld4(s.beta + c);
+            pC = s.vec ? nd_ld4(s.vec + (size_t)b * Cin + c) : zero;
+        }
+        if (MODE == ND_PRO_AFFINE_SILU) {
+            const float* m = s.mad + (size_t)b * 3 * Cin + c;
+            pA = nd_ld4(m); pB = nd_ld4(m + Cin); pC = nd_ld4(m + 2 * Cin);
+        }
+    };
+    auto stage_write = [&](float* dst) {
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int r = prow + it * 16;
+            f32x4 v = raw[it];
+            if (MODE == ND_PRO_LAYERNORM) v = ((v + pC) - rmean[it]) * rrstd[it] * pA + pB;
+            else if (MODE == ND_PRO_SILU) v = nd_silu4(v);
+            else if (MODE == ND_PRO_AFFINE_SILU) v = nd_silu4((v - pA) * pB + pC);
+            else if (MODE == ND_PRO_LEAKY) v = nd_leaky4(v);
+            const f32x4 zero = {0, 0, 0, 0};
+            v = (p0 + r < HW) ? v : zero;
+            nd_st4(&dst[r * BLDA + quad * 4], v);
+        }
+    };
+
+    const int n_chunks = a.cinP / BKC;
+    stage_load(0);
+    load_b(0, 0, 0);  load_b(1, 0, 1);  load_b(2, 0, 2);
+    stage_write(Ab);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const float* cur = Ab + (c & 1) * ABUF;
+        float* nxt = Ab + ((c + 1) & 1) * ABUF;
+        const int cb = c * BKC, cbn = (c + 1 < n_chunks ? c + 1 : c) * BKC;      // behind the last chunk: a harmless re-stage of it
+        load_a(0, cur, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            // (no branch between a load and the MFMAs it overlaps, see above; sched_barriers pin load / MFMA order)
+            if (g + 3 < 8) load_b(g + 3, cb, g + 3); else load_b(g + 3, cbn, g + 3 - 8);
+            if (g + 1 < 8) load_a(g + 1, cur, g + 1);
+            if (g == 0) stage_load(cbn);
+            if (g == 4) stage_write(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) PWB_MFMA(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                       // the other buffer is complete, this one has been consumed
+    }
+    // the MFMAs are asm statements: hipcc does not know their results are still in flight
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+a"(acc[mb][nb]));
+    pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0);
 }
 
 // NOTE on code shape: every global load below is unconditional (clamped address + select) and the prologue mode is a
@@ -455,6 +609,27 @@ void launch_pipe(const PwArgs& a, hipStream_t st) {
     }
 }
 
+template <int NB>
+int launch_big(const PwArgs& a, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * (2 * 128 * BLDA > 128 * (64 * NB + 4) ? 2 * 128 * BLDA : 128 * (64 * NB + 4));
+    const dim3 grid(a.total_wg), block(256);
+#define PWB_LAUNCH(MODE)                                                                                                      \
+    {                                                                                                                         \
+        static nd_device_once configured;                                                                                     \
+        if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(pointwise_big_kernel<NB, MODE>), lds, "nd_pointwise")) return e; \
+        hipLaunchKernelGGL((pointwise_big_kernel<NB, MODE>), grid, block, lds, st, a);                                        \
+    }
+    switch (a.d.src.mode) {
+        case ND_PRO_LAYERNORM: PWB_LAUNCH(ND_PRO_LAYERNORM) break;
+        case ND_PRO_SILU: PWB_LAUNCH(ND_PRO_SILU) break;
+        case ND_PRO_AFFINE_SILU: PWB_LAUNCH(ND_PRO_AFFINE_SILU) break;
+        case ND_PRO_LEAKY: PWB_LAUNCH(ND_PRO_LEAKY) break;
+        default: PWB_LAUNCH(ND_PRO_NONE)
+    }
+#undef PWB_LAUNCH
+    return 0;
+}
+
 template <int MB, int NB>
 void launch(const PwArgs& a, hipStream_t st) {
     const dim3 grid(a.total_wg), block(256);
@@ -548,6 +723,22 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     static const bool use_pipe = !(getenv("ND_PW_PIPE") && atoi(getenv("ND_PW_PIPE")) == 0);   // A/B knob (tools/ only)
     const bool pipe = use_pipe && d->cin % PKC == 0 && d->cin >= 2 * PKC && !s.unshuffle &&
                       (s.mode != ND_PRO_LAYERNORM || s.rowstats) && (s.c1 == 0 || nd_aligned16(s.p1));
+    // large tiles, one wave per SIMD: wide layers with enough 128-pixel tiles to fill the chip
+    static const int use_big = getenv("ND_PW_BIG") ? atoi(getenv("ND_PW_BIG")) : 1;            // A/B knob (tools/ only): 0 off, 3 = 256-cout tiles where they fill the chip (measured slower than 128)
+    if (pipe && use_big && d->cin % BKC == 0 && d->cin >= 2 * BKC && d->cout % 128 == 0 && d->shuffle_c == 0 &&
+        (s.c1 == 0 || s.c0 % BKC == 0) && (long)d->B * d->HW * s.ld0 * 4 < (1L << 32) && (long)d->B * d->HW * s.ld1 * 4 < (1L << 32)) {
+        const long mt = nd_cdiv(d->HW, 128);
+        const int cus = nd_device_cus();
+        const bool wide = use_big == 3 && d->cout % 256 == 0 && (long)d->B * mt * (d->cout / 256) >= cus;
+        const long tiles = (long)d->B * mt * (d->cout / (wide ? 256 : 128));
+        if (tiles >= cus) {
+            a.m_tiles = (int)mt;
+            a.n_tiles = d->cout / (wide ? 256 : 128);
+            a.total_wg = (int)tiles;
+            if (int e = wide ? launch_big<4>(a, st) : launch_big<2>(a, st)) return e;
+            return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
+        }
+    }
     if (pipe) {
         if (mb == 2 && nb == 2) launch_pipe<2, 2>(a, st);
         else if (mb == 2) launch_pipe<2, 1>(a, st);

@@ -352,6 +352,38 @@ def test_pointwise_pipelined_chunks_concat_and_prologues(ctx, cin):
     assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
 
 
+def test_pointwise_large_tile_kernel(ctx):
+    """The one-wave-per-SIMD form of the 1x1 GEMM (pointwise_big_kernel: cin % 64 == 0, cout % 128 == 0 and at least one 128-pixel
+    tile per CU): 3 chunks of 64 channels, a ragged last pixel tile, concat on a chunk boundary, every prologue, all epilogue operands."""
+    import hiputil as hu
+    B, HW, W, cin, cout = 2, 8200, 100, 192, 256              # 2 x 65 x 2 = 260 workgroups
+    x = U("big.x", (B, HW, cin), -1.5, 1.5)
+    w, b = U("big.w", (cout, cin), -0.2, 0.2), U("big.b", (cout,))
+    wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
+    lin = F.linear(x, w, b)
+    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
+    xa, xb = hu.dev(x[..., :128].contiguous()), hu.dev(x[..., 128:].contiguous())
+    assert rel_err(hu.pointwise(ctx, hu.src(xa, xb), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
+    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_SILU), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(F.silu(x), w, b)) < TOL
+    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_LEAKY), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(F.leaky_relu(x, 0.2), w, b)) < TOL
+    mad = U("big.mad", (B, 3, cin), 0.5, 1.5)
+    ref = F.linear(F.silu((x - mad[:, None, 0]) * mad[:, None, 1] + mad[:, None, 2]), w, b)
+    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_AFFINE_SILU, mad=hu.dev(mad)), wp, bd, B, HW, W, cin, cout).cpu(), ref) < TOL
+    vec, g, be = U("big.v", (B, cin)), U("big.g", (cin,), 0.5, 1.5), U("big.be", (cin,))
+    rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
+    L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
+    ctx.sync()
+    s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
+    ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
+    assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
+    # epilogue operands: two residuals, a per-sample vector, the fused ResnetBlock tail silu(GroupNorm-affine(t))
+    r0, r1, ov, t = U("big.r0", (B, HW, cout)), U("big.r1", (B, HW, cout)), U("big.ov", (B, cout)), U("big.t", (B, HW, cout), -1.5, 1.5)
+    tm = U("big.tm", (B, 3, cout), 0.5, 1.5)
+    ref = lin + r0 + r1 + ov[:, None] + F.silu((t - tm[:, None, 0]) * tm[:, None, 1] + tm[:, None, 2])
+    out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), res1=hu.dev(r1), vec=hu.dev(ov), gn_t=hu.dev(t), gn_mad=hu.dev(tm))
+    assert rel_err(out.cpu(), ref) < TOL
+
+
 def test_affine_silu_add_and_rmsnorm(ctx):
     import hiputil as hu
     B, HW, Cc = 3, 100, 48
