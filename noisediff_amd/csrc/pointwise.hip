@@ -22,12 +22,12 @@ constexpr int LDA = KC + 4;
 
 struct PwArgs {
     nd_pointwise d;
-    int m_tiles, n_tiles, coutP, cinP, total_wg;
+    int m_tiles, n_tiles, coutP, cinP, total_wg, cus, stagger, stagger_shift;
 };
 
 // Epilogue shared by both kernels: accumulators -> LDS -> (bias, activation, residuals, fused ResnetBlock tail) -> global.
 template <int MB, int NB, int JB = 0>
-__device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][NB], float* As, int b, int p0, int n0) {
+__device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][NB], float* As, int b, int p0, int n0, unsigned long long* ph = nullptr) {   // ph: diagnostic phase stamps
     constexpr int BM = 2 * MB * 32, BN = 2 * NB * 32;
     constexpr int LDO = BN + 4;                               // output tile row stride in LDS (floats)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,7 +38,9 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
     // Accumulators go through LDS so that every global access of the epilogue (residual reads, the store) is a
     // 16-byte-per-lane, row-contiguous access like the staging loads -- 4x fewer memory instructions than storing
     // the MFMA layout directly (one dword per lane), which capped these HBM-bound layers at ~1.7 TB/s of writes.
+    if (ph) ph[0] = __builtin_amdgcn_s_memtime();
     __syncthreads();                                          // all waves are done reading the A tile
+    if (ph) ph[1] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -46,7 +48,9 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 As[((wm * MB + mb) * 32 + nd_acc_row(r, lane)) * LDO + (wn * NB + nb) * 32 + col] = acc[mb][nb][r];
+    if (ph) ph[2] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (ph) ph[3] = __builtin_amdgcn_s_memtime();
     {
         constexpr int QPR = BN / 4;                           // quads per tile row
         constexpr int RPI = 256 / QPR;                        // rows covered per pass of the 256 threads
@@ -66,9 +70,70 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
             }
         }
         float* out = a.d.out;
-        if (vec_ok) {
-            constexpr int NJ = BM / RPI, JBLK = JB > 0 ? JB : NJ;  // residual reads in flight together: a block of JBLK rows per thread
-            static_assert(NJ % JBLK == 0, "row block");
+        constexpr int NJ = BM / RPI, JBLK = JB > 0 ? JB : NJ;  // residual reads in flight together: a block of JBLK rows per thread
+        static_assert(NJ % JBLK == 0, "row block");
+        if (vec_ok && p0 + BM <= HW && a.d.shuffle_c == 0) {
+            // whole tile inside the image (the common case): row pointers advance by a scalar stride -- no per-row multiplies, clamps
+            // or bounds tests.  Every VALU instruction here waits behind the 64-cycle MFMAs of the workgroup that shares the SIMDs.
+            const size_t pix0 = (size_t)b * HW + p0 + rbase;
+            float* orow = out + pix0 * a.d.ldo + n;
+            const float* p_r0 = a.d.res0 ? a.d.res0 + pix0 * a.d.ldr0 + ns : nullptr;
+            const float* p_r1 = a.d.res1 ? a.d.res1 + pix0 * a.d.ldr1 + ns : nullptr;
+            const float* p_t = a.d.gn_t ? a.d.gn_t + pix0 * a.d.ldt + ns : nullptr;
+            const float* lrow = As + rbase * LDO + q * 4;
+            const int so = RPI * a.d.ldo, s0 = RPI * a.d.ldr0, s1 = RPI * a.d.ldr1, st = RPI * a.d.ldt;
+            const int act = a.d.act;
+            constexpr int FB = JB > 0 ? 4 : 2;                    // rows per thread in flight (a float4 each of the tile, two residuals, the tail input); 2 where 168 registers must do
+            static_assert(NJ % FB == 0, "row block");
+#pragma unroll 1
+            for (int j0 = 0; j0 < NJ; j0 += FB) {
+                f32x4 r0[FB], r1[FB], rt[FB];
+                if (p_r0) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) r0[j] = nd_ld4(p_r0 + (size_t)(j * s0));
+                    p_r0 += (size_t)(FB * s0);
+                }
+                if (p_r1) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) r1[j] = nd_ld4(p_r1 + (size_t)(j * s1));
+                    p_r1 += (size_t)(FB * s1);
+                }
+                if (p_t) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) rt[j] = nd_ld4(p_t + (size_t)(j * st));
+                    p_t += (size_t)(FB * st);
+                }
+                f32x4 v[FB];
+#pragma unroll
+                for (int j = 0; j < FB; ++j) v[j] = nd_ld4(lrow + (j0 + j) * (RPI * LDO)) + bias4;
+                if (act == ND_ACT_GELU) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) { v[j].x = nd_gelu(v[j].x); v[j].y = nd_gelu(v[j].y); v[j].z = nd_gelu(v[j].z); v[j].w = nd_gelu(v[j].w); }
+                } else if (act == ND_ACT_SILU) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) v[j] = nd_silu4(v[j]);
+                }
+                if (a.d.vec) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) v[j] += vadd4;
+                }
+                if (p_r0) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) v[j] += r0[j];
+                }
+                if (p_r1) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) v[j] += r1[j];
+                }
+                if (p_t) {
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) v[j] += nd_silu4((rt[j] - gM) * gA + gD);
+                }
+#pragma unroll
+                for (int j = 0; j < FB; ++j) nd_st4(orow + (size_t)(j * so), v[j]);
+                orow += (size_t)(FB * so);
+            }
+        } else if (vec_ok) {
 #pragma unroll 1
             for (int j0 = 0; j0 < NJ; j0 += JBLK) {
                 f32x4 r0[JBLK], r1[JBLK], rt[JBLK];
@@ -274,15 +339,22 @@ __global__ __launch_bounds__(256, (MB == 1 ? PW_PIPE_OCC : 2)) void pointwise_pi
 // written (prologue applied) to the other LDS buffer in its middle; weight fragments run three 8-channel groups ahead in a register
 // ring that crosses chunk boundaries.  Everything between two MFMA groups is loads -- the fp32 MFMA and the VALU share issue cycles.
 #define PWB_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#define PWB_MFMA_V(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 constexpr int BKC = 64, BLDA = BKC + 4;
 
 #ifndef PWB_OCC2
-#define PWB_OCC2 1           // workgroups per CU of the 128-cout form (2: both fit, but they run in phase -- epilogues do not overlap MFMAs; measured slower)
+#define PWB_OCC2 2           // workgroups per CU of the 128-cout form.  2: accumulators in ordinary registers (64 + ~150 fit 256), the second
+#endif                       // workgroup of a CU starts PWB_STAGGER x 64 cycles late so that one's epilogue runs under the other's MFMAs
+#ifndef PWB_STAGGER
+#define PWB_STAGGER 384
 #endif
 template <int NB, int MODE>
 __global__ __launch_bounds__(256, (NB == 2 ? PWB_OCC2 : 1)) void pointwise_big_kernel(const PwArgs a) {
     constexpr int MB = 2, BM = 2 * MB * 32;                   // 128 pixels
+    constexpr bool VACC = NB == 2 && PWB_OCC2 == 2;           // two workgroups per CU: 256 registers each, no AGPR half to pin into
     constexpr int SIT = BM / 16;                              // staging passes: 128 rows x 16 channel quads / 256 threads
+    if (VACC && (int)blockIdx.x < 2 * a.cus && (((int)blockIdx.x >> a.stagger_shift) & 1))   // the second workgroup a CU receives:
+        for (int k = 0; k < a.stagger; k += 16) __builtin_amdgcn_s_sleep(16);  // a.stagger x 64 cycles late; later workgroups inherit the phase
     constexpr int ABUF = BM * BLDA;
     extern __shared__ __attribute__((aligned(16))) float Ab[]; // two A buffers during the K loop, the output tile in the epilogue
 
@@ -379,10 +451,16 @@ __global__ __launch_bounds__(256, (NB == 2 ? PWB_OCC2 : 1)) void pointwise_big_k
     };
 
     const int n_chunks = a.cinP / BKC;
+#ifdef PWB_STAMP                 // diagnostic (tools/pw_clock.py): phase stamps of a workgroup, written over the first 32 bytes of its output tile
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     stage_load(0);
     load_b(0, 0, 0);  load_b(1, 0, 1);  load_b(2, 0, 2);
     stage_write(Ab);
     __syncthreads();
+#ifdef PWB_STAMP
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int c = 0; c < n_chunks; ++c) {
         const float* cur = Ab + (c & 1) * ABUF;
         float* nxt = Ab + ((c + 1) & 1) * ABUF;
@@ -401,18 +479,39 @@ __global__ __launch_bounds__(256, (NB == 2 ? PWB_OCC2 : 1)) void pointwise_big_k
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) PWB_MFMA(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (VACC) PWB_MFMA_V(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
+                        else PWB_MFMA(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
+                    }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                       // the other buffer is complete, this one has been consumed
     }
+#ifdef PWB_STAMP
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
     // the MFMAs are asm statements: hipcc does not know their results are still in flight
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+a"(acc[mb][nb]));
+        for (int nb = 0; nb < NB; ++nb) {
+            if (VACC) asm volatile("" : "+v"(acc[mb][nb])); else asm volatile("" : "+a"(acc[mb][nb]));
+        }
+#ifdef PWB_STAMP
+    unsigned long long ph[4];
+    pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0, ph);
+#else
     pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0);
+#endif
+#ifdef PWB_STAMP
+    if (tid == 0) {                                           // (row 0, columns 0-7 of the tile are this wave's own stores: program order)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.d.out + ((size_t)b * HW + p0) * a.d.ldo + n0);
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        o[0] = st1 - st0;  o[1] = st2 - st1;  o[2] = st3 - st2;
+        o[3] = (ph[1] - ph[0]) | ((ph[2] - ph[1]) << 16) | ((ph[3] - ph[2]) << 32) | ((st3 - ph[3]) << 48);    // 16 bits each: barrier, acc -> LDS, barrier, rows -> global
+    }
+#endif
 }
 
 // NOTE on code shape: every global load below is unconditional (clamped address + select) and the prologue mode is a
@@ -702,6 +801,7 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     ND_REQUIRE(d->act >= ND_ACT_NONE && d->act <= ND_ACT_SILU, ND_E_BADARG, "nd_pointwise: bad act");
 
     PwArgs a;
+    a.cus = 1;  a.stagger = 0;  a.stagger_shift = 8;
     a.d = *d;
     a.cinP = nd_round_up(d->cin, 8);
     a.coutP = nd_round_up(d->cout, 64);
@@ -735,6 +835,11 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
             a.m_tiles = (int)mt;
             a.n_tiles = d->cout / (wide ? 256 : 128);
             a.total_wg = (int)tiles;
+            a.cus = cus;
+            static const int stagger = getenv("ND_PW_STAGGER") ? atoi(getenv("ND_PW_STAGGER")) : PWB_STAGGER;      // tuning knob (tools/ only), x 64 cycles
+            a.stagger = stagger / 64;
+            static const int sshift = getenv("ND_PW_STAGGER_SHIFT") ? atoi(getenv("ND_PW_STAGGER_SHIFT")) : 8;
+            a.stagger_shift = sshift;
             if (int e = wide ? launch_big<4>(a, st) : launch_big<2>(a, st)) return e;
             return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
         }
