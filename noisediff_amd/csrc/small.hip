@@ -223,31 +223,33 @@ inline int grid_for(size_t total, int cap = 4096) {
 // applies first (:149) -> all ResnetBlock.mlp Linears stacked into one (J, 4d) matrix (:150-152).  Every workgroup recomputes the
 // small head (emb, t1, st: 0.3 MFLOP per sample at d = 64) into LDS -- cheaper than a grid-wide hand-off -- and then produces its own
 // slice of the J output rows, one wave per row as nd_linear_rows_f32 does.
-__global__ __launch_bounds__(256) void cond_step_kernel(const int64_t* __restrict__ time, const float* __restrict__ freqs,
-                                                        const float* __restrict__ W1, const float* __restrict__ b1,
-                                                        const float* __restrict__ W2, const float* __restrict__ b2,
-                                                        const float* __restrict__ Wp, const float* __restrict__ bp,
-                                                        float* __restrict__ out, int ld_out, int B, int d, int J) {
+__global__ __launch_bounds__(1024) void cond_step_kernel(const int64_t* __restrict__ time, const float* __restrict__ freqs,
+                                                         const float* __restrict__ W1, const float* __restrict__ b1,
+                                                         const float* __restrict__ W2, const float* __restrict__ b2,
+                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                         float* __restrict__ out, int ld_out, int B, int d, int J) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int D4 = 4 * d, half = d / 2, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D4 = 4 * d, half = d / 2, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     float* emb = sm;                    // [B][d]
     float* t1 = emb + B * d;            // [B][4d]
     float* st = t1 + B * D4;            // [B][4d]
-    for (int i = tid; i < B * half; i += 256) {
+    for (int i = tid; i < B * half; i += blockDim.x) {
         const int b = i / half, j = i - b * half;
         const float ang = (float)time[b] * freqs[j];
         emb[b * d + j] = sinf(ang);
         emb[b * d + half + j] = cosf(ang);
     }
     __syncthreads();
-    // the two small Linears: one output column per thread, the batch in registers (B <= 16 per pass)
+    // the two small Linears: 16 lanes per output column (coalesced 256-byte pieces of its weight row, the activations from LDS),
+    // four columns per wave, the batch in registers (B <= 16 per pass); the 16 partial dot products meet in a DPP row sum
+    const int grp = lane >> 4, l16 = lane & 15;
     auto linear = [&](const float* x, int K, const float* W, const float* bias, float* y, int act) {
-        for (int n = tid; n < D4; n += 256) {
+        for (int n = wave * 4 + grp; n < D4; n += nwaves * 4) {
             for (int b0 = 0; b0 < B; b0 += 16) {
                 float acc[16];
 #pragma unroll
                 for (int b = 0; b < 16; ++b) acc[b] = 0.0f;
-                for (int k = 0; k < K; k += 4) {
+                for (int k = l16 * 4; k < K; k += 64) {
                     const f32x4 w = nd_ld4(W + (size_t)n * K + k);
 #pragma unroll
                     for (int b = 0; b < 16; ++b) {
@@ -259,8 +261,10 @@ __global__ __launch_bounds__(256) void cond_step_kernel(const int64_t* __restric
                 }
                 const float bv = bias[n];
 #pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    if (b0 + b < B) y[(b0 + b) * D4 + n] = nd_act(acc[b] + bv, act);
+                for (int b = 0; b < 16; ++b) {
+                    const float sum = nd_row16_sum(acc[b]);       // (every lane of the wave takes part: the loop bounds are wave-uniform)
+                    if (l16 == 0 && b0 + b < B) y[(b0 + b) * D4 + n] = nd_act(sum + bv, act);
+                }
             }
         }
     };
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void cond_step_kernel(const int64_t* __restric
     linear(t1, D4, W2, b2, st, ND_ACT_SILU);
     __syncthreads();
     // this workgroup's rows of the stacked projection: one wave per row, the weight row in registers (4d <= 2048)
-    for (int n = blockIdx.x * 4 + wave; n < J; n += gridDim.x * 4) {
+    for (int n = blockIdx.x * nwaves + wave; n < J; n += gridDim.x * nwaves) {
         float w[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
@@ -314,8 +318,8 @@ extern "C" int nd_cond_step_f32(const int64_t* time, const float* freqs, const f
     static nd_device_once configured;
     if (lds > 64 * 1024)
         if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(cond_step_kernel), 160 * 1024, "nd_cond_step")) return e;
-    const int rows4 = nd_cdiv(J, 4), cus = nd_device_cus();
-    hipLaunchKernelGGL(cond_step_kernel, dim3(rows4 < cus ? rows4 : cus), dim3(256), (size_t)lds, (hipStream_t)stream, time, freqs, W1, b1, W2, b2, Wp, bp,
+    const int rows16 = nd_cdiv(J, 16), cus = nd_device_cus();
+    hipLaunchKernelGGL(cond_step_kernel, dim3(rows16 < cus ? rows16 : cus), dim3(1024), (size_t)lds, (hipStream_t)stream, time, freqs, W1, b1, W2, b2, Wp, bp,
                        out, ld_out, B, dim, J);
     return nd_launch_status("nd_cond_step_f32");
 }
