@@ -67,9 +67,11 @@ typedef struct nd_src {
                              Diffusion_arch.py:74); conv3x3 only                        */
     int32_t unshuffle;    /* 1: p0 is (2H, 2W, c0/4) read as 'b c (h p1)(w p2) -> b (c p1 p2) h w'
                              (Diffusion_arch.py:80) with K order (p1 p2 c); pointwise only */
-    int32_t _pad;
+    int32_t map_blocked;  /* AFFINE_MAP: 0: `map` is [B][H][W][scale C | shift C] (the layout torch.chunk(2, dim=1) reads,
+                             Diffusion_arch.py:188); 1: blocked by 16 channels, [B][H][W][C/16][scale 16 | shift 16] -- one
+                             128-byte line per pixel and 16-channel K chunk; nd_conv3x3_wino4_nhwc_f32 only (C % 16 == 0) */
     const float* mad;     /* [B][3][C] M, A, D for the AFFINE modes (from nd_groupnorm_finalize_f32) */
-    const float* map;     /* [B][H][W][2C] scale|shift map (AFFINE_MAP)                 */
+    const float* map;     /* [B][H][W][2C] scale / shift map (AFFINE_MAP), layout per map_blocked */
     const float* vec;     /* [B][C] per-sample vector added before LayerNorm            */
     const float* gamma;   /* [C] LayerNorm weight                                       */
     const float* beta;    /* [C] LayerNorm bias                                         */

@@ -27,7 +27,7 @@ class HipError(RuntimeError):
 
 class Src(C.Structure):
     _fields_ = [("p0", fptr), ("p1", fptr), ("c0", C.c_int32), ("c1", C.c_int32), ("ld0", C.c_int32), ("ld1", C.c_int32),
-                ("mode", C.c_int32), ("upsample", C.c_int32), ("unshuffle", C.c_int32), ("_pad", C.c_int32),
+                ("mode", C.c_int32), ("upsample", C.c_int32), ("unshuffle", C.c_int32), ("map_blocked", C.c_int32),
                 ("mad", fptr), ("map", fptr), ("vec", fptr), ("gamma", fptr), ("beta", fptr), ("rowstats", fptr)]
 
 

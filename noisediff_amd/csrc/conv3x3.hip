@@ -400,6 +400,7 @@ extern "C" int nd_conv3x3_nhwc_f32(const nd_conv3x3* d, void* stream) {
                "nd_conv3x3: unsupported prologue %d", s.mode);
     ND_REQUIRE(!affine || s.mad, ND_E_BADARG, "nd_conv3x3: affine prologue needs mad");
     ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || s.map, ND_E_BADARG, "nd_conv3x3: map prologue needs map");
+    ND_REQUIRE(!s.map_blocked, ND_E_BADARG, "nd_conv3x3: the blocked map layout is read by nd_conv3x3_wino4_nhwc_f32 only");
     ND_REQUIRE(!s.upsample || (d->H % 2 == 0 && d->W % 2 == 0 && s.c1 == 0), ND_E_SHAPE, "nd_conv3x3: upsample needs even H, W and one source");
     ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3: unshuffle is a pointwise-only addressing mode");
     ND_REQUIRE((d->stats == nullptr) == (d->slot_count == nullptr), ND_E_BADARG, "nd_conv3x3: stats and slot_count go together");

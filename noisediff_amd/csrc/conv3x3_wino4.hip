@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     const __amdgpu_buffer_rsrc_t rsrc0 = src_rsrc(s.p0, s.ld0);
     const __amdgpu_buffer_rsrc_t rsrc1 = s.p1 ? src_rsrc(s.p1, s.ld1) : rsrc0;
     const __amdgpu_buffer_rsrc_t rsrcm = MAP ? src_rsrc(s.map, 2 * Ctot) : rsrc0;
+    const int map_shift = s.map_blocked ? 64 : Ctot * 4;                 // bytes from a channel's scale to its shift (blocked layout: [chunk][scale 16 | shift 16])
     float* const vd_tg = Vd + tg * VD_FLOATS;                            // this tile group's V image
     char* const rawbuf = reinterpret_cast<char*>(Vd + 2 * VD_FLOATS);    // [18][40] records of 64 bytes
     lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + 18 * RAW_ROWP * 16) + tid;      // [10][256] source pixel of this thread's items
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     auto stage_issue_begin = [&](int cb_) {
         const bool sec = cb_ >= s.c0;                                    // wave-uniform: a chunk never straddles the sources (host check)
         i_second = sec;
-        i_mapoff = (int)(cb_ * 4u + spx_ * (unsigned)(2 * Ctot * 4));
+        i_mapoff = (int)(cb_ * (s.map_blocked ? 8u : 4u) + spx_ * (unsigned)(2 * Ctot * 4));   // blocked: chunk cb / 16 at 128 bytes each
         i_rs = sec ? rsrc1 : rsrc0;
         i_ld4 = (unsigned)(sec ? s.ld1 : s.ld0) * 4u;
         i_soff = (int)((sec ? cb_ - s.c0 : cb_) * 4u + spx_ * i_ld4);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         if (MAP) {                                                       // the maps have the conv's resolution (host: no upsample with MAP): [pixel][scale C | shift C]
             const unsigned mo = __umul24(px, (unsigned)(2 * Ctot * 4)) + i_bias;
             msc[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff, 0));
-            msh[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff + Ctot * 4, 0));
+            msh[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff + map_shift, 0));
         }
 #else
         raw[k] = f32x4{(float)k, 1.0f, 0.5f, 0.25f};
@@ -771,6 +772,8 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || (long)(d->B * (long)d->H + 2) * d->W * 2 * (s.c0 + s.c1) * 4 < (1L << 30) - 65536, ND_E_SHAPE,
                "nd_conv3x3_wino4: a scale / shift map of 1 GiB or more");
     ND_REQUIRE(s.mode != ND_PRO_LEAKY_SECOND || s.p1, ND_E_BADARG, "nd_conv3x3_wino4: LEAKY_SECOND needs a second source");
+    ND_REQUIRE(!s.map_blocked || (s.mode == ND_PRO_AFFINE_MAP_SILU && (s.c0 + s.c1) % 16 == 0), ND_E_BADARG,
+               "nd_conv3x3_wino4: map_blocked needs the map prologue and a channel count that is a multiple of 16");
     ND_REQUIRE(!s.unshuffle, ND_E_BADARG, "nd_conv3x3_wino4: no unshuffle addressing");
     ND_REQUIRE(!s.upsample || (d->H % 2 == 0 && d->W % 2 == 0 && s.c1 == 0), ND_E_SHAPE,
                "nd_conv3x3_wino4: nearest-x2 upsample addressing needs even H, W and a single source");

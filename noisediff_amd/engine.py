@@ -39,6 +39,7 @@ CHAIN = os.environ.get("ND_CHAIN", "1") != "0"           # A-B knob: 0 = one poi
 _CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that can open / continue a fused chain (pwchain.hip)
 _CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
 WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two-waves-per-SIMD Winograd kernel (conv3x3_wino.hip)
+MAP_BLOCKED = os.environ.get("ND_MAP_BLOCKED", "1") != "0"   # A-B knob: 0 = ResnetBlock2 scale / shift maps in the planar [scale C | shift C] layout
 COND_STEP = os.environ.get("ND_COND_STEP", "1") != "0"   # A-B knob: 0 = time embedding / time_mlp / projections as four launches
 WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel (conv3x3_wino4.hip)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
@@ -47,6 +48,17 @@ _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 def _wino4_layer(cin: int, cout: int) -> bool:
     """Layers whose weights are also packed for the F(4x4,3x3) kernel: at least two 16-channel K chunks (conv3x3_wino4.hip)."""
     return cin > 16 and cin % 4 == 0 and cout % 4 == 0
+
+
+_MAP_PRODUCERS = ("pos_block1.mlp.1.weight", "pos_block2.mlp.1.weight")
+
+
+def _blocked_map_rows(C_: int) -> torch.Tensor:
+    """Row order of a (2C, K) scale|shift producer for the blocked map layout: position 32 c + j holds scale channel 16 c + j
+    (j < 16) or shift channel 16 c + j - 16 (include/noisediff_hip.h, nd_src.map_blocked)."""
+    i = torch.arange(2 * C_)
+    c, j = i // 32, i % 32
+    return torch.where(j < 16, 16 * c + j, C_ + 16 * c + j - 16)
 
 
 def _classify(name: str, shape: Sequence[int]) -> str:
@@ -132,6 +144,11 @@ class Engine:
                     add(p.name + ".wino4", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind in ("pw", "pw_unshuffle"):
                 n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
+                if p.name in _MAP_PRODUCERS and p.shape[0] % 32 == 0:
+                    # ResnetBlock2.mlp[1] writes the per-pixel scale / shift map; a second copy with its output rows permuted writes
+                    # the 16-channel-blocked layout the F(4x4,3x3) kernel reads one 128-byte line at a time (nd_src.map_blocked)
+                    add(p.name + ".blk16", n, "derived", p.shape)
+                    add(p.name[:-len("weight")] + "bias.blk16", p.shape[0], "derived", (p.shape[0],))
                 if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
                     first = int(p.name.endswith(_CHAIN_FIRST))
                     add(p.name + ".chain", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
@@ -185,6 +202,13 @@ class Engine:
                         L.call("nd_pack_conv3x3_wino4_weight", t.data_ptr(), self.p(p.name + ".wino4"), p.shape[1], p.shape[0], st)
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
+                    if p.name + ".blk16" in self.slots:
+                        perm = _blocked_map_rows(p.shape[0] // 2).to(self.device)
+                        tp = t[perm].contiguous()
+                        keep.append(tp)
+                        L.call("nd_pack_pointwise_weight", tp.data_ptr(), self.p(p.name + ".blk16"), p.shape[1], p.shape[0], 0, st)
+                        bname = p.name[:-len("weight")] + "bias"
+                        self.view(bname + ".blk16").copy_(sd[bname].detach().to(device=self.device, dtype=torch.float32)[perm])
                     if p.name + ".chain" in self.slots:
                         L.call("nd_pack_chain_weight", t.data_ptr(), self.p(p.name + ".chain"), p.shape[1], p.shape[0],
                                int(p.name.endswith(_CHAIN_FIRST)), st)
@@ -258,6 +282,9 @@ class Plan:
             self.pos_emb = f(B, H, W, POS_DIM)
             self.posmap1 = f(B, H, W, 2 * d)
             self.posmap2 = f(B, H, W, 2 * d)
+            # the maps' consumers are pos_block{1,2}.block2.proj (d -> d, map prologue): blocked layout when those run on conv3x3_wino4
+            self.posmap_blocked = (MAP_BLOCKED and "pos_block1.mlp.1.weight.blk16" in eng.slots and
+                                   self._wino4_takes("pos_block1.block2.proj", L.PRO_AFFINE_MAP_SILU, False, d, 0, d, 0, d, H, W))
             self.iso_emb = f(B, ISO_DIM)
             self.attn_names = [p.name[:-len(".attn.to_v.weight")] for p in eng.spec if p.name.endswith(".attn.to_v.weight")]
             self.cb = {n: f(B, eng.slots[n + ".proj_out.bias"].shape[0]) for n in self.attn_names}
@@ -334,16 +361,9 @@ class Plan:
         wino2 = (wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
                  and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
                  and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
-        # F(4x4,3x3) (1.78x fewer MFMAs again; 16 x 32-pixel regions, 16-channel K chunks) wherever its kernel takes the layer:
-        # plain / GroupNorm-affine (+ per-pixel map) + SiLU inputs, concat on a chunk boundary, images that fill its regions, sources below 1 GiB
-        up = 1 if src.upsample else 0
-        src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
-        src_bytes = src_px * 4 * max(src.ld0, src.ld1)
-        wino4 = (wino and WINO4 and (name + ".weight.wino4") in e.slots and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU)
-                 and not (src.mode == L.PRO_AFFINE_MAP_SILU and (up or (self.B * H + 2) * W * 8 * cin >= (1 << 30) - (1 << 16)))
-                 and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (src.c1 == 0 or (src.c0 % 16 == 0 and not up))
-                 and src_bytes < (1 << 30) - (1 << 16) and src_px < (1 << 24)
-                 and (not up or (H % 2 == 0 and W % 2 == 0)))
+        wino4 = wino and self._wino4_takes(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, H, W)
+        if src.map_blocked and not wino4:
+            raise L.HipError(f"{name}: the scale / shift map was produced in the blocked layout but the layer does not run on conv3x3_wino4")
         if wino4:
             d.weight = e.p(name + ".weight.wino4")
         entry = ("nd_conv3x3_wino4_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
@@ -354,15 +374,29 @@ class Plan:
         self._keep.append(d)
         return out, st, sc, slots
 
+    def _wino4_takes(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, H: int, W: int) -> bool:
+        """F(4x4,3x3) (1.78x fewer MFMAs than F(2x2,3x3); 16 x 32-pixel regions, 16-channel K chunks) wherever its kernel takes the
+        layer: plain / GroupNorm-affine (+ per-pixel map) + SiLU inputs, concat on a chunk boundary, images that fill its regions,
+        sources below 1 GiB and 2^24 pixels (the host checks of nd_conv3x3_wino4_nhwc_f32)."""
+        up = 1 if upsample else 0
+        src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
+        src_bytes = src_px * 4 * max(ld0, ld1)
+        return (WINOGRAD and WINO4 and H >= 16 and W >= 16 and (name + ".weight.wino4") in self.e.slots
+                and mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU)
+                and not (mode == L.PRO_AFFINE_MAP_SILU and (up or (self.B * H + 2) * W * 8 * cin >= (1 << 30) - (1 << 16)))
+                and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (c1 == 0 or (c0 % 16 == 0 and not up))
+                and src_bytes < (1 << 30) - (1 << 16) and src_px < (1 << 24)
+                and (not up or (H % 2 == 0 and W % 2 == 0)))
+
     def pw(self, name: str, src: L.Src, cin: int, cout: int, HW: int, W: int, act=L.ACT_NONE, bias=True,
-           res0=None, res1=None, vec=None, gn_t=None, gn_mad=None, out=None) -> torch.Tensor:
-        """1x1 conv / token Linear with fused prologue/epilogue."""
+           res0=None, res1=None, vec=None, gn_t=None, gn_mad=None, out=None, variant: str = "") -> torch.Tensor:
+        """1x1 conv / token Linear with fused prologue/epilogue (`variant`: suffix of a permuted copy of weight and bias)."""
         e = self.e
         if out is None:
             out = self._alloc(self.B, HW, cout)
         d = L.Pointwise()
-        d.src, d.weight, d.out = src, e.p(name + ".weight"), out.data_ptr()
-        d.bias = e.p(name + ".bias") if bias else None
+        d.src, d.weight, d.out = src, e.p(name + ".weight" + variant), out.data_ptr()
+        d.bias = e.p(name + ".bias" + variant) if bias else None
         d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = self.B, HW, W, cin, cout, cout, act
         if res0 is not None:
             d.res0, d.ldr0 = res0.data_ptr(), res0.shape[-1]
@@ -409,7 +443,7 @@ class Plan:
             src2 = self._src(a1)
         else:
             mode = L.PRO_AFFINE_MAP_SILU if posmap is not None else L.PRO_AFFINE_SILU
-            src2 = self._src(c1, None, mode, mad=mad1, **({"map": posmap} if posmap is not None else {}))
+            src2 = self._src(c1, None, mode, mad=mad1, **({"map": posmap, "map_blocked": int(self.posmap_blocked)} if posmap is not None else {}))
         c2, st2, sc2, n2 = self.conv3(name + ".block2.proj", src2, cout, cout, H, W, stats=True)
         if a1 is not None:
             self._release(a1)
@@ -493,7 +527,8 @@ class Plan:
             h = self.pw("pos_mlp.fc1", self._src(pe), 3 * POS_DIM, 2 * POS_DIM, H * W, W, act=L.ACT_GELU)
             self.pw("pos_mlp.fc2", self._src(h), 2 * POS_DIM, POS_DIM, H * W, W, out=self.pos_emb)
             for blk, dst in (("pos_block1", self.posmap1), ("pos_block2", self.posmap2)):
-                self.pw(blk + ".mlp.1", self._src(self.pos_emb, None, L.PRO_SILU), POS_DIM, 2 * e.dim, H * W, W, out=dst)
+                self.pw(blk + ".mlp.1", self._src(self.pos_emb, None, L.PRO_SILU), POS_DIM, 2 * e.dim, H * W, W, out=dst,
+                        variant=".blk16" if self.posmap_blocked else "")
             self._release(pe, h)
         if tr.iso_attn:
             self._add("nd_embedding_rows_f32", self.iso_idx.data_ptr(), e.p("iso_embed.weight"), self.iso_emb.data_ptr(), B,

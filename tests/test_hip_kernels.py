@@ -666,6 +666,16 @@ def test_conv3x3_winograd_f4x4_matches_direct_semantics(ctx, case):
     sm = hu.src(hu.nhwc(x), None, L.PRO_AFFINE_MAP_SILU, mad=hu.dev(torch.stack((M, A, D), 1)), map=hu.nhwc(torch.cat((sc, sh), 1)))
     out, *_ = run(sm, stats=False)
     assert rel_err(hu.nchw(out), F.conv2d(actm, w, b, padding=1)) < 5e-5
+    if cin % 16 == 0:                                                    # the 16-channel-blocked map layout (nd_src.map_blocked): [chunk][scale 16 | shift 16]
+        blk = torch.stack((sc.permute(0, 2, 3, 1).reshape(B, H, W, cin // 16, 16), sh.permute(0, 2, 3, 1).reshape(B, H, W, cin // 16, 16)), 4).reshape(B, H, W, 2 * cin)
+        smb = hu.src(hu.nhwc(x), None, L.PRO_AFFINE_MAP_SILU, mad=hu.dev(torch.stack((M, A, D), 1)), map=hu.dev(blk), map_blocked=1)
+        out, *_ = run(smb, stats=False)
+        assert rel_err(hu.nchw(out), F.conv2d(actm, w, b, padding=1)) < 5e-5
+        for other in ("nd_conv3x3_wino2_nhwc_f32", "nd_conv3x3_nhwc_f32"):   # the other kernels read the planar layout only: refused loudly
+            d = L.Conv3x3()
+            d.src, d.weight, d.bias, d.out = smb, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
+            d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+            assert getattr(ctx.lib, other)(C.byref(d), ctx.stream) != 0
     out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_LEAKY), stats=False)
     assert rel_err(hu.nchw(out), F.conv2d(F.leaky_relu(x, 0.2), w, b, padding=1)) < 5e-5
     if c0:
