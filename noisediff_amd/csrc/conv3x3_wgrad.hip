@@ -49,21 +49,61 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
         const int b = lid / a.tiles_y;
         const int y0 = ty * WG_TILE, x0 = tx * WG_TILE;
         __syncthreads();                                             // the previous tile's operands have been consumed
-        // ---- stage dY (16 x 16 x 64 couts) and X (18 x 18 x 64 cins); outside the image / beyond the channels: zeros
-        for (int i = tid; i < WG_TILE * WG_TILE * (CB / 4); i += 256) {
-            const int q = i & 15, p = i >> 4, py = p >> 4, px = p & 15;
-            const int gy = y0 + py, gx = x0 + px, c = co0 + 4 * q;
-            f32x4 v = {0, 0, 0, 0};
-            if (gy < a.H && gx < a.W && c < a.cout) v = nd_ld4(a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldy + c);
-            nd_st4(dYs + p * CB + 4 * q, v);
-        }
-        for (int i = tid; i < HALO * HALO * (CB / 4); i += 256) {
-            const int q = i & 15, p = i >> 4, py = p / HALO, px = p - py * HALO;
-            const int gy = y0 + py - 1, gx = x0 + px - 1, c = ci0 + 4 * q;
-            f32x4 v = {0, 0, 0, 0};
-            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c < a.cin)
-                v = nd_ld4(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx + c);
-            nd_st4(Xs + p * CB + 4 * q, v);
+        // ---- stage dY (16 x 16 x 64 couts) and X (18 x 18 x 64 cins); outside the image / beyond the channels: zeros.
+        //      Every load is unconditional (clamped address, select afterwards) and a batch of them is in flight before the first LDS
+        //      write: with a branch around each load hipcc waits for it on the spot, and the ~37 serialized memory round trips per tile
+        //      took as long as the tile's MFMAs.
+        {
+            const f32x4 zero = {0, 0, 0, 0};
+            const int q = tid & 15;
+            constexpr int DY_IT = WG_TILE * WG_TILE * (CB / 4) / 256;            // 16
+            constexpr int X_IT = (HALO * HALO * (CB / 4) + 255) / 256;            // 21
+            constexpr int BATCH = 11;
+            const int cy = co0 + 4 * q, cx = ci0 + 4 * q;
+            const bool cy_ok = cy < a.cout, cx_ok = cx < a.cin;
+            const float* dyb = a.dy + (cy_ok ? cy : 0);
+            const float* xb = a.x + (cx_ok ? cx : 0);
+#pragma unroll
+            for (int i0 = 0; i0 < DY_IT; i0 += BATCH) {
+                f32x4 v[BATCH];
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) {
+                    if (i0 + j < DY_IT) {
+                        const int p = (tid >> 4) + 16 * (i0 + j), py = p >> 4, px = p & 15;
+                        const int gy = min(y0 + py, a.H - 1), gx = min(x0 + px, a.W - 1);
+                        v[j] = nd_ld4(dyb + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldy);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) {
+                    if (i0 + j < DY_IT) {
+                        const int p = (tid >> 4) + 16 * (i0 + j), py = p >> 4, px = p & 15;
+                        const bool ok = cy_ok && y0 + py < a.H && x0 + px < a.W;
+                        nd_st4(dYs + p * CB + 4 * q, ok ? v[j] : zero);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i0 = 0; i0 < X_IT; i0 += BATCH) {
+                f32x4 v[BATCH];
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) {
+                    if (i0 + j < X_IT) {
+                        const int p = min((tid >> 4) + 16 * (i0 + j), HALO * HALO - 1), py = p / HALO, px = p - py * HALO;
+                        const int gy = min(max(y0 + py - 1, 0), a.H - 1), gx = min(max(x0 + px - 1, 0), a.W - 1);
+                        v[j] = nd_ld4(xb + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) {
+                    if (i0 + j < X_IT) {
+                        const int p = (tid >> 4) + 16 * (i0 + j), py = p / HALO, px = p - py * HALO;
+                        const int gy = y0 + py - 1, gx = x0 + px - 1;
+                        const bool ok = cx_ok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                        if (p < HALO * HALO) nd_st4(Xs + p * CB + 4 * q, ok ? v[j] : zero);
+                    }
+                }
+            }
         }
         __syncthreads();
         // ---- 128 pixel pairs x 9 taps: lane (col, half) feeds dY[pixel + half][co_w + col] and X[pixel + half + tap][ci_w + col]
