@@ -142,6 +142,19 @@ int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout
 int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* workspace,
                               int B, int H, int W, int cin, int cout, void* stream);
 
+/* nn.GroupNorm(groups, C) forward and backward on NHWC fp32 for training: Block.norm (Diffusion_arch.py:132,138) under
+ * GaussianDiffusion.p_losses -> loss.backward().  Statistics per (sample, group) over (C / groups) x HW values, eps inside the
+ * square root, affine weight and bias -- torch.nn.functional.group_norm's definition.  Forward: y = (x - mean) rstd gamma + beta and
+ * `mean_rstd` [B][groups][2] for the backward.  Backward: dx, dgamma [C], dbeta [C] from dy, x and the saved statistics.
+ * Every pass streams NHWC once (partial sums per pixel slot, fp64 finalize, one elementwise pass); fixed summation order.
+ * `workspace`: nd_groupnorm_train_workspace_floats(B, HW, C) floats, shared by both directions. */
+int64_t nd_groupnorm_train_workspace_floats(int B, int HW, int C);
+int nd_groupnorm_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean_rstd,
+                                   float* workspace, int B, int HW, int C, int groups, float eps, void* stream);
+int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean_rstd,
+                                    float* dx, int lddx, float* dgamma, float* dbeta, float* workspace, int B, int HW, int C, int groups,
+                                    void* stream);
+
 /* ------------------------------------------------------------------ pointwise GEMM */
 
 /* out[p, n] = epi( sum_k pro(in[p, k]) * W[k, n] + bias[n] ) per pixel: nn.Conv2d(k=1) and

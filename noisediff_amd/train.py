@@ -14,7 +14,10 @@
   * grad bias    a sum over pixels (torch)
 Tensors stay what PyTorch hands over: NCHW-shaped, ``channels_last`` in memory (= the library's NHWC; other layouts are
 converted once per call), fp32, on the caller's CUDA stream -- so autograd's stream ordering holds without synchronisation.
-Everything else in the network (norms, activations, 1x1 convolutions, attention) stays on PyTorch's own ROCm kernels for now.
+``GroupNormFunction`` (second slice) does the same for nn.GroupNorm: nd_groupnorm_train_forward_f32 / _backward_f32 (norm_train.hip) stream
+the channels_last tensors once per pass, where PyTorch's NCHW group norm first copies them to NCHW and back -- on the full-resolution
+blocks the norms cost more than the convolutions before this.  Everything else in the network (activations, 1x1 convolutions,
+attention) stays on PyTorch's own ROCm kernels for now.
 
 There is no fallback: a CPU tensor or a missing library raises.
 """
@@ -120,6 +123,62 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     return Conv3x3Function.apply(x, weight, bias)
 
 
+class GroupNormFunction(torch.autograd.Function):
+    """nn.GroupNorm(groups, C) forward and backward on libnoisediff_hip (norm_train.hip), channels_last in and out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        lib = L.load()
+        xn = _nhwc(x)
+        if xn.device.type != "cuda":
+            raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {xn.device} and there is no CPU path")
+        B, C_, H, W = xn.shape
+        st = _stream()
+        with torch.cuda.device(xn.device):
+            y = torch.empty_like(xn, memory_format=torch.channels_last)
+            mean_rstd = torch.empty((B, groups, 2), dtype=torch.float32, device=xn.device)
+            ws = torch.empty(int(lib.nd_groupnorm_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
+            w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+            L.call("nd_groupnorm_train_forward_f32", xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), y.data_ptr(), C_, mean_rstd.data_ptr(),
+                   ws.data_ptr(), B, H * W, C_, groups, float(eps), st)
+        ctx.save_for_backward(xn, weight, mean_rstd)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xn, weight, mean_rstd = ctx.saved_tensors
+        lib = L.load()
+        g = _nhwc(grad_out)
+        B, C_, H, W = xn.shape
+        with torch.cuda.device(xn.device):
+            dx = torch.empty_like(xn, memory_format=torch.channels_last)
+            dgamma = torch.empty(C_, dtype=torch.float32, device=xn.device)
+            dbeta = torch.empty(C_, dtype=torch.float32, device=xn.device)
+            ws = torch.empty(int(lib.nd_groupnorm_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
+            w32 = weight.detach().float().contiguous()
+            L.call("nd_groupnorm_train_backward_f32", g.data_ptr(), C_, xn.data_ptr(), C_, w32.data_ptr(), mean_rstd.data_ptr(), dx.data_ptr(), C_,
+                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), B, H * W, C_, ctx.groups, _stream())
+        return dx, dgamma, dbeta, None, None
+
+
+def group_norm(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """Differentiable F.group_norm(x, groups, weight, bias, eps) for 4-D inputs on the HIP library."""
+    if x.dim() != 4 or x.shape[1] % groups or x.shape[1] % 4 or x.shape[1] > 1024 or weight is None or bias is None:
+        raise ValueError(f"group_norm: x {tuple(x.shape)}, groups {groups}: needs a 4-D input, C a multiple of 4 and of groups (<= 1024), affine parameters")
+    return GroupNormFunction.apply(x, weight, bias, groups, eps)
+
+
+def _eligible_norm(m: nn.Module) -> bool:
+    return isinstance(m, nn.GroupNorm) and m.affine and m.num_channels % 4 == 0 and m.num_channels <= 1024 and m.num_channels // m.num_groups <= 512
+
+
+def _hip_norm_forward(self: nn.GroupNorm, x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 4:                                                     # (the reference applies GroupNorm to images only)
+        return torch.nn.functional.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+    return group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+
+
 def _eligible(m: nn.Module) -> bool:
     return (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
             and m.groups == 1 and m.padding_mode == "zeros" and m.in_channels % 8 == 0 and m.out_channels % 8 == 0)
@@ -129,14 +188,17 @@ def _hip_conv_forward(self: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return conv3x3(x, self.weight, self.bias)
 
 
-def accelerate(model: nn.Module) -> int:
-    """Route every eligible 3x3 convolution of ``model`` (stride 1, padding 1, channel counts multiples of 8) through the HIP
-    library, forward and backward.  Parameters, module tree and state dict are untouched; the replacement is a bound method, so
-    ``copy.deepcopy`` (the trainer's EMA) rebinds it to the copy.  Returns the number of layers taken."""
+def accelerate(model: nn.Module, norms: bool = True) -> int:
+    """Route every eligible 3x3 convolution of ``model`` (stride 1, padding 1, channel counts multiples of 8) and -- unless
+    ``norms=False`` -- every affine nn.GroupNorm (C a multiple of 4) through the HIP library, forward and backward.  Parameters,
+    module tree and state dict are untouched; the replacement is a bound method, so ``copy.deepcopy`` (the trainer's EMA) rebinds
+    it to the copy.  Returns the number of convolutions taken."""
     import types
     n = 0
     for m in model.modules():
         if _eligible(m) and getattr(m.forward, "__func__", None) is not _hip_conv_forward:
             m.forward = types.MethodType(_hip_conv_forward, m)
             n += 1
+        elif norms and _eligible_norm(m) and getattr(m.forward, "__func__", None) is not _hip_norm_forward:
+            m.forward = types.MethodType(_hip_norm_forward, m)
     return n

@@ -101,3 +101,56 @@ def test_accelerate_keeps_losses_and_gradients_of_a_resnet_block():
         assert rel_err(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 2e-4, k
     with pytest.raises(L.HipError, match="no CPU path"):
         train.conv3x3(torch.zeros(1, 8, 8, 8), torch.zeros(8, 8, 3, 3))
+
+
+GN_CASES = {"full_res": (2, 64, 8, 96, 64), "wide": (3, 256, 8, 16, 16), "one_group": (2, 32, 1, 20, 12), "narrow_rows": (2, 8, 2, 9, 7),
+            "c1024": (1, 1024, 32, 8, 8)}
+
+
+@pytest.mark.parametrize("case", sorted(GN_CASES))
+def test_group_norm_autograd_matches_torch(case):
+    """nd_groupnorm_train_forward / _backward == F.group_norm and its autograd (output, dx, dgamma, dbeta) on channels_last and on
+    NCHW-contiguous inputs, inputs with a large mean (the pivot keeps the variance well conditioned), bitwise repeatable."""
+    B, C_, G, H, W = GN_CASES[case]
+    x = (U(case + ".x", (B, C_, H, W), -1.5, 1.5) + 3.0 * U(case + ".m", (B, C_, 1, 1))).to(DEV)
+    gamma, beta = U(case + ".g", (C_,), 0.5, 1.5).to(DEV), U(case + ".b", (C_,)).to(DEV)
+    gy = U(case + ".gy", (B, C_, H, W)).to(DEV)
+    outs = []
+    for fn, fmt in ((lambda a, w, b: F.group_norm(a, G, w, b, 1e-5), torch.contiguous_format),
+                    (lambda a, w, b: train.group_norm(a, G, w, b, 1e-5), torch.channels_last),
+                    (lambda a, w, b: train.group_norm(a, G, w, b, 1e-5), torch.contiguous_format)):
+        xa = x.clone().contiguous(memory_format=fmt).requires_grad_()
+        wa, ba = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        y = fn(xa, wa, ba)
+        y.backward(gy)
+        outs.append([t.detach().float().cpu().contiguous() for t in (y, xa.grad, wa.grad, ba.grad)])
+    ref64 = []
+    xa, wa, ba = x.double().cpu().requires_grad_(), gamma.double().cpu().requires_grad_(), beta.double().cpu().requires_grad_()
+    y = F.group_norm(xa, G, wa, ba, 1e-5)
+    y.backward(gy.double().cpu())
+    ref64 = [t.detach() for t in (y, xa.grad, wa.grad, ba.grad)]
+    for i, name in enumerate(("y", "dx", "dgamma", "dbeta")):
+        for got in (outs[1][i], outs[2][i]):
+            assert got.shape == ref64[i].shape
+            assert rel_err(got.numpy(), ref64[i].numpy()) < 2e-5, (case, name)
+        assert torch.equal(outs[1][i], outs[2][i]), (case, name)                  # the memory format of the input does not change the bits
+    with pytest.raises(ValueError):
+        train.group_norm(x[:, :6], 2, gamma[:6], beta[:6])                          # C % 4 != 0: not taken
+
+
+def test_accelerate_takes_the_norms_too():
+    torch.manual_seed(1)
+    ref = nn.Sequential(_Block(32, 64), _Block(64, 64), nn.Conv2d(64, 4, 1)).to(DEV).to(memory_format=torch.channels_last)
+    hip, convs_only = copy.deepcopy(ref), copy.deepcopy(ref)
+    train.accelerate(hip)
+    train.accelerate(convs_only, norms=False)
+    assert sum(getattr(m.forward, "__func__", None) is train._hip_norm_forward for m in hip.modules()) == 4
+    assert sum(getattr(m.forward, "__func__", None) is train._hip_norm_forward for m in convs_only.modules()) == 0
+    x = U("nrm.x", (2, 32, 48, 32)).to(DEV)
+    target = U("nrm.t", (2, 4, 48, 32)).to(DEV)
+    grads = []
+    for net in (ref, hip):
+        F.mse_loss(net(x), target).backward()
+        grads.append({k: p.grad.detach().cpu() for k, p in net.named_parameters()})
+    for k in grads[0]:
+        assert rel_err(grads[1][k].numpy(), grads[0][k].numpy()) < 2e-4, k
