@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int WG_TILE = 16, HALO = 18, CB = 64;                        // pixels per tile side, halo side, channel block
-constexpr int WGRAD_TARGET_WGS = 512;
+constexpr int WGRAD_TARGET_WGS = 256;                                  // one workgroup per CU of an MI355X (LDS: one fits); fixed: the summation order must not depend on the device
 
 struct WgradArgs {
     const float* x; const float* dy; float* ws;
@@ -133,16 +133,27 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
-// dW (OIHW, torch layout) = sum over the S partials in a fixed order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int cin, int cout, int coP, int ciP) {
-    const size_t total = (size_t)cout * cin * 9;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i % 9);
-        const size_t oc = i / 9;
-        const int ci = (int)(oc % cin), co = (int)(oc / cin);
+// dW (OIHW, torch layout) = sum over the S partials in a fixed order.  A thread owns one element (tap, co, ci) of the partial
+// blocks -- consecutive threads read consecutive cins, every load of the S-deep sum is coalesced -- and scatters its one result.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int cin, int cout, int coP, int ciP) {
+    const size_t block = (size_t)9 * coP * ciP;
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < block; j += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(j % ciP);
+        const int co = (int)((j / ciP) % coP);
+        const int t = (int)(j / ((size_t)ciP * coP));
+        if (co >= cout || ci >= cin) continue;
+        const float* p = ws + j;
         float sum = 0.0f;
-        for (int s = 0; s < S; ++s) sum += ws[(((size_t)s * 9 + t) * coP + co) * ciP + ci];
-        dw[i] = sum;
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {                                     // eight loads in flight, added in slot order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s + k) * block];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[k];
+        }
+        for (; s < S; ++s) sum += p[(size_t)s * block];
+        dw[((size_t)co * cin + ci) * 9 + t] = sum;
     }
 }
 
@@ -187,8 +198,8 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wgs), dim3(256), lds, st, a);
     if (int e = nd_launch_status("nd_conv3x3_wgrad_nhwc_f32")) return e;
-    const size_t total = (size_t)cout * cin * 9;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const size_t total = (size_t)9 * a.n_co * CB * a.n_ci * CB;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw_oihw, a.S, cin, cout, a.n_co * CB, a.n_ci * CB);
     return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (reduce)");
 }

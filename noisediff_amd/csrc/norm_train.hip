@@ -8,8 +8,9 @@
 //              finalize  fp64 over slots and the group's channels -> {mean, rstd} per (sample, group), (M, A, D) per channel  [gn_fwd_finalize_kernel]
 //              apply     y = (x - M) A + D                                                                               [affine3_kernel, mode 0]
 //   backward   partials  {sum(dy x), sum(dy)} per (sample, slot, channel)                                                 [gn_partials_kernel, mode 1]
-//              finalize  dgamma, dbeta; per (sample, channel) c0 = rstd gamma, c1 = -rstd^2 S1 / N, c2 = mean rstd^2 S1 / N - rstd S2 / N
-//                        with S1 = sum_c gamma_c rstd (sum dy x - mean sum dy), S2 = sum_c gamma_c sum dy over the group  [gn_bwd_finalize_kernel]
+//              finalize  per (sample, channel) c0 = rstd gamma, c1 = -rstd^2 S1 / N, c2 = mean rstd^2 S1 / N - rstd S2 / N
+//                        with S1 = sum_c gamma_c rstd (sum dy x - mean sum dy), S2 = sum_c gamma_c sum dy over the group  [gn_bwd_finalize_kernel];
+//                        dgamma, dbeta = the same per-channel sums added over the samples                                [gn_dparam_kernel]
 //              apply     dx = dy c0 + x c1 + c2                                                                          [affine3_kernel, mode 1]
 //
 // All sums have a fixed order (no atomics): bitwise repeatable.
@@ -68,86 +69,107 @@ __global__ __launch_bounds__(256) void gn_partials_kernel(const float* __restric
     }
 }
 
-// one workgroup (64 threads) per (sample, group)
-__global__ __launch_bounds__(64) void gn_fwd_finalize_kernel(const float* __restrict__ part, int slots, int HW, const float* __restrict__ x, int ldx,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ mean_rstd, float* __restrict__ mad, int C, int G, float eps) {
-    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G, lane = threadIdx.x;
-    double S = 0.0, Q2 = 0.0;
-    for (int i = lane; i < cpg; i += 64) {                     // a channel per lane: its slots in order, then un-shift by its pivot
-        const int c = g * cpg + i;
+// Per-channel totals of a (sample, group) over the slots, fp64, fixed order: thread (channel i, stripe) adds its slots, the stripes
+// of a channel are then added in order.  Result in tot[0][i], tot[1][i] (i < cpg <= 512); 256 threads.
+__device__ __forceinline__ void gt_channel_totals(const float* __restrict__ part, int slots, int C, int b, int g, int cpg, double (&tot)[2][512],
+                                                  double (&red)[2][256]) {
+    const int tid = threadIdx.x;
+    if (256 % cpg == 0) {
+        const int i = tid % cpg, stripe = tid / cpg, nstr = 256 / cpg, c = g * cpg + i;
         double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < slots; ++s) {
+        for (int s = stripe; s < slots; s += nstr) {
             const float* o = part + (((size_t)b * slots + s) * C + c) * 2;
             s1 += (double)o[0];  s2 += (double)o[1];
         }
-        const double p = (double)x[(size_t)b * HW * ldx + c], n = (double)HW;
-        S += s1 + n * p;
-        Q2 += s2 + 2.0 * p * s1 + n * p * p;
+        red[0][tid] = s1;  red[1][tid] = s2;
+        __syncthreads();
+        if (stripe == 0) {
+            for (int r = 1; r < nstr; ++r) { s1 += red[0][r * cpg + i]; s2 += red[1][r * cpg + i]; }
+            tot[0][i] = s1;  tot[1][i] = s2;
+        }
+    } else {                                                   // group widths that do not divide 256: a channel per thread, all its slots
+        for (int i = tid; i < cpg; i += 256) {
+            const int c = g * cpg + i;
+            double s1 = 0.0, s2 = 0.0;
+            for (int s = 0; s < slots; ++s) {
+                const float* o = part + (((size_t)b * slots + s) * C + c) * 2;
+                s1 += (double)o[0];  s2 += (double)o[1];
+            }
+            tot[0][i] = s1;  tot[1][i] = s2;
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o); Q2 += __shfl_xor(Q2, o); }
-    const double N = (double)cpg * (double)HW;
-    const double mean = S / N;
-    double var = Q2 / N - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), fmean = (float)mean;
-    if (lane == 0) { mean_rstd[((size_t)b * G + g) * 2] = fmean; mean_rstd[((size_t)b * G + g) * 2 + 1] = rstd; }
-    for (int i = lane; i < cpg; i += 64) {
+    __syncthreads();
+}
+
+// one workgroup per (sample, group)
+__global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const float* __restrict__ part, int slots, int HW, const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ mean_rstd, float* __restrict__ mad, int C, int G, float eps) {
+    __shared__ double tot[2][512], red[2][256], stat[2];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G, tid = threadIdx.x;
+    gt_channel_totals(part, slots, C, b, g, cpg, tot, red);
+    if (tid == 0) {                                            // un-shift every channel by its pivot, then the group's moments (in channel order)
+        double S = 0.0, Q2 = 0.0;
+        const double n = (double)HW;
+        for (int i = 0; i < cpg; ++i) {
+            const double p = (double)x[(size_t)b * HW * ldx + g * cpg + i];
+            S += tot[0][i] + n * p;
+            Q2 += tot[1][i] + 2.0 * p * tot[0][i] + n * p * p;
+        }
+        const double N = (double)cpg * n, mean = S / N;
+        double var = Q2 / N - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        stat[0] = mean;  stat[1] = 1.0 / sqrt(var + (double)eps);
+        mean_rstd[((size_t)b * G + g) * 2] = (float)mean;
+        mean_rstd[((size_t)b * G + g) * 2 + 1] = (float)stat[1];
+    }
+    __syncthreads();
+    const float fmean = (float)stat[0], rstd = (float)stat[1];
+    for (int i = tid; i < cpg; i += 256) {
         const int c = g * cpg + i;
         float* o = mad + (size_t)b * 3 * C + c;
         o[0] = fmean;  o[C] = rstd * gamma[c];  o[2 * C] = beta[c];
     }
 }
 
-// one workgroup (64 threads) per group; the samples in order (dgamma / dbeta sum over them)
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ part, int slots, int HW, const float* __restrict__ mean_rstd,
-                                                            const float* __restrict__ gamma, float* __restrict__ coef,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int G) {
-    const int g = blockIdx.x, cpg = C / G, lane = threadIdx.x;
+// one workgroup per (sample, group): the coefficients of dx and this sample's terms {sum dy xhat, sum dy} of dgamma / dbeta
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int slots, int HW, const float* __restrict__ mean_rstd,
+                                                             const float* __restrict__ gamma, float* __restrict__ coef, float* __restrict__ ab,
+                                                             int C, int G) {
+    __shared__ double tot[2][512], red[2][256], sums[2];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G, tid = threadIdx.x;
+    gt_channel_totals(part, slots, C, b, g, cpg, tot, red);
+    const double mean = (double)mean_rstd[((size_t)b * G + g) * 2], rstd = (double)mean_rstd[((size_t)b * G + g) * 2 + 1];
+    for (int i = tid; i < cpg; i += 256) {                     // tot <- {A = sum dy xhat, B = sum dy} per channel
+        const double sdx = tot[0][i], sd = tot[1][i];
+        tot[0][i] = rstd * (sdx - mean * sd);
+        tot[1][i] = sd;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int i = 0; i < cpg; ++i) { const double gm = (double)gamma[g * cpg + i]; S1 += gm * tot[0][i]; S2 += gm * tot[1][i]; }
+        sums[0] = S1;  sums[1] = S2;
+    }
+    __syncthreads();
     const double N = (double)cpg * (double)HW;
-    // lane i owns channels i, i + 64, ... of the group (cpg <= 64 * 8 per the host check)
-    double dg[8], db[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dg[k] = db[k] = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const double mean = (double)mean_rstd[((size_t)b * G + g) * 2], rstd = (double)mean_rstd[((size_t)b * G + g) * 2 + 1];
-        double A[8], Bs[8], S1 = 0.0, S2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = lane + 64 * k;
-            A[k] = Bs[k] = 0.0;
-            if (i < cpg) {
-                const int c = g * cpg + i;
-                double sdx = 0.0, sd = 0.0;
-                for (int s = 0; s < slots; ++s) {
-                    const float* o = part + (((size_t)b * slots + s) * C + c) * 2;
-                    sdx += (double)o[0];  sd += (double)o[1];
-                }
-                A[k] = rstd * (sdx - mean * sd);               // sum over pixels of dy * xhat
-                Bs[k] = sd;
-                dg[k] += A[k];  db[k] += Bs[k];
-                S1 += (double)gamma[c] * A[k];  S2 += (double)gamma[c] * Bs[k];
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { S1 += __shfl_xor(S1, o); S2 += __shfl_xor(S2, o); }
-        const float c1 = (float)(-rstd * rstd * S1 / N), c2 = (float)(mean * rstd * rstd * S1 / N - rstd * S2 / N);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = lane + 64 * k;
-            if (i < cpg) {
-                const int c = g * cpg + i;
-                float* o = coef + (size_t)b * 3 * C + c;
-                o[0] = (float)rstd * gamma[c];  o[C] = c1;  o[2 * C] = c2;
-            }
-        }
+    const float c1 = (float)(-rstd * rstd * sums[0] / N), c2 = (float)(mean * rstd * rstd * sums[0] / N - rstd * sums[1] / N);
+    for (int i = tid; i < cpg; i += 256) {
+        const int c = g * cpg + i;
+        float* o = coef + (size_t)b * 3 * C + c;
+        o[0] = (float)rstd * gamma[c];  o[C] = c1;  o[2 * C] = c2;
+        ab[((size_t)b * C + c) * 2] = (float)tot[0][i];
+        ab[((size_t)b * C + c) * 2 + 1] = (float)tot[1][i];
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = lane + 64 * k;
-        if (i < cpg) { dgamma[g * cpg + i] = (float)dg[k]; dbeta[g * cpg + i] = (float)db[k]; }
-    }
+}
+
+// dgamma[c] = sum over the samples of sum dy xhat, dbeta[c] = ... of sum dy (in sample order)
+__global__ __launch_bounds__(256) void gn_dparam_kernel(const float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) { dg += (double)ab[((size_t)b * C + c) * 2]; db += (double)ab[((size_t)b * C + c) * 2 + 1]; }
+    dgamma[c] = (float)dg;  dbeta[c] = (float)db;
 }
 
 // mode 0: out = (u - c0) c1 + c2;  mode 1: out = u c0 + v c1 + c2;  coefficients per (sample, channel).  Pure HBM streaming.
@@ -183,7 +205,7 @@ extern "C" int nd_groupnorm_train_forward_f32(const float* x, int ldx, const flo
     float* mad = workspace + (size_t)B * slots * C * 2;        // [B][3][C]
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partials_kernel, dim3(B * slots), dim3(256), 0, st, x, ldx, x, ldx, 0, part, HW, C, slots);
-    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, slots, HW, x, ldx, gamma, beta, mean_rstd, mad, C, groups, eps);
+    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, part, slots, HW, x, ldx, gamma, beta, mean_rstd, mad, C, groups, eps);
     const size_t total = (size_t)B * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(affine3_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, x, ldx, mad, y, ldy, B, HW, C, 0);
@@ -192,7 +214,7 @@ extern "C" int nd_groupnorm_train_forward_f32(const float* x, int ldx, const flo
 
 extern "C" int64_t nd_groupnorm_train_workspace_floats(int B, int HW, int C) {
     if (B <= 0 || HW <= 0 || C <= 0) return -1;
-    return (int64_t)B * gt_slots(HW) * C * 2 + (int64_t)B * 3 * C;
+    return (int64_t)B * gt_slots(HW) * C * 2 + (int64_t)B * 3 * C + (int64_t)B * C * 2;     // slot partials, per-channel coefficients, per-sample dgamma / dbeta terms
 }
 
 extern "C" int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean_rstd,
@@ -207,9 +229,11 @@ extern "C" int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const 
     const int slots = gt_slots(HW);
     float* part = workspace;
     float* coef = workspace + (size_t)B * slots * C * 2;
+    float* ab = coef + (size_t)B * 3 * C;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partials_kernel, dim3(B * slots), dim3(256), 0, st, dy, lddy, x, ldx, 1, part, HW, C, slots);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(64), 0, st, part, slots, HW, mean_rstd, gamma, coef, dgamma, dbeta, B, C, groups);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, part, slots, HW, mean_rstd, gamma, coef, ab, C, groups);
+    hipLaunchKernelGGL(gn_dparam_kernel, dim3(nd_cdiv(C, 256)), dim3(256), 0, st, ab, dgamma, dbeta, B, C);
     const size_t total = (size_t)B * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(affine3_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, coef, dx, lddx, B, HW, C, 1);
