@@ -70,6 +70,9 @@ constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 10 + 12)
 #ifndef W4_XF_AT
 #define W4_XF_AT 10          // position pair of stage 1 behind which the raw image is complete (barrier); the transform's 36 raw reads follow,
 #endif                       // six per position pair, under the MFMAs of the stage's tail
+#ifndef W4_U_AUX
+#define W4_U_AUX 0           // cache-policy bits of the weight-fragment loads (experiment: 2 = nt)
+#endif
 #ifndef W4_NT_STORE
 #define W4_NT_STORE 0
 #endif
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     static_assert(36 % UR == 0, "the ring must close over a chunk's two stages of 18 fragments");
     auto load_u = [&](int slot, int q, int wb) {                         // q in [0, 18): position pair
 #if !(W4_ABLATE & 2)
-        U[slot % UR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wb + q * 1024, 0));
+        U[slot % UR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wb + q * 1024, W4_U_AUX));
 #endif
     };
     auto read_v = [&](const char* v0base, const char* v1base, int pp) {

@@ -22,7 +22,7 @@ constexpr int LDA = KC + 4;
 
 struct PwArgs {
     nd_pointwise d;
-    int m_tiles, n_tiles, coutP, cinP, total_wg, cus, stagger, stagger_shift;
+    int m_tiles, n_tiles, coutP, cinP, total_wg;
 };
 
 // Epilogue shared by both kernels: accumulators -> LDS -> (bias, activation, residuals, fused ResnetBlock tail) -> global.
@@ -339,22 +339,12 @@ __global__ __launch_bounds__(256, (MB == 1 ? PW_PIPE_OCC : 2)) void pointwise_pi
 // written (prologue applied) to the other LDS buffer in its middle; weight fragments run three 8-channel groups ahead in a register
 // ring that crosses chunk boundaries.  Everything between two MFMA groups is loads -- the fp32 MFMA and the VALU share issue cycles.
 #define PWB_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-#define PWB_MFMA_V(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 constexpr int BKC = 64, BLDA = BKC + 4;
 
-#ifndef PWB_OCC2
-#define PWB_OCC2 2           // workgroups per CU of the 128-cout form.  2: accumulators in ordinary registers (64 + ~150 fit 256), the second
-#endif                       // workgroup of a CU starts PWB_STAGGER x 64 cycles late so that one's epilogue runs under the other's MFMAs
-#ifndef PWB_STAGGER
-#define PWB_STAGGER 384
-#endif
 template <int NB, int MODE>
-__global__ __launch_bounds__(256, (NB == 2 ? PWB_OCC2 : 1)) void pointwise_big_kernel(const PwArgs a) {
+__global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {     // (218 registers at NB = 2: two workgroups still share a CU)
     constexpr int MB = 2, BM = 2 * MB * 32;                   // 128 pixels
-    constexpr bool VACC = NB == 2 && PWB_OCC2 == 2;           // two workgroups per CU: 256 registers each, no AGPR half to pin into
     constexpr int SIT = BM / 16;                              // staging passes: 128 rows x 16 channel quads / 256 threads
-    if (VACC && (int)blockIdx.x < 2 * a.cus && (((int)blockIdx.x >> a.stagger_shift) & 1))   // the second workgroup a CU receives:
-        for (int k = 0; k < a.stagger; k += 16) __builtin_amdgcn_s_sleep(16);  // a.stagger x 64 cycles late; later workgroups inherit the phase
     constexpr int ABUF = BM * BLDA;
     extern __shared__ __attribute__((aligned(16))) float Ab[]; // two A buffers during the K loop, the output tile in the epilogue
 
@@ -479,10 +469,7 @@ __global__ __launch_bounds__(256, (NB == 2 ? PWB_OCC2 : 1)) void pointwise_big_k
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        if (VACC) PWB_MFMA_V(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
-                        else PWB_MFMA(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
-                    }
+                    for (int nb = 0; nb < NB; ++nb) PWB_MFMA(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                       // the other buffer is complete, this one has been consumed
@@ -495,9 +482,7 @@ __global__ __launch_bounds__(256, (NB == 2 ? PWB_OCC2 : 1)) void pointwise_big_k
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            if (VACC) asm volatile("" : "+v"(acc[mb][nb])); else asm volatile("" : "+a"(acc[mb][nb]));
-        }
+        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+a"(acc[mb][nb]));
 #ifdef PWB_STAMP
     unsigned long long ph[4];
     pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0, ph);
@@ -801,7 +786,6 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     ND_REQUIRE(d->act >= ND_ACT_NONE && d->act <= ND_ACT_SILU, ND_E_BADARG, "nd_pointwise: bad act");
 
     PwArgs a;
-    a.cus = 1;  a.stagger = 0;  a.stagger_shift = 8;
     a.d = *d;
     a.cinP = nd_round_up(d->cin, 8);
     a.coutP = nd_round_up(d->cout, 64);
@@ -824,23 +808,17 @@ extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {
     const bool pipe = use_pipe && d->cin % PKC == 0 && d->cin >= 2 * PKC && !s.unshuffle &&
                       (s.mode != ND_PRO_LAYERNORM || s.rowstats) && (s.c1 == 0 || nd_aligned16(s.p1));
     // large tiles, one wave per SIMD: wide layers with enough 128-pixel tiles to fill the chip
-    static const int use_big = getenv("ND_PW_BIG") ? atoi(getenv("ND_PW_BIG")) : 1;            // A/B knob (tools/ only): 0 off, 3 = 256-cout tiles where they fill the chip (measured slower than 128)
+    static const int use_big = getenv("ND_PW_BIG") ? atoi(getenv("ND_PW_BIG")) : 1;            // A/B knob (tools/ only): 0 off
     if (pipe && use_big && d->cin % BKC == 0 && d->cin >= 2 * BKC && d->cout % 128 == 0 && d->shuffle_c == 0 &&
         (s.c1 == 0 || s.c0 % BKC == 0) && (long)d->B * d->HW * s.ld0 * 4 < (1L << 32) && (long)d->B * d->HW * s.ld1 * 4 < (1L << 32)) {
         const long mt = nd_cdiv(d->HW, 128);
         const int cus = nd_device_cus();
-        const bool wide = use_big == 3 && d->cout % 256 == 0 && (long)d->B * mt * (d->cout / 256) >= cus;
-        const long tiles = (long)d->B * mt * (d->cout / (wide ? 256 : 128));
+        const long tiles = (long)d->B * mt * (d->cout / 128);      // (256-cout tiles measured slower: 2429 vs 2318 us over the workload's wide layers)
         if (tiles >= cus) {
             a.m_tiles = (int)mt;
-            a.n_tiles = d->cout / (wide ? 256 : 128);
+            a.n_tiles = d->cout / 128;
             a.total_wg = (int)tiles;
-            a.cus = cus;
-            static const int stagger = getenv("ND_PW_STAGGER") ? atoi(getenv("ND_PW_STAGGER")) : PWB_STAGGER;      // tuning knob (tools/ only), x 64 cycles
-            a.stagger = stagger / 64;
-            static const int sshift = getenv("ND_PW_STAGGER_SHIFT") ? atoi(getenv("ND_PW_STAGGER_SHIFT")) : 8;
-            a.stagger_shift = sshift;
-            if (int e = wide ? launch_big<4>(a, st) : launch_big<2>(a, st)) return e;
+            if (int e = launch_big<2>(a, st)) return e;
             return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
         }
     }
