@@ -2,7 +2,7 @@
 __version__ = "0.1.0"
 
 __all__ = ["GaussianDiffusion", "NoiseDiffNet", "UNet_PosEmbV2", "UNet_PosEmbV2_NoPosition", "UNet_PosEmbV2_CameraCond", "LSID",
-           "__version__"]
+           "TrainableNoiseDiffNet", "__version__"]
 
 
 def __getattr__(name):
@@ -16,4 +16,7 @@ def __getattr__(name):
     if name == "LSID":
         from .lsid import LSID
         return LSID
+    if name == "TrainableNoiseDiffNet":
+        from .trainable import TrainableNoiseDiffNet
+        return TrainableNoiseDiffNet
     raise AttributeError(name)

@@ -125,7 +125,7 @@ class NoiseDiffNet(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
                 f"noisediff_amd.{self.ARCH} implements the inference (sampling) path only; call it under "
-                "torch.no_grad()/inference_mode().  Training stays on the reference network -- its weights load here unchanged.")
+                "torch.no_grad()/inference_mode().  Train noisediff_amd.TrainableNoiseDiffNet (or the reference network) -- its weights load here unchanged.")
         assert all(d % self.downsample_factor == 0 for d in x.shape[-2:]), \
             f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {self.downsample_factor}, given the unet"
         B, Cc, H, W = x.shape

@@ -1,0 +1,172 @@
+"""A differentiable NoiseDiffNet for training on MI355X without the reference tree.
+
+    net = noisediff_amd.TrainableNoiseDiffNet(args).cuda().hip()          # same constructor argument as the registry's cls(args)
+    loss = noisediff_amd.GaussianDiffusion(net, image_size=256, ...)(img, condition); loss.backward(); opt.step()
+    noisediff_amd.NoiseDiffNet(args).load_state_dict(net.state_dict())   # the HIP sampler takes the trained weights as they are
+
+The graph is the reference network's (models/archs/Diffusion_arch.py:447-646) written as one functional forward
+over a flat parameter table; parameters are registered under the reference's own dotted names, so ``state_dict()`` is
+interchangeable with the reference class and with ``noisediff_amd.NoiseDiffNet``.  ``.hip()`` routes every 3x3 convolution and
+GroupNorm through the HIP library forward and backward (noisediff_amd/train.py); everything else is PyTorch.  Parity: the
+forward against the reference's golden activations and loss / gradients against tests/golden/training.npz (tests/test_trainable.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import synth
+from .spec import noisediff_param_spec
+
+P = Dict[str, torch.Tensor]
+GROUPS, POS_GROUPS, HEADS = 8, 2, 4
+
+
+class _Ops:
+    """Layer primitives over the parameter table; 3x3 convolutions and GroupNorms go to the HIP library when asked to and able to."""
+
+    def __init__(self, params: P, hip: bool):
+        self.p, self.hip = params, hip
+
+    def conv(self, name: str, x: torch.Tensor, padding: int = 0) -> torch.Tensor:
+        w, b = self.p[name + ".weight"], self.p.get(name + ".bias")
+        if self.hip and x.is_cuda and w.shape[2:] == (3, 3) and padding == 1 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+            from . import train
+            return train.conv3x3(x, w, b)
+        return F.conv2d(x, w, b, padding=padding)
+
+    def linear(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        return F.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"))
+
+    def group_norm(self, name: str, x: torch.Tensor, groups: int) -> torch.Tensor:
+        w, b = self.p[name + ".weight"], self.p[name + ".bias"]
+        if self.hip and x.is_cuda and x.shape[1] % 4 == 0:
+            from . import train
+            return train.group_norm(x, groups, w, b, 1e-5)
+        return F.group_norm(x, groups, w, b, eps=1e-5)
+
+    def layer_norm(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        return F.layer_norm(x, x.shape[-1:], self.p[name + ".weight"], self.p[name + ".bias"], eps=1e-5)
+
+    # ---- composite layers ------------------------------------------------------------------------------------------
+    def block(self, name: str, x, groups: int, scale=None, shift=None):
+        """Block: conv3x3 -> GroupNorm -> optional x (scale + 1) + shift -> SiLU   (Diffusion_arch.py:128-144)."""
+        x = self.group_norm(name + ".norm", self.conv(name + ".proj", x, 1), groups)
+        if scale is not None:
+            x = x * (scale + 1) + shift
+        return F.silu(x)
+
+    def resnet(self, name: str, x, emb, groups: int, per_pixel: bool = False):
+        """ResnetBlock (per-sample scale / shift from the time embedding, :146-170) and ResnetBlock2 (per-pixel maps from the
+        position embedding, :173-196); the shortcut is a 1x1 conv iff the channel count changes."""
+        scale = shift = None
+        if emb is not None:
+            e = self.conv(name + ".mlp.1", F.silu(emb)) if per_pixel else self.linear(name + ".mlp.1", F.silu(emb))[:, :, None, None]
+            scale, shift = e.chunk(2, dim=1)
+        h = self.block(name + ".block2", self.block(name + ".block1", x, groups, scale, shift), groups)
+        return h + (self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x)
+
+    def mlp(self, name: str, x):
+        """Mlp: conv1x1 -> GELU -> conv1x1   (:340-356)."""
+        return self.conv(name + ".fc2", F.gelu(self.conv(name + ".fc1", x)))
+
+    def cross_attention(self, name: str, x, ctx):
+        """CrossAttention over the ISO context, in full (:361-402)."""
+        b, n, _ = x.shape
+        q, k, v = self.linear(name + ".to_q", x), self.linear(name + ".to_k", ctx), self.linear(name + ".to_v", ctx)
+        d = q.shape[-1] // HEADS
+        heads = lambda t: t.reshape(b, t.shape[1], HEADS, d).transpose(1, 2)               # b h n d
+        q, k, v = heads(q), heads(k), heads(v)
+        attn = (q @ k.transpose(-1, -2) * d ** -0.5).softmax(dim=-1)
+        out = (attn @ v).transpose(1, 2).reshape(b, n, HEADS * d)
+        return self.linear(name + ".to_out.0", out)
+
+    def attn_block(self, name: str, x, ctx):
+        """AttnBlock: tokens; x += attn(LN1 x, ctx); x += FF(LN2 x); proj_out + input   (:425-443)."""
+        b, c, h, w = x.shape
+        t = x.flatten(2).transpose(1, 2)
+        t = self.cross_attention(name + ".attn", self.layer_norm(name + ".norm1", t), ctx) + t
+        t = self.linear(name + ".ff.net.2", F.gelu(self.linear(name + ".ff.net.0.0", self.layer_norm(name + ".norm2", t)))) + t
+        return self.conv(name + ".proj_out", t.transpose(1, 2).reshape(b, c, h, w)) + x
+
+
+def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """NoiseDiffNet.forward (:577-646): shot-noise branch on cat(clean, x) + the U-Net's read-noise branch."""
+    p = o.p
+    dim = p["init_conv.weight"].shape[0]
+    if x.shape[-1] % 8 or x.shape[-2] % 8:
+        raise ValueError(f"NoiseDiffNet needs image sides that are multiples of 8, got {tuple(x.shape[-2:])}")
+    clean = condition["clean_img"]
+    # condition embeddings: learned sinusoidal position features -> Mlp; ISO table row as a one-token context; time MLP
+    w = o.conv("pos_enc.weights", condition["position"])
+    pos = o.mlp("pos_mlp", torch.cat((w, (2 * math.pi * w).sin(), (2 * math.pi * w).cos()), dim=1))
+    iso = F.embedding(condition["iso_ratio_idx"].long(), p["iso_embed.weight"])[:, None]
+    half = dim // 2
+    freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000.0) / (half - 1)))
+    ang = time[:, None] * freqs[None]
+    t = o.linear("time_mlp.3", F.gelu(o.linear("time_mlp.1", torch.cat((ang.sin(), ang.cos()), dim=-1))))
+
+    s0 = o.mlp("shot_mlp1", torch.cat((clean, x), dim=1))
+    s = o.mlp("shot_mlp2", o.attn_block("shot_attn", s0, iso))
+    shot = o.mlp("shot_mlp3", o.resnet("shot_time", s, t, POS_GROUPS) + s0)
+
+    x = o.conv("init_conv", x, 3)
+    stem = x
+    x = o.resnet("pos_block1", x, pos, POS_GROUPS, per_pixel=True)
+    skips: List[torch.Tensor] = []
+    for i in range(4):
+        n = f"downs.{i}"
+        x = o.resnet(n + ".0", x, t, GROUPS); skips.append(x)
+        x = o.resnet(n + ".1", x, t, GROUPS); skips.append(x)
+        x = o.attn_block(n + ".2", x, iso)
+        x = o.conv(n + ".3", x, 1) if i == 3 else o.conv(n + ".3.1", F.pixel_unshuffle(x, 2))
+    x = o.resnet("mid_block2", o.resnet("mid_block1", x, t, GROUPS), t, GROUPS)
+    for i in range(4):
+        n = f"ups.{i}"
+        x = o.resnet(n + ".0", torch.cat((x, skips.pop()), dim=1), t, GROUPS)
+        x = o.resnet(n + ".1", torch.cat((x, skips.pop()), dim=1), t, GROUPS)
+        x = o.attn_block(n + ".2", x, iso)
+        x = o.conv(n + ".3", x, 1) if i == 3 else o.conv(n + ".3.1", F.interpolate(x, scale_factor=2, mode="nearest"), 1)
+    x = o.resnet("pos_block2", x, pos, POS_GROUPS, per_pixel=True)
+    x = o.resnet("final_res_block", torch.cat((x, stem), dim=1), t, GROUPS)
+    return shot + o.conv("final_conv", x)
+
+
+class TrainableNoiseDiffNet(nn.Module):
+    """``TrainableNoiseDiffNet(args)``: args.dim (default 64), the other fields of the reference's argument object are accepted and
+    must describe the configuration this package implements (4 input channels, no self-conditioning)."""
+    channels = out_dim = 4
+    self_condition = False
+    random_or_learned_sinusoidal_cond = False
+
+    def __init__(self, args=None, seed: int = 0):
+        super().__init__()
+        dim = int(getattr(args, "dim", 64))
+        if getattr(args, "self_condition", False) or int(getattr(args, "inp_dim", 4)) != 4 or int(getattr(args, "cond_dim", 4)) != 4:
+            raise ValueError("TrainableNoiseDiffNet implements the reference's configuration: inp_dim = cond_dim = 4, self_condition = False")
+        self.dim = dim
+        self._hip = False
+        for name, value in synth.make_state_dict(noisediff_param_spec(dim), seed).items():      # PyTorch's default-init statistics
+            parts, m = name.split("."), self
+            for part in parts[:-1]:
+                if part not in m._modules:
+                    m.add_module(part, nn.Module())
+                m = m._modules[part]
+            m.register_parameter(parts[-1], nn.Parameter(value))
+
+    def hip(self, on: bool = True) -> "TrainableNoiseDiffNet":
+        """3x3 convolutions and GroupNorms forward and backward on libnoisediff_hip (CUDA tensors only; raises without the library)."""
+        if on:
+            from . import _lib
+            _lib.load()
+        self._hip = bool(on)
+        return self
+
+    def forward(self, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, torch.Tensor], x_self_cond: Optional[torch.Tensor] = None):
+        if x_self_cond is not None:
+            raise ValueError("self-conditioning is not part of this configuration")
+        return _forward(_Ops(dict(self.named_parameters()), self._hip), x, time, condition)

@@ -1,0 +1,98 @@
+"""noisediff_amd.TrainableNoiseDiffNet: the differentiable network of the training path.
+
+CPU: its parameter names are the reference's, its forward equals the oracle's (which the reference's golden activations pin,
+tests/test_oracle.py) and -- wrapped by GaussianDiffusion -- it reproduces the reference's training loss and parameter gradients
+(tests/golden/training.npz, captured from the reference by tests/golden/capture_training.py).
+GPU: with .hip() (3x3 convolutions and GroupNorms on the HIP library, forward and backward) loss and gradients stay the same, and the
+trained weights load into the HIP sampler unchanged."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from noisediff_amd import GaussianDiffusion, TrainableNoiseDiffNet, synth
+from noisediff_amd.spec import noisediff_param_spec
+from oracle import noisediff_oracle as O
+from util import rel_err, state_dict, sub
+
+DIM, B, H, T = 16, 2, 32, 1000
+GRAD_KEYS = ["final_conv.weight", "downs.0.0.block1.proj.weight", "time_mlp.1.weight", "mid_block1.block2.norm.weight",
+             "ups.3.2.ff.net.2.weight", "shot_mlp1.fc1.weight", "pos_block1.mlp.1.bias", "iso_embed.weight"]
+
+
+def _net(dim=DIM):
+    net = TrainableNoiseDiffNet(SimpleNamespace(dim=dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, phase="train"))
+    net.load_state_dict(state_dict(dim), strict=True)
+    return net
+
+
+def _inputs():
+    return (synth.uniform(5, "train.x0", (B, 4, H, H), -1.0, 1.0), synth.make_noise(5, "train.noise", B, 4, H),
+            torch.tensor([3, 777], dtype=torch.long), synth.make_condition(B, H, seed=1))
+
+
+def test_parameter_names_and_default_init_follow_the_spec():
+    net = TrainableNoiseDiffNet(SimpleNamespace(dim=DIM))
+    spec = noisediff_param_spec(DIM)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(p.name, tuple(p.shape)) for p in spec]
+    assert all(v.requires_grad for v in net.parameters())
+    with pytest.raises(ValueError):
+        TrainableNoiseDiffNet(SimpleNamespace(dim=DIM, self_condition=True))
+
+
+def test_forward_equals_the_oracle():
+    net = _net()
+    x0, _, t, cond = _inputs()
+    with torch.no_grad():
+        got = net(x0, t, cond)
+        ref = O.noisediff_forward(state_dict(DIM), x0, t, cond)
+    assert got.shape == ref.shape == (B, 4, H, H)
+    assert rel_err(got.numpy(), ref.numpy()) < 1e-6
+
+
+def test_loss_and_gradients_match_the_reference(golden):
+    x0, noise, t, cond = _inputs()
+    net = _net()
+    gd = GaussianDiffusion(nn.DataParallel(net), image_size=H, timesteps=T, beta_schedule="sigmoid2", objective="pred_v")
+    loss = gd.p_losses(x0, t, cond, noise=noise.clone())
+    assert float(loss.detach()) == pytest.approx(float(golden("training", "train.loss.pred_v")), rel=2e-5)
+    loss.backward()
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    for k in GRAD_KEYS:
+        ref = golden("training", f"train.grad.{k}")
+        got = sub(grads[k], 2048)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+    sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
+    assert sq == pytest.approx(float(golden("training", "train.grad_sq_norm")), rel=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_convs_and_norms_keep_loss_and_gradients_and_weights_load_into_the_sampler():
+    from noisediff_amd import NoiseDiffNet
+    dev = torch.device("cuda", 0)
+    x0, noise, t, cond = _inputs()
+    x0, noise, t = x0.to(dev), noise.to(dev), t.to(dev)
+    cond = {k: v.to(dev) for k, v in cond.items()}
+    out = []
+    for hip in (False, True):
+        net = _net().to(dev).hip(hip)
+        gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+        loss = gd.p_losses(x0, t, cond, noise=noise.clone())
+        loss.backward()
+        out.append((float(loss.detach()), {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}))
+    assert out[1][0] == pytest.approx(out[0][0], rel=2e-5)
+    assert out[0][1].keys() == out[1][1].keys()
+    for k in out[0][1]:
+        assert rel_err(out[1][1][k].numpy(), out[0][1][k].numpy()) < 5e-4, k
+    # a step of Adam on the accelerated net, then its weights sample on the HIP network
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt.step()
+    hipnet = NoiseDiffNet(SimpleNamespace(dim=DIM, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False))
+    hipnet.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    hipnet = hipnet.to(dev).eval()
+    with torch.no_grad():
+        ref = net.hip(False)(x0, t, cond)
+        y = hipnet(x0, t, cond)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-4

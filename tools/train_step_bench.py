@@ -40,6 +40,39 @@ def step_time(net, x, target, reps=5):
     return (time.perf_counter() - t0) / reps, float(loss)
 
 
+def real_net():
+    """The whole NoiseDiffNet (d = 64) under GaussianDiffusion.p_losses: forward + backward + Adam, PyTorch vs .hip()."""
+    from types import SimpleNamespace
+    from noisediff_amd import GaussianDiffusion, TrainableNoiseDiffNet, synth
+    for (B, S) in [(4, 256), (8, 128)]:
+        cond = {k: v.to(dev) for k, v in synth.make_condition(B, S, seed=1).items()}
+        img = synth.uniform(7, "img", (B, 4, S, S), -1.0, 1.0).to(dev)
+        res = []
+        for hip in (False, True):
+            torch.manual_seed(0)
+            net = TrainableNoiseDiffNet(SimpleNamespace(dim=64)).to(dev).hip(hip)
+            gd = GaussianDiffusion(net, image_size=S, timesteps=1000, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+            def one():
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(1)
+                loss = gd(img, cond)
+                loss.backward()
+                opt.step()
+                return loss.detach()
+            one(); one(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3): loss = one()
+            torch.cuda.synchronize()
+            res.append(((time.perf_counter() - t0) / 3, float(loss), torch.cuda.max_memory_allocated() / 2**30))
+            del net, gd, opt
+            torch.cuda.empty_cache()
+        print(f"NoiseDiffNet d=64, B={B} {S}x{S}: PyTorch {res[0][0] * 1e3:7.1f} ms/step | .hip() {res[1][0] * 1e3:7.1f} ms/step | x{res[0][0] / res[1][0]:.2f} | "
+              f"loss {res[0][1]:.6f} / {res[1][1]:.6f} | peak memory {res[1][2]:.1f} GiB", flush=True)
+
+
+if os.environ.get("REAL_NET", "1") != "0":
+    real_net()
 for (B, S, C, nblk) in [(8, 256, 64, 4), (8, 64, 256, 4)]:
     torch.manual_seed(0)
     ref = nn.Sequential(nn.Conv2d(4, C, 1), *[Block(C, C) for _ in range(nblk)], nn.Conv2d(C, 4, 1)).to(dev).to(memory_format=torch.channels_last)
