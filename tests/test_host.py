@@ -226,3 +226,17 @@ def test_generated_npy_contract(tmp_path):
     a = torch.rand(4, 8, 8)
     assert io.psnr(a, a) == float("inf")
     assert io.psnr(torch.zeros(4), torch.full((4,), 0.1)) == pytest.approx(20.0, abs=1e-4)
+
+
+def test_blocked_map_row_permutation():
+    """engine._blocked_map_rows: output row order of the ResnetBlock2 map Linear for nd_src.map_blocked (include/noisediff_hip.h):
+    position 32 c + j holds scale channel 16 c + j (j < 16) or shift channel 16 c + j - 16."""
+    from noisediff_amd.engine import _blocked_map_rows
+    for C_ in (16, 64, 128):
+        perm = _blocked_map_rows(C_)
+        assert sorted(perm.tolist()) == list(range(2 * C_))                      # a permutation of the 2C producer rows
+        planar = torch.arange(2 * C_)                                            # value = original row: scale rows 0..C-1, shift rows C..2C-1
+        blocked = planar[perm].view(C_ // 16, 2, 16)
+        for c in range(C_ // 16):
+            assert blocked[c, 0].tolist() == list(range(16 * c, 16 * c + 16))              # scale channels of chunk c
+            assert blocked[c, 1].tolist() == list(range(C_ + 16 * c, C_ + 16 * c + 16))    # shift channels of chunk c
