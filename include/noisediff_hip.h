@@ -155,6 +155,15 @@ int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const float* x, i
                                     float* dx, int lddx, float* dgamma, float* dbeta, float* workspace, int B, int HW, int C, int groups,
                                     void* stream);
 
+/* Weight and bias gradient of a token Linear / 1x1 convolution: dw[co][ci] = sum_p dy[p][co] * x[p][ci], dbias[co] = sum_p dy[p][co]
+ * over N tokens (x, dy: [N][ld] fp32, NHWC pixels are tokens; dw in torch's (cout, cin) layout; dbias may be NULL).  The backward of
+ * res_conv, Mlp.fc1/fc2, FeedForward, proj_out and the attention projections (Diffusion_arch.py:156,345-347,410-419,432) under
+ * GaussianDiffusion.p_losses.  Exact-fp32 MFMA, fixed split and summation order (bitwise repeatable).
+ * `workspace`: nd_linear_wgrad_workspace_floats(N, cin, cout) floats.  (The data gradient is a plain GEMM, dy @ W.) */
+int64_t nd_linear_wgrad_workspace_floats(int64_t N, int cin, int cout);
+int nd_linear_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw, float* dbias, float* workspace,
+                        int64_t N, int cin, int cout, void* stream);
+
 /* ------------------------------------------------------------------ pointwise GEMM */
 
 /* out[p, n] = epi( sum_k pro(in[p, k]) * W[k, n] + bias[n] ) per pixel: nn.Conv2d(k=1) and

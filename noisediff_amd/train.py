@@ -16,8 +16,10 @@ Tensors stay what PyTorch hands over: NCHW-shaped, ``channels_last`` in memory (
 converted once per call), fp32, on the caller's CUDA stream -- so autograd's stream ordering holds without synchronisation.
 ``GroupNormFunction`` (second slice) does the same for nn.GroupNorm: nd_groupnorm_train_forward_f32 / _backward_f32 (norm_train.hip) stream
 the channels_last tensors once per pass, where PyTorch's NCHW group norm first copies them to NCHW and back -- on the full-resolution
-blocks the norms cost more than the convolutions before this.  Everything else in the network (activations, 1x1 convolutions,
-attention) stays on PyTorch's own ROCm kernels for now.
+blocks the norms cost more than the convolutions before this.  ``LinearFunction`` (third slice) keeps the output and the data
+gradient of token Linears / 1x1 convolutions on the library GEMM and takes their weight and bias gradient -- a reduction over up to
+10^6 tokens that library GEMMs run at a tenth of HBM speed -- to nd_linear_wgrad_f32 (linear_wgrad.hip).  Activations, LayerNorm and
+attention stay on PyTorch's own ROCm kernels for now.
 
 There is no fallback: a CPU tensor or a missing library raises.
 """
@@ -179,6 +181,77 @@ def _hip_norm_forward(self: nn.GroupNorm, x: torch.Tensor) -> torch.Tensor:
     return group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
 
 
+class LinearFunction(torch.autograd.Function):
+    """y = x @ W^T + b over tokens (x: (..., cin) with the tokens contiguous).  Output and data gradient are plain GEMMs (the library's);
+    the weight and bias gradients -- a reduction over 10^5..10^6 tokens into a 64..1024-wide matrix, where library GEMMs run at a
+    tenth of HBM speed -- come from nd_linear_wgrad_f32 (linear_wgrad.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        cout, cin = weight.shape
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_x = grad_out @ weight
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            g2 = grad_out.reshape(-1, cout)
+            x2 = x.reshape(-1, cin)
+            if g2.dtype != torch.float32 or not g2.is_contiguous():
+                g2 = g2.float().contiguous()
+            if x2.dtype != torch.float32 or not x2.is_contiguous():
+                x2 = x2.float().contiguous()
+            if x2.device.type != "cuda":
+                raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {x2.device} and there is no CPU path")
+            N = x2.shape[0]
+            with torch.cuda.device(x2.device):
+                grad_w = torch.empty((cout, cin), dtype=torch.float32, device=x2.device)
+                grad_b = torch.empty(cout, dtype=torch.float32, device=x2.device) if ctx.has_bias else None
+                ws = torch.empty(int(lib.nd_linear_wgrad_workspace_floats(N, cin, cout)), dtype=torch.float32, device=x2.device)
+                L.call("nd_linear_wgrad_f32", x2.data_ptr(), cin, g2.data_ptr(), cout, grad_w.data_ptr(),
+                       grad_b.data_ptr() if grad_b is not None else None, ws.data_ptr(), N, cin, cout, _stream())
+        return grad_x, grad_w, grad_b
+
+
+def _linear_ok(cin: int, cout: int) -> bool:
+    return cin % 4 == 0 and cout % 4 == 0
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable F.linear(x, weight, bias) with the weight / bias gradient on the HIP library (channel counts multiples of 4)."""
+    if weight.dim() != 2 or x.shape[-1] != weight.shape[1] or not _linear_ok(weight.shape[1], weight.shape[0]):
+        raise ValueError(f"linear: x {tuple(x.shape)} / weight {tuple(weight.shape)}: needs a 2-D weight with channel counts that are multiples of 4")
+    return LinearFunction.apply(x, weight, bias)
+
+
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable F.conv2d(x, weight, bias) for 1x1 kernels as a Linear over the pixels (NHWC tokens; channels_last in and out)."""
+    if x.dim() != 4 or tuple(weight.shape[2:]) != (1, 1) or x.shape[1] != weight.shape[1]:
+        raise ValueError(f"conv1x1: x {tuple(x.shape)} / weight {tuple(weight.shape)} is not a 1x1 convolution")
+    t = x.permute(0, 2, 3, 1)                                              # a view; contiguous when x is channels_last
+    y = linear(t if t.is_contiguous() else t.contiguous(), weight.flatten(1), bias)
+    return y.permute(0, 3, 1, 2)                                           # NCHW-shaped, channels_last in memory
+
+
+def _eligible_linear(m: nn.Module) -> bool:
+    if isinstance(m, nn.Linear):
+        return _linear_ok(m.in_features, m.out_features)
+    return (isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.groups == 1
+            and _linear_ok(m.in_channels, m.out_channels))
+
+
+def _hip_linear_forward(self, x: torch.Tensor) -> torch.Tensor:
+    if isinstance(self, nn.Linear):
+        return linear(x, self.weight, self.bias)
+    return conv1x1(x, self.weight, self.bias)
+
+
 def _eligible(m: nn.Module) -> bool:
     return (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
             and m.groups == 1 and m.padding_mode == "zeros" and m.in_channels % 8 == 0 and m.out_channels % 8 == 0)
@@ -188,9 +261,10 @@ def _hip_conv_forward(self: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     return conv3x3(x, self.weight, self.bias)
 
 
-def accelerate(model: nn.Module, norms: bool = True) -> int:
+def accelerate(model: nn.Module, norms: bool = True, linears: bool = True) -> int:
     """Route every eligible 3x3 convolution of ``model`` (stride 1, padding 1, channel counts multiples of 8) and -- unless
-    ``norms=False`` -- every affine nn.GroupNorm (C a multiple of 4) through the HIP library, forward and backward.  Parameters,
+    ``norms=False`` / ``linears=False`` -- every affine nn.GroupNorm (C a multiple of 4) and the weight / bias gradient of every
+    nn.Linear and 1x1 nn.Conv2d (channel counts multiples of 4) through the HIP library, forward and backward.  Parameters,
     module tree and state dict are untouched; the replacement is a bound method, so ``copy.deepcopy`` (the trainer's EMA) rebinds
     it to the copy.  Returns the number of convolutions taken."""
     import types
@@ -201,4 +275,6 @@ def accelerate(model: nn.Module, norms: bool = True) -> int:
             n += 1
         elif norms and _eligible_norm(m) and getattr(m.forward, "__func__", None) is not _hip_norm_forward:
             m.forward = types.MethodType(_hip_norm_forward, m)
+        elif linears and _eligible_linear(m) and getattr(m.forward, "__func__", None) is not _hip_linear_forward:
+            m.forward = types.MethodType(_hip_linear_forward, m)
     return n

@@ -7,7 +7,8 @@
 The graph is the reference network's (models/archs/Diffusion_arch.py:447-646) written as one functional forward
 over a flat parameter table; parameters are registered under the reference's own dotted names, so ``state_dict()`` is
 interchangeable with the reference class and with ``noisediff_amd.NoiseDiffNet``.  ``.hip()`` routes every 3x3 convolution and
-GroupNorm through the HIP library forward and backward (noisediff_amd/train.py); everything else is PyTorch.  Parity: the
+GroupNorm through the HIP library forward and backward and the weight / bias gradients of the Linears and 1x1 convolutions
+(noisediff_amd/train.py); everything else is PyTorch.  Parity: the
 forward against the reference's golden activations and loss / gradients against tests/golden/training.npz (tests/test_trainable.py).
 """
 from __future__ import annotations
@@ -37,10 +38,17 @@ class _Ops:
         if self.hip and x.is_cuda and w.shape[2:] == (3, 3) and padding == 1 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
             from . import train
             return train.conv3x3(x, w, b)
+        if self.hip and x.is_cuda and w.shape[2:] == (1, 1) and padding == 0 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+            from . import train
+            return train.conv1x1(x, w, b)
         return F.conv2d(x, w, b, padding=padding)
 
     def linear(self, name: str, x: torch.Tensor) -> torch.Tensor:
-        return F.linear(x, self.p[name + ".weight"], self.p.get(name + ".bias"))
+        w, b = self.p[name + ".weight"], self.p.get(name + ".bias")
+        if self.hip and x.is_cuda and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+            from . import train
+            return train.linear(x, w, b)
+        return F.linear(x, w, b)
 
     def group_norm(self, name: str, x: torch.Tensor, groups: int) -> torch.Tensor:
         w, b = self.p[name + ".weight"], self.p[name + ".bias"]
@@ -159,7 +167,7 @@ class TrainableNoiseDiffNet(nn.Module):
             m.register_parameter(parts[-1], nn.Parameter(value))
 
     def hip(self, on: bool = True) -> "TrainableNoiseDiffNet":
-        """3x3 convolutions and GroupNorms forward and backward on libnoisediff_hip (CUDA tensors only; raises without the library)."""
+        """3x3 convolutions and GroupNorms forward and backward, Linear / 1x1 weight gradients on libnoisediff_hip (CUDA tensors only; raises without the library)."""
         if on:
             from . import _lib
             _lib.load()

@@ -154,3 +154,57 @@ def test_accelerate_takes_the_norms_too():
         grads.append({k: p.grad.detach().cpu() for k, p in net.named_parameters()})
     for k in grads[0]:
         assert rel_err(grads[1][k].numpy(), grads[0][k].numpy()) < 2e-4, k
+
+
+LIN_CASES = {"tokens": (3 * 1000, 64, 128), "ragged": (777, 36, 20), "wide": (4096, 512, 1024), "one_token_per_sample": (4, 16, 64),
+             "many": (262144, 64, 64)}
+
+
+@pytest.mark.parametrize("case", sorted(LIN_CASES))
+def test_linear_weight_and_bias_gradient_match_a_float64_sum(case):
+    """nd_linear_wgrad_f32 through train.linear: dW and db against float64, dX and y against F.linear; bitwise repeatable."""
+    N, cin, cout = LIN_CASES[case]
+    x = U(case + ".x", (N, cin), -1.5, 1.5).to(DEV)
+    w = (U(case + ".w", (cout, cin)) / cin ** 0.5).to(DEV)
+    b = U(case + ".b", (cout,)).to(DEV)
+    gy = U(case + ".gy", (N, cout)).to(DEV)
+    outs = []
+    for _ in range(2):
+        xa, wa, ba = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        y = train.linear(xa, wa, ba)
+        y.backward(gy)
+        outs.append([t.detach().cpu() for t in (y, xa.grad, wa.grad, ba.grad)])
+    assert all(torch.equal(p, q) for p, q in zip(*outs))
+    x64, g64 = x.double().cpu(), gy.double().cpu()
+    assert rel_err(outs[0][2].numpy(), (g64.T @ x64).numpy()) < 2e-5 * max(1.0, (N / 4096) ** 0.5)
+    assert rel_err(outs[0][3].numpy(), g64.sum(0).numpy()) < 2e-5 * max(1.0, (N / 4096) ** 0.5)
+    assert rel_err(outs[0][1].numpy(), (g64 @ w.double().cpu()).numpy()) < 2e-5
+    assert rel_err(outs[0][0].numpy(), F.linear(x64, w.double().cpu(), b.double().cpu()).numpy()) < 2e-5
+    wa = w.clone().requires_grad_()                                         # no bias
+    train.linear(x, wa).backward(gy)
+    assert torch.equal(wa.grad.cpu(), outs[0][2])
+
+
+def test_conv1x1_and_accelerated_linears():
+    torch.manual_seed(2)
+    ref = nn.Sequential(nn.Conv2d(32, 64, 1), nn.SiLU(), nn.Conv2d(64, 64, 3, padding=1), nn.GroupNorm(8, 64), nn.Conv2d(64, 8, 1)).to(DEV)
+    hip = copy.deepcopy(ref)
+    train.accelerate(hip)
+    assert sum(getattr(m.forward, "__func__", None) is train._hip_linear_forward for m in hip.modules()) == 2
+    x = U("c11.x", (2, 32, 24, 40)).to(DEV)
+    target = U("c11.t", (2, 8, 24, 40)).to(DEV)
+    grads = []
+    for net in (ref, hip):
+        xa = x.clone().requires_grad_()
+        F.mse_loss(net(xa), target).backward()
+        grads.append({**{k: p.grad.detach().cpu() for k, p in net.named_parameters()}, "x": xa.grad.detach().cpu()})
+    for k in grads[0]:
+        assert rel_err(grads[1][k].numpy(), grads[0][k].numpy()) < 2e-4, k
+    tok = nn.Linear(48, 96).to(DEV)
+    tok_hip = copy.deepcopy(tok)
+    train.accelerate(tok_hip)
+    t = U("tok.x", (3, 50, 48)).to(DEV)
+    for net in (tok, tok_hip):
+        net(t).square().mean().backward()
+    assert rel_err(tok_hip.weight.grad.cpu().numpy(), tok.weight.grad.cpu().numpy()) < 2e-5
+    assert rel_err(tok_hip.bias.grad.cpu().numpy(), tok.bias.grad.cpu().numpy()) < 2e-5
