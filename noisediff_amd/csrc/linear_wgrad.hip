@@ -86,34 +86,45 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const LwArgs a) {
     }
 }
 
-// dW[co][ci] = sum over the S partials (consecutive threads: consecutive cins), db[co] likewise; fixed order
+// dW[co][ci] = sum over the S partials, db[co] likewise.  A workgroup owns 32 consecutive elements of the partial blocks; its eight
+// 32-thread stripes add the slots s = stripe, stripe + 8, ... (eight loads in flight each) and the stripes then meet in stripe order:
+// a fixed order, eight times shallower than one thread per element (which made this pass slower than the gradient kernel itself).
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw,
                                                                   float* __restrict__ db, int S, int cin, int cout, int coP, int ciP) {
-    const size_t block = (size_t)coP * ciP;
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < block + coP; j += (size_t)gridDim.x * blockDim.x) {
-        if (j >= block) {                                                // the bias tail
-            const int co = (int)(j - block);
-            if (db && co < cout) {
-                float sum = 0.0f;
-                for (int s = 0; s < S; ++s) sum += wsb[(size_t)s * coP + co];
-                db[co] = sum;
-            }
-            continue;
-        }
-        const int ci = (int)(j % ciP), co = (int)(j / ciP);
-        if (co >= cout || ci >= cin) continue;
-        const float* p = ws + j;
+    __shared__ float red[8][32];
+    const size_t block = (size_t)coP * ciP, total = block + coP;         // the bias partials follow the weight partials element-wise
+    const int o = threadIdx.x & 31, stripe = threadIdx.x >> 5;
+    for (size_t j0 = (size_t)blockIdx.x * 32; j0 < total; j0 += (size_t)gridDim.x * 32) {
+        const size_t j = j0 + o;
+        const bool bias = j >= block;
+        const float* p = bias ? wsb + (j - block) : ws + j;
+        const size_t stride = bias ? (size_t)coP : block;
         float sum = 0.0f;
-        int s = 0;
-        for (; s + 8 <= S; s += 8) {
-            float v[8];
+        if (j < total && (!bias || db)) {
+            int s = stripe;
+            for (; s + 56 < S; s += 64) {
+                float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s + k) * block];
+                for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s + 8 * k) * stride];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sum += v[k];
+                for (int k = 0; k < 8; ++k) sum += v[k];
+            }
+            for (; s < S; s += 8) sum += p[(size_t)s * stride];
         }
-        for (; s < S; ++s) sum += p[(size_t)s * block];
-        dw[(size_t)co * cin + ci] = sum;
+        __syncthreads();
+        red[stripe][o] = sum;
+        __syncthreads();
+        if (stripe == 0 && j < total) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k) sum += red[k][o];
+            if (bias) {
+                const int co = (int)(j - block);
+                if (db && co < cout) db[co] = sum;
+            } else {
+                const int ci = (int)(j % ciP), co = (int)(j / ciP);
+                if (co < cout && ci < cin) dw[(size_t)co * cin + ci] = sum;
+            }
+        }
     }
 }
 
@@ -155,7 +166,7 @@ extern "C" int nd_linear_wgrad_f32(const float* x, int ldx, const float* dy, int
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
     if (int e = nd_launch_status("nd_linear_wgrad_f32")) return e;
     const size_t total = (size_t)a.n_co * LW_CB * (a.n_ci * LW_CB + 1);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int blocks = (int)((total + 31) / 32 < 8192 ? (total + 31) / 32 : 8192);
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, a.wsb, dw, dbias, a.S, cin, cout, a.n_co * LW_CB, a.n_ci * LW_CB);
     return nd_launch_status("nd_linear_wgrad_f32 (reduce)");
 }
