@@ -155,6 +155,17 @@ int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const float* x, i
                                     float* dx, int lddx, float* dgamma, float* dbeta, float* workspace, int B, int HW, int C, int groups,
                                     void* stream);
 
+/* nn.LayerNorm(C) over the channels of NHWC tokens for training (AttnBlock.norm1 / norm2, Diffusion_arch.py:427-428): forward
+ * y = (x - mean) rstd gamma + beta with `stats` [N][2] = {mean, rstd} per token saved for the backward; backward dx, dgamma [C],
+ * dbeta [C].  C = 64, 128 or a multiple of 256 up to 1024 (a row lives in 16 / 32 / 64 lanes); eps inside the square root, biased
+ * variance -- torch.nn.functional.layer_norm's definition.  One streaming pass per direction, fixed summation order.
+ * `workspace` (backward): nd_layernorm_train_workspace_floats(N, C) floats. */
+int64_t nd_layernorm_train_workspace_floats(int64_t N, int C);
+int nd_layernorm_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* stats,
+                                   int64_t N, int C, float eps, void* stream);
+int nd_layernorm_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* stats,
+                                    float* dx, int lddx, float* dgamma, float* dbeta, float* workspace, int64_t N, int C, void* stream);
+
 /* Weight and bias gradient of a token Linear / 1x1 convolution: dw[co][ci] = sum_p dy[p][co] * x[p][ci], dbias[co] = sum_p dy[p][co]
  * over N tokens (x, dy: [N][ld] fp32, NHWC pixels are tokens; dw in torch's (cout, cin) layout; dbias may be NULL).  The backward of
  * res_conv, Mlp.fc1/fc2, FeedForward, proj_out and the attention projections (Diffusion_arch.py:156,345-347,410-419,432) under

@@ -239,3 +239,191 @@ extern "C" int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const 
     hipLaunchKernelGGL(affine3_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, coef, dx, lddx, B, HW, C, 1);
     return nd_launch_status("nd_groupnorm_train_backward_f32");
 }
+
+// ====================================================================================================================================
+// nn.LayerNorm over the channels of NHWC tokens, forward and backward (AttnBlock.norm1 / norm2, Diffusion_arch.py:427-428,438-439):
+// a row of C channels is held by G = min(64, C / 4) lanes (one float4 each, C / 256 of them beyond C = 256), so a wave works on
+// 64 / G rows at once and every row reduction is a DPP / shuffle sum inside the lane group.  PyTorch's kernels take 100-170 us for
+// the 268 MB of a full-resolution token tensor; one streaming pass is 50-90.
+//   forward    y = (x - mean) rstd gamma + beta, {mean, rstd} per row saved
+//   backward   a = dy gamma, dx = rstd (a - mean_c(a) - xhat mean_c(a xhat)); per-lane running sums of dy xhat / dy over the workgroup's
+//              rows -> partials [workgroup][C][2] -> dgamma / dbeta in a second kernel (fixed order)
+namespace {
+
+template <int G>
+__device__ __forceinline__ float lt_group_sum(float v) {
+    v = nd_row16_sum(v);
+    if (G >= 32) v += __shfl_xor(v, 16);
+    if (G >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+constexpr int LT_MAXQ = 4;                                               // float4s per lane: C <= 1024
+
+template <int G>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ y, int ldy, float* __restrict__ stats, long N, int C, float eps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane % G, rw = lane / G, RPW = 64 / G, QL = C / (4 * G);
+    f32x4 gm[LT_MAXQ], bt[LT_MAXQ];
+#pragma unroll
+    for (int k = 0; k < LT_MAXQ; ++k)
+        if (k < QL) { gm[k] = nd_ld4(gamma + 4 * (g + k * G)); bt[k] = nd_ld4(beta + 4 * (g + k * G)); }
+    const float inv = 1.0f / (float)C;
+    for (long row = ((long)blockIdx.x * 4 + wave) * RPW + rw; row < N + rw; row += (long)gridDim.x * 4 * RPW) {
+        const bool ok = row < N;                                         // (all lanes of a wave stay in the loop together: the sums are wave-wide instructions)
+        const long rr = ok ? row : N - 1;
+        f32x4 v[LT_MAXQ];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LT_MAXQ; ++k)
+            if (k < QL) { v[k] = nd_ld4(x + (size_t)rr * ldx + 4 * (g + k * G)); s += v[k].x + v[k].y + v[k].z + v[k].w; }
+        const float mean = lt_group_sum<G>(s) * inv;
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LT_MAXQ; ++k)
+            if (k < QL) { v[k] = v[k] - mean; q += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w; }
+        const float rstd = rsqrtf(lt_group_sum<G>(q) * inv + eps);
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < LT_MAXQ; ++k)
+                if (k < QL) nd_st4(y + (size_t)row * ldy + 4 * (g + k * G), v[k] * rstd * gm[k] + bt[k]);
+            if (g == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                    const float* __restrict__ gamma, const float* __restrict__ stats, float* __restrict__ dx, int lddx,
+                                                    float* __restrict__ part, long N, int C, long rows_per_wg) {
+    __shared__ __attribute__((aligned(16))) float red[2][256][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane % G, rw = lane / G, RPW = 64 / G, QL = C / (4 * G);
+    f32x4 gm[LT_MAXQ], dg[LT_MAXQ], db[LT_MAXQ];
+#pragma unroll
+    for (int k = 0; k < LT_MAXQ; ++k) {
+        dg[k] = f32x4{0, 0, 0, 0};  db[k] = f32x4{0, 0, 0, 0};
+        if (k < QL) gm[k] = nd_ld4(gamma + 4 * (g + k * G));
+    }
+    const float inv = 1.0f / (float)C;
+    const long r_begin = (long)blockIdx.x * rows_per_wg, r_end = min(r_begin + rows_per_wg, N);
+    for (long row = r_begin + wave * RPW + rw; row < r_end + rw; row += 4 * RPW) {
+        const bool ok = row < r_end;
+        const long rr = ok ? row : max(r_end - 1, 0L);
+        const float mean = stats[2 * rr], rstd = stats[2 * rr + 1];
+        f32x4 a[LT_MAXQ], xh[LT_MAXQ];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LT_MAXQ; ++k)
+            if (k < QL) {
+                const f32x4 d = nd_ld4(dy + (size_t)rr * lddy + 4 * (g + k * G));
+                xh[k] = (nd_ld4(x + (size_t)rr * ldx + 4 * (g + k * G)) - mean) * rstd;
+                a[k] = d * gm[k];
+                if (ok) { dg[k] += d * xh[k];  db[k] += d; }
+                const f32x4 ax = a[k] * xh[k];
+                s1 += ax.x + ax.y + ax.z + ax.w;
+                s2 += a[k].x + a[k].y + a[k].z + a[k].w;
+            }
+        s1 = lt_group_sum<G>(s1) * inv;
+        s2 = lt_group_sum<G>(s2) * inv;
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < LT_MAXQ; ++k)
+                if (k < QL) nd_st4(dx + (size_t)row * lddx + 4 * (g + k * G), (a[k] - s2 - xh[k] * s1) * rstd);
+        }
+    }
+    // the workgroup's column sums: the 4 * RPW row lanes of every channel quad meet in LDS, in lane order
+    float* o = part + (size_t)blockIdx.x * C * 2;
+#pragma unroll
+    for (int k = 0; k < LT_MAXQ; ++k) {
+        if (k < QL) {                                                    // (QL is uniform over the workgroup: the barriers below are reached by everyone)
+            __syncthreads();
+            *reinterpret_cast<f32x4*>(red[0][tid]) = dg[k];
+            *reinterpret_cast<f32x4*>(red[1][tid]) = db[k];
+            __syncthreads();
+            if (tid < G) {
+                f32x4 sg = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+                for (int w = 0; w < 4; ++w)
+                    for (int r = 0; r < RPW; ++r) {
+                        sg += *reinterpret_cast<const f32x4*>(red[0][w * 64 + r * G + tid]);
+                        sb += *reinterpret_cast<const f32x4*>(red[1][w * 64 + r * G + tid]);
+                    }
+                const int c = 4 * (tid + k * G);
+                nd_st4(o + 2 * c, f32x4{sg.x, sb.x, sg.y, sb.y});
+                nd_st4(o + 2 * c + 4, f32x4{sg.z, sb.z, sg.w, sb.w});
+            }
+        }
+    }
+}
+
+// dgamma[c], dbeta[c] = sum over the workgroups' partials: 32 channels per workgroup, eight stripes of partials (w = stripe, stripe + 8, ...,
+// eight loads in flight each) that meet in stripe order -- fixed order, fp64
+__global__ __launch_bounds__(256) void ln_dparam_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, int wgs, int C) {
+    __shared__ double red[2][8][32];
+    const int o = threadIdx.x & 31, stripe = threadIdx.x >> 5, c = blockIdx.x * 32 + o;
+    double sg = 0.0, sb = 0.0;
+    if (c < C) {
+        const float2* p = reinterpret_cast<const float2*>(part) + c;
+        int w = stripe;
+        for (; w + 56 < wgs; w += 64) {
+            float2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(w + 8 * k) * C];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sg += (double)v[k].x; sb += (double)v[k].y; }
+        }
+        for (; w < wgs; w += 8) { const float2 v = p[(size_t)w * C]; sg += (double)v.x; sb += (double)v.y; }
+    }
+    red[0][stripe][o] = sg;  red[1][stripe][o] = sb;
+    __syncthreads();
+    if (stripe == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { sg += red[0][k][o]; sb += red[1][k][o]; }
+        dgamma[c] = (float)sg;  dbeta[c] = (float)sb;
+    }
+}
+
+constexpr int LT_BWD_WGS = 1024;                                         // fixed: the summation order must not depend on the device
+
+inline int lt_group(int C) { return C >= 256 ? 64 : C / 4; }
+inline bool lt_ok(int C) { return C == 64 || C == 128 || (C % 256 == 0 && C <= 1024); }
+
+}  // namespace
+
+extern "C" int64_t nd_layernorm_train_workspace_floats(int64_t N, int C) { return N > 0 && C > 0 ? (int64_t)LT_BWD_WGS * C * 2 : -1; }
+
+extern "C" int nd_layernorm_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* stats,
+                                              int64_t N, int C, float eps, void* stream) {
+    ND_REQUIRE(x && gamma && beta && y && stats, ND_E_BADARG, "nd_layernorm_train_forward: null pointer");
+    ND_REQUIRE(N > 0 && lt_ok(C), ND_E_SHAPE, "nd_layernorm_train_forward: C=%d (64, 128 or a multiple of 256 up to 1024)", C);
+    ND_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && nd_aligned16(x) && nd_aligned16(y) && nd_aligned16(gamma) && nd_aligned16(beta),
+               ND_E_ALIGN, "nd_layernorm_train_forward: strides must be multiples of 4 floats >= C, pointers 16-byte aligned");
+    const int G = lt_group(C), rows_per_pass = 4 * (64 / G);
+    const long want = (N + rows_per_pass - 1) / rows_per_pass;
+    const dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 16) hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, stats, (long)N, C, eps);
+    else if (G == 32) hipLaunchKernelGGL(ln_fwd_kernel<32>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, stats, (long)N, C, eps);
+    else hipLaunchKernelGGL(ln_fwd_kernel<64>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, stats, (long)N, C, eps);
+    return nd_launch_status("nd_layernorm_train_forward_f32");
+}
+
+extern "C" int nd_layernorm_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* stats,
+                                               float* dx, int lddx, float* dgamma, float* dbeta, float* workspace, int64_t N, int C, void* stream) {
+    ND_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta && workspace, ND_E_BADARG, "nd_layernorm_train_backward: null pointer");
+    ND_REQUIRE(N > 0 && lt_ok(C), ND_E_SHAPE, "nd_layernorm_train_backward: C=%d (64, 128 or a multiple of 256 up to 1024)", C);
+    ND_REQUIRE(lddy >= C && ldx >= C && lddx >= C && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && nd_aligned16(dy) && nd_aligned16(x) &&
+               nd_aligned16(dx) && nd_aligned16(gamma) && nd_aligned16(workspace), ND_E_ALIGN,
+               "nd_layernorm_train_backward: strides must be multiples of 4 floats >= C, pointers 16-byte aligned");
+    const int G = lt_group(C);
+    const long rows_per_wg = (N + LT_BWD_WGS - 1) / LT_BWD_WGS;
+    const int wgs = (int)((N + rows_per_wg - 1) / rows_per_wg);
+    const dim3 grid(wgs), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, 0, st, dy, lddy, x, ldx, gamma, stats, dx, lddx, workspace, (long)N, C, rows_per_wg);
+    else if (G == 32) hipLaunchKernelGGL(ln_bwd_kernel<32>, grid, block, 0, st, dy, lddy, x, ldx, gamma, stats, dx, lddx, workspace, (long)N, C, rows_per_wg);
+    else hipLaunchKernelGGL(ln_bwd_kernel<64>, grid, block, 0, st, dy, lddy, x, ldx, gamma, stats, dx, lddx, workspace, (long)N, C, rows_per_wg);
+    hipLaunchKernelGGL(ln_dparam_kernel, dim3(nd_cdiv(C, 32)), dim3(256), 0, st, workspace, dgamma, dbeta, wgs, C);
+    return nd_launch_status("nd_layernorm_train_backward_f32");
+}

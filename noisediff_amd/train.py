@@ -18,8 +18,8 @@ converted once per call), fp32, on the caller's CUDA stream -- so autograd's str
 the channels_last tensors once per pass, where PyTorch's NCHW group norm first copies them to NCHW and back -- on the full-resolution
 blocks the norms cost more than the convolutions before this.  ``LinearFunction`` (third slice) keeps the output and the data
 gradient of token Linears / 1x1 convolutions on the library GEMM and takes their weight and bias gradient -- a reduction over up to
-10^6 tokens that library GEMMs run at a tenth of HBM speed -- to nd_linear_wgrad_f32 (linear_wgrad.hip).  Activations, LayerNorm and
-attention stay on PyTorch's own ROCm kernels for now.
+10^6 tokens that library GEMMs run at a tenth of HBM speed -- to nd_linear_wgrad_f32 (linear_wgrad.hip); ``LayerNormFunction``:
+nn.LayerNorm over token channels forward and backward (norm_train.hip).  Activations and attention stay on PyTorch's own ROCm kernels for now.
 
 There is no fallback: a CPU tensor or a missing library raises.
 """
@@ -41,6 +41,23 @@ def _nhwc(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous(memory_format=torch.channels_last)
 
 
+class _Nop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOP = _Nop()
+
+
+def _on(device: torch.device):
+    """The library launches on the CURRENT device: switch only when the tensors live elsewhere (the context manager costs ~10 us of
+    host time per call, and a training step makes several hundred calls)."""
+    return _NOP if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -56,7 +73,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
         raise L.HipError(f"conv3x3 on the HIP library needs channel counts that are multiples of 4 (cin={cin}, cout={cout})")
     st = _stream()
     w_oihw = w_oihw.detach().to(torch.float32).contiguous()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         src_bytes = B * H * W * cin * 4
         wino = H >= 16 and W >= 16 and cin % 8 == 0
@@ -108,7 +125,7 @@ class Conv3x3Function(torch.autograd.Function):
             # dL/dx = conv(dL/dy, flip(w)^T): the forward operator itself
             grad_x = _conv3x3_nhwc(g, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None)
         if ctx.needs_input_grad[1]:
-            with torch.cuda.device(xn.device):
+            with _on(xn.device):
                 grad_w = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xn.device)
                 ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, cin, cout)), dtype=torch.float32, device=xn.device)
                 L.call("nd_conv3x3_wgrad_nhwc_f32", xn.data_ptr(), cin, g.data_ptr(), cout, grad_w.data_ptr(), ws.data_ptr(),
@@ -136,7 +153,7 @@ class GroupNormFunction(torch.autograd.Function):
             raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {xn.device} and there is no CPU path")
         B, C_, H, W = xn.shape
         st = _stream()
-        with torch.cuda.device(xn.device):
+        with _on(xn.device):
             y = torch.empty_like(xn, memory_format=torch.channels_last)
             mean_rstd = torch.empty((B, groups, 2), dtype=torch.float32, device=xn.device)
             ws = torch.empty(int(lib.nd_groupnorm_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
@@ -153,7 +170,7 @@ class GroupNormFunction(torch.autograd.Function):
         lib = L.load()
         g = _nhwc(grad_out)
         B, C_, H, W = xn.shape
-        with torch.cuda.device(xn.device):
+        with _on(xn.device):
             dx = torch.empty_like(xn, memory_format=torch.channels_last)
             dgamma = torch.empty(C_, dtype=torch.float32, device=xn.device)
             dbeta = torch.empty(C_, dtype=torch.float32, device=xn.device)
@@ -210,7 +227,7 @@ class LinearFunction(torch.autograd.Function):
             if x2.device.type != "cuda":
                 raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {x2.device} and there is no CPU path")
             N = x2.shape[0]
-            with torch.cuda.device(x2.device):
+            with _on(x2.device):
                 grad_w = torch.empty((cout, cin), dtype=torch.float32, device=x2.device)
                 grad_b = torch.empty(cout, dtype=torch.float32, device=x2.device) if ctx.has_bias else None
                 ws = torch.empty(int(lib.nd_linear_wgrad_workspace_floats(N, cin, cout)), dtype=torch.float32, device=x2.device)
@@ -252,6 +269,67 @@ def _hip_linear_forward(self, x: torch.Tensor) -> torch.Tensor:
     return conv1x1(x, self.weight, self.bias)
 
 
+def _layer_norm_ok(C_: int) -> bool:
+    return C_ in (64, 128) or (C_ % 256 == 0 and C_ <= 1024)
+
+
+class LayerNormFunction(torch.autograd.Function):
+    """nn.LayerNorm(C) over the last dimension of contiguous tokens, forward and backward on libnoisediff_hip (norm_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = L.load()
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != torch.float32 or not x2.is_contiguous():
+            x2 = x2.float().contiguous()
+        if x2.device.type != "cuda":
+            raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {x2.device} and there is no CPU path")
+        N, C_ = x2.shape
+        with _on(x2.device):
+            y = torch.empty_like(x2)
+            stats = torch.empty((N, 2), dtype=torch.float32, device=x2.device)
+            w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+            L.call("nd_layernorm_train_forward_f32", x2.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), y.data_ptr(), C_, stats.data_ptr(),
+                   N, C_, float(eps), _stream())
+        ctx.save_for_backward(x2, weight, stats)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x2, weight, stats = ctx.saved_tensors
+        lib = L.load()
+        N, C_ = x2.shape
+        g2 = grad_out.reshape(N, C_)
+        if g2.dtype != torch.float32 or not g2.is_contiguous():
+            g2 = g2.float().contiguous()
+        with _on(x2.device):
+            dx = torch.empty_like(x2)
+            dgamma = torch.empty(C_, dtype=torch.float32, device=x2.device)
+            dbeta = torch.empty(C_, dtype=torch.float32, device=x2.device)
+            ws = torch.empty(int(lib.nd_layernorm_train_workspace_floats(N, C_)), dtype=torch.float32, device=x2.device)
+            w32 = weight.detach().float().contiguous()
+            L.call("nd_layernorm_train_backward_f32", g2.data_ptr(), C_, x2.data_ptr(), C_, w32.data_ptr(), stats.data_ptr(), dx.data_ptr(), C_,
+                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, C_, _stream())
+        return dx.view(ctx.shape), dgamma, dbeta, None
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """Differentiable F.layer_norm(x, (C,), weight, bias, eps) over the last dimension on the HIP library (C = 64, 128 or a multiple of 256 <= 1024)."""
+    if weight is None or bias is None or not _layer_norm_ok(x.shape[-1]) or weight.shape != (x.shape[-1],):
+        raise ValueError(f"layer_norm: x {tuple(x.shape)}: needs affine parameters and C = 64, 128 or a multiple of 256 up to 1024")
+    return LayerNormFunction.apply(x, weight, bias, eps)
+
+
+def _eligible_layer_norm(m: nn.Module) -> bool:
+    return (isinstance(m, nn.LayerNorm) and len(m.normalized_shape) == 1 and m.elementwise_affine and m.bias is not None
+            and _layer_norm_ok(m.normalized_shape[0]))
+
+
+def _hip_layer_norm_forward(self: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    return layer_norm(x, self.weight, self.bias, self.eps)
+
+
 def _eligible(m: nn.Module) -> bool:
     return (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
             and m.groups == 1 and m.padding_mode == "zeros" and m.in_channels % 8 == 0 and m.out_channels % 8 == 0)
@@ -263,7 +341,7 @@ def _hip_conv_forward(self: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
 
 def accelerate(model: nn.Module, norms: bool = True, linears: bool = True) -> int:
     """Route every eligible 3x3 convolution of ``model`` (stride 1, padding 1, channel counts multiples of 8) and -- unless
-    ``norms=False`` / ``linears=False`` -- every affine nn.GroupNorm (C a multiple of 4) and the weight / bias gradient of every
+    ``norms=False`` / ``linears=False`` -- every affine nn.GroupNorm (C a multiple of 4) and nn.LayerNorm (C = 64, 128, 256 k) and the weight / bias gradient of every
     nn.Linear and 1x1 nn.Conv2d (channel counts multiples of 4) through the HIP library, forward and backward.  Parameters,
     module tree and state dict are untouched; the replacement is a bound method, so ``copy.deepcopy`` (the trainer's EMA) rebinds
     it to the copy.  Returns the number of convolutions taken."""
@@ -275,6 +353,8 @@ def accelerate(model: nn.Module, norms: bool = True, linears: bool = True) -> in
             n += 1
         elif norms and _eligible_norm(m) and getattr(m.forward, "__func__", None) is not _hip_norm_forward:
             m.forward = types.MethodType(_hip_norm_forward, m)
+        elif norms and _eligible_layer_norm(m) and getattr(m.forward, "__func__", None) is not _hip_layer_norm_forward:
+            m.forward = types.MethodType(_hip_layer_norm_forward, m)
         elif linears and _eligible_linear(m) and getattr(m.forward, "__func__", None) is not _hip_linear_forward:
             m.forward = types.MethodType(_hip_linear_forward, m)
     return n

@@ -7,7 +7,7 @@
 The graph is the reference network's (models/archs/Diffusion_arch.py:447-646) written as one functional forward
 over a flat parameter table; parameters are registered under the reference's own dotted names, so ``state_dict()`` is
 interchangeable with the reference class and with ``noisediff_amd.NoiseDiffNet``.  ``.hip()`` routes every 3x3 convolution and
-GroupNorm through the HIP library forward and backward and the weight / bias gradients of the Linears and 1x1 convolutions
+GroupNorm / LayerNorm through the HIP library forward and backward and the weight / bias gradients of the Linears and 1x1 convolutions
 (noisediff_amd/train.py); everything else is PyTorch.  Parity: the
 forward against the reference's golden activations and loss / gradients against tests/golden/training.npz (tests/test_trainable.py).
 """
@@ -58,7 +58,12 @@ class _Ops:
         return F.group_norm(x, groups, w, b, eps=1e-5)
 
     def layer_norm(self, name: str, x: torch.Tensor) -> torch.Tensor:
-        return F.layer_norm(x, x.shape[-1:], self.p[name + ".weight"], self.p[name + ".bias"], eps=1e-5)
+        w, b = self.p[name + ".weight"], self.p[name + ".bias"]
+        if self.hip and x.is_cuda:
+            from . import train
+            if train._layer_norm_ok(x.shape[-1]):
+                return train.layer_norm(x, w, b, 1e-5)
+        return F.layer_norm(x, x.shape[-1:], w, b, eps=1e-5)
 
     # ---- composite layers ------------------------------------------------------------------------------------------
     def block(self, name: str, x, groups: int, scale=None, shift=None):

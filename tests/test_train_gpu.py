@@ -208,3 +208,35 @@ def test_conv1x1_and_accelerated_linears():
         net(t).square().mean().backward()
     assert rel_err(tok_hip.weight.grad.cpu().numpy(), tok.weight.grad.cpu().numpy()) < 2e-5
     assert rel_err(tok_hip.bias.grad.cpu().numpy(), tok.bias.grad.cpu().numpy()) < 2e-5
+
+
+LN_CASES = {"c64": (3001, 64), "c128": (1000, 128), "c256": (515, 256), "c512": (300, 512), "c1024": (70, 1024), "many": (262144, 64)}
+
+
+@pytest.mark.parametrize("case", sorted(LN_CASES))
+def test_layer_norm_autograd_matches_a_float64_reference(case):
+    """nd_layernorm_train_forward / _backward == F.layer_norm and its autograd in float64 (y, dx, dgamma, dbeta); row counts that do not fill
+    the last wave / workgroup, rows with a large mean, bitwise repeatable."""
+    N, C_ = LN_CASES[case]
+    x = (U(case + ".x", (N, C_), -1.5, 1.5) + 3.0 * U(case + ".m", (N, 1))).to(DEV)
+    gamma, beta = U(case + ".g", (C_,), 0.5, 1.5).to(DEV), U(case + ".b", (C_,)).to(DEV)
+    gy = U(case + ".gy", (N, C_)).to(DEV)
+    outs = []
+    for _ in range(2):
+        xa, wa, ba = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        y = train.layer_norm(xa.view(1, N, C_), wa, ba, 1e-5)
+        assert y.shape == (1, N, C_)
+        y.backward(gy.view(1, N, C_))
+        outs.append([t.detach().cpu() for t in (y.view(N, C_), xa.grad, wa.grad, ba.grad)])
+    assert all(torch.equal(p, q) for p, q in zip(*outs))
+    xa, wa, ba = x.double().cpu().requires_grad_(), gamma.double().cpu().requires_grad_(), beta.double().cpu().requires_grad_()
+    y = F.layer_norm(xa, (C_,), wa, ba, 1e-5)
+    y.backward(gy.double().cpu())
+    tol = 2e-5 * max(1.0, (N / 4096) ** 0.5)
+    for got, ref, name in zip(outs[0], (y, xa.grad, wa.grad, ba.grad), ("y", "dx", "dgamma", "dbeta")):
+        assert rel_err(got.numpy(), ref.detach().numpy()) < tol, (case, name)
+    with pytest.raises(ValueError):
+        train.layer_norm(x[:, :48].contiguous(), gamma[:48], beta[:48])      # C = 48: not taken
+    ln = nn.LayerNorm(C_).to(DEV)
+    train.accelerate(ln)
+    assert getattr(ln.forward, "__func__", None) is train._hip_layer_norm_forward

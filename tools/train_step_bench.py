@@ -60,11 +60,12 @@ def real_net():
                 loss.backward()
                 opt.step()
                 return loss.detach()
-            one(); one(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3): loss = one()
+            for _ in range(4): one()
             torch.cuda.synchronize()
-            res.append(((time.perf_counter() - t0) / 3, float(loss), torch.cuda.max_memory_allocated() / 2**30))
+            t0 = time.perf_counter()
+            for _ in range(8): loss = one()
+            torch.cuda.synchronize()
+            res.append(((time.perf_counter() - t0) / 8, float(loss), torch.cuda.max_memory_allocated() / 2**30))
             del net, gd, opt
             torch.cuda.empty_cache()
         print(f"NoiseDiffNet d=64, B={B} {S}x{S}: PyTorch {res[0][0] * 1e3:7.1f} ms/step | .hip() {res[1][0] * 1e3:7.1f} ms/step | x{res[0][0] / res[1][0]:.2f} | "
