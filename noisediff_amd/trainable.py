@@ -88,8 +88,15 @@ class _Ops:
         return self.conv(name + ".fc2", F.gelu(self.conv(name + ".fc1", x)))
 
     def cross_attention(self, name: str, x, ctx):
-        """CrossAttention over the ISO context, in full (:361-402)."""
+        """CrossAttention over the ISO context (:361-402).  The context is ONE token (iso_embed row, :591), so the softmax runs over a
+        single key: its weights are exactly 1 and its derivative exactly 0 -- the output is to_out(to_v(ctx)) for every query token,
+        bit for bit, and to_q / to_k (and the LayerNorm that feeds only them) receive exactly-zero gradients in the reference too
+        (the sampling path uses the same identity).  The general form stays for longer contexts."""
         b, n, _ = x.shape
+        if ctx.shape[1] == 1:
+            out = self.linear(name + ".to_out.0", self.linear(name + ".to_v", ctx))              # (b, 1, C): broadcasts over the n tokens
+            dead = (self.p[name + ".to_q.weight"].sum() + self.p[name + ".to_k.weight"].sum()) * 0.0   # zero gradients, as autograd gives them there
+            return out + dead
         q, k, v = self.linear(name + ".to_q", x), self.linear(name + ".to_k", ctx), self.linear(name + ".to_v", ctx)
         d = q.shape[-1] // HEADS
         heads = lambda t: t.reshape(b, t.shape[1], HEADS, d).transpose(1, 2)               # b h n d
@@ -102,7 +109,11 @@ class _Ops:
         """AttnBlock: tokens; x += attn(LN1 x, ctx); x += FF(LN2 x); proj_out + input   (:425-443)."""
         b, c, h, w = x.shape
         t = x.flatten(2).transpose(1, 2)
-        t = self.cross_attention(name + ".attn", self.layer_norm(name + ".norm1", t), ctx) + t
+        if ctx.shape[1] == 1:                                                # norm1 feeds only the (dead) queries: skipped, its gradient is zero
+            dead = (self.p[name + ".norm1.weight"].sum() + self.p[name + ".norm1.bias"].sum()) * 0.0
+            t = self.cross_attention(name + ".attn", t, ctx) + dead + t
+        else:
+            t = self.cross_attention(name + ".attn", self.layer_norm(name + ".norm1", t), ctx) + t
         t = self.linear(name + ".ff.net.2", F.gelu(self.linear(name + ".ff.net.0.0", self.layer_norm(name + ".norm2", t)))) + t
         return self.conv(name + ".proj_out", t.transpose(1, 2).reshape(b, c, h, w)) + x
 

@@ -66,6 +66,23 @@ def test_loss_and_gradients_match_the_reference(golden):
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
     sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
     assert sq == pytest.approx(float(golden("training", "train.grad_sq_norm")), rel=1e-4)
+    # every parameter gets a gradient (DDP needs that); the queries / keys of the one-token cross attention and the LayerNorm in front
+    # of them are dead in the reference too: exactly zero
+    assert all(g is not None for g in grads.values())
+    dead = [k for k in grads if k.endswith((".attn.to_q.weight", ".attn.to_k.weight", ".norm1.weight", ".norm1.bias"))]
+    assert len(dead) == 9 * 4 and all(float(grads[k].abs().max()) == 0.0 for k in dead)
+
+
+def test_cross_attention_general_form_equals_the_one_token_identity():
+    from noisediff_amd.trainable import _Ops
+    net = _net()
+    o = _Ops(dict(net.named_parameters()), False)
+    x = synth.uniform(9, "ca.x", (2, 50, DIM), -1.0, 1.0)
+    ctx = synth.uniform(9, "ca.ctx", (2, 1, 16), -1.0, 1.0)
+    with torch.no_grad():
+        fast = o.cross_attention("shot_attn.attn", x, ctx).expand(2, 50, DIM)
+        two = o.cross_attention("shot_attn.attn", x, torch.cat((ctx, ctx), dim=1))           # two identical keys: the general path, same result
+    assert rel_err(fast.numpy(), two.numpy()) < 1e-6
 
 
 @pytest.mark.gpu
