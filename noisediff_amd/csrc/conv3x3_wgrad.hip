@@ -17,8 +17,11 @@
 
 namespace {
 
-constexpr int WG_TILE = 16, HALO = 18, CB = 64;                        // pixels per tile side, halo side, channel block
-constexpr int WGRAD_TARGET_WGS = 256;                                  // one workgroup per CU of an MI355X (LDS: one fits); fixed: the summation order must not depend on the device
+#ifndef WG_TILE_ROWS
+#define WG_TILE_ROWS 8        // 16 x 8-pixel tiles: 78 KB of LDS, so TWO workgroups share a CU and one's staging runs under the other's MFMAs
+#endif                        // (16 x 16: 145 KB, one workgroup per CU, every tile's staging exposed)
+constexpr int WG_TILE = 16, TILE_H = WG_TILE_ROWS, HALO = 18, HALO_H = TILE_H + 2, CB = 64;   // tile width / height, halo width / height, channel block
+constexpr int WGRAD_TARGET_WGS = (WG_TILE_ROWS <= 8 ? 512 : 256);                                  // one workgroup per CU of an MI355X (LDS: one fits); fixed: the summation order must not depend on the device
 
 struct WgradArgs {
     const float* x; const float* dy; float* ws;
@@ -26,10 +29,10 @@ struct WgradArgs {
     int n_co, n_ci, S, tiles_x, tiles_y, n_tiles;
 };
 
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dYs = sm;                                                 // [256 pixels][64 couts]
-    float* Xs = sm + WG_TILE * WG_TILE * CB;                         // [324 halo pixels][64 cins]
+    float* Xs = sm + WG_TILE * TILE_H * CB;                          // [halo pixels][64 cins]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int co_w = 32 * (wave >> 1), ci_w = 32 * (wave & 1);       // this wave's 32 x 32 block of the 64 x 64
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
         const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
         const int ty = lid % a.tiles_y;
         const int b = lid / a.tiles_y;
-        const int y0 = ty * WG_TILE, x0 = tx * WG_TILE;
+        const int y0 = ty * TILE_H, x0 = tx * WG_TILE;
         __syncthreads();                                             // the previous tile's operands have been consumed
         // ---- stage dY (16 x 16 x 64 couts) and X (18 x 18 x 64 cins); outside the image / beyond the channels: zeros.
         //      Every load is unconditional (clamped address, select afterwards) and a batch of them is in flight before the first LDS
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
         {
             const f32x4 zero = {0, 0, 0, 0};
             const int q = tid & 15;
-            constexpr int DY_IT = WG_TILE * WG_TILE * (CB / 4) / 256;            // 16
-            constexpr int X_IT = (HALO * HALO * (CB / 4) + 255) / 256;            // 21
+            constexpr int DY_IT = WG_TILE * TILE_H * (CB / 4) / 256;             // 8 (16)
+            constexpr int X_IT = (HALO * HALO_H * (CB / 4) + 255) / 256;          // 12 (21)
             constexpr int BATCH = 11;
             const int cy = co0 + 4 * q, cx = ci0 + 4 * q;
             const bool cy_ok = cy < a.cout, cx_ok = cx < a.cin;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < BATCH; ++j) {
                     if (i0 + j < X_IT) {
-                        const int p = min((tid >> 4) + 16 * (i0 + j), HALO * HALO - 1), py = p / HALO, px = p - py * HALO;
+                        const int p = min((tid >> 4) + 16 * (i0 + j), HALO * HALO_H - 1), py = p / HALO, px = p - py * HALO;
                         const int gy = min(max(y0 + py - 1, 0), a.H - 1), gx = min(max(x0 + px - 1, 0), a.W - 1);
                         v[j] = nd_ld4(xb + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldx);
                     }
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
                         const int p = (tid >> 4) + 16 * (i0 + j), py = p / HALO, px = p - py * HALO;
                         const int gy = y0 + py - 1, gx = x0 + px - 1;
                         const bool ok = cx_ok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                        if (p < HALO * HALO) nd_st4(Xs + p * CB + 4 * q, ok ? v[j] : zero);
+                        if (p < HALO * HALO_H) nd_st4(Xs + p * CB + 4 * q, ok ? v[j] : zero);
                     }
                 }
             }
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
         const float* ap = dYs + half * CB + co_w + col;
         const float* bp = Xs + half * CB + ci_w + col;
 #pragma unroll 2
-        for (int py = 0; py < WG_TILE; ++py) {
+        for (int py = 0; py < TILE_H; ++py) {
 #pragma unroll
             for (int px = 0; px < WG_TILE; px += 2) {
                 const float av = ap[(py * WG_TILE + px) * CB];
@@ -162,7 +165,7 @@ void plan(int B, int H, int W, int cin, int cout, WgradArgs& a) {
     a.n_co = nd_cdiv(cout, CB);
     a.n_ci = nd_cdiv(cin, CB);
     a.tiles_x = nd_cdiv(W, WG_TILE);
-    a.tiles_y = nd_cdiv(H, WG_TILE);
+    a.tiles_y = nd_cdiv(H, TILE_H);
     a.n_tiles = B * a.tiles_x * a.tiles_y;
     const int blocks = a.n_co * a.n_ci;
     int S = WGRAD_TARGET_WGS / blocks;                               // fixed by the shape: the summation order never depends on the device
@@ -192,7 +195,7 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
     a.x = x; a.dy = dy; a.ws = workspace; a.ldx = ldx; a.ldy = ldy;
     const long wgs = (long)a.n_co * a.n_ci * a.S;
     ND_REQUIRE(wgs < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wgrad: grid too large");
-    const size_t lds = (size_t)(WG_TILE * WG_TILE + HALO * HALO) * CB * sizeof(float);
+    const size_t lds = (size_t)(WG_TILE * TILE_H + HALO * HALO_H) * CB * sizeof(float);
     static nd_device_once configured;
     if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wgrad_kernel), lds, "nd_conv3x3_wgrad")) return e;
     hipStream_t st = (hipStream_t)stream;
