@@ -113,3 +113,42 @@ def test_hip_convs_and_norms_keep_loss_and_gradients_and_weights_load_into_the_s
         ref = net.hip(False)(x0, t, cond)
         y = hipnet(x0, t, cond)
     assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-4
+
+
+@pytest.mark.gpu
+def test_a_whole_training_step_captures_into_one_graph():
+    """forward + backward + Adam of the .hip() network as one torch.cuda.CUDAGraph: the library launches on torch's capture stream.
+    Replays keep training: the loss of a fixed batch goes down and the weights move."""
+    dev = torch.device("cuda", 0)
+    x0, noise, t, cond = _inputs()
+    x0, noise, t = x0.to(dev), noise.to(dev), t.to(dev)
+    cond = {k: v.to(dev) for k, v in cond.items()}
+
+    def make():
+        net = _net().to(dev).hip()
+        gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+        return net, gd, torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+
+    net, gd, opt = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up outside the capture: lazy library / optimizer state initialisation
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            gd.p_losses(x0, t, cond, noise=noise.clone()).backward()
+            opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    start = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        loss = gd.p_losses(x0, t, cond, noise=noise.clone())
+        loss.backward()
+        opt.step()
+    losses = []
+    for _ in range(4):
+        g.replay()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert any(not torch.equal(v, start[k]) for k, v in net.state_dict().items())
