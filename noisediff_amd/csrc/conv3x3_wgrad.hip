@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel
         //      Every load is unconditional (clamped address, select afterwards) and a batch of them is in flight before the first LDS
         //      write: with a branch around each load hipcc waits for it on the spot, and the ~37 serialized memory round trips per tile
         //      took as long as the tile's MFMAs.
+#ifdef WG_ABLATE_STAGE          // diagnostic: operands staged for the first tile only
+        if (tile == s)
+#endif
         {
             const f32x4 zero = {0, 0, 0, 0};
             const int q = tid & 15;
