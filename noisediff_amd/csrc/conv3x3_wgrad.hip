@@ -26,7 +26,8 @@ constexpr int WGRAD_TARGET_WGS = (WG_TILE_ROWS <= 8 ? 512 : 256);               
 struct WgradArgs {
     const float* x; const float* dy; float* ws;
     int ldx, ldy, B, H, W, cin, cout;
-    int n_co, n_ci, S, tiles_x, tiles_y, n_tiles;
+    int n_co, n_ci, S, tiles_x, tiles_y, n_tiles, fast;
+    unsigned dy_bytes, x_bytes;
 };
 
 __global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
@@ -45,6 +46,23 @@ __global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = nd_zero16();
 
+    // Interior tiles (no image border inside the halo, whole channel blocks) take a path without per-item vector arithmetic: buffer loads
+    // with the tile's base in the scalar offset and per-thread item offsets computed once -- every VALU instruction of the staging pass
+    // waits behind a 64-cycle MFMA of the workgroup that shares the SIMDs (12 % of the kernel with the clamped / select form below).
+    constexpr int DY_IT = WG_TILE * TILE_H * (CB / 4) / 256;             // 8 (16)
+    constexpr int X_IT = (HALO * HALO_H * (CB / 4) + 255) / 256;          // 12 (21)
+    const bool fast_ok = a.fast && co0 + CB <= a.cout && ci0 + CB <= a.cin;
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, fast_ok ? (int)a.dy_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, fast_ok ? (int)a.x_bytes : 0, 0x00020000);
+    const unsigned dy_voff = (unsigned)(((tid >> 4) * a.ldy + co0 + 4 * (tid & 15)) * 4);          // item i: + i rows
+    // X halo (18 wide): columns 0-15 of halo row i are item i of thread row tid >> 4 (a scalar row stride apart); the 2 x HALO_H edge pixels
+    // (columns 16, 17) take two more items: edge pixel e = row e >> 1, column 16 + (e & 1)
+    const int tr = tid >> 4, e1 = min(16 + tr, 2 * HALO_H - 1);
+    const unsigned xm_voff = (unsigned)((tr * a.ldx + ci0 + 4 * (tid & 15)) * 4);
+    const unsigned xe0_voff = (unsigned)((((tr >> 1) * a.W + 16 + (tr & 1)) * a.ldx + ci0 + 4 * (tid & 15)) * 4);
+    const unsigned xe1_voff = (unsigned)((((e1 >> 1) * a.W + 16 + (e1 & 1)) * a.ldx + ci0 + 4 * (tid & 15)) * 4);
+    static_assert(2 * HALO_H <= 32, "edge pixels fit two passes of 16 thread rows");
+
     for (int tile = s; tile < a.n_tiles; tile += a.S) {
         int lid = tile;
         const int tx = lid % a.tiles_x;  lid /= a.tiles_x;
@@ -56,14 +74,51 @@ __global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel
         //      Every load is unconditional (clamped address, select afterwards) and a batch of them is in flight before the first LDS
         //      write: with a branch around each load hipcc waits for it on the spot, and the ~37 serialized memory round trips per tile
         //      took as long as the tile's MFMAs.
+        const bool interior = fast_ok && y0 >= 1 && y0 + TILE_H + 1 <= a.H && x0 >= 1 && x0 + WG_TILE + 1 <= a.W;      // workgroup-uniform
 #ifdef WG_ABLATE_STAGE          // diagnostic: operands staged for the first tile only
+        if (tile == s)
+#endif
+        if (interior) {
+            const int q = tid & 15;
+            const unsigned dy_base = (unsigned)(((b * a.H + y0) * a.W + x0) * a.ldy) * 4u;
+            const unsigned x_base = (unsigned)(((b * a.H + y0 - 1) * a.W + x0 - 1) * a.ldx) * 4u;
+            const unsigned dy_row = (unsigned)(a.W * a.ldy) * 4u;
+            const unsigned x_row = (unsigned)(a.W * a.ldx) * 4u;
+            float* xdst = Xs + tr * CB + 4 * q;
+            {   // two batches (registers: 144 accumulators live): dY + the first halo rows, then the rest and the edge columns
+                constexpr int XA = HALO_H / 2;
+                f32x4 vy[DY_IT], vx[XA];
+#pragma unroll
+                for (int i = 0; i < DY_IT; ++i)
+                    vy[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, dy_voff, dy_base + i * dy_row, 0));
+#pragma unroll
+                for (int i = 0; i < XA; ++i)
+                    vx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xm_voff, x_base + i * x_row, 0));
+#pragma unroll
+                for (int i = 0; i < DY_IT; ++i) nd_st4(dYs + (tr + 16 * i) * CB + 4 * q, vy[i]);
+#pragma unroll
+                for (int i = 0; i < XA; ++i) nd_st4(xdst + i * HALO * CB, vx[i]);
+            }
+            {
+                constexpr int XA = HALO_H / 2, XB = HALO_H - XA;
+                f32x4 vx[XB], ve0, ve1;
+#pragma unroll
+                for (int i = 0; i < XB; ++i)
+                    vx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xm_voff, x_base + (XA + i) * x_row, 0));
+                ve0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xe0_voff, x_base, 0));
+                ve1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xe1_voff, x_base, 0));
+#pragma unroll
+                for (int i = 0; i < XB; ++i) nd_st4(xdst + (XA + i) * HALO * CB, vx[i]);
+                nd_st4(Xs + ((tr >> 1) * HALO + 16 + (tr & 1)) * CB + 4 * q, ve0);
+                if (16 + tr < 2 * HALO_H) nd_st4(Xs + ((e1 >> 1) * HALO + 16 + (e1 & 1)) * CB + 4 * q, ve1);
+            }
+        } else
+#ifdef WG_ABLATE_STAGE
         if (tile == s)
 #endif
         {
             const f32x4 zero = {0, 0, 0, 0};
             const int q = tid & 15;
-            constexpr int DY_IT = WG_TILE * TILE_H * (CB / 4) / 256;             // 8 (16)
-            constexpr int X_IT = (HALO * HALO_H * (CB / 4) + 255) / 256;          // 12 (21)
             constexpr int BATCH = 11;
             const int cy = co0 + 4 * q, cx = ci0 + 4 * q;
             const bool cy_ok = cy < a.cout, cx_ok = cx < a.cin;
@@ -196,6 +251,12 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
     WgradArgs a;
     plan(B, H, W, cin, cout, a);
     a.x = x; a.dy = dy; a.ws = workspace; a.ldx = ldx; a.ldy = ldy;
+    {   // the interior-tile path addresses both tensors with 32-bit byte offsets
+        const long xb = (long)B * H * W * ldx * 4, dyb = (long)B * H * W * ldy * 4;
+        a.fast = xb < (1L << 31) && dyb < (1L << 31) && nd_aligned16(x) && nd_aligned16(dy);
+        a.x_bytes = a.fast ? (unsigned)xb : 0u;
+        a.dy_bytes = a.fast ? (unsigned)dyb : 0u;
+    }
     const long wgs = (long)a.n_co * a.n_ci * a.S;
     ND_REQUIRE(wgs < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wgrad: grid too large");
     const size_t lds = (size_t)(WG_TILE * TILE_H + HALO * HALO_H) * CB * sizeof(float);
