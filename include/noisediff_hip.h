@@ -155,6 +155,19 @@ int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const float* x, i
                                     float* dx, int lddx, float* dgamma, float* dbeta, float* workspace, int B, int HW, int C, int groups,
                                     void* stream);
 
+/* Block's tail as one training operator: y = silu(GroupNorm(x) * (scale + 1) + shift) (Block.forward, Diffusion_arch.py:137-143) with the
+ * per-(sample, channel) scale / shift of the time embedding (`scale_shift` [B][2C] = scale | shift as ResnetBlock.mlp emits it, :150-152,162-164;
+ * NULL: plain GroupNorm + SiLU).  Forward saves `mean_rstd` [B][groups][2] and `mad` [B][3][C]; backward returns dx, dgamma, dbeta and
+ * `dscale_shift` [B][2C] (NULL iff scale_shift is NULL).  Two passes over the tensor per direction (the separate ops take four and seven).
+ * `workspace`: nd_groupnorm_silu_train_workspace_floats(B, HW, C) floats. */
+int64_t nd_groupnorm_silu_train_workspace_floats(int B, int HW, int C);
+int nd_groupnorm_silu_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, const float* scale_shift, float* y, int ldy,
+                                        float* mean_rstd, float* mad, float* workspace, int B, int HW, int C, int groups, float eps, void* stream);
+int nd_groupnorm_silu_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
+                                         const float* scale_shift, const float* mean_rstd, const float* mad, float* dx, int lddx,
+                                         float* dgamma, float* dbeta, float* dscale_shift, float* workspace, int B, int HW, int C, int groups,
+                                         void* stream);
+
 /* nn.LayerNorm(C) over the channels of NHWC tokens for training (AttnBlock.norm1 / norm2, Diffusion_arch.py:427-428): forward
  * y = (x - mean) rstd gamma + beta with `stats` [N][2] = {mean, rstd} per token saved for the backward; backward dx, dgamma [C],
  * dbeta [C].  C = 64, 128 or a multiple of 256 up to 1024 (a row lives in 16 / 32 / 64 lanes); eps inside the square root, biased

@@ -427,3 +427,194 @@ extern "C" int nd_layernorm_train_backward_f32(const float* dy, int lddy, const 
     hipLaunchKernelGGL(ln_dparam_kernel, dim3(nd_cdiv(C, 32)), dim3(256), 0, st, workspace, dgamma, dbeta, wgs, C);
     return nd_launch_status("nd_layernorm_train_backward_f32");
 }
+
+// ====================================================================================================================================
+// Block's tail as ONE operator for training: y = silu(GroupNorm(x) * (scale + 1) + shift) with per-(sample, channel) scale / shift from the
+// time embedding (Block.forward, Diffusion_arch.py:137-143; ResnetBlock.mlp :150-152,162-164), forward and backward.  As separate PyTorch
+// ops this is the norm plus three elementwise passes forward and five backward over full-resolution tensors; here the forward is the two
+// passes of the norm (the activation rides on its apply pass) and the backward its two passes with d(silu) recomputed from x on the fly.
+//   forward    m = (x - M) A + D with A = rstd gamma (1 + s), D = beta (1 + s) + h, M = mean;  y = m sigmoid(m);  (M, A, D) saved
+//   backward   dm = dy sigmoid(m) (1 + m (1 - sigmoid(m)));  P1 = rstd sum_p dm (x - M), P2 = sum_p dm per (sample, channel)
+//              dshift = P2, dscale = gamma P1 + beta P2, dgamma = sum_b (1 + s) P1, dbeta = sum_b (1 + s) P2
+//              dx = dm A + x c1 + c2, c1 = -rstd^2 S1 / N, c2 = mean rstd^2 S1 / N - rstd S2 / N, S1 = sum_c gamma (1 + s) P1, S2 = sum_c gamma (1 + s) P2
+namespace {
+
+__device__ __forceinline__ f32x4 gs_dsilu(f32x4 dy, f32x4 m) {           // dy * d/dm (m sigmoid(m))
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-m[k]));
+        r[k] = dy[k] * sg * (1.0f + m[k] * (1.0f - sg));
+    }
+    return r;
+}
+
+// {sum dm (x - M), sum dm} per (sample, slot, channel); same layout and reduction as gn_partials_kernel
+__global__ __launch_bounds__(256) void gs_partials_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ mad, float* __restrict__ part, int HW, int C, int slots) {
+    __shared__ __attribute__((aligned(16))) float red[2][256][4];
+    const int Q = C >> 2, R = 256 / Q;
+    const int tid = threadIdx.x, q = tid % Q, rq = tid / Q;
+    const int b = blockIdx.x / slots, slot = blockIdx.x % slots;
+    const int p_begin = (int)((long)slot * HW / slots), p_end = (int)((long)(slot + 1) * HW / slots);
+    const float* db = dy + (size_t)b * HW * lddy + 4 * q;
+    const float* xb = x + (size_t)b * HW * ldx + 4 * q;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (rq < R) {
+        const float* m = mad + (size_t)b * 3 * C + 4 * q;
+        const f32x4 M = nd_ld4(m), A = nd_ld4(m + C), D = nd_ld4(m + 2 * C);
+        int p = p_begin + rq;
+        for (; p + 3 * R < p_end; p += 4 * R) {
+            f32x4 g[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { g[k] = nd_ld4(db + (size_t)(p + k * R) * lddy); v[k] = nd_ld4(xb + (size_t)(p + k * R) * ldx); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 xc = v[k] - M, dm = gs_dsilu(g[k], xc * A + D);
+                s1 += dm * xc;  s2 += dm;
+            }
+        }
+        for (; p < p_end; p += R) {
+            const f32x4 xc = nd_ld4(xb + (size_t)p * ldx) - M, dm = gs_dsilu(nd_ld4(db + (size_t)p * lddy), xc * A + D);
+            s1 += dm * xc;  s2 += dm;
+        }
+    }
+    *reinterpret_cast<f32x4*>(red[0][tid]) = s1;
+    *reinterpret_cast<f32x4*>(red[1][tid]) = s2;
+    __syncthreads();
+    if (rq == 0) {
+        for (int r = 1; r < R; ++r) {
+            s1 += *reinterpret_cast<const f32x4*>(red[0][r * Q + q]);
+            s2 += *reinterpret_cast<const f32x4*>(red[1][r * Q + q]);
+        }
+        float* o = part + (((size_t)b * slots + slot) * C + 4 * q) * 2;
+        nd_st4(o, f32x4{s1.x, s2.x, s1.y, s2.y});
+        nd_st4(o + 4, f32x4{s1.z, s2.z, s1.w, s2.w});
+    }
+}
+
+// (M, A, D) of the fused forward from the group statistics: one thread per (sample, channel)
+__global__ __launch_bounds__(256) void gs_mad_kernel(const float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ ss, float* __restrict__ mad, int B, int C, int G) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C, g = c / (C / G);
+    const float mean = mean_rstd[((size_t)b * G + g) * 2], rstd = mean_rstd[((size_t)b * G + g) * 2 + 1];
+    const float s1 = ss ? ss[(size_t)b * 2 * C + c] + 1.0f : 1.0f, h = ss ? ss[(size_t)b * 2 * C + C + c] : 0.0f;
+    float* o = mad + (size_t)b * 3 * C + c;
+    o[0] = mean;  o[C] = rstd * gamma[c] * s1;  o[2 * C] = beta[c] * s1 + h;
+}
+
+// one workgroup per (sample, group): c1 / c2 of dx, dscale / dshift, this sample's terms of dgamma / dbeta
+__global__ __launch_bounds__(256) void gs_bwd_finalize_kernel(const float* __restrict__ part, int slots, int HW, const float* __restrict__ mean_rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ ss,
+                                                             float* __restrict__ coef, float* __restrict__ ab, float* __restrict__ dss, int C, int G) {
+    __shared__ double tot[2][512], red[2][256], sums[2];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G, tid = threadIdx.x;
+    gt_channel_totals(part, slots, C, b, g, cpg, tot, red);
+    const double mean = (double)mean_rstd[((size_t)b * G + g) * 2], rstd = (double)mean_rstd[((size_t)b * G + g) * 2 + 1];
+    for (int i = tid; i < cpg; i += 256) {
+        const int c = g * cpg + i;
+        const double P1 = rstd * tot[0][i], P2 = tot[1][i];
+        const double s1 = ss ? (double)ss[(size_t)b * 2 * C + c] + 1.0 : 1.0;
+        if (dss) {
+            dss[(size_t)b * 2 * C + c] = (float)((double)gamma[c] * P1 + (double)beta[c] * P2);     // d scale = sum_p dm n
+            dss[(size_t)b * 2 * C + C + c] = (float)P2;                                           // d shift
+        }
+        tot[0][i] = s1 * P1;  tot[1][i] = s1 * P2;                                                // sum_p dn xhat, sum_p dn
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int i = 0; i < cpg; ++i) { const double gm = (double)gamma[g * cpg + i]; S1 += gm * tot[0][i]; S2 += gm * tot[1][i]; }
+        sums[0] = S1;  sums[1] = S2;
+    }
+    __syncthreads();
+    const double N = (double)cpg * (double)HW;
+    const float c1 = (float)(-rstd * rstd * sums[0] / N), c2 = (float)(mean * rstd * rstd * sums[0] / N - rstd * sums[1] / N);
+    for (int i = tid; i < cpg; i += 256) {
+        const int c = g * cpg + i;
+        coef[(size_t)b * 2 * C + c] = c1;  coef[(size_t)b * 2 * C + C + c] = c2;
+        ab[((size_t)b * C + c) * 2] = (float)tot[0][i];
+        ab[((size_t)b * C + c) * 2 + 1] = (float)tot[1][i];
+    }
+}
+
+// mode 0: y = silu((x - M) A + D);  mode 1: dx = dm A + x c1 + c2 with dm recomputed from (dy, x)
+__global__ __launch_bounds__(256) void gs_apply_kernel(const float* __restrict__ u, int ldu, const float* __restrict__ x, int ldx, const float* __restrict__ mad,
+                                                      const float* __restrict__ coef, float* __restrict__ out, int ldo, int B, int HW, int C, int mode) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)B * HW * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const size_t pix = i / cq;
+        const int b = (int)(pix / HW);
+        const float* m = mad + (size_t)b * 3 * C + 4 * q;
+        const f32x4 M = nd_ld4(m), A = nd_ld4(m + C), D = nd_ld4(m + 2 * C);
+        const f32x4 xv = nd_ld4(x + pix * ldx + 4 * q), xc = xv - M, mm = xc * A + D;
+        f32x4 r;
+        if (mode == 0) r = nd_silu4(mm);
+        else {
+            const float* cf = coef + (size_t)b * 2 * C + 4 * q;
+            r = gs_dsilu(nd_ld4(u + pix * ldu + 4 * q), mm) * A + xv * nd_ld4(cf) + nd_ld4(cf + C);
+        }
+        nd_st4(out + pix * ldo + 4 * q, r);
+    }
+}
+
+int gs_check(const char* who, int B, int HW, int C, int groups) {
+    ND_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 1024 && C / groups <= 512, ND_E_SHAPE,
+               "%s: C=%d groups=%d (C a multiple of 4 and of groups, <= 1024)", who, C, groups);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t nd_groupnorm_silu_train_workspace_floats(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return -1;
+    return (int64_t)B * gt_slots(HW) * C * 2 + (int64_t)B * 3 * C + (int64_t)B * 2 * C + (int64_t)B * C * 2;
+}
+
+extern "C" int nd_groupnorm_silu_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, const float* scale_shift, float* y, int ldy,
+                                                   float* mean_rstd, float* mad, float* workspace, int B, int HW, int C, int groups, float eps, void* stream) {
+    ND_REQUIRE(x && gamma && beta && y && mean_rstd && mad && workspace, ND_E_BADARG, "nd_groupnorm_silu_train_forward: null pointer");
+    if (int e = gs_check("nd_groupnorm_silu_train_forward", B, HW, C, groups)) return e;
+    ND_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && nd_aligned16(x) && nd_aligned16(y) && nd_aligned16(workspace) && nd_aligned16(mad),
+               ND_E_ALIGN, "nd_groupnorm_silu_train_forward: strides must be multiples of 4 floats >= C, pointers 16-byte aligned");
+    const int slots = gt_slots(HW);
+    float* part = workspace;
+    float* mad0 = workspace + (size_t)B * slots * C * 2;          // the plain norm's coefficients (scratch)
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partials_kernel, dim3(B * slots), dim3(256), 0, st, x, ldx, x, ldx, 0, part, HW, C, slots);
+    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, part, slots, HW, x, ldx, gamma, beta, mean_rstd, mad0, C, groups, eps);
+    hipLaunchKernelGGL(gs_mad_kernel, dim3(nd_cdiv(B * C, 256)), dim3(256), 0, st, mean_rstd, gamma, beta, scale_shift, mad, B, C, groups);
+    const size_t total = (size_t)B * HW * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gs_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, x, ldx, mad, mad, y, ldy, B, HW, C, 0);
+    return nd_launch_status("nd_groupnorm_silu_train_forward_f32");
+}
+
+extern "C" int nd_groupnorm_silu_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
+                                                    const float* scale_shift, const float* mean_rstd, const float* mad, float* dx, int lddx,
+                                                    float* dgamma, float* dbeta, float* dscale_shift, float* workspace, int B, int HW, int C, int groups,
+                                                    void* stream) {
+    ND_REQUIRE(dy && x && gamma && beta && mean_rstd && mad && dx && dgamma && dbeta && workspace, ND_E_BADARG, "nd_groupnorm_silu_train_backward: null pointer");
+    ND_REQUIRE((scale_shift == nullptr) == (dscale_shift == nullptr), ND_E_BADARG, "nd_groupnorm_silu_train_backward: scale_shift and dscale_shift go together");
+    if (int e = gs_check("nd_groupnorm_silu_train_backward", B, HW, C, groups)) return e;
+    ND_REQUIRE(lddy >= C && ldx >= C && lddx >= C && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && nd_aligned16(dy) && nd_aligned16(x) &&
+               nd_aligned16(dx) && nd_aligned16(workspace) && nd_aligned16(mad), ND_E_ALIGN,
+               "nd_groupnorm_silu_train_backward: strides must be multiples of 4 floats >= C, pointers 16-byte aligned");
+    const int slots = gt_slots(HW);
+    float* part = workspace;
+    float* coef = workspace + (size_t)B * slots * C * 2 + (size_t)B * 3 * C;       // [B][2][C]: c1, c2
+    float* ab = coef + (size_t)B * 2 * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gs_partials_kernel, dim3(B * slots), dim3(256), 0, st, dy, lddy, x, ldx, mad, part, HW, C, slots);
+    hipLaunchKernelGGL(gs_bwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, part, slots, HW, mean_rstd, gamma, beta, scale_shift, coef, ab, dscale_shift,
+                       C, groups);
+    hipLaunchKernelGGL(gn_dparam_kernel, dim3(nd_cdiv(C, 256)), dim3(256), 0, st, ab, dgamma, dbeta, B, C);
+    const size_t total = (size_t)B * HW * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gs_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mad, coef, dx, lddx, B, HW, C, 1);
+    return nd_launch_status("nd_groupnorm_silu_train_backward_f32");
+}

@@ -188,6 +188,60 @@ def group_norm(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.T
     return GroupNormFunction.apply(x, weight, bias, groups, eps)
 
 
+class GroupNormSiLUFunction(torch.autograd.Function):
+    """y = silu(GroupNorm(x) * (scale + 1) + shift) -- Block's tail (Diffusion_arch.py:137-143) -- as one operator on libnoisediff_hip
+    (norm_train.hip); ``scale_shift`` is the (B, 2C) output of ResnetBlock.mlp (scale | shift) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale_shift, groups, eps):
+        lib = L.load()
+        xn = _nhwc(x)
+        if xn.device.type != "cuda":
+            raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {xn.device} and there is no CPU path")
+        B, C_, H, W = xn.shape
+        ss = None if scale_shift is None else scale_shift.detach().reshape(B, 2 * C_).float().contiguous()
+        with _on(xn.device):
+            y = torch.empty_like(xn, memory_format=torch.channels_last)
+            mean_rstd = torch.empty((B, groups, 2), dtype=torch.float32, device=xn.device)
+            mad = torch.empty((B, 3, C_), dtype=torch.float32, device=xn.device)
+            ws = torch.empty(int(lib.nd_groupnorm_silu_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
+            w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+            L.call("nd_groupnorm_silu_train_forward_f32", xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), None if ss is None else ss.data_ptr(),
+                   y.data_ptr(), C_, mean_rstd.data_ptr(), mad.data_ptr(), ws.data_ptr(), B, H * W, C_, groups, float(eps), _stream())
+        ctx.save_for_backward(xn, weight, bias, mean_rstd, mad, ss if ss is not None else mean_rstd.new_empty(0))
+        ctx.groups, ctx.has_ss, ctx.ss_shape = groups, ss is not None, None if scale_shift is None else scale_shift.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xn, weight, bias, mean_rstd, mad, ss = ctx.saved_tensors
+        lib = L.load()
+        g = _nhwc(grad_out)
+        B, C_, H, W = xn.shape
+        with _on(xn.device):
+            dx = torch.empty_like(xn, memory_format=torch.channels_last)
+            dgamma = torch.empty(C_, dtype=torch.float32, device=xn.device)
+            dbeta = torch.empty(C_, dtype=torch.float32, device=xn.device)
+            dss = torch.empty((B, 2 * C_), dtype=torch.float32, device=xn.device) if ctx.has_ss else None
+            ws = torch.empty(int(lib.nd_groupnorm_silu_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
+            w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+            L.call("nd_groupnorm_silu_train_backward_f32", g.data_ptr(), C_, xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(),
+                   ss.data_ptr() if ctx.has_ss else None, mean_rstd.data_ptr(), mad.data_ptr(), dx.data_ptr(), C_, dgamma.data_ptr(), dbeta.data_ptr(),
+                   dss.data_ptr() if ctx.has_ss else None, ws.data_ptr(), B, H * W, C_, ctx.groups, _stream())
+        return dx, dgamma, dbeta, (dss.view(ctx.ss_shape) if ctx.has_ss else None), None, None
+
+
+def group_norm_silu(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.Tensor, scale_shift: Optional[torch.Tensor] = None,
+                    eps: float = 1e-5) -> torch.Tensor:
+    """Differentiable silu(F.group_norm(x, groups, weight, bias, eps) * (scale + 1) + shift), scale | shift = the halves of ``scale_shift``
+    ((B, 2C) or (B, 2C, 1, 1)), on the HIP library."""
+    if x.dim() != 4 or x.shape[1] % groups or x.shape[1] % 4 or x.shape[1] > 1024 or weight is None or bias is None:
+        raise ValueError(f"group_norm_silu: x {tuple(x.shape)}, groups {groups}: needs a 4-D input, C a multiple of 4 and of groups (<= 1024), affine parameters")
+    if scale_shift is not None and scale_shift.numel() != x.shape[0] * 2 * x.shape[1]:
+        raise ValueError(f"group_norm_silu: scale_shift {tuple(scale_shift.shape)} is not (B, 2C) for x {tuple(x.shape)}")
+    return GroupNormSiLUFunction.apply(x, weight, bias, scale_shift, groups, eps)
+
+
 def _eligible_norm(m: nn.Module) -> bool:
     return isinstance(m, nn.GroupNorm) and m.affine and m.num_channels % 4 == 0 and m.num_channels <= 1024 and m.num_channels // m.num_groups <= 512
 

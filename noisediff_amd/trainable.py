@@ -66,21 +66,26 @@ class _Ops:
         return F.layer_norm(x, x.shape[-1:], w, b, eps=1e-5)
 
     # ---- composite layers ------------------------------------------------------------------------------------------
-    def block(self, name: str, x, groups: int, scale=None, shift=None):
-        """Block: conv3x3 -> GroupNorm -> optional x (scale + 1) + shift -> SiLU   (Diffusion_arch.py:128-144)."""
-        x = self.group_norm(name + ".norm", self.conv(name + ".proj", x, 1), groups)
-        if scale is not None:
+    def block(self, name: str, x, groups: int, ss=None):
+        """Block: conv3x3 -> GroupNorm -> optional x (scale + 1) + shift -> SiLU   (Diffusion_arch.py:128-144); ``ss`` = scale | shift
+        along dim 1: (B, 2C, 1, 1) from the time embedding or (B, 2C, H, W) per-pixel maps."""
+        x = self.conv(name + ".proj", x, 1)
+        if self.hip and x.is_cuda and x.shape[1] % 4 == 0 and (ss is None or ss.numel() == x.shape[0] * 2 * x.shape[1]):
+            from . import train                                              # norm, per-sample modulation and SiLU as one operator
+            return train.group_norm_silu(x, groups, self.p[name + ".norm.weight"], self.p[name + ".norm.bias"], ss, 1e-5)
+        x = self.group_norm(name + ".norm", x, groups)
+        if ss is not None:
+            scale, shift = ss.chunk(2, dim=1)
             x = x * (scale + 1) + shift
         return F.silu(x)
 
     def resnet(self, name: str, x, emb, groups: int, per_pixel: bool = False):
         """ResnetBlock (per-sample scale / shift from the time embedding, :146-170) and ResnetBlock2 (per-pixel maps from the
         position embedding, :173-196); the shortcut is a 1x1 conv iff the channel count changes."""
-        scale = shift = None
+        ss = None
         if emb is not None:
-            e = self.conv(name + ".mlp.1", F.silu(emb)) if per_pixel else self.linear(name + ".mlp.1", F.silu(emb))[:, :, None, None]
-            scale, shift = e.chunk(2, dim=1)
-        h = self.block(name + ".block2", self.block(name + ".block1", x, groups, scale, shift), groups)
+            ss = self.conv(name + ".mlp.1", F.silu(emb)) if per_pixel else self.linear(name + ".mlp.1", F.silu(emb))[:, :, None, None]
+        h = self.block(name + ".block2", self.block(name + ".block1", x, groups, ss), groups)
         return h + (self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x)
 
     def mlp(self, name: str, x):

@@ -240,3 +240,36 @@ def test_layer_norm_autograd_matches_a_float64_reference(case):
     ln = nn.LayerNorm(C_).to(DEV)
     train.accelerate(ln)
     assert getattr(ln.forward, "__func__", None) is train._hip_layer_norm_forward
+
+
+@pytest.mark.parametrize("case", sorted(GN_CASES))
+@pytest.mark.parametrize("modulated", [False, True])
+def test_group_norm_silu_fused_matches_a_float64_reference(case, modulated):
+    """nd_groupnorm_silu_train_forward / _backward == silu(group_norm(x) * (scale + 1) + shift) and its autograd in float64:
+    y, dx, dgamma, dbeta and d(scale | shift); bitwise repeatable."""
+    B, C_, G, H, W = GN_CASES[case]
+    x = (U(case + ".x", (B, C_, H, W), -1.5, 1.5) + 3.0 * U(case + ".m", (B, C_, 1, 1))).to(DEV)
+    gamma, beta = U(case + ".g", (C_,), 0.5, 1.5).to(DEV), U(case + ".b", (C_,)).to(DEV)
+    ss = U(case + ".ss", (B, 2 * C_, 1, 1), -0.5, 0.5).to(DEV) if modulated else None
+    gy = U(case + ".gy", (B, C_, H, W)).to(DEV)
+    outs = []
+    for _ in range(2):
+        xa, wa, ba = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        sa = ss.clone().requires_grad_() if modulated else None
+        y = train.group_norm_silu(xa, G, wa, ba, sa, 1e-5)
+        y.backward(gy)
+        outs.append([t.detach().float().cpu().contiguous() for t in (y, xa.grad, wa.grad, ba.grad) + ((sa.grad,) if modulated else ())])
+    assert all(torch.equal(p, q) for p, q in zip(*outs))
+    xa, wa, ba = x.double().cpu().requires_grad_(), gamma.double().cpu().requires_grad_(), beta.double().cpu().requires_grad_()
+    n = F.group_norm(xa, G, wa, ba, 1e-5)
+    sa = None
+    if modulated:
+        sa = ss.double().cpu().requires_grad_()
+        scale, shift = sa.chunk(2, dim=1)
+        n = n * (scale + 1) + shift
+    y = F.silu(n)
+    y.backward(gy.double().cpu())
+    refs = (y, xa.grad, wa.grad, ba.grad) + ((sa.grad,) if modulated else ())
+    for got, ref, name in zip(outs[0], refs, ("y", "dx", "dgamma", "dbeta", "dscale_shift")):
+        assert got.shape == ref.shape, name
+        assert rel_err(got.numpy(), ref.detach().numpy()) < 3e-5, (case, name)
