@@ -384,6 +384,26 @@ def _hip_layer_norm_forward(self: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor
     return layer_norm(x, self.weight, self.bias, self.eps)
 
 
+def _eligible_block(m: nn.Module) -> bool:
+    """A module shaped like the reference's ``Block`` (Diffusion_arch.py:128-144): children proj (conv), norm (affine GroupNorm), act (SiLU)
+    applied in that order with an optional (scale, shift) modulation in between -- recognised by structure, not by import."""
+    proj, norm, act = getattr(m, "proj", None), getattr(m, "norm", None), getattr(m, "act", None)
+    return (isinstance(proj, nn.Conv2d) and isinstance(norm, nn.GroupNorm) and isinstance(act, nn.SiLU) and _eligible_norm(norm)
+            and len(list(m.children())) == 3 and type(m).__name__ == "Block")
+
+
+def _hip_block_forward(self, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
+    """Block.forward with the norm, the per-sample modulation and the activation as one operator (train.group_norm_silu)."""
+    x = self.proj(x)
+    n = self.norm
+    if scale_shift is None:
+        return group_norm_silu(x, n.num_groups, n.weight, n.bias, None, n.eps)
+    scale, shift = scale_shift
+    if scale.numel() == x.shape[0] * x.shape[1] and shift.numel() == scale.numel():              # (B, C, 1, 1): the time embedding's
+        return group_norm_silu(x, n.num_groups, n.weight, n.bias, torch.cat((scale.reshape(x.shape[0], -1), shift.reshape(x.shape[0], -1)), 1), n.eps)
+    return self.act(self.norm(x) * (scale + 1) + shift)                                           # per-pixel maps (ResnetBlock2): unfused
+
+
 def _eligible(m: nn.Module) -> bool:
     return (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
             and m.groups == 1 and m.padding_mode == "zeros" and m.in_channels % 8 == 0 and m.out_channels % 8 == 0)
@@ -396,7 +416,8 @@ def _hip_conv_forward(self: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
 def accelerate(model: nn.Module, norms: bool = True, linears: bool = True) -> int:
     """Route every eligible 3x3 convolution of ``model`` (stride 1, padding 1, channel counts multiples of 8) and -- unless
     ``norms=False`` / ``linears=False`` -- every affine nn.GroupNorm (C a multiple of 4) and nn.LayerNorm (C = 64, 128, 256 k) and the weight / bias gradient of every
-    nn.Linear and 1x1 nn.Conv2d (channel counts multiples of 4) through the HIP library, forward and backward.  Parameters,
+    nn.Linear and 1x1 nn.Conv2d (channel counts multiples of 4) through the HIP library, forward and backward; modules shaped like the
+    reference's ``Block`` (proj / norm / act) get their norm + modulation + SiLU tail as one operator.  Parameters,
     module tree and state dict are untouched; the replacement is a bound method, so ``copy.deepcopy`` (the trainer's EMA) rebinds
     it to the copy.  Returns the number of convolutions taken."""
     import types
@@ -411,4 +432,6 @@ def accelerate(model: nn.Module, norms: bool = True, linears: bool = True) -> in
             m.forward = types.MethodType(_hip_layer_norm_forward, m)
         elif linears and _eligible_linear(m) and getattr(m.forward, "__func__", None) is not _hip_linear_forward:
             m.forward = types.MethodType(_hip_linear_forward, m)
+        elif norms and _eligible_block(m) and getattr(m.forward, "__func__", None) is not _hip_block_forward:
+            m.forward = types.MethodType(_hip_block_forward, m)
     return n

@@ -273,3 +273,40 @@ def test_group_norm_silu_fused_matches_a_float64_reference(case, modulated):
     for got, ref, name in zip(outs[0], refs, ("y", "dx", "dgamma", "dbeta", "dscale_shift")):
         assert got.shape == ref.shape, name
         assert rel_err(got.numpy(), ref.detach().numpy()) < 3e-5, (case, name)
+
+
+class Block(nn.Module):
+    """The reference's Block by shape (Diffusion_arch.py:128-144): what accelerate() recognises structurally."""
+
+    def __init__(self, cin, cout, groups=8):
+        super().__init__()
+        self.proj, self.norm, self.act = nn.Conv2d(cin, cout, 3, padding=1), nn.GroupNorm(groups, cout), nn.SiLU()
+
+    def forward(self, x, scale_shift=None):
+        x = self.norm(self.proj(x))
+        if scale_shift is not None:
+            scale, shift = scale_shift
+            x = x * (scale + 1) + shift
+        return self.act(x)
+
+
+def test_accelerate_fuses_the_tail_of_block_shaped_modules():
+    torch.manual_seed(3)
+    ref = Block(32, 64).to(DEV)
+    hip = copy.deepcopy(ref)
+    train.accelerate(hip)
+    assert getattr(hip.forward, "__func__", None) is train._hip_block_forward
+    x = U("bk.x", (2, 32, 24, 40)).to(DEV)
+    e = U("bk.e", (2, 128, 1, 1), -0.5, 0.5).to(DEV)
+    maps = U("bk.m", (2, 128, 24, 40), -0.5, 0.5).to(DEV)
+    for ss_src in (None, e, maps):                         # plain, the time embedding's per-sample modulation (fused), per-pixel maps (unfused path)
+        res = []
+        for net in (ref, hip):
+            net.zero_grad(set_to_none=True)
+            xa = x.clone().requires_grad_()
+            sa = None if ss_src is None else ss_src.clone().requires_grad_()
+            y = net(xa, None if sa is None else sa.chunk(2, dim=1))
+            y.square().mean().backward()
+            res.append([y.detach().cpu(), xa.grad.cpu()] + [p.grad.detach().cpu() for p in net.parameters()] + ([sa.grad.cpu()] if sa is not None else []))
+        for got, want in zip(res[1], res[0]):
+            assert rel_err(got.numpy(), want.numpy()) < 2e-4
