@@ -108,14 +108,16 @@ constexpr int ACC_AGPR = 64;                         // accumulators [0, 64) in 
 
 // one row of B^T applied to six packed values (the same code serves the column pass)
 __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
-    const f32x2 p = d[4] - 4.0f * d[2], q = d[3] - 4.0f * d[1];
+    // twelve packed instructions: every multiply rides in an fma (written out: left to itself hipcc spends fourteen)
+    const f32x2 c4 = {4.0f, 4.0f}, cm4 = {-4.0f, -4.0f}, cm5 = {-5.0f, -5.0f}, c2 = {2.0f, 2.0f}, cm2 = {-2.0f, -2.0f};
+    const f32x2 p = __builtin_elementwise_fma(cm4, d[2], d[4]), q = __builtin_elementwise_fma(cm4, d[1], d[3]);
     const f32x2 r = d[4] - d[2], s = d[3] - d[1];
-    t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+    t[0] = __builtin_elementwise_fma(c4, d[0], __builtin_elementwise_fma(cm5, d[2], d[4]));
     t[1] = p + q;
     t[2] = p - q;
-    t[3] = r + 2.0f * s;
-    t[4] = r - 2.0f * s;
-    t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+    t[3] = __builtin_elementwise_fma(c2, s, r);
+    t[4] = __builtin_elementwise_fma(cm2, s, r);
+    t[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(cm5, d[3], d[5]));
 }
 
 // A^T applied to six float4s (four consecutive couts each)
