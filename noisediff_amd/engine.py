@@ -284,7 +284,7 @@ class Plan:
             self.posmap2 = f(B, H, W, 2 * d)
             # the maps' consumers are pos_block{1,2}.block2.proj (d -> d, map prologue): blocked layout when those run on conv3x3_wino4
             self.posmap_blocked = (MAP_BLOCKED and "pos_block1.mlp.1.weight.blk16" in eng.slots and
-                                   self._wino4_takes("pos_block1.block2.proj", L.PRO_AFFINE_MAP_SILU, False, d, 0, d, 0, d, H, W))
+                                   self._wino4_takes("pos_block1.block2.proj", L.PRO_AFFINE_MAP_SILU, False, d, 0, d, 0, d, d, H, W))
             self.iso_emb = f(B, ISO_DIM)
             self.attn_names = [p.name[:-len(".attn.to_v.weight")] for p in eng.spec if p.name.endswith(".attn.to_v.weight")]
             self.cb = {n: f(B, eng.slots[n + ".proj_out.bias"].shape[0]) for n in self.attn_names}
@@ -361,7 +361,7 @@ class Plan:
         wino2 = (wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
                  and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
                  and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
-        wino4 = wino and self._wino4_takes(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, H, W)
+        wino4 = wino and self._wino4_takes(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W)
         if src.map_blocked and not wino4:
             raise L.HipError(f"{name}: the scale / shift map was produced in the blocked layout but the layer does not run on conv3x3_wino4")
         if wino4:
@@ -374,11 +374,17 @@ class Plan:
         self._keep.append(d)
         return out, st, sc, slots
 
-    def _wino4_takes(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, H: int, W: int) -> bool:
+    def _wino4_takes(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int) -> bool:
         """F(4x4,3x3) (1.78x fewer MFMAs than F(2x2,3x3); 16 x 32-pixel regions, 16-channel K chunks) wherever its kernel takes the
         layer: plain / GroupNorm-affine (+ per-pixel map) + SiLU inputs, concat on a chunk boundary, images that fill its regions,
         sources below 1 GiB and 2^24 pixels (the host checks of nd_conv3x3_wino4_nhwc_f32)."""
         up = 1 if upsample else 0
+        # Layers with at most eight F(4x4) workgroup tiles (16 x 32 pixels x 64 couts) per SAMPLE -- 256 -> 256 at 32 x 32 -- fill half of an
+        # MI355X at the usual 16 patches per GPU; F(2x2)'s 16 x 16-pixel tiles fill it (84 vs 114 us per layer).  The rule looks at the
+        # sample's geometry only: the kernel choice -- and with it the bits of a sample -- must not depend on the batch it is sharded into.
+        if (WINO2 and ((H + 15) // 16) * ((W + 31) // 32) * ((cout + 63) // 64) <= 8 and (c1 == 0 or c0 % 32 == 0)
+                and not (mode == L.PRO_AFFINE_MAP_SILU and up)):
+            return False
         src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
         src_bytes = src_px * 4 * max(ld0, ld1)
         return (WINOGRAD and WINO4 and H >= 16 and W >= 16 and (name + ".weight.wino4") in self.e.slots
