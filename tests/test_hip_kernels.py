@@ -384,6 +384,30 @@ def test_pointwise_large_tile_kernel(ctx):
     assert rel_err(out.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("cin,cout", [(1024, 2048), (2048, 1024), (1024, 1024)])
+def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout):
+    """pointwise_big_kernel at BASELINE config 4's widths (d=128: FeedForward 1024 -> 2048 -> 1024 and proj_out 1024 -> 1024 on the
+    32 x 32 = 1024 tokens of the H/8 stage; 16 / 32 K chunks of 64): LayerNorm prologue + GELU, plain, residual + per-sample vector."""
+    import hiputil as hu
+    B, HW, W = 4, 1024, 32                                    # 4 x 8 pixel tiles x cout/128 >= 256 workgroups: the large-tile kernel takes it
+    bound = 1.0 / np.sqrt(cin)
+    x = U(f"c4pw.x.{cin}", (B, HW, cin), -1.5, 1.5)
+    w, b = U(f"c4pw.w.{cin}.{cout}", (cout, cin), -bound, bound), U(f"c4pw.b.{cout}", (cout,), -bound, bound)
+    wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
+    lin = F.linear(x, w, b)
+    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
+    vec, g, be = U(f"c4pw.v.{cin}", (B, cin)), U(f"c4pw.g.{cin}", (cin,), 0.5, 1.5), U(f"c4pw.be.{cin}", (cin,))
+    rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
+    L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
+    ctx.sync()
+    s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
+    ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
+    assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
+    r0, ov = U(f"c4pw.r0.{cout}", (B, HW, cout)), U(f"c4pw.ov.{cout}", (B, cout))
+    out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), vec=hu.dev(ov))
+    assert rel_err(out.cpu(), lin + r0 + ov[:, None]) < TOL
+
+
 def test_affine_silu_add_and_rmsnorm(ctx):
     import hiputil as hu
     B, HW, Cc = 3, 100, 48
@@ -719,6 +743,12 @@ HEADLINE_CASES = {
     "h4_384cat_256": (2, 64, 64, 384, 256, 256, 0),
     "h1_up_128_64": (2, 128, 128, 128, 64, 0, 1),
     "h1_64_64": (1, 256, 256, 64, 64, 0, 0),
+    # BASELINE config 4 (d=128, 256x256): the H/8 stage at 32x32 with 1024 / 1536 (= 1024 + 512 concat) input channels -- 64 / 96 K chunks of
+    # the F(4x4) kernel, 16 cout tiles -- and the 1024 -> 512 convs behind it (plain at 32x32, with nearest-x2 addressing at 64x64)
+    "c4_1024_1024": (1, 32, 32, 1024, 1024, 0, 0),
+    "c4_1536cat_1024": (1, 32, 32, 1536, 1024, 1024, 0),
+    "c4_1024_512": (1, 32, 32, 1024, 512, 0, 0),
+    "c4_up_1024_512": (1, 64, 64, 1024, 512, 0, 1),
 }
 
 

@@ -317,11 +317,13 @@ def _oracle_threads():
     torch.set_num_threads(max(1, min(n, 32)))
 
 
-@pytest.mark.parametrize("dim,H,B,mid", [(64, 256, 1, False), (64, 128, 2, False), (128, 64, 1, True)])
+@pytest.mark.parametrize("dim,H,B,mid", [(64, 256, 1, False), (64, 128, 2, False), (128, 64, 1, True), (128, 256, 1, True)])
 def test_net_forward_headline_sizes_match_oracle(dim, H, B, mid):
     """One NoiseDiffNet.forward at the sizes the bench runs: d=64 at 256x256 (cfg3: every conv on the Winograd
-    kernel, 512/768-channel layers on 32x32 images, the separate activation pass for cout >= 256), d=64 at 128x128 (cfg2) and the
-    cfg4 width d=128 with the mid Attention (channel counts 1024 / 1536 / 2048)."""
+    kernel, 512/768-channel layers on 32x32 images, the separate activation pass for cout >= 256), d=64 at 128x128 (cfg2), the
+    cfg4 width d=128 with the mid Attention (channel counts 1024 / 1536 / 2048) at 64x64, and cfg4 AT ITS SIZE: d=128 + mid Attention at
+    256x256 -- the F(4x4) kernel at 1024 / 1536 -> 1024 on 32x32 (64 / 96 K chunks), the large-tile 1x1 kernel at 1024 -> 2048 -> 1024
+    and the attention kernel inside the net at N = 1024: the kernel selection of `bench.py --config cfg4`."""
     _oracle_threads()
     net = make_net(dim, mid_attn=mid)
     sd = state_dict(dim, mid_attn=mid)
@@ -333,6 +335,63 @@ def test_net_forward_headline_sizes_match_oracle(dim, H, B, mid):
         ref = O.noisediff_forward(sd, x, t, cond, mid_attention="mid_attn" if mid else None)
     assert float(ref.abs().max()) > 0.1
     assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
+
+
+def test_config4_kernel_selection_at_its_size():
+    """What `bench.py --config cfg4` launches (d=128 + mid Attention, 256x256): the 1024 / 1536 -> 1024 convs at 32x32 run on conv3x3_wino4,
+    the wide token Linears are in the plan and the attention kernel sees N = 1024 -- so the parity cases above / below cover that selection."""
+    net = make_net(128, mid_attn=True)
+    plan = net.hip_engine(DEV).plan(1, 256, 256)
+    by_layer = {m["layer"]: (name, m) for _, _, name, m in plan.step_ops if m}
+    for layer, cin in (("mid_block1.block1.proj", 1024), ("ups.0.0.block1.proj", 1536), ("ups.0.1.block1.proj", 1536)):
+        name, m = by_layer[layer]
+        assert name == "nd_conv3x3_wino4_nhwc_f32" and (m["cin"], m["cout"], m["H"], m["W"]) == (cin, 1024, 32, 32), (layer, name, m)
+    assert by_layer["downs.3.2.ff.net.0.0"][1]["cin"] == 512 and by_layer["downs.3.2.ff.net.0.0"][1]["cout"] == 1024
+    assert by_layer["ups.0.2.ff.net.0.0"][1]["cin"] == 1024 and by_layer["ups.0.2.ff.net.0.0"][1]["cout"] == 2048
+    assert by_layer["ups.0.2.ff.net.2"][1]["cin"] == 2048 and by_layer["ups.0.2.ff.net.2"][1]["cout"] == 1024
+    assert any(name == "nd_attention_mfma_f32" and args[5] == 1024 for _, args, name, _ in plan.step_ops)
+
+
+def test_sampler_config4_ddim8_at_256_matches_oracle():
+    """BASELINE config 4 at its size -- d=128 with the mid-block Attention, 256x256x4, DDIM (8 of its 250 steps) -- against the oracle,
+    with the un-clamped x_0 prediction path exercised by the trajectory (return_all_timesteps)."""
+    _oracle_threads()
+    dim, B, H, S = 128, 1, 256, 8
+    net = make_net(dim, mid_attn=True)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=1000, sampling_timesteps=S, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(B, H, seed=1)
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(S - 1)])
+    traj = gd.sample(batch_size=B, condition=to_dev(cond), return_all_timesteps=True, noise={"x_T": x_T, "steps": steps}).cpu()
+    ref = O.sample(state_dict(dim, mid_attn=True), cond, image_size=H, batch_size=B, timesteps=1000, sampling_timesteps=S, x_T=x_T,
+                   noise=lambda i, s: steps[i], return_all=True, mid_attention="mid_attn")
+    assert traj.shape == ref.shape == (B, S + 1, 4, H, H)
+    worst = max(rel_err(traj[:, k].numpy(), ref[:, k].numpy()) for k in range(S + 1))
+    assert worst < SAMPLE_TOL, worst
+
+
+def test_config5_at_512_lsid_and_compose_psnr_match_oracle():
+    """BASELINE config 5 at its stated size: LSID.forward on a 512x512x4 frame against the oracle (every conv on conv3x3_wino4 with the
+    LeakyReLU prologues -- at 64x64 the narrow layers fall to the F(2x2) kernel), then noise -> clip / compose -> denoise -> PSNR on both sides."""
+    from noisediff_amd import io
+    from noisediff_amd.spec import lsid_param_spec
+    _oracle_threads()
+    lsid = make_lsid()
+    sd_l = synth.make_state_dict(lsid_param_spec(), 0)
+    H = 512
+    x = synth.uniform(9, "lsid.x.512", (1, 4, H, H), 0.0, 1.0)
+    with torch.inference_mode():
+        y = lsid(x.to(DEV)).cpu()
+        ref = O.lsid_forward(sd_l, x)
+    assert float(ref.abs().max()) > 0.05
+    assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
+    clean = synth.uniform(9, "lsid.clean.512", (1, 4, H, H), 0.0, 1.0)
+    noise = synth.make_noise(9, "lsid.noise.512", 1, 4, H) * 0.1
+    with torch.inference_mode():
+        den = lsid(io.compose_noisy(noise, clean).to(DEV)).clamp(0, 1).cpu()
+    noisy, ref_den, ref_psnr = O.compose_and_denoise(sd_l, noise, clean)
+    assert rel_err(den.numpy(), ref_den.numpy()) < NET_TOL
+    assert abs(io.psnr(den, clean) - ref_psnr) < 1e-3
 
 
 def test_sampler_25_step_ddpm_at_256_matches_oracle_along_the_trajectory():
