@@ -396,13 +396,14 @@ def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout):
     wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
     lin = F.linear(x, w, b)
     assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
-    vec, g, be = U(f"c4pw.v.{cin}", (B, cin)), U(f"c4pw.g.{cin}", (cin,), 0.5, 1.5), U(f"c4pw.be.{cin}", (cin,))
-    rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
-    L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
-    ctx.sync()
-    s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
-    ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
-    assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
+    if cin <= 1024:                                           # LayerNorm feeds ff.net.0.0 only (its rows are at most 8 d = 1024 wide)
+        vec, g, be = U(f"c4pw.v.{cin}", (B, cin)), U(f"c4pw.g.{cin}", (cin,), 0.5, 1.5), U(f"c4pw.be.{cin}", (cin,))
+        rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
+        L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
+        ctx.sync()
+        s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
+        ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
+        assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
     r0, ov = U(f"c4pw.r0.{cout}", (B, HW, cout)), U(f"c4pw.ov.{cout}", (B, cout))
     out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), vec=hu.dev(ov))
     assert rel_err(out.cpu(), lin + r0 + ov[:, None]) < TOL
