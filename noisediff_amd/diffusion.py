@@ -64,6 +64,17 @@ def make_buffers(betas: torch.Tensor, objective: str) -> Dict[str, torch.Tensor]
     return {n: v.to(torch.float32) for n, v in zip(BUFFER_NAMES, vals)}
 
 
+def _rows(v, lo: int, hi: int, B: int):
+    """Batch rows [lo, hi) of a tensor, or of every tensor of a condition dict (whose leading dimension is the batch)."""
+    if v is None:
+        return None
+    if isinstance(v, dict):
+        return {k: _rows(t, lo, hi, B) for k, t in v.items()}
+    if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B:
+        return v[lo:hi]
+    return v
+
+
 def _unwrap(model: nn.Module) -> nn.Module:
     return model.module if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else model
 
@@ -174,22 +185,61 @@ class GaussianDiffusion(nn.Module):
         if not hasattr(net, "hip_engine"):
             raise TypeError("noisediff_amd.GaussianDiffusion.sample drives a noisediff_amd network (HIP engine); got "
                             f"{type(net).__name__}.  Other nn.Modules are accepted for the training entry points only.")
-        dev = self.device
-        B, Cc, S = int(batch_size), self.channels, self.image_size
-        plan = net.hip_engine(dev).plan(B, S, S)
-        plan.set_condition(condition)
-        loop = self._loop_for(plan)
+        B, S = int(batch_size), self.image_size
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        ddim = self.is_ddim_sampling
         x_T = None
         if noise is not None and "x_T" in noise:
             x_T = noise["x_T"]
-        if preset_mean is not None and not ddim:       # ddim_sample accepts but ignores preset_mean (:405,413)
+        if preset_mean is not None and not self.is_ddim_sampling:   # ddim_sample accepts but ignores preset_mean (:405,413)
             x_T = preset_mean
-        ret = loop.run(x_T=x_T, step_noise=None if noise is None else noise.get("steps"), seed=seed,
-                       first_sample=int(self.sample_offset), return_all=return_all_timesteps)
-        return self.unnormalize(ret)
+        step_noise = None if noise is None else noise.get("steps")
+        devices = self._sampling_devices()
+        if len(devices) == 1:
+            plan = net.hip_engine(devices[0]).plan(B, S, S)
+            plan.set_condition(condition)
+            ret = self._loop_for(plan).run(x_T=x_T, step_noise=step_noise, seed=seed, first_sample=int(self.sample_offset),
+                                           return_all=return_all_timesteps)
+            return self.unnormalize(ret)
+        # ---- nn.DataParallel(net, device_ids=[...]) with several devices: the reference's --gpu_ids entry (models/modules.py:73-83).
+        # The reference replicates the weights and scatters / gathers the batch on EVERY step (:332); here the batch rows are split
+        # once, every device gets its own engine (arena copied device to device from the first), plan and captured step graph, and
+        # the host thread launches the graphs round-robin: no per-step traffic between the devices.  Row i of the batch draws the
+        # same Philox noise (keyed by its global index) and runs the same kernels whatever the number of devices.
+        from .shard import shard_bounds
+        shards = []
+        for k, dev in enumerate(devices):
+            lo, hi = shard_bounds(B, k, len(devices))
+            if hi == lo:
+                continue
+            plan = net.hip_engine(dev, like=devices[0]).plan(hi - lo, S, S, tag=k)
+            plan.set_condition(_rows(condition, lo, hi, B))
+            loop = self._loop_for(plan)
+            loop.start(_rows(x_T, lo, hi, B), None if step_noise is None else step_noise[:, lo:hi], seed, int(self.sample_offset) + lo)
+            shards.append((loop, plan))
+        n_steps = shards[0][0].n_steps
+        out_dev = self.device
+        gather = lambda: torch.cat([p.read_nchw(p.x).to(out_dev) for _, p in shards], dim=0)
+        if not return_all_timesteps:
+            for _ in range(n_steps):
+                for loop, _p in shards:
+                    loop.advance(1)
+            return self.unnormalize(gather())
+        frames = [gather()]
+        for _ in range(n_steps):
+            for loop, _p in shards:
+                loop.advance(1)
+            frames.append(gather())
+        return self.unnormalize(torch.stack(frames, dim=1))
+
+    def _sampling_devices(self) -> List[torch.device]:
+        """The devices sample() shards the batch over: the wrapper's own device, or -- when the model is wrapped in
+        nn.DataParallel with several device_ids, as ``define_G`` does for ``--gpu_ids 0,1,...`` -- those devices."""
+        if isinstance(self.model, nn.DataParallel) and len(self.model.device_ids) > 1:
+            if self.device.type != "cuda":
+                raise L.HipError(f"noisediff_amd runs on MI355X only: the diffusion wrapper is on {self.device}")
+            return [torch.device("cuda", int(i)) for i in self.model.device_ids]
+        return [self.device]
 
     # copies (EMA's deepcopy of the trainer, pickling) never carry device loops: they hold ctypes handles
     def __getstate__(self):
@@ -321,7 +371,8 @@ class _Loop:
         with torch.cuda.device(p.dev):
             e.sync()                                           # a previous run may still read step / rng
             self.step.zero_()
-            self.rng.copy_(torch.tensor([int(seed), int(first_sample)], dtype=torch.int64))
+            seed = int(seed) & (2 ** 64 - 1)                   # any 64-bit seed: stored as its two's-complement int64 (the kernel casts back)
+            self.rng.copy_(torch.tensor([seed - 2 ** 64 if seed >= 2 ** 63 else seed, int(first_sample)], dtype=torch.int64))
             noise_ptr, stride = None, 0
             if step_noise is not None:
                 need = self.n_steps - 1

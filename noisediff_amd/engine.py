@@ -22,6 +22,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -240,10 +241,23 @@ class Engine:
         self.loaded = True
 
     # ------------------------------------------------------------------ plans
-    def plan(self, B: int, H: int, W: int, debug: bool = False) -> "Plan":
+    def copy_from(self, other: "Engine") -> None:
+        """Fill the arena from another device's engine of the same network (one device-to-device copy of the packed weights)."""
+        if other.arena_floats != self.arena_floats or not other.loaded:
+            raise L.HipError("Engine.copy_from: the source engine has no weights or another layout")
+        other.sync()
+        torch.cuda.synchronize(other.device)
+        with torch.cuda.device(self.device):
+            self.arena.copy_(other.arena)
+            torch.cuda.synchronize(self.device)
+        self.loaded = True
+
+    def plan(self, B: int, H: int, W: int, debug: bool = False, tag: int = 0) -> "Plan":
+        """The plan (workspace + recorded launches) of one problem size; ``tag`` separates plans of equal size that must not share
+        a workspace (several shards of one batch on the same device)."""
         if not self.loaded:
             raise L.HipError("Engine has no weights: call load_state_dict() or broadcast() first")
-        key = (B, H, W, debug)
+        key = (B, H, W, debug, tag)
         if key not in self.plans:
             self.plans[key] = Plan(self, B, H, W, debug)
         return self.plans[key]
@@ -261,6 +275,7 @@ class Plan:
     def __init__(self, eng: Engine, B: int, H: int, W: int, debug: bool = False):
         # debug=True: no workspace reuse and named intermediates kept in self.taps (tests / diagnosis only)
         self.debug, self.taps = debug, {}
+        self.lock = threading.Lock()           # callers that may share a plan across threads (NoiseDiffNet.forward under nn.DataParallel)
         if H % 8 or W % 8:
             raise AssertionError(f"your input dimensions {(H, W)} need to be divisible by 8, given the unet")  # :578
         self.e, self.B, self.H, self.W = eng, B, H, W

@@ -3,7 +3,8 @@
 Drop-in contract (models/modules.py:20-41, models/archs/Diffusion_arch.py:447-646):
 constructed as ``NoiseDiffNet(args)`` from the reference's argparse namespace; an ``nn.Module``
 whose state-dict has the reference's 416 names/shapes (so ``DiffusionNet_ckpt.pth`` loads with
-``strict=True`` and EMA deep-copies / DataParallel wrapping work); attributes ``channels``,
+``strict=True`` and EMA deep-copies / DataParallel wrapping work: ``GaussianDiffusion.sample`` shards the batch over the
+wrapper's ``device_ids`` itself, and a replica made by ``nn.DataParallel.forward`` uses the owning module's per-device engine); attributes ``channels``,
 ``out_dim``, ``self_condition``, ``random_or_learned_sinusoidal_cond``, ``downsample_factor``;
 ``forward(x, time, condition)`` with NCHW tensors and the ``clean_img`` / ``position`` /
 ``iso_ratio_idx`` condition dict.
@@ -76,6 +77,7 @@ class NoiseDiffNet(nn.Module):
         self._engines: Dict[int, object] = {}
         self._engine_sig: Dict[int, tuple] = {}
         self._lock = threading.Lock()
+        self._dp_root: Optional["NoiseDiffNet"] = None          # set on nn.DataParallel replicas: the module that owns the parameters
 
     @property
     def downsample_factor(self) -> int:                         # :573-575
@@ -90,14 +92,27 @@ class NoiseDiffNet(nn.Module):
     def __setstate__(self, state):
         super().__setstate__(state)
         self._lock = threading.Lock()
+        self._dp_root = None
+
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel.forward on several devices (models/modules.py:81): a replica shares ``__dict__`` entries with the module it
+        was made from but has no parameters of its own (``replicate`` hands it broadcast copies as plain attributes).  It keeps a
+        reference to the owning module and uses ITS engines -- one per device, filled from the owner's parameters (device to device
+        from the first engine), so the per-step weight broadcast of the reference's DataParallel never feeds the kernels."""
+        replica = super()._replicate_for_data_parallel()
+        replica._dp_root = self._dp_root or self
+        return replica
 
     # ------------------------------------------------------------------ engine management
     def _signature(self) -> tuple:
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def hip_engine(self, device: torch.device):
-        """The packed-weight engine for ``device`` (rebuilt when parameters changed)."""
+    def hip_engine(self, device: torch.device, like: Optional[torch.device] = None):
+        """The packed-weight engine for ``device`` (rebuilt when parameters changed).  ``like``: another device whose engine is
+        current -- the arena is then copied from it device to device instead of being packed again from the state dict."""
         from .engine import Engine
+        if self._dp_root is not None:                           # a DataParallel replica: the owner's engines (its parameters are the source)
+            return self._dp_root.hip_engine(device, like)
         if device.type != "cuda":
             raise L.HipError(f"{self.ARCH} runs on the HIP library only; tensor is on {device} and there is no CPU path")
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -110,7 +125,17 @@ class NoiseDiffNet(nn.Module):
                 self._engines[idx] = eng
                 self._engine_sig[idx] = None
             if self._engine_sig[idx] != sig:
-                eng.load_state_dict({k: v for k, v in self.state_dict().items()})
+                src = None
+                if like is not None and like.index != idx:
+                    src = self._engines.get(like.index)
+                    if src is not None and self._engine_sig.get(like.index) != sig:
+                        src = None
+                if src is None:
+                    src = next((e for i, e in self._engines.items() if i != idx and self._engine_sig.get(i) == sig), None)
+                if src is not None:
+                    eng.copy_from(src)
+                else:
+                    eng.load_state_dict({k: v for k, v in self.state_dict().items()})
                 self._engine_sig[idx] = sig
             return eng
 
@@ -130,8 +155,9 @@ class NoiseDiffNet(nn.Module):
             f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {self.downsample_factor}, given the unet"
         B, Cc, H, W = x.shape
         plan = self.hip_engine(x.device).plan(B, H, W)
-        plan.set_condition(condition)
-        return plan.forward(x, time)
+        with plan.lock:            # nn.DataParallel.forward calls replicas from several threads: one device's plan serves one call at a time
+            plan.set_condition(condition)
+            return plan.forward(x, time)
 
 
 class UNet_PosEmbV2(NoiseDiffNet):

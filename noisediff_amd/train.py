@@ -26,9 +26,10 @@ There is no fallback: a CPU tensor or a missing library raises.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
+from torch.autograd.function import once_differentiable
 from torch import nn
 
 from . import _lib as L
@@ -58,8 +59,9 @@ def _on(device: torch.device):
     return _NOP if device.index == torch.cuda.current_device() else torch.cuda.device(device)
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device: Optional[torch.device] = None) -> C.c_void_p:
+    """torch's current stream OF THE TENSORS' DEVICE (not of the current device: a caller may sit on another GPU)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
@@ -71,7 +73,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
         raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {x.device} and there is no CPU path")
     if cin % 4 or cout % 4:
         raise L.HipError(f"conv3x3 on the HIP library needs channel counts that are multiples of 4 (cin={cin}, cout={cout})")
-    st = _stream()
+    st = _stream(x.device)
     w_oihw = w_oihw.detach().to(torch.float32).contiguous()
     with _on(x.device):
         out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
@@ -114,6 +116,7 @@ class Conv3x3Function(torch.autograd.Function):
         return _conv3x3_nhwc(xn, weight, bias)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         xn, weight = ctx.saved_tensors
         lib = L.load()
@@ -152,7 +155,7 @@ class GroupNormFunction(torch.autograd.Function):
         if xn.device.type != "cuda":
             raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {xn.device} and there is no CPU path")
         B, C_, H, W = xn.shape
-        st = _stream()
+        st = _stream(xn.device)
         with _on(xn.device):
             y = torch.empty_like(xn, memory_format=torch.channels_last)
             mean_rstd = torch.empty((B, groups, 2), dtype=torch.float32, device=xn.device)
@@ -165,6 +168,7 @@ class GroupNormFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         xn, weight, mean_rstd = ctx.saved_tensors
         lib = L.load()
@@ -213,6 +217,7 @@ class GroupNormSiLUFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         xn, weight, bias, mean_rstd, mad, ss = ctx.saved_tensors
         lib = L.load()
@@ -242,8 +247,13 @@ def group_norm_silu(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: to
     return GroupNormSiLUFunction.apply(x, weight, bias, scale_shift, groups, eps)
 
 
+def _group_norm_ok(channels: int, groups: int) -> bool:
+    """Channel counts the norm_train.hip kernels take (the C side rejects the rest): C % 4 == 0, C <= 1024, C / groups <= 512."""
+    return channels % 4 == 0 and channels % groups == 0 and channels <= 1024 and channels // groups <= 512
+
+
 def _eligible_norm(m: nn.Module) -> bool:
-    return isinstance(m, nn.GroupNorm) and m.affine and m.num_channels % 4 == 0 and m.num_channels <= 1024 and m.num_channels // m.num_groups <= 512
+    return isinstance(m, nn.GroupNorm) and m.affine and _group_norm_ok(m.num_channels, m.num_groups)
 
 
 def _hip_norm_forward(self: nn.GroupNorm, x: torch.Tensor) -> torch.Tensor:
@@ -264,6 +274,7 @@ class LinearFunction(torch.autograd.Function):
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors
         lib = L.load()
@@ -350,6 +361,7 @@ class LayerNormFunction(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         x2, weight, stats = ctx.saved_tensors
         lib = L.load()
@@ -418,20 +430,38 @@ def accelerate(model: nn.Module, norms: bool = True, linears: bool = True) -> in
     ``norms=False`` / ``linears=False`` -- every affine nn.GroupNorm (C a multiple of 4) and nn.LayerNorm (C = 64, 128, 256 k) and the weight / bias gradient of every
     nn.Linear and 1x1 nn.Conv2d (channel counts multiples of 4) through the HIP library, forward and backward; modules shaped like the
     reference's ``Block`` (proj / norm / act) get their norm + modulation + SiLU tail as one operator.  Parameters,
-    module tree and state dict are untouched; the replacement is a bound method, so ``copy.deepcopy`` (the trainer's EMA) rebinds
-    it to the copy.  Returns the number of convolutions taken."""
-    import types
+    module tree and state dict are untouched.  The replacement is made on the module's CLASS (a cached subclass of its own type
+    whose ``forward`` is the HIP version), not as an instance attribute: ``copy.deepcopy`` (the trainer's EMA) and
+    ``nn.DataParallel`` replicas (``define_G`` wraps the net, models/modules.py:81; a replica copies ``__dict__``, so an instance-bound
+    method would keep running on the ORIGINAL module's cuda:0 parameters) resolve ``forward`` through their own ``self``.
+    Returns the number of convolutions taken."""
     n = 0
     for m in model.modules():
         if _eligible(m) and getattr(m.forward, "__func__", None) is not _hip_conv_forward:
-            m.forward = types.MethodType(_hip_conv_forward, m)
+            _retarget(m, _hip_conv_forward)
             n += 1
         elif norms and _eligible_norm(m) and getattr(m.forward, "__func__", None) is not _hip_norm_forward:
-            m.forward = types.MethodType(_hip_norm_forward, m)
+            _retarget(m, _hip_norm_forward)
         elif norms and _eligible_layer_norm(m) and getattr(m.forward, "__func__", None) is not _hip_layer_norm_forward:
-            m.forward = types.MethodType(_hip_layer_norm_forward, m)
+            _retarget(m, _hip_layer_norm_forward)
         elif linears and _eligible_linear(m) and getattr(m.forward, "__func__", None) is not _hip_linear_forward:
-            m.forward = types.MethodType(_hip_linear_forward, m)
+            _retarget(m, _hip_linear_forward)
         elif norms and _eligible_block(m) and getattr(m.forward, "__func__", None) is not _hip_block_forward:
-            m.forward = types.MethodType(_hip_block_forward, m)
+            _retarget(m, _hip_block_forward)
     return n
+
+
+_RETARGETED: Dict[tuple, type] = {}
+
+
+def _retarget(m: nn.Module, fn) -> None:
+    """m.__class__ <- the cached subclass of type(m) whose forward is ``fn`` (same name / module / qualname, so structural
+    checks by class name and ``isinstance`` keep working)."""
+    base = type(m)
+    cls = _RETARGETED.get((base, fn))
+    if cls is None:
+        cls = type(base.__name__, (base,), {"forward": fn, "__module__": base.__module__, "__qualname__": base.__qualname__,
+                                             "__doc__": base.__doc__, "_nd_accelerated_base": base})
+        _RETARGETED[(base, fn)] = cls
+    m.__dict__.pop("forward", None)          # an instance attribute (older accelerate(), user patches) would shadow the class
+    m.__class__ = cls

@@ -52,9 +52,10 @@ class _Ops:
 
     def group_norm(self, name: str, x: torch.Tensor, groups: int) -> torch.Tensor:
         w, b = self.p[name + ".weight"], self.p[name + ".bias"]
-        if self.hip and x.is_cuda and x.shape[1] % 4 == 0:
+        if self.hip and x.is_cuda:
             from . import train
-            return train.group_norm(x, groups, w, b, 1e-5)
+            if train._group_norm_ok(x.shape[1], groups):                     # wider nets (dim > 128: C > 1024) stay on PyTorch's norm
+                return train.group_norm(x, groups, w, b, 1e-5)
         return F.group_norm(x, groups, w, b, eps=1e-5)
 
     def layer_norm(self, name: str, x: torch.Tensor) -> torch.Tensor:
@@ -70,8 +71,9 @@ class _Ops:
         """Block: conv3x3 -> GroupNorm -> optional x (scale + 1) + shift -> SiLU   (Diffusion_arch.py:128-144); ``ss`` = scale | shift
         along dim 1: (B, 2C, 1, 1) from the time embedding or (B, 2C, H, W) per-pixel maps."""
         x = self.conv(name + ".proj", x, 1)
-        if self.hip and x.is_cuda and x.shape[1] % 4 == 0 and (ss is None or ss.numel() == x.shape[0] * 2 * x.shape[1]):
-            from . import train                                              # norm, per-sample modulation and SiLU as one operator
+        from . import train
+        if (self.hip and x.is_cuda and train._group_norm_ok(x.shape[1], groups)
+                and (ss is None or ss.numel() == x.shape[0] * 2 * x.shape[1])):  # norm, per-sample modulation and SiLU as one operator
             return train.group_norm_silu(x, groups, self.p[name + ".norm.weight"], self.p[name + ".norm.bias"], ss, 1e-5)
         x = self.group_norm(name + ".norm", x, groups)
         if ss is not None:

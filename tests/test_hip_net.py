@@ -306,6 +306,49 @@ def test_condition_batch_mismatch_and_bad_iso_are_rejected():
     assert out.shape == (3, 4, 32, 32)
 
 
+# --------------------------------------------------------------------------- the reference's single-process multi-GPU entry (nn.DataParallel)
+
+def test_data_parallel_device_ids_shard_the_batch_in_sample():
+    """define_G wraps the net in nn.DataParallel(net, gpu_ids) (models/modules.py:73-83).  With several device_ids GaussianDiffusion.sample
+    splits the batch rows over those devices -- one engine / plan / step graph per shard, launched round-robin -- instead of running
+    silently on one.  Two logical shards on cuda:0 (ragged 3 + 2 and even 2 + 2): equal to the one-device run bit for bit (device Philox
+    keyed by the global sample index; batch-invariant kernel selection) and, with injected noise, to the oracle along the trajectory."""
+    dim, H, T = 16, 32, 6
+    net = make_net(dim)
+    one = GaussianDiffusion(torch.nn.DataParallel(net, device_ids=[0]), image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    two = GaussianDiffusion(torch.nn.DataParallel(net, device_ids=[0, 0]), image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    assert [d.index for d in two._sampling_devices()] == [0, 0] and len(one._sampling_devices()) == 1
+    for B in (5, 4):
+        cond = synth.make_condition(B, H, seed=1)
+        a = one.sample(batch_size=B, condition=to_dev(cond), seed=11)
+        b = two.sample(batch_size=B, condition=to_dev(cond), seed=11)
+        assert b.shape == (B, 4, H, H) and b.device == a.device
+        assert torch.equal(a, b)
+    B = 5
+    cond = synth.make_condition(B, H, seed=1)
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(T - 1)])
+    traj = two.sample(batch_size=B, condition=to_dev(cond), return_all_timesteps=True, noise={"x_T": x_T, "steps": steps}).cpu()
+    ref = O.sample(state_dict(dim), cond, image_size=H, batch_size=B, timesteps=T, x_T=x_T, noise=lambda i, s: steps[i], return_all=True)
+    assert traj.shape == ref.shape == (B, T + 1, 4, H, H)
+    assert rel_err(traj.numpy(), ref.numpy()) < SAMPLE_TOL
+
+
+def test_data_parallel_forward_replicas_use_the_owners_engines():
+    """nn.DataParallel.forward with several device_ids replicates the module (replicas have no parameters of their own) and calls the
+    replicas from threads: they must find the owning module's packed weights.  Same result as the bare module."""
+    dim, B, H = 16, 4, 32
+    net = make_net(dim)
+    dp = torch.nn.DataParallel(net, device_ids=[0, 0])
+    cond = synth.make_condition(B, H, seed=3)
+    x = synth.make_noise(4, "net.x", B, 4, H)
+    t = torch.tensor([17, 640, 3, 999])
+    with torch.inference_mode():
+        ref = net(x.to(DEV), t.to(DEV), to_dev(cond))
+        y = dp(x.to(DEV), t.to(DEV), {k: v.to(DEV) for k, v in cond.items()})
+    assert y.shape == ref.shape and torch.equal(y, ref)
+
+
 # --------------------------------------------------------------------------- the bench workload's own sizes, against the oracle
 
 def _oracle_threads():

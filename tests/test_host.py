@@ -240,3 +240,29 @@ def test_blocked_map_row_permutation():
         for c in range(C_ // 16):
             assert blocked[c, 0].tolist() == list(range(16 * c, 16 * c + 16))              # scale channels of chunk c
             assert blocked[c, 1].tolist() == list(range(C_ + 16 * c, C_ + 16 * c + 16))    # shift channels of chunk c
+
+
+def test_accelerate_retargets_the_class_so_replicas_and_copies_resolve_forward_through_themselves():
+    """train.accelerate() must survive nn.DataParallel's replicate() (define_G wraps the net, models/modules.py:81): a replica copies
+    ``__dict__``, so an instance-bound forward would keep running on the original module's parameters.  The HIP forward sits
+    on the module's class instead: replicas, deep copies and pickles call it with their own ``self``; state dict and module type names
+    are unchanged."""
+    import copy
+    import pickle
+    from torch import nn
+    from noisediff_amd import train
+    net = nn.Sequential(nn.Conv2d(8, 16, 3, padding=1), nn.GroupNorm(4, 16), nn.SiLU(), nn.Conv2d(16, 16, 1), nn.LayerNorm(64), nn.Linear(64, 64))
+    keys = list(net.state_dict().keys())
+    assert train.accelerate(net) == 1 and train.accelerate(net) == 0
+    conv, norm = net[0], net[1]
+    assert conv.forward.__func__ is train._hip_conv_forward and norm.forward.__func__ is train._hip_norm_forward
+    assert "forward" not in conv.__dict__ and isinstance(conv, nn.Conv2d) and type(conv).__name__ == "Conv2d"
+    assert type(conv)._nd_accelerated_base is nn.Conv2d and type(net[5])._nd_accelerated_base is nn.Linear
+    for m in (conv, norm, net[3], net[4], net[5]):
+        for other in (m._replicate_for_data_parallel(), copy.deepcopy(m)):
+            assert other is not m and other.forward.__self__ is other and other.forward.__func__ is m.forward.__func__
+    assert list(net.state_dict().keys()) == keys
+    clone = pickle.loads(pickle.dumps(nn.Conv2d(8, 8, 3, padding=1)))          # plain modules still pickle; accelerated ones: state dicts travel
+    assert isinstance(clone, nn.Conv2d)
+    with pytest.raises(Exception, match="HIP library only|no CPU path"):
+        conv(torch.zeros(1, 8, 16, 16))                                          # still no CPU fallback
