@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for plumbing tests)")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0 (single-GPU box)")
+    ap.add_argument("--broadcast-all", action="store_true", help="broadcast the whole weight arena instead of the slices the plan reads")
     ap.add_argument("--soak-s", type=float, default=3.0, help="seconds of untimed step replays before the W warm-up steps")
     return ap.parse_args()
 
@@ -383,21 +384,21 @@ def main():
         eng = Engine(a.dim, dev, mid_attn=a.mid_attn)
         if rank == 0:
             eng.load_state_dict(sd)
+        eng.plan(B, S, S, allow_empty=True)  # recorded before the weights arrive: the broadcast carries only what this plan reads
         torch.cuda.synchronize(dev)
         dist.barrier()
         t0 = time.perf_counter()
-        eng.broadcast(src=0)                 # returns with the arena complete on this rank (device-synchronised)
+        nbytes = eng.broadcast(src=0, only_used=not a.broadcast_all)   # returns with the slices complete on this rank (device-synchronised)
         bt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         net.adopt_engine(eng)
         # evidence that every rank holds rank 0's weights: min and max over ranks of a checksum of the arena
-        cs = eng.arena.double().abs().sum().reshape(1)
+        cs = torch.stack([eng.view(n).double().abs().sum() for n in sorted(eng.used)]).sum().reshape(1)   # over the slices the plan reads
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-        nbytes = eng.arena.numel() * 4
         bcast = {"ranks_in_broadcast": dist.get_world_size(), "backend": dist.get_backend() + (" (RCCL)" if a.backend == "nccl" else ""),
-                 "broadcast_bytes": nbytes, "broadcast_ms": float(bt.item()) * 1e3,
+                 "broadcast_bytes": nbytes, "arena_bytes": eng.arena.numel() * 4, "broadcast_ms": float(bt.item()) * 1e3,
                  "broadcast_GBps_per_rank": nbytes / float(bt.item()) / 1e9,
                  "arena_checksum_equal_on_all_ranks": bool(lo.item() == hi.item() and hi.item() > 0),
                  "per_step_collectives": 0, "devices": "all ranks on cuda:0 (--one-device rehearsal)" if a.one_device else
@@ -455,10 +456,32 @@ def main():
         per_step = dt / a.steps
         value = world * B / (n_sample_steps * per_step)
     if world > 1:
-        tt = torch.tensor([per_step], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        per_step = float(tt.item())
+        # every rank timed the same K steps between the same two barriers; its own GPU-side time for them (HIP events on the
+        # library's stream around a second, untimed-by-the-metric replay of K steps) tells a slow rank from a slow barrier
+        own_ms = None
+        if not a.full:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ext = torch.cuda.ExternalStream(plan.e.stream.value, device=dev)
+            e0.record(ext)
+            loop.advance(a.steps)
+            e1.record(ext)
+            plan.e.sync()
+            own_ms = e0.elapsed_time(e1) / a.steps
+        mine = torch.tensor([per_step * 1e3, own_ms if own_ms is not None else per_step * 1e3], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        wall = [float(t[0]) for t in every]
+        gpu = [float(t[1]) for t in every]
+        per_step = max(wall) * 1e-3
         value = world * B / per_step if a.full else world * B / (n_sample_steps * per_step)
+        if bcast is not None:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as ex:          # noqa: BLE001 -- diagnostic field only
+                ver = f"unavailable ({type(ex).__name__})"
+            bcast.update({"rccl_version": ver if a.backend == "nccl" else None,
+                          "ms_per_step_by_rank_wall": wall, "ms_per_step_by_rank_gpu_events": gpu,
+                          "ms_per_step_min_over_ranks": min(wall), "ms_per_step_max_over_ranks": max(wall)})
 
     sampler = f"{a.sampling_timesteps}-step DDIM of {T}" if a.sampling_timesteps else f"{T}-step DDPM"
     out = {

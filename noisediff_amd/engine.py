@@ -114,6 +114,8 @@ class Engine:
         self.stream = s
         self.plans: Dict[Tuple[int, int, int], "Plan"] = {}
         self.loaded = False
+        self.used: set = set()                     # arena slices the recorded plans read (Engine.p): what a broadcast has to carry
+        self.valid: Optional[set] = None           # slices this rank holds after a partial broadcast (None: the whole arena)
 
     def __del__(self):                      # the engine owns its HIP stream (plans and loops only borrow it)
         s, self.stream = getattr(self, "stream", None), None
@@ -175,6 +177,10 @@ class Engine:
 
     def p(self, name: str) -> int:
         s = self.slots[name]
+        if self.valid is not None and name not in self.valid:
+            raise L.HipError(f"arena slice {name!r} was not part of this rank's weight broadcast (it carried the slices of the plans "
+                             "recorded before it): record the plan before Engine.broadcast(only_used=True), or broadcast the whole arena")
+        self.used.add(name)
         return self.arena.data_ptr() + 4 * s.offset
 
     # ------------------------------------------------------------------ loading
@@ -227,18 +233,52 @@ class Engine:
             e = math.log(10000) / (half - 1)
             self.view("time_freqs").copy_(torch.exp(torch.arange(half) * -e).to(torch.float32))
             torch.cuda.synchronize(self.device)
-        self.loaded = True
+        self.loaded, self.valid = True, None
 
-    def broadcast(self, src: int = 0, group=None) -> None:
-        """The ONE collective of the sampling path: packed weights root -> all ranks (RCCL over xGMI)."""
+    def broadcast(self, src: int = 0, group=None, only_used: bool = False) -> int:
+        """The ONE collective of the sampling path: packed weights root -> all ranks (RCCL over xGMI).  Returns the bytes sent.
+
+        ``only_used``: carry only the arena slices the plans recorded so far read (``Engine.plan(..., allow_empty=True)`` records a
+        plan on a rank that has no weights yet).  The arena holds up to three packings of every 3x3 weight (direct, F(2x2), F(4x4))
+        plus chain / blocked copies; a given problem size reads one of them per layer -- at d=64, 256x256 that is 0.27 of the
+        arena.  The slices travel as one gathered buffer (still a single broadcast); other slices are marked absent on the receivers."""
         import torch.distributed as dist
         with torch.cuda.device(self.device):
             torch.cuda.synchronize(self.device)          # rank src: the packing kernels ran on the library's stream
-            dist.broadcast(self.arena, src=src, group=group)
+            if not only_used:
+                dist.broadcast(self.arena, src=src, group=group)
+                nbytes = self.arena.numel() * 4
+            else:
+                names = sorted(self.used, key=lambda n: self.slots[n].offset)
+                every = [None] * dist.get_world_size(group)
+                dist.all_gather_object(every, names, group=group)      # control plane: every rank must have recorded the same plans
+                if any(e != names for e in every):
+                    raise L.HipError("Engine.broadcast(only_used=True): the ranks recorded different plans")
+                ranges: List[List[int]] = []
+                for n in names:
+                    sl = self.slots[n]
+                    lo, hi = sl.offset, sl.offset + (sl.numel + _ALIGN - 1) // _ALIGN * _ALIGN
+                    if ranges and ranges[-1][1] == lo:
+                        ranges[-1][1] = hi
+                    else:
+                        ranges.append([lo, hi])
+                is_src = dist.get_rank(group) == src
+                with torch.inference_mode(False):
+                    stage = (torch.cat([self.arena[lo:hi] for lo, hi in ranges]) if is_src
+                             else torch.empty(sum(hi - lo for lo, hi in ranges), dtype=torch.float32, device=self.device))
+                dist.broadcast(stage, src=src, group=group)
+                if not is_src:
+                    at = 0
+                    for lo, hi in ranges:
+                        self.arena[lo:hi].copy_(stage[at:at + hi - lo])
+                        at += hi - lo
+                    self.valid = set(names)
+                nbytes = stage.numel() * 4
             # the collective is asynchronous to the host and ordered only against torch's stream; the kernels that read the
             # arena run on the library's own non-blocking stream, so the arena must be complete before this returns
             torch.cuda.synchronize(self.device)
         self.loaded = True
+        return nbytes
 
     # ------------------------------------------------------------------ plans
     def copy_from(self, other: "Engine") -> None:
@@ -250,12 +290,13 @@ class Engine:
         with torch.cuda.device(self.device):
             self.arena.copy_(other.arena)
             torch.cuda.synchronize(self.device)
-        self.loaded = True
+        self.loaded, self.valid = True, other.valid
 
-    def plan(self, B: int, H: int, W: int, debug: bool = False, tag: int = 0) -> "Plan":
+    def plan(self, B: int, H: int, W: int, debug: bool = False, tag: int = 0, allow_empty: bool = False) -> "Plan":
         """The plan (workspace + recorded launches) of one problem size; ``tag`` separates plans of equal size that must not share
-        a workspace (several shards of one batch on the same device)."""
-        if not self.loaded:
+        a workspace (several shards of one batch on the same device).  ``allow_empty``: record the plan before the weights arrive
+        (recording needs the arena's layout only) -- see ``broadcast(only_used=True)``."""
+        if not self.loaded and not allow_empty:
             raise L.HipError("Engine has no weights: call load_state_dict() or broadcast() first")
         key = (B, H, W, debug, tag)
         if key not in self.plans:

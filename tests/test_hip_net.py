@@ -490,8 +490,19 @@ def _rank_worker(rank, world, port, q, mode):
     if rank == 0:
         net.load_state_dict(state_dict(dim), strict=True)          # ... only rank 0 holds the checkpoint
     net = net.to(DEV).eval()
-    eng = broadcast_weights(net, DEV, src=0)
+    from noisediff_amd.shard import shard_bounds
+    lo, hi = shard_bounds(total, rank, world)
+    # philox mode: the broadcast carries only the arena slices this job's plans read (recorded before the weights arrive)
+    eng = broadcast_weights(net, DEV, src=0, shapes=[(hi - lo, H, H)] if mode == "philox" else None)
     assert net.hip_engine(DEV) is eng                              # the broadcast arena is the one the forward uses
+    if mode == "philox":
+        assert 0 < eng.last_broadcast_bytes < eng.arena.numel() * 4
+        if rank != 0:
+            absent = next(n for n in eng.slots if n not in eng.valid)
+            with pytest.raises(Exception, match="not part of this rank's weight broadcast"):
+                eng.p(absent)
+    else:
+        assert eng.last_broadcast_bytes == eng.arena.numel() * 4 and eng.valid is None
     gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
 
     def make_cond(lo, hi):
