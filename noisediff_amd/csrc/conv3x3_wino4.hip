@@ -41,13 +41,21 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(3))) short* lds_short_ptr;
 typedef __attribute__((address_space(3))) unsigned* lds_u32_ptr;
+typedef __attribute__((address_space(3))) unsigned short* lds_u16_ptr;
 typedef __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
 
 constexpr int KC4 = 16;                              // channels per K chunk
 constexpr int NPOS = 36;                             // positions (xi, nu) == patch entries (a, b)
 constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk image: 36 entries x 1 KB = 36 KB
 
-constexpr int LDS_BYTES = 2 * VD_FLOATS * 4 + 18 * 40 * 64 + (10 + 10 + 10 + 12) * 256 * 4;   // [tg 2] V images + raw halo + per-thread tables
+// LDS map (bytes): [raw halo image 46080][V image of tile group 0 / 1: 2 x 36864][per-thread tables: source pixel u32 x 10, (row, column) u32 x 10,
+// raw-image address of a staged item u16 x 10, raw-image address of the transform lane's patch columns u16 x 12][bias of every cout].  The raw
+// image sits at address 0 so that its addresses fit 16 bits.
+constexpr int RAW_FLOATS = 18 * 40 * 16;                                  // 18 halo rows x 40 records of 64 bytes
+constexpr int TAB_BYTES = (10 + 10) * 256 * 4 + (10 + 12) * 256 * 2;
+constexpr int BIAS_OFF_BYTES = RAW_FLOATS * 4 + 2 * VD_FLOATS * 4 + TAB_BYTES;
+constexpr int MAX_COUT = (160 * 1024 - BIAS_OFF_BYTES) / 4 / 64 * 64;     // 3072: the whole bias vector (padded to cout tiles) lives in LDS
+constexpr int LDS_BYTES = BIAS_OFF_BYTES + MAX_COUT * 4;
 
 #ifndef W4_UR
 #define W4_UR 18             // weight fragments in flight per wave in the K loop (x 4 registers); a stage consumes 18
@@ -120,9 +128,16 @@ __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
     t[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(cm5, d[3], d[5]));
 }
 
+// a - b on packed floats as ONE v_pk_fma_f32 per pair: fma(b, -1, a) == a - b exactly.  hipcc expands a vector subtraction into scalar
+// v_sub_f32 (and folds an fma with the literal -1 back into one), so the -1 arrives in a register the compiler cannot see through (`neg1`)
+__device__ __forceinline__ f32x4 w4_sub4(f32x4 a, f32x4 b, float neg1) {
+    const f32x4 m1 = {neg1, neg1, neg1, neg1};
+    return __builtin_elementwise_fma(b, m1, a);
+}
+
 // A^T applied to six float4s (four consecutive couts each)
-__device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
-    const f32x4 a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], e = m[3] - m[4];
+__device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4], float neg1) {
+    const f32x4 a = m[1] + m[2], b = w4_sub4(m[1], m[2], neg1), c = m[3] + m[4], e = w4_sub4(m[3], m[4], neg1);
     y[0] = m[0] + a + c;
     y[1] = b + 2.0f * e;
     y[2] = a + 4.0f * c;
@@ -135,7 +150,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAP;               // GroupNorm-affine + SiLU applied while the halo is written to LDS
     constexpr bool LEAKY = MODE == ND_PRO_LEAKY || MODE == ND_PRO_LEAKY_SECOND;      // LSID: LeakyReLU(0.2) of the producer, applied by the consumer
     constexpr int UR = MAP ? W4_UR_MAP : AFF ? W4_UR_AFF : W4_UR, UR_EPI = W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
-    extern __shared__ __attribute__((aligned(16))) float Vd[];          // [tg 2][buf 2][VD_FLOATS], then the border table
+    extern __shared__ __attribute__((aligned(16))) float lds_[];        // the LDS map above (dynamic shared memory starts at LDS address 0)
+    float* const Vd = lds_ + RAW_FLOATS;                                // [tg 2][VD_FLOATS]: the V images
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,23 +219,24 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     const __amdgpu_buffer_rsrc_t rsrcm = MAP ? src_rsrc(s.map, 2 * Ctot) : rsrc0;
     const int map_shift = s.map_blocked ? 64 : Ctot * 4;                 // bytes from a channel's scale to its shift (blocked layout: [chunk][scale 16 | shift 16])
     float* const vd_tg = Vd + tg * VD_FLOATS;                            // this tile group's V image
-    char* const rawbuf = reinterpret_cast<char*>(Vd + 2 * VD_FLOATS);    // [18][40] records of 64 bytes
-    lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS + 18 * RAW_ROWP * 16) + tid;      // [10][256] source pixel of this thread's items
+    char* const rawbuf = reinterpret_cast<char*>(lds_);                  // [18][40] records of 64 bytes
+    lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS) + tid;    // [10][256] source pixel of this thread's items
     auto cperm = [](int c) { return ((c >> 2) & 3) | ((c & 3) << 2) | (c & 48); };
     auto swz = [](int r, int c) { return (2 * ((r >> 2) & 3)) ^ (4 * ((c >> 3) & 1)); };       // slot swizzle of a pixel's 8 channel pairs (even: quads stay 16 contiguous bytes)
     const int sq = tid & 3;                                              // channel quad of this thread's items
     // per-thread constants live in LDS tables (thread-private columns), not in registers: [10] LDS address of staged item k,
     // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
     // patch crosses a multiple-of-4 row): entry (a, b) is at ttab[(a >> 2) * 6 + b] + a * RAW_ROWP * 64
-    lds_u32_ptr const dtab = ptab + RAW_IT * 256;
-    lds_u32_ptr const rtab = dtab + RAW_IT * 256;                       // [10] item k: pixel relative to the region | halo row << 16 | column << 24 (stage_tile, once per tile)
-    lds_u32_ptr const ttab = rtab + RAW_IT * 256;
+    lds_u32_ptr const rtab = ptab + RAW_IT * 256;                       // [10] item k: pixel relative to the region | halo row << 16 | column << 24 (stage_tile, once per tile)
+    lds_u16_ptr const dtab = (lds_u16_ptr)(rtab - tid + RAW_IT * 256) + tid;    // [10] LDS address of staged item k (16 bits: the raw image starts at 0)
+    lds_u16_ptr const ttab = dtab + RAW_IT * 256;
+    float* const bias_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_) + BIAS_OFF_BYTES);
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) {
         const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
         // (the per-item values are tables, not registers: kept in registers they get spilled, and a scratch reload in the K loop
         //  drains the weight ring; any per-item VALU arithmetic in the stage loops costs an MFMA <-> VALU switch)
-        dtab[k * 256] = (unsigned)(2 * VD_FLOATS * 4 + (r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS
+        dtab[k * 256] = (unsigned short)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS (items beyond pixel 611 are never written)
         // pixel of halo entry (r, c) relative to the region's base pixel (one source row above, one pixel left of the halo origin):
         // nearest-x2 upsample addressing halves the coordinates -- (16 ty - 1 + r) >> 1 = 8 ty - 1 + ((r + 1) >> 1)
         const int dy = up ? (r + 1) >> 1 : r, dx = up ? (c + 1) >> 1 : c;
@@ -234,9 +251,12 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #pragma unroll
         for (int bx = 0; bx < 6; ++bx) {
             const int r0 = 4 * (t_tile >> 2) + 4 * h, c = 16 * tg + 4 * (t_tile & 3) + bx;
-            ttab[(h * 6 + bx) * 256] = (unsigned)((4 * (t_tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + t_kq) ^ swz(r0, c)) * 8));
+            ttab[(h * 6 + bx) * 256] = (unsigned short)((4 * (t_tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + t_kq) ^ swz(r0, c)) * 8));
         }
     const unsigned t_lds = (unsigned)(ch2 * 1024 + (t_kq >> 1) * 512 + t_tile * 32 + (t_kq & 1) * 16);  // V image address of the transform lane
+    // the bias of every cout (zero beyond cout / without a bias) -> LDS, once per workgroup: the epilogues read it with an LDS load.  (A global
+    // load there shares the in-order vmcnt counter with the output stores: waiting for it drained every store issued before it.)
+    for (int i = tid; i < a.n_tiles * 64; i += 256) bias_lds[i] = (a.d.bias && i < Cout) ? a.d.bias[i] : 0.0f;
 
     const unsigned OOB = 0x7FFFFFF0u;                                    // byte offset beyond any tensor: the load returns zeros (padding)
     int sb_ = 0;
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             v = inside ? x * r : zero;
         }
         if (MODE == ND_PRO_LEAKY || (MODE == ND_PRO_LEAKY_SECOND && i_second)) v = nd_leaky4(v);      // keeps zeros: the padding needs no mask
-        *reinterpret_cast<lds_f32x4_ptr>(dtab[k * 256]) = v;
+        *reinterpret_cast<lds_f32x4_ptr>((unsigned)dtab[k * 256]) = v;
     };
 
     // ---- V image of a tile group (36 KB): [position pair 18][8-channel half g2][kq >> 1][tile 16][kq & 1] x 16 bytes, the 16 bytes
@@ -581,8 +601,9 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 const bool cok = co + 3 < Cout;
                 float z0 = 0.0f;
                 asm volatile("" : "+v"(z0));                               // a fresh zero per tile: hipcc otherwise keeps one zero float4 alive (and spilled) for the whole kernel
-                f32x4 bias4 = {z0, z0, z0, z0};
-                if (a.d.bias && cok) bias4 = nd_ld4(a.d.bias + co);
+                float neg1 = -1.0f;
+                asm volatile("" : "+v"(neg1));                             // (see w4_sub4)
+                const float* const bias_p = bias_lds + co;                 // read where it is used (an LDS load: held in registers it gets spilled)
                 const int py0 = ty * 16 + sty, px0 = tx * 16 + stx;
                 f32x4 sum4 = {z0, z0, z0, z0}, sq4 = {z0, z0, z0, z0}, pivot4 = {z0, z0, z0, z0};
                 int cnt = 0;
@@ -601,10 +622,12 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #pragma unroll
                         for (int nu = 0; nu < 6; ++nu) {
                             auto M = [&](int xi) { return read_acc(2 * (xi * 6 + nu) + j); };
-                            const f32x4 m1 = M(1), m2 = M(2);
-                            const f32x4 p = m1 + m2, q = m1 - m2;
+                            f32x4 m1 = M(1);
+                            const f32x4 m2 = M(2);
+                            if (nu == 1) m1 += *reinterpret_cast<const f32x4*>(bias_p);                   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
+                            const f32x4 p = m1 + m2, q = w4_sub4(m1, m2, neg1);
                             const f32x4 m3 = M(3), m4 = M(4);
-                            const f32x4 r = m3 + m4, u = m3 - m4;
+                            const f32x4 r = m3 + m4, u = w4_sub4(m3, m4, neg1);
                             if (ih == 0) { Z[0][nu] = M(0) + p + r;  Z[1][nu] = q + 2.0f * u; }
                             else         { Z[0][nu] = p + 4.0f * r;  Z[1][nu] = q + 8.0f * u + M(5); }
                             __builtin_amdgcn_sched_barrier(0);            // one column at a time: short live ranges
@@ -613,35 +636,33 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                         for (int i2 = 0; i2 < 2; ++i2) {
                             const int i = 2 * ih + i2;
                             f32x4 y[4];
-                            w4_at(Z[i2], y);
+                            w4_at(Z[i2], y, neg1);
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
-                                const f32x4 v = y[jj] + bias4;
+                                const f32x4 v = y[jj];
                                 if (STATS && i == 0 && jj == 0) {        // one pivot per cout for the whole 16x16 tile: tile 0's first pixel
-                                    pivot4.x = __shfl(v.x, lane & 48); pivot4.y = __shfl(v.y, lane & 48);
-                                    pivot4.z = __shfl(v.z, lane & 48); pivot4.w = __shfl(v.w, lane & 48);
+                                    pivot4.x = nd_row16_first(v.x); pivot4.y = nd_row16_first(v.y);
+                                    pivot4.z = nd_row16_first(v.z); pivot4.w = nd_row16_first(v.w);
                                 }
                                 const bool inside = FULL || (py0 + i < H && px0 + jj < W);
-                                if (inside) {
-                                    if (STATS) {
-                                        const f32x4 dv = v - pivot4;
-                                        sum4 += dv;
-                                        sq4 += dv * dv;
-                                        ++cnt;
-                                    }
-#if !(W4_ABLATE & 8)
-#if W4_ABLATE & 128                 // timing experiment only (results land in the wrong pixels): every wave store covers eight whole 128-byte lines
-                                    if (FULL || cok) nd_st4(a.d.out + (((size_t)b * H + ty * 16 + (i * 4 + jj)) * Wt + tx * 16) * ldot + wave * 256 + lane * 4, v);
-#else
-                                    if (FULL || cok)
-                                        // (the pixel offset goes through the vector offset: with it in the scalar offset field the
-                                        //  kernel stored wrong values for one lane quad -- not understood, measured)
-                                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), orsrc, lane_off + (unsigned)((i * Wt + jj) * ldot * 4), 0, W4_NT_STORE ? 2 : 0);
-#endif
-#else
-                                    asm volatile("" :: "v"(v));          // (the output transform stays: only the store is gone)
-#endif
+                                if (STATS && inside) {
+                                    const f32x4 dv = w4_sub4(v, pivot4, neg1);
+                                    sum4 += dv;
+                                    sq4 += dv * dv;
+                                    ++cnt;
                                 }
+#if !(W4_ABLATE & 8)
+                                // EVERY path issues the same 16 store instructions per tile: a pixel / cout quad outside the tensor gets an offset
+                                // beyond the resource (the store is dropped by the range check) instead of a branch around the store.  vmcnt counts
+                                // loads and stores in one in-order queue; with a store-free path through the epilogue hipcc sized the next tile's
+                                // first weight-fragment waits as if NO store were in flight, i.e. they drained the epilogue's stores every tile.
+                                // (The pixel offset goes through the vector offset: see tools/microbench/buffer_store_soffset.hip.)
+                                unsigned off = lane_off + (unsigned)((i * Wt + jj) * ldot * 4);
+                                if (!FULL) off = (inside && cok) ? off : 0xFFFFFFF0u;
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), orsrc, off, 0, W4_NT_STORE ? 2 : 0);
+#else
+                                asm volatile("" :: "v"(v));              // (the output transform stays: only the store is gone)
+#endif
                             }
                         }
                     }
@@ -760,8 +781,8 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3_wino4: null tensor pointer");
     ND_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->cin > 0 && d->cout > 0, ND_E_BADARG, "nd_conv3x3_wino4: non-positive size");
-    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->cin > KC4, ND_E_SHAPE,
-               "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4, cin > 16 (at least two K chunks)", d->cin, d->cout);
+    ND_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->cin > KC4 && d->cout <= MAX_COUT, ND_E_SHAPE,
+               "nd_conv3x3_wino4: cin=%d and cout=%d must be multiples of 4, cin > 16 (at least two K chunks), cout <= %d", d->cin, d->cout, MAX_COUT);
     ND_REQUIRE(s.c0 + s.c1 == d->cin && s.c0 % 4 == 0 && s.c1 % 4 == 0 && s.c0 > 0, ND_E_SHAPE,
                "nd_conv3x3_wino4: source channels %d+%d do not match cin=%d (multiples of 4)", s.c0, s.c1, d->cin);
     ND_REQUIRE((s.c1 == 0) == (s.p1 == nullptr), ND_E_BADARG, "nd_conv3x3_wino4: p1/c1 mismatch");

@@ -116,6 +116,12 @@ __device__ __forceinline__ float nd_row16_sum(float v) {
     return v;
 }
 
+// The value of the first lane of each DPP row (lane 16k) in all 16 lanes of the row: one v_mov_b32 with row_newbcast:0 (gfx90a+), no LDS
+// crossbar and no lane-index register (unlike __shfl(v, lane & 48) = ds_bpermute_b32).
+__device__ __forceinline__ float nd_row16_first(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150, 0xF, 0xF, true));
+}
+
 // exact-fp32 matrix FMA: D(32x32) += A(32x2) * B(2x32); lane l gives A[l&31][l>>5], B[l>>5][l&31]
 __device__ __forceinline__ f32x16 nd_zero16() {
     f32x16 z;

@@ -8,7 +8,10 @@ from noisediff_amd import _lib as L
 L.load(os.environ["ND_LIB"])
 import hiputil as hu
 ctx = hu.Ctx()
-for (B, H, W, cin, cout) in [(16, 256, 256, 64, 64), (16, 32, 32, 512, 512)]:
+SHAPES = [(16, 256, 256, 64, 64), (16, 32, 32, 512, 512)]
+if os.environ.get("W4_SHAPES"):          # e.g. W4_SHAPES="1,256,256,64,64;2,256,256,64,64"
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["W4_SHAPES"].split(";")]
+for (B, H, W, cin, cout) in SHAPES:
     x = torch.randn(B, H, W, cin, device=hu.DEV); w = torch.randn(cout, cin, 3, 3) * 0.05
     wd = hu.dev(w); wp = torch.empty(ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout), device=hu.DEV)
     L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream); ctx.sync()
@@ -22,6 +25,8 @@ for (B, H, W, cin, cout) in [(16, 256, 256, 64, 64), (16, 32, 32, 512, 512)]:
     for _ in range(3):
         L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream); ctx.sync()
     v = dbg.cpu().view(256, 16).double()
+    v = v[v[:, 2] > 0]                                  # workgroups that had work (small problems start fewer than 256)
+    print(f"{v.shape[0]} workgroups;", end=" ")
     cyc, real, chunks, epi, xf, second, first, last, third, wait, pro, top, stile = (v[:, i] for i in range(13))
     n_chunks = (cin + 15) // 16
     mhz = cyc / (real / 100.0)
