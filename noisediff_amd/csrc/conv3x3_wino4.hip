@@ -107,10 +107,11 @@ struct Wino4Args {
 #ifndef W4_NOP
 #define W4_NOP ""
 #endif
-#define W4_MFMA_A(acc, av, bv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-#define W4_MFMA_V(acc, av, bv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
-#define W4_MFMA_AZ(acc, av, bv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "v"(bv))
-#define W4_MFMA_VZ(acc, av, bv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(av), "v"(bv))
+// (uv = a weight-fragment register: lane (cout l & 15, channel l >> 4) -> the B operand; vv = a V register: lane (tile l & 15, channel l >> 4) -> A)
+#define W4_MFMA_A(acc, uv, vv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+a"(acc) : "v"(uv), "v"(vv))
+#define W4_MFMA_V(acc, uv, vv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+v"(acc) : "v"(uv), "v"(vv))
+#define W4_MFMA_AZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, 0" : "=&a"(acc) : "v"(uv), "v"(vv))
+#define W4_MFMA_VZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, 0" : "=&v"(acc) : "v"(uv), "v"(vv))
 #define W4_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 constexpr int ACC_AGPR = 64;                         // accumulators [0, 64) in a[0:255], [64, 72) in VGPRs
 
@@ -201,7 +202,6 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     //      0-1 with bits 2-3, and the channel pair P of a pixel in 8-byte slot P ^ swz(r, c): the transform's reads -- tiles 4 pixels
     //      apart in x and y -- then fall on different banks.
     constexpr int RAW_ROWP = 40, RAW_ITEMS = 18 * 34 * 4, RAW_IT = (RAW_ITEMS + 255) / 256;      // 10
-    const int sty = 4 * (tile >> 2), stx = 4 * (tile & 3);              // tile origin inside the 16x16 pixels (entry (0,0) is one up-left)
     // Source addressing: byte address = resource base + soffset (SGPR: the region's base pixel and the chunk's channel base) +
     // voffset (VGPR: item pixel relative to the region x pixel stride + channel quad).  The resources start one row + one pixel in
     // front of the tensors, so that soffset is never negative, and end with the tensors.  Halo entries outside the image carry
@@ -304,11 +304,12 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             tD4 = D - M * A;                                             // (v - M) * A + D = v * A + (D - M * A)
         }
     };
-    auto stage_issue_one = [&](int k) {
+    auto stage_issue_one = [&](int k, unsigned px) {                     // px = ptab[k * 256], read by the caller one step ahead
 #if !(W4_ABLATE & 1)
         // ONE VALU instruction per item (no branch, no masking: every per-item instruction in a stage loop costs an MFMA <-> VALU
-        // switch): pixel x stride + this lane's channel-quad offset, the latter out of range for a quad beyond cin
-        const unsigned px = ptab[k * 256];
+        // switch): pixel x stride + this lane's channel-quad offset, the latter out of range for a quad beyond cin.  The table entry
+        // is read from LDS BEFORE the position pair's eight MFMAs (`pre`): read behind them, its ~100 cycles of LDS latency stood between
+        // the last MFMA of one position pair and the first of the next, twenty times per chunk.
         const unsigned voff = __umul24(px, i_ld4) + i_bias;
         raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i_rs, voff, i_soff, 0));
         if (MAP) {                                                       // the maps have the conv's resolution (host: no upsample with MAP): [pixel][scale C | shift C]
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         raw[k] = f32x4{(float)k, 1.0f, 0.5f, 0.25f};
 #endif
     };
-    auto stage_commit_one = [&](int k) {
+    auto stage_commit_one = [&](int k, unsigned daddr, unsigned pxk) {   // daddr = dtab[k * 256], pxk = ptab[k * 256] (AFF only): read ahead by the caller
         if (k == RAW_IT - 1 && (tid >> 2) + 64 * k >= 18 * 34) return;   // the last round covers 36 pixels only
         f32x4 v = raw[k];
         if (AFF) {
@@ -334,12 +335,12 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             e = e + 1.0f;
             f32x4 r;
             r.x = __builtin_amdgcn_rcpf(e.x); r.y = __builtin_amdgcn_rcpf(e.y); r.z = __builtin_amdgcn_rcpf(e.z); r.w = __builtin_amdgcn_rcpf(e.w);
-            const bool inside = ptab[k * 256] != PX_MARK && i_bias != OOB;
+            const bool inside = pxk != PX_MARK && i_bias != OOB;
             const f32x4 zero = {0, 0, 0, 0};
             v = inside ? x * r : zero;
         }
         if (MODE == ND_PRO_LEAKY || (MODE == ND_PRO_LEAKY_SECOND && i_second)) v = nd_leaky4(v);      // keeps zeros: the padding needs no mask
-        *reinterpret_cast<lds_f32x4_ptr>((unsigned)dtab[k * 256]) = v;
+        *reinterpret_cast<lds_f32x4_ptr>(daddr) = v;
     };
 
     // ---- V image of a tile group (36 KB): [position pair 18][8-channel half g2][kq >> 1][tile 16][kq & 1] x 16 bytes, the 16 bytes
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     // requested.  `mid(pp)` runs behind position pair pp (halo loads of stage 0, their LDS writes in stage 1).
     // `off_c`: ring slot of the stage's fragment 0 (stage 0 of a chunk: 0, stage 1: 18 % UR; a chunk's 36 fragments close the ring).
     // `din_c` fragments of this stage are in flight on entry, `dout_c` of the next stage on exit (UR in the steady state).
-    auto stage = [&](auto first_c, auto off_c, auto din_c, auto dout_c, const char* v0base, const char* v1base, int wb, int nb, auto&& mid) {
+    auto stage = [&](auto first_c, auto off_c, auto din_c, auto dout_c, const char* v0base, const char* v1base, int wb, int nb, auto&& pre, auto&& mid) {
         constexpr int OFF = decltype(off_c)::value, DIN = decltype(din_c)::value, DOUT = decltype(dout_c)::value;
         auto hi = [](int pp) { const int h = pp + UR; return h < 18 + DOUT ? h : 18 + DOUT; };   // fragments requested before position pair pp
 #pragma unroll
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #pragma unroll
         for (int pp = 0; pp < 18; ++pp) {
             if (pp + W4_VR - 1 < 18) read_v(v0base, v1base, pp + W4_VR - 1);
+            pre(pp);                                                     // LDS table reads of mid(pp): their latency hides under the MFMAs
             const f32x4 u = U[(OFF + pp) % UR];
             const f32x4 va = Vr[pp % W4_VR][0], vb = Vr[pp % W4_VR][1];     // {pos 2pp: ch even, odd; pos 2pp+1: ch even, odd}
             __builtin_amdgcn_sched_barrier(0);
@@ -483,14 +485,14 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     stage_tile(b, ty, rx);
     stage_issue_begin(0);
 #pragma unroll
-    for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k);
+    for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k, ptab[k * 256]);
     {
         const int wb = wblock(0, nt * 4 + wave);
 #pragma unroll
         for (int q = 0; q < UR_EPI; ++q) load_u(q, q, wb);
     }
 #pragma unroll
-    for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k);
+    for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, dtab[k * 256], AFF ? ptab[k * 256] : 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
@@ -539,9 +541,24 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             // the next item's halo: requested over the first position pairs of stage 0, written to the raw image over stage 1
             // (unconditional: behind the very last item this is a harmless re-stage of the tile's first chunk -- a conditional load /
             // store pair would keep the staging registers alive everywhere)
+            unsigned tab1 = 0;                                            // the table entry of position pair pp's item, read ahead of its MFMAs
+            constexpr bool PRE_P = AFF && !MAP;                           // (the map variant has no registers to spare: it reads ptab inside the clump)
+            unsigned tabd[(AFF || LEAKY) ? RAW_IT : 1], tabp[PRE_P ? RAW_IT : 1];   // AFF / LEAKY: the clump's ten items
+            auto issue_pre = [&](int pp) { if (pp < RAW_IT) tab1 = ptab[pp * 256]; };
             auto issue = [&](int pp) {
                 if (pp == 0) stage_issue_begin(last ? 0 : (ch + 1) * KC4);
-                if (pp < RAW_IT) stage_issue_one(pp);
+                if (pp < RAW_IT) stage_issue_one(pp, tab1);
+            };
+            auto commit_pre = [&](int pp) {
+                if (AFF || LEAKY) {
+                    if (pp == W4_COMMIT_AT) {
+#pragma unroll
+                        for (int k = 0; k < RAW_IT; ++k) {
+                            tabd[k] = dtab[k * 256];
+                            if (PRE_P) tabp[k] = ptab[k * 256];
+                        }
+                    }
+                } else if (pp < RAW_IT) tab1 = dtab[pp * 256];
             };
             f32x2 T[6][6];                                                // the next item's patch of this transform lane: read under the tail of stage 1
             unsigned t_addr[12];
@@ -549,9 +566,9 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 if (AFF || LEAKY) {     // the activation is VALU work: one clump (every MFMA <-> VALU switch costs ~18 cycles)
                     if (pp == W4_COMMIT_AT) {
 #pragma unroll
-                        for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k);
+                        for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, tabd[(AFF || LEAKY) ? k : 0], PRE_P ? tabp[PRE_P ? k : 0] : MAP ? ptab[k * 256] : 0u);
                     }
-                } else if (pp < RAW_IT) stage_commit_one(pp);
+                } else if (pp < RAW_IT) stage_commit_one(pp, tab1, 0u);
                 if (pp == W4_XF_AT) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this thread's share of the raw image is written ...
                     __builtin_amdgcn_s_barrier();                        // ... and so is every other wave's
@@ -560,8 +577,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 if (pp > W4_XF_AT && pp <= W4_XF_AT + 6) xf_read(T, t_addr, pp - W4_XF_AT - 1);
             };
             W4_T0();
-            stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IUR>{}, IUR{}, v0cur, v1cur, w0, w1, issue);
-            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit);
+            stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IUR>{}, IUR{}, v0cur, v1cur, w0, w1, issue_pre, issue);
+            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit_pre, commit);
 #ifdef W4_STAMP
             if (FIRST) W4_ACC(stamp_first);
             if (last) W4_ACC(stamp_last);
@@ -586,36 +603,48 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         for (int ch = 1; ch + 1 < n_chunks; ++ch) chunk(ch, std::false_type{}, std::false_type{});
         chunk(n_chunks - 1, std::false_type{}, std::true_type{});
 
-        // ---- output transform Y = A^T M A on float4s (couts co .. co+3 of tile `tile`), bias, 16-byte stores, GN partials
+        // ---- output transform Y = A^T M A, bias, stores, GN partials.  The MFMA operands are A = V (rows = the tile group's 16 tiles),
+        //      B = U (columns = the wave's 16 couts): lane (cout = l & 15, kq = l >> 4) holds in the four registers of an accumulator
+        //      the four tiles 4 kq .. 4 kq + 3 = the four 4x4-pixel blocks of tile-row kq, i.e. pixels x = 4 r + jj (r = register, jj < 4),
+        //      y = 4 kq + i of the 16x16 tile, for ONE cout.  The float4 arithmetic below runs over those four tiles, and a store of
+        //      register r is a dword per lane with 16 consecutive lanes = 16 consecutive couts = 64 contiguous bytes: the CU's store
+        //      path takes such a wave store in ~4 requests (58 B/clk).  With the roles the other way round (r2: lane = four couts of
+        //      one tile, 16-byte stores) consecutive lanes hit different pixels, every lane is a request of its own and the path runs
+        //      at 16 B/clk -- 8 k cycles per 128 KB region tile (tools/microbench/store_patterns.hip).
         W4_T0();
         W4_MFMA_DRAIN();
 
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d.out, 0, (int)((unsigned)a.d.B * H * W * a.d.ldo * 4u), 0x00020000);
         int Wt = __builtin_amdgcn_readfirstlane(W), ldot = __builtin_amdgcn_readfirstlane(a.d.ldo);
-        asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the 16 store offsets from being hoisted into (spilled) SGPRs
+        asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the store offsets from being hoisted into (spilled) SGPRs
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                                    // the two 16x16-pixel tiles (tile groups) of the region
             const int tx = 2 * rx + j;
             if (tx < a.tiles_x) {
-                const int co = cg * 16 + 4 * kq;
-                const bool cok = co + 3 < Cout;
+                int l15 = lane;
+                asm volatile("" : "+v"(l15));                              // (lane-derived values are recomputed per tile: hoisted to the kernel's start they get spilled)
+                l15 &= 15;
+                const int co = cg * 16 + l15;                              // this lane's cout
+                const bool cok = co < Cout;
                 float z0 = 0.0f;
                 asm volatile("" : "+v"(z0));                               // a fresh zero per tile: hipcc otherwise keeps one zero float4 alive (and spilled) for the whole kernel
                 float neg1 = -1.0f;
                 asm volatile("" : "+v"(neg1));                             // (see w4_sub4)
                 const float* const bias_p = bias_lds + co;                 // read where it is used (an LDS load: held in registers it gets spilled)
-                const int py0 = ty * 16 + sty, px0 = tx * 16 + stx;
-                f32x4 sum4 = {z0, z0, z0, z0}, sq4 = {z0, z0, z0, z0}, pivot4 = {z0, z0, z0, z0};
-                int cnt = 0;
+                const int py0 = ty * 16 + 4 * kq, px0 = tx * 16;           // the lane's tile row; register r covers columns px0 + 4 r .. + 3
+                f32x4 sum4 = {z0, z0, z0, z0}, sq4 = {z0, z0, z0, z0}, cnt4 = {z0, z0, z0, z0};
+                float pivot = z0;
                 const bool full = ty * 16 + 16 <= H && tx * 16 + 16 <= W && cg * 16 + 16 <= Cout;      // wave-uniform
                 const bool want_stats = a.d.stats != nullptr;
-                // stores: buffer addressing -- one 32-bit lane offset per tile + one 32-bit add per output pixel instead of 64-bit
-                // address arithmetic on scalar pairs (the output stays below 4 GiB, host check)
+                // stores: buffer addressing -- one 32-bit lane offset per tile, the pixel's offset (uniform) in the scalar offset
+                // field (the output stays below 4 GiB, host check)
                 const unsigned lane_off = (unsigned)((((unsigned)b * H + py0) * Wt + px0) * ldot + co) * 4u;
                 // two output rows at a time (Z[2][6]: the full Z[4][6] next to the live weight ring and the accumulators that sit in
                 // ordinary registers does not fit the 256 registers VALU instructions can address)
                 auto emit = [&](auto full_c, auto stats_c) {
                     constexpr bool FULL = decltype(full_c)::value, STATS = decltype(stats_c)::value;
+                    int soff = 0, step4 = ldot * 16, back11 = ldot * -44, rowadv = (Wt - 15) * ldot * 4;   // pixel (i, 4 r + jj): r -> r + 1, jj -> jj + 1, next row
+                    asm volatile("" : "+s"(soff), "+s"(step4), "+s"(back11), "+s"(rowadv));
 #pragma unroll
                     for (int ih = 0; ih < 2; ++ih) {
                         f32x4 Z[2][6];
@@ -624,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                             auto M = [&](int xi) { return read_acc(2 * (xi * 6 + nu) + j); };
                             f32x4 m1 = M(1);
                             const f32x4 m2 = M(2);
-                            if (nu == 1) m1 += *reinterpret_cast<const f32x4*>(bias_p);                   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
+                            if (nu == 1) m1 += *bias_p;                   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
                             const f32x4 p = m1 + m2, q = w4_sub4(m1, m2, neg1);
                             const f32x4 m3 = M(3), m4 = M(4);
                             const f32x4 r = m3 + m4, u = w4_sub4(m3, m4, neg1);
@@ -639,29 +668,49 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                             w4_at(Z[i2], y, neg1);
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
-                                const f32x4 v = y[jj];
-                                if (STATS && i == 0 && jj == 0) {        // one pivot per cout for the whole 16x16 tile: tile 0's first pixel
-                                    pivot4.x = nd_row16_first(v.x); pivot4.y = nd_row16_first(v.y);
-                                    pivot4.z = nd_row16_first(v.z); pivot4.w = nd_row16_first(v.w);
+                                const f32x4 v = y[jj];                   // pixel (4 kq + i, 4 r + jj) of the tile, r = component
+                                if (STATS && i == 0 && jj == 0)          // one pivot per cout for the whole 16x16 tile: its first pixel (lane l & 15, r = 0)
+                                    pivot = __shfl(v.x, l15);
+                                f32x4 in4 = {1.0f, 1.0f, 1.0f, 1.0f};    // !FULL: which of the four pixels are inside the image
+                                if (!FULL) {
+                                    const bool row_in = py0 + i < H;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) in4[r] = (row_in && px0 + 4 * r + jj < W) ? 1.0f : 0.0f;
                                 }
-                                const bool inside = FULL || (py0 + i < H && px0 + jj < W);
-                                if (STATS && inside) {
-                                    const f32x4 dv = w4_sub4(v, pivot4, neg1);
+                                if (STATS) {
+                                    f32x4 dv = w4_sub4(v, f32x4{pivot, pivot, pivot, pivot}, neg1);
+                                    if (!FULL) { dv *= in4;  cnt4 += in4; }
                                     sum4 += dv;
                                     sq4 += dv * dv;
-                                    ++cnt;
                                 }
 #if !(W4_ABLATE & 8)
-                                // EVERY path issues the same 16 store instructions per tile: a pixel / cout quad outside the tensor gets an offset
-                                // beyond the resource (the store is dropped by the range check) instead of a branch around the store.  vmcnt counts
-                                // loads and stores in one in-order queue; with a store-free path through the epilogue hipcc sized the next tile's
-                                // first weight-fragment waits as if NO store were in flight, i.e. they drained the epilogue's stores every tile.
-                                // (The pixel offset goes through the vector offset: see tools/microbench/buffer_store_soffset.hip.)
-                                unsigned off = lane_off + (unsigned)((i * Wt + jj) * ldot * 4);
-                                if (!FULL) off = (inside && cok) ? off : 0xFFFFFFF0u;
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), orsrc, off, 0, W4_NT_STORE ? 2 : 0);
+                                // EVERY path issues the same store instructions: a pixel / cout outside the tensor gets an offset beyond the
+                                // resource (the store is dropped by the range check) instead of a branch around the store.  vmcnt counts loads
+                                // and stores in one in-order queue; with a store-free path through the epilogue hipcc sizes the next tile's first
+                                // weight-fragment waits as if NO store were in flight.
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float vr = v[r];               // (by value: hipcc 7.2 evaluates __builtin_bit_cast(unsigned, v[r]) on the element
+                                                                         //  reference as element 0 for every r -- four stores of the same register)
+                                    unsigned off = lane_off;
+#if W4_ABLATE & 256                 // diagnostic: every store out of range (issued, range-checked, dropped: no memory traffic)
+                                    off = 0xFFFFFFF0u;
+#endif
+#if W4_ABLATE & 512                 // diagnostic: every store into the tensor's first 128 KB (cache-resident lines)
+                                    off &= 0x1FFFCu;
+#endif
+                                    if (!FULL) off = (in4[r] != 0.0f && cok) ? off : 0xFFFFFFF0u;
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vr), orsrc, off, soff, W4_NT_STORE ? 2 : 0);
+#if !(W4_ABLATE & 512)
+                                    // the pixel's offset ((i W + 4 r + jj) ldo 4 bytes, uniform) is ONE running scalar, advanced by a scalar add behind
+                                    // every store.  Written as 64 expressions of W and ldo, hipcc computes them all at the kernel's start, spills them,
+                                    // and every store waits for a v_readlane_b32 + the VALU-writes-SGPR -> VMEM wait states: 32 cycles per store
+                                    // measured, against 8 for the store itself (profiles/r3_w4_store_ablation.txt)
+                                    asm volatile("s_add_i32 %0, %0, %1" : "+s"(soff) : "s"(r < 3 ? step4 : jj < 3 ? back11 : rowadv) : "scc");
+#endif
+                                }
 #else
-                                asm volatile("" :: "v"(v));              // (the output transform stays: only the store is gone)
+                                asm volatile("" :: "v"(v));              // (the output transform stays: only the stores are gone)
 #endif
                             }
                         }
@@ -670,22 +719,17 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 if (full) { if (want_stats) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
                 else { if (want_stats) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
                 if (a.d.stats) {
-                    // pool over the 16 tiles (the 16 lanes of a DPP row share their couts): sum = S + n p, M2 = Q - S^2 / n
-                    float fc = nd_row16_sum((float)cnt);
-                    f32x4 S, Q;
-                    S.x = nd_row16_sum(sum4.x); S.y = nd_row16_sum(sum4.y); S.z = nd_row16_sum(sum4.z); S.w = nd_row16_sum(sum4.w);
-                    Q.x = nd_row16_sum(sq4.x); Q.y = nd_row16_sum(sq4.y); Q.z = nd_row16_sum(sq4.z); Q.w = nd_row16_sum(sq4.w);
+                    // pool the lane's four tiles, then the four tile rows (lanes l, l + 16, l + 32, l + 48 share the cout): sum = S + n p, M2 = Q - S^2 / n
+                    float fc = full ? 64.0f : cnt4.x + cnt4.y + cnt4.z + cnt4.w;
+                    float S = (sum4.x + sum4.y) + (sum4.z + sum4.w), Q = (sq4.x + sq4.y) + (sq4.z + sq4.w);
+                    fc += __shfl_xor(fc, 16);  S += __shfl_xor(S, 16);  Q += __shfl_xor(Q, 16);
+                    fc += __shfl_xor(fc, 32);  S += __shfl_xor(S, 32);  Q += __shfl_xor(Q, 32);
                     const int slot = (ty * a.tiles_x + tx) * 2;
-                    if (tile == 0 && cok) {
+                    if (kq == 0 && cok) {
                         fc = fmaxf(fc, 1.0f);
                         float* o = a.d.stats + (((size_t)b * a.slots + slot) * Cout + co) * 2;
-                        const f32x4 sm = S + fc * pivot4;
-                        const f32x4 m2 = Q - S * S / fc;
-                        nd_st4(o, f32x4{sm.x, fmaxf(m2.x, 0.0f), sm.y, fmaxf(m2.y, 0.0f)});
-                        nd_st4(o + 4, f32x4{sm.z, fmaxf(m2.z, 0.0f), sm.w, fmaxf(m2.w, 0.0f)});
-                        const f32x4 zero = {0, 0, 0, 0};             // the second slot of the tile (F(2x2) kernels: lower half) stays empty
-                        nd_st4(o + (size_t)Cout * 2, zero);
-                        nd_st4(o + (size_t)Cout * 2 + 4, zero);
+                        *reinterpret_cast<f32x2*>(o) = f32x2{S + fc * pivot, fmaxf(Q - S * S / fc, 0.0f)};
+                        *reinterpret_cast<f32x2*>(o + (size_t)Cout * 2) = f32x2{0.0f, 0.0f};   // the second slot of the tile (F(2x2) kernels: lower half) stays empty
                     }
 #ifndef W4_STAMP
                     if (b == 0 && nt == 0 && wave == 0 && lane == 0) {

@@ -188,6 +188,7 @@ class Engine:
         """Pack a reference-layout state dict (any device) into the arena."""
         st = self.stream
         keep = []
+        used = set(self.used)                      # packing addresses every slice; `used` records what the PLANS read
         with torch.cuda.device(self.device):
             for p in self.spec:
                 if p.name not in self.slots:
@@ -233,7 +234,7 @@ class Engine:
             e = math.log(10000) / (half - 1)
             self.view("time_freqs").copy_(torch.exp(torch.arange(half) * -e).to(torch.float32))
             torch.cuda.synchronize(self.device)
-        self.loaded, self.valid = True, None
+        self.loaded, self.valid, self.used = True, None, used
 
     def broadcast(self, src: int = 0, group=None, only_used: bool = False) -> int:
         """The ONE collective of the sampling path: packed weights root -> all ranks (RCCL over xGMI).  Returns the bytes sent.

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, int W, int ldo, int H, u
         const f32x4 v = {(float)(py0 + i), (float)(px0 + jj), (float)co, (float)p};
         if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off + soff, 0, 0);
         if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, (int)soff, 0);
-        if (MODE == 2) spill = __builtin_amdgcn_writelane(soff, p, spill);
+        if (MODE == 2) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(spill) : "s"(soff), "n"(p));
     }
     if (MODE == 2) {
 #pragma unroll
