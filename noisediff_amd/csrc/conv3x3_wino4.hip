@@ -54,8 +54,9 @@ constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk i
 constexpr int RAW_FLOATS = 18 * 40 * 16;                                  // 18 halo rows x 40 records of 64 bytes
 constexpr int TAB_BYTES = (10 + 10) * 256 * 4 + (10 + 12) * 256 * 2;
 constexpr int BIAS_OFF_BYTES = RAW_FLOATS * 4 + 2 * VD_FLOATS * 4 + TAB_BYTES;
-constexpr int MAX_COUT = (160 * 1024 - BIAS_OFF_BYTES) / 4 / 64 * 64;     // 3072: the whole bias vector (padded to cout tiles) lives in LDS
+constexpr int MAX_COUT = 2048;                                           // the whole bias vector (padded to cout tiles) lives in LDS
 constexpr int LDS_BYTES = BIAS_OFF_BYTES + MAX_COUT * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
 
 #ifndef W4_UR
 #define W4_UR 18             // weight fragments in flight per wave in the K loop (x 4 registers); a stage consumes 18

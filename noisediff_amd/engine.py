@@ -444,7 +444,7 @@ class Plan:
             return False
         src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
         src_bytes = src_px * 4 * max(ld0, ld1)
-        return (WINOGRAD and WINO4 and H >= 16 and W >= 16 and cout <= 3072 and (name + ".weight.wino4") in self.e.slots
+        return (WINOGRAD and WINO4 and H >= 16 and W >= 16 and cout <= 2048 and (name + ".weight.wino4") in self.e.slots
                 and mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU)
                 and not (mode == L.PRO_AFFINE_MAP_SILU and (up or (self.B * H + 2) * W * 8 * cin >= (1 << 30) - (1 << 16)))
                 and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (c1 == 0 or (c0 % 16 == 0 and not up))

@@ -79,7 +79,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
         out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         src_bytes = B * H * W * cin * 4
         wino = H >= 16 and W >= 16 and cin % 8 == 0
-        wino4 = (wino and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and cin > 16 and cout <= 3072
+        wino4 = (wino and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and cin > 16 and cout <= 2048
                  and (B * H * W + W + 2) * cin * 4 < (1 << 30) - (1 << 16) and B * H * W + W + 2 < (1 << 24))
         wino2 = wino and B * H * W < (1 << 24) and src_bytes < (1 << 31)
         if wino4:
