@@ -86,7 +86,7 @@ def test_cross_attention_general_form_equals_the_one_token_identity():
 
 
 @pytest.mark.gpu
-def test_hip_convs_and_norms_keep_loss_and_gradients_and_weights_load_into_the_sampler():
+def test_hip_convs_and_norms_keep_loss_and_gradients_and_weights_load_into_the_sampler(golden):
     from noisediff_amd import NoiseDiffNet
     dev = torch.device("cuda", 0)
     x0, noise, t, cond = _inputs()
@@ -101,6 +101,17 @@ def test_hip_convs_and_norms_keep_loss_and_gradients_and_weights_load_into_the_s
         out.append((float(loss.detach()), {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}))
     assert out[1][0] == pytest.approx(out[0][0], rel=2e-5)
     assert out[0][1].keys() == out[1][1].keys()
+    # ... and both paths ON THE GPU reproduce the REFERENCE's loss and parameter gradients (tests/golden/training.npz, captured from
+    # models/denoising_diffusion_pytorch.py:481-531 driving the reference net): the .hip() kernels are pinned to the reference itself,
+    # not only to PyTorch-on-GPU
+    for loss_val, grads in out:
+        assert loss_val == pytest.approx(float(golden("training", "train.loss.pred_v")), rel=5e-5)
+        for k in GRAD_KEYS:
+            ref = golden("training", f"train.grad.{k}")
+            got = sub(grads[k], 2048)
+            assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), k
+        sq = sum(float((g.double() ** 2).sum()) for g in grads.values())
+        assert sq == pytest.approx(float(golden("training", "train.grad_sq_norm")), rel=1e-3)
     for k in out[0][1]:
         assert rel_err(out[1][1][k].numpy(), out[0][1][k].numpy()) < 5e-4, k
     # a step of Adam on the accelerated net, then its weights sample on the HIP network
