@@ -694,21 +694,12 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                                     const float vr = v[r];               // (by value: hipcc 7.2 evaluates __builtin_bit_cast(unsigned, v[r]) on the element
                                                                          //  reference as element 0 for every r -- four stores of the same register)
                                     unsigned off = lane_off;
-#if W4_ABLATE & 256                 // diagnostic: every store out of range (issued, range-checked, dropped: no memory traffic)
-                                    off = 0xFFFFFFF0u;
-#endif
-#if W4_ABLATE & 512                 // diagnostic: every store into the tensor's first 128 KB (cache-resident lines)
-                                    off &= 0x1FFFCu;
-#endif
                                     if (!FULL) off = (in4[r] != 0.0f && cok) ? off : 0xFFFFFFF0u;
                                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vr), orsrc, off, soff, W4_NT_STORE ? 2 : 0);
-#if !(W4_ABLATE & 512)
                                     // the pixel's offset ((i W + 4 r + jj) ldo 4 bytes, uniform) is ONE running scalar, advanced by a scalar add behind
-                                    // every store.  Written as 64 expressions of W and ldo, hipcc computes them all at the kernel's start, spills them,
-                                    // and every store waits for a v_readlane_b32 + the VALU-writes-SGPR -> VMEM wait states: 32 cycles per store
-                                    // measured, against 8 for the store itself (profiles/r3_w4_store_ablation.txt)
+                                    // every store.  Written as 64 expressions of W and ldo, hipcc computes them all at the kernel's start, spills them
+                                    // to VGPR lanes and reloads one with v_readlane_b32 (+ the VALU-writes-SGPR -> VMEM wait states) in front of every store
                                     asm volatile("s_add_i32 %0, %0, %1" : "+s"(soff) : "s"(r < 3 ? step4 : jj < 3 ? back11 : rowadv) : "scc");
-#endif
                                 }
 #else
                                 asm volatile("" :: "v"(v));              // (the output transform stays: only the stores are gone)

@@ -404,7 +404,7 @@ class Plan:
         # images of at least one 16x16 tile go through the Winograd F(2x2,3x3) kernel (2.25x fewer MFMAs)
         wino = WINOGRAD and H >= 16 and W >= 16
         d = L.Conv3x3()
-        d.src, d.weight, d.bias, d.out = src, e.p(name + (".weight.wino" if wino else ".weight")), e.p(name + ".bias"), out.data_ptr()
+        d.src, d.bias, d.out = src, e.p(name + ".bias"), out.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, H, W, cin, cout, cout
         st = sc = None
         slots = 0
@@ -421,8 +421,8 @@ class Plan:
         wino4 = wino and self._wino4_takes(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W)
         if src.map_blocked and not wino4:
             raise L.HipError(f"{name}: the scale / shift map was produced in the blocked layout but the layer does not run on conv3x3_wino4")
-        if wino4:
-            d.weight = e.p(name + ".weight.wino4")
+        # ONE packing of the weight is read (and marked for the weight broadcast): F(4x4), F(2x2) or the direct form
+        d.weight = e.p(name + (".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
         entry = ("nd_conv3x3_wino4_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
                  "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32")
         self._add(entry, C.byref(d), e.stream,
