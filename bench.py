@@ -61,7 +61,8 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for plumbing tests)")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0 (single-GPU box)")
-    ap.add_argument("--broadcast-all", action="store_true", help="broadcast the whole weight arena instead of the slices the plan reads")
+    ap.add_argument("--broadcast", choices=["weights", "plan-slices", "arena"], default="weights",
+                    help="what the one collective carries: the raw fp32 weights (every rank packs its arena), the packed slices the plan reads, the whole packed arena")
     ap.add_argument("--soak-s", type=float, default=3.0, help="seconds of untimed step replays before the W warm-up steps")
     return ap.parse_args()
 
@@ -419,14 +420,18 @@ def main():
     if world > 1:
         # the ONE collective of the data path: packed weight arena, rank 0 -> everyone, over xGMI
         eng = Engine(a.dim, dev, mid_attn=a.mid_attn)
-        if rank == 0:
-            eng.load_state_dict(sd)
-        eng.plan(B, S, S, allow_empty=True)  # recorded before the weights arrive: the broadcast carries only what this plan reads
         torch.cuda.synchronize(dev)
         dist.barrier()
         t0 = time.perf_counter()
-        nbytes = eng.broadcast(src=0, only_used=not a.broadcast_all)   # returns with the slices complete on this rank (device-synchronised)
+        if a.broadcast == "weights":         # the network's own fp32 weights (150 MB at d=64); every rank packs its arena itself
+            nbytes = eng.broadcast_state_dict(sd, src=0)
+        else:                                # rank 0's packed arena: all of it, or the slices this plan reads
+            if rank == 0:
+                eng.load_state_dict(sd)
+            eng.plan(B, S, S, allow_empty=True)
+            nbytes = eng.broadcast(src=0, only_used=a.broadcast == "plan-slices")
         bt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        eng.plan(B, S, S)
         net.adopt_engine(eng)
         # evidence that every rank holds rank 0's weights: min and max over ranks of a checksum of the arena
         cs = torch.stack([eng.view(n).double().abs().sum() for n in sorted(eng.used)]).sum().reshape(1)   # over the slices the plan reads
@@ -435,8 +440,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(bt, op=dist.ReduceOp.MAX)
         bcast = {"ranks_in_broadcast": dist.get_world_size(), "backend": dist.get_backend() + (" (RCCL)" if a.backend == "nccl" else ""),
-                 "broadcast_bytes": nbytes, "arena_bytes": eng.arena.numel() * 4, "broadcast_ms": float(bt.item()) * 1e3,
-                 "broadcast_GBps_per_rank": nbytes / float(bt.item()) / 1e9,
+                 "broadcast_carries": a.broadcast, "broadcast_bytes": nbytes, "arena_bytes": eng.arena.numel() * 4, "broadcast_and_pack_ms": float(bt.item()) * 1e3,
                  "arena_checksum_equal_on_all_ranks": bool(lo.item() == hi.item() and hi.item() > 0),
                  "per_step_collectives": 0, "devices": "all ranks on cuda:0 (--one-device rehearsal)" if a.one_device else
                  f"one GPU per rank (cuda:0..{world - 1})",

@@ -1,29 +1,31 @@
 // conv3x3_wino4.hip -- Winograd F(4x4,3x3) 3x3 convolution on v_mfma_f32_16x16x4_f32.
 //
 // F(4x4,3x3) needs 36 multiplies per 16 outputs (2.25 per output) against 4 for F(2x2,3x3): 1.78x fewer MFMAs than
-// conv3x3_wino2.hip, 4x fewer than the direct form.  On this chip the fp32 MFMA and ordinary VALU work share issue
-// cycles (tools/microbench/mfma_issue.hip: every VALU instruction next to an fp32 MFMA costs ~4.5 cycles of matrix time,
-// every MFMA<->VALU switch ~18 more), so the structure is built around ONE rule: no VALU instruction inside the MFMA
+// conv3x3_wino2.hip, 4x fewer than the direct form.  On this chip the fp32 MFMA runs on the VALU's own lanes
+// (tools/microbench/mfma_overlap.hip, r3: a second wave on the SIMD that issues only VALU work gets 0.01 instructions in per
+// MFMA of the first; in the same wave a packed VALU instruction costs ~5 cycles of matrix time, v_accvgpr_read / v_exp / v_rcp
+// ~8, every MFMA <-> VALU switch ~8 more), so the structure is built around ONE rule: no VALU instruction inside the MFMA
 // loop, and every transform computed once per workgroup.
 //
 //   * workgroup = 4 waves, one per SIMD, the whole register file each; its tile = a 16 x 32 pixel region (two "tile
-//     groups" of 16 tiles of 4x4 pixels) x 64 output channels.  Wave (tg, ch) owns tile group tg and the 32 couts
-//     [32 ch, 32 ch + 32): 36 positions x 2 cout groups of 16 = 72 accumulators of 4 registers (288: the first 64 live
-//     in the accumulator half of the file, the last 8 in ordinary registers).  Operand roles are swapped (A = transformed
-//     weights U, B = transformed input V) so that a lane ends up with FOUR CONSECUTIVE COUTS of one tile: the output
-//     transform runs on float4s and stores 16 bytes.  Each V operand serves the wave's two cout groups.
-//   * K is processed in chunks of 16 channels.  The halo of a chunk lives in LDS as [patch entry 36][channel quad 4]
-//     [tile 16] float4 per tile group: a halo pixel is stored once per (tile, entry) it belongs to (2.25x duplication),
-//     which makes every access a conflict-free row and lets the halo arrive by LDS-DMA (buffer_load ... lds: 1 KB per
-//     wave instruction, no registers, zero padding from out-of-range lanes).
-//   * the input transform V = B^T d B runs IN PLACE on that image, once per workgroup: lane (tile, channel pair) reads
-//     its 36 patch entries, transforms them with packed float2 math and writes the 36 positions back to the same
-//     addresses.  The two waves of a tile group take one 8-channel half each -- the waves that consume a V image are
-//     the ones that produced it.  GroupNorm-affine + SiLU prologues are applied here too (on the raw values).
-//   * the MFMA loop of a wave is then nothing but: 2 ds_read_b64 (V of two positions) + 2 buffer_load_b128 (U of two
-//     positions x two cout groups, a ring of fragments deep) per 8 MFMAs.  Per 16-channel chunk: stage 0, stage 1
-//     (8 channels each, 144 MFMAs), then [wait for the next chunk's LDS-DMA, barrier, transform it in place, barrier].
-//     The DMA of chunk c+1 is issued early in chunk c into the buffer chunk c-1 was read from.
+//     groups" of 16 tiles of 4x4 pixels) x 64 output channels.  Wave w owns the 16 couts [16 w, 16 w + 16) of BOTH tile groups:
+//     36 positions x 2 tile groups = 72 accumulators of 4 registers (288: the first 64 live in the accumulator half of the
+//     file, the last 8 in ordinary registers), so every weight fragment is loaded once per workgroup and serves two MFMAs.
+//     Operands: A = transformed input V (rows = the 16 tiles of a tile group), B = transformed weights U (columns = the
+//     wave's 16 couts): lane (cout = l & 15, kq = l >> 4) ends up with the four tiles of tile row kq for ONE cout, the output
+//     transform runs on float4s over those four tiles and a store of one register is a dword per lane with 16 consecutive
+//     lanes = 64 contiguous bytes (r3; r2 had the roles the other way round: four couts of one tile per lane, 16-byte stores
+//     that the store path takes lane by lane).
+//   * K is processed in chunks of 16 channels.  The 18 x 34 pixel halo of the region is fetched ONCE per chunk (10 x 16 bytes
+//     per thread, registers) into a swizzled raw LDS image; GroupNorm-affine (+ per-pixel map) + SiLU / LeakyReLU prologues are
+//     applied once per raw pixel when it is written to LDS.
+//   * the input transform V = B^T d B runs once per workgroup on packed float2 (lane = (tile, channel pair): 36 raw reads, 168
+//     packed VALU instructions, 18 16-byte writes into the tile group's V image [position pair][half][tile][pair]).
+//   * the MFMA loop of a wave is then nothing but, per position pair: 2 ds_read_b128 (V of both tile groups), 1 buffer_load_b128
+//     (U, a ring a whole 8-channel stage ahead), 8 MFMAs, and the staging of one halo item (stage 0: its address, one
+//     v_mad_u32_u24, and the load; stage 1: its LDS write) whose LDS table entry is read BEFORE the eight MFMAs -- one wave per
+//     SIMD means nobody else covers an LDS round trip.
+//   * LDS (160 KB): raw image 45 KB at address 0, two V images 72 KB, per-thread tables 31 KB, the bias of every cout 8 KB.
 //
 // Transform matrices (Lavin & Gray, interpolation points 0, +-1, +-2, inf):
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]

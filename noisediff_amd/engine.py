@@ -236,6 +236,32 @@ class Engine:
             torch.cuda.synchronize(self.device)
         self.loaded, self.valid, self.used = True, None, used
 
+    def broadcast_state_dict(self, sd: Optional[Dict[str, torch.Tensor]], src: int = 0, group=None) -> int:
+        """The ONE collective of the sampling path in its smallest form: the network's own fp32 weights (150 MB at d=64, 598 MB at
+        d=128 -- SURVEY 8e) as one flat buffer, root -> all ranks; every rank then packs its arena itself (the packings are pure
+        functions of the weights: F(4x4)-transformed 3x3 weights alone are 4x the raw ones, so shipping the packed arena costs 3-6x
+        the bytes).  ``sd``: the state dict on rank ``src`` (ignored elsewhere).  Returns the bytes sent."""
+        import torch.distributed as dist
+        names = [p for p in self.spec if p.name in self.slots]
+        total = sum(math.prod(p.shape) for p in names)
+        with torch.cuda.device(self.device), torch.inference_mode(False):
+            if dist.get_rank(group) == src:
+                flat = torch.cat([sd[p.name].detach().reshape(-1).to(torch.float32) for p in names]).to(self.device)
+                if flat.numel() != total:
+                    raise ValueError("broadcast_state_dict: the state dict does not match the network's parameter spec")
+            else:
+                flat = torch.empty(total, dtype=torch.float32, device=self.device)
+            torch.cuda.synchronize(self.device)
+            dist.broadcast(flat, src=src, group=group)
+            torch.cuda.synchronize(self.device)
+            views, at = {}, 0
+            for p in names:
+                n = math.prod(p.shape)
+                views[p.name] = flat[at:at + n].view(*p.shape)
+                at += n
+        self.load_state_dict(views)
+        return total * 4
+
     def broadcast(self, src: int = 0, group=None, only_used: bool = False) -> int:
         """The ONE collective of the sampling path: packed weights root -> all ranks (RCCL over xGMI).  Returns the bytes sent.
 

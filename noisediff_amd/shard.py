@@ -25,20 +25,25 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_weights(net, device: torch.device, src: int = 0, group=None, shapes: Optional[Sequence[Tuple[int, int, int]]] = None):
-    """Fill this rank's engine from rank `src`'s packed arena: the one collective of the data path.
+def broadcast_weights(net, device: torch.device, src: int = 0, group=None, shapes: Optional[Sequence[Tuple[int, int, int]]] = None,
+                      packed: bool = False):
+    """Fill this rank's engine from rank `src`'s weights: the one collective of the data path.
 
-    ``shapes``: the (batch, height, width) problems this job will run.  Their plans are recorded first (recording needs the arena's
-    layout, not its contents) and the broadcast then carries only the slices those plans read -- one of the up to three packings
-    of every 3x3 weight -- instead of the whole arena (0.24 GB instead of 0.9 GB at d=64, 256x256).  Another problem size on a
-    receiving rank then raises instead of reading weights that never arrived."""
+    Default: the network's own fp32 weights travel as one flat buffer (150 MB at d=64) and every rank packs its arena itself
+    (``Engine.broadcast_state_dict``).  ``packed=True`` ships rank `src`'s packed arena instead (0.9 GB at d=64: it holds up to three
+    packings of every 3x3 weight); with ``shapes`` -- the (batch, height, width) problems this job will run -- only the slices
+    those plans read (0.5 GB), and another problem size on a receiving rank then raises instead of reading weights that never arrived."""
     from .engine import Engine
     eng = Engine(net.dim, device, mid_attn=net.has_mid_attn, inp_dim=net.channels, arch=getattr(net, "ARCH", "NoiseDiffNet"))
-    if dist.get_rank(group) == src:
-        eng.load_state_dict(net.state_dict())
-    for B, H, W in shapes or ():
-        eng.plan(B, H, W, allow_empty=True)
-    eng.last_broadcast_bytes = eng.broadcast(src=src, group=group, only_used=bool(shapes))
+    is_src = dist.get_rank(group) == src
+    if not packed:
+        eng.last_broadcast_bytes = eng.broadcast_state_dict(net.state_dict() if is_src else None, src=src, group=group)
+    else:
+        if is_src:
+            eng.load_state_dict(net.state_dict())
+        for B, H, W in shapes or ():
+            eng.plan(B, H, W, allow_empty=True)
+        eng.last_broadcast_bytes = eng.broadcast(src=src, group=group, only_used=bool(shapes))
     net.adopt_engine(eng)
     return eng
 

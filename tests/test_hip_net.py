@@ -493,8 +493,10 @@ def _rank_worker(rank, world, port, q, mode):
     from noisediff_amd.shard import shard_bounds
     lo, hi = shard_bounds(total, rank, world)
     # philox mode: the broadcast carries only the arena slices this job's plans read (recorded before the weights arrive)
-    eng = broadcast_weights(net, DEV, src=0, shapes=[(hi - lo, H, H)] if mode == "philox" else None)
-    assert net.hip_engine(DEV) is eng                              # the broadcast arena is the one the forward uses
+    # explicit mode: the network's raw fp32 weights travel and every rank packs its own arena (the default); philox mode: rank 0's
+    # packed arena travels, only the slices this job's plans read (recorded before the weights arrive)
+    eng = broadcast_weights(net, DEV, src=0, packed=mode == "philox", shapes=[(hi - lo, H, H)] if mode == "philox" else None)
+    assert net.hip_engine(DEV) is eng                              # the broadcast weights are the ones the forward uses
     if mode == "philox":
         assert 0 < eng.last_broadcast_bytes < eng.arena.numel() * 4
         if rank != 0:
@@ -502,7 +504,8 @@ def _rank_worker(rank, world, port, q, mode):
             with pytest.raises(Exception, match="not part of this rank's weight broadcast"):
                 eng.p(absent)
     else:
-        assert eng.last_broadcast_bytes == eng.arena.numel() * 4 and eng.valid is None
+        n_raw = sum(v.numel() for k, v in state_dict(dim).items() if k in eng.slots) * 4
+        assert eng.last_broadcast_bytes == n_raw < eng.arena.numel() * 4 and eng.valid is None
     gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
 
     def make_cond(lo, hi):

@@ -19,5 +19,6 @@ rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/
 python bench.py --config cfg2 --no-cpu > gpurun_out/${T}_bench_cfg2.jsonl 2>/dev/null
 python bench.py --config cfg4 --no-cpu > gpurun_out/${T}_bench_cfg4.jsonl 2>/dev/null
 python bench.py --gpus 2 --one-device --backend gloo --no-cpu --steps 10 > gpurun_out/${T}_bench_2rank_selflaunch_one_device.jsonl 2>/dev/null
+python bench.py --full --steps 1 --warmup 0 --no-cpu --no-roofline > gpurun_out/${T}_bench_full.jsonl 2>/dev/null
 python tools/lsid_bench.py > gpurun_out/${T}_lsid.log 2>&1
 tail -2 gpurun_out/${T}_pytest.log
