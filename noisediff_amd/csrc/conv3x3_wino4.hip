@@ -84,8 +84,8 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
 #ifndef W4_U_AUX
 #define W4_U_AUX 0           // cache-policy bits of the weight-fragment loads (experiment: 2 = nt)
 #endif
-#ifndef W4_NT_STORE
-#define W4_NT_STORE 0
+#ifndef W4_STORE_AUX
+#define W4_STORE_AUX 19      // cache-policy bits of the STREAMING output stores (sc0 | nt | sc1): see wino4_kernel's STREAM parameter
 #endif
 #ifndef W4_STAGGER
 #define W4_STAGGER 12        // s_sleep units (64 cycles) between the 16 start phases of the workgroups; 0 = all start together
@@ -148,7 +148,12 @@ __device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4], float 
     y[3] = b + 8.0f * e + m[5];
 }
 
-template <int MODE>
+// STREAM: the output tensor is far larger than the L2s (host: >= ND_W4_STREAM_MB, default 48 MB): its stores carry the non-temporal
+// system-scope policy bits, so the L2s stream them out instead of allocating lines for them.  With the default policy a 64 -> 64 layer at
+// 256 x 256 spends 2.3 k cycles more in the K chunk that follows an epilogue (its halo reads queue behind the output's write-back) and
+// 4.6 k more per workgroup in the prologue: -4 % per region tile (profiles/r3_w4_store_policy.txt); small outputs keep the default (the next
+// kernel finds them in the L2 / Infinity Cache).
+template <int MODE, bool STREAM>
 __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     constexpr bool MAP = MODE == ND_PRO_AFFINE_MAP_SILU;                  // + per-pixel scale / shift maps (ResnetBlock2)
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAP;               // GroupNorm-affine + SiLU applied while the halo is written to LDS
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                                                                          //  reference as element 0 for every r -- four stores of the same register)
                                     unsigned off = lane_off;
                                     if (!FULL) off = (in4[r] != 0.0f && cok) ? off : 0xFFFFFFF0u;
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vr), orsrc, off, soff, W4_NT_STORE ? 2 : 0);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vr), orsrc, off, soff, STREAM ? W4_STORE_AUX : 0);
                                     // the pixel's offset ((i W + 4 r + jj) ldo 4 bytes, uniform) is ONE running scalar, advanced by a scalar add behind
                                     // every store.  Written as 64 expressions of W and ldo, hipcc computes them all at the kernel's start, spills them
                                     // to VGPR lanes and reloads one with v_readlane_b32 (+ the VALU-writes-SGPR -> VMEM wait states) in front of every store
@@ -789,13 +794,22 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+template <int MODE, bool STREAM>
+int launch4s(const Wino4Args& a, hipStream_t st) {
+    static nd_device_once configured;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, STREAM>), LDS_BYTES, "nd_conv3x3_wino4")) return e;
+    const long resident = nd_device_cus();                // one workgroup per CU (registers, LDS)
+    hipLaunchKernelGGL((wino4_kernel<MODE, STREAM>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    return 0;
+}
+
 template <int MODE>
 int launch4(const Wino4Args& a, hipStream_t st) {
-    static nd_device_once configured;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE>), LDS_BYTES, "nd_conv3x3_wino4")) return e;
-    const long resident = nd_device_cus();                // one workgroup per CU (registers, LDS)
-    hipLaunchKernelGGL((wino4_kernel<MODE>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
-    return 0;
+    static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;     // A/B knob (tools/ only)
+    static const int stream_kinds = getenv("ND_W4_STREAM_KINDS") ? atoi(getenv("ND_W4_STREAM_KINDS")) : 7;           // A/B knob (tools/ only)
+    const int kind = (MODE == ND_PRO_AFFINE_SILU || MODE == ND_PRO_AFFINE_MAP_SILU) ? 2 : a.d.stats ? 1 : 4;   // block2 / block1 / resampling convs
+    const long out_bytes = (long)a.d.B * a.d.H * a.d.W * a.d.ldo * 4;
+    return (out_bytes >= stream_min && (stream_kinds & kind)) ? launch4s<MODE, true>(a, st) : launch4s<MODE, false>(a, st);
 }
 
 }  // namespace
