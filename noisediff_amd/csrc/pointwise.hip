@@ -108,7 +108,7 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
                 for (int j = 0; j < FB; ++j) v[j] = nd_ld4(lrow + (j0 + j) * (RPI * LDO)) + bias4;
                 if (act == ND_ACT_GELU) {
 #pragma unroll
-                    for (int j = 0; j < FB; ++j) { v[j].x = nd_gelu(v[j].x); v[j].y = nd_gelu(v[j].y); v[j].z = nd_gelu(v[j].z); v[j].w = nd_gelu(v[j].w); }
+                    for (int j = 0; j < FB; ++j) v[j] = nd_gelu4(v[j]);
                 } else if (act == ND_ACT_SILU) {
 #pragma unroll
                     for (int j = 0; j < FB; ++j) v[j] = nd_silu4(v[j]);
@@ -148,7 +148,7 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
                 for (int j = 0; j < JBLK; ++j) {
                     const int r = rbase + (j0 + j) * RPI;
                     f32x4 v = nd_ld4(&As[r * LDO + q * 4]) + bias4;
-                    if (a.d.act == ND_ACT_GELU) { v.x = nd_gelu(v.x); v.y = nd_gelu(v.y); v.z = nd_gelu(v.z); v.w = nd_gelu(v.w); }
+                    if (a.d.act == ND_ACT_GELU) v = nd_gelu4(v);
                     else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
                     v += r0[j] + r1[j] + vadd4;
                     if (a.d.gn_t) v += nd_silu4((rt[j] - gM) * gA + gD);

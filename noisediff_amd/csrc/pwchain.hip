@@ -56,7 +56,12 @@ __device__ __forceinline__ void chain_act(f32x16 (&acc)[N / 32], const int act) 
 #pragma unroll
     for (int nt = 0; nt < N / 32; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = act == ND_ACT_GELU ? nd_gelu(acc[nt][r]) : nd_silu(acc[nt][r]);
+        for (int r = 0; r < 16; r += 2) {
+            if (act == ND_ACT_GELU) {                                    // two accumulator registers at a time on the packed pipe
+                const f32x2 g = nd_gelu2(f32x2{acc[nt][r], acc[nt][r + 1]});
+                acc[nt][r] = g.x;  acc[nt][r + 1] = g.y;
+            } else { acc[nt][r] = nd_silu(acc[nt][r]);  acc[nt][r + 1] = nd_silu(acc[nt][r + 1]); }
+        }
 }
 
 // acc[nt][r] += x[q = 4*nt + (r >> 2)][r & 3] (- v): the residual lives in the input registers
