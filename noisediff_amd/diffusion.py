@@ -165,7 +165,7 @@ class GaussianDiffusion(nn.Module):
         loop = self._loop_cache.pop(key, None)
         if loop is None:
             loop = _Loop(self, plan)
-            while len(self._loop_cache) >= self._MAX_LOOPS:
+            while len(self._loop_cache) >= max(self._MAX_LOOPS, 2 * len(self._sampling_devices())):   # (one loop per device shard stays resident)
                 self._loop_cache.pop(next(iter(self._loop_cache))).destroy()     # oldest first; frees its hipGraphExec
         self._loop_cache[key] = loop                                            # most recently used last
         return loop
