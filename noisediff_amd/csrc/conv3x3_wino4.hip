@@ -132,22 +132,6 @@ __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
     t[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(cm5, d[3], d[5]));
 }
 
-// a - b on packed floats as ONE v_pk_fma_f32 per pair: fma(b, -1, a) == a - b exactly.  hipcc expands a vector subtraction into scalar
-// v_sub_f32 (and folds an fma with the literal -1 back into one), so the -1 arrives in a register the compiler cannot see through (`neg1`)
-__device__ __forceinline__ f32x4 w4_sub4(f32x4 a, f32x4 b, float neg1) {
-    const f32x4 m1 = {neg1, neg1, neg1, neg1};
-    return __builtin_elementwise_fma(b, m1, a);
-}
-
-// A^T applied to six float4s (four consecutive couts each)
-__device__ __forceinline__ void w4_at(const f32x4 (&m)[6], f32x4 (&y)[4], float neg1) {
-    const f32x4 a = m[1] + m[2], b = w4_sub4(m[1], m[2], neg1), c = m[3] + m[4], e = w4_sub4(m[3], m[4], neg1);
-    y[0] = m[0] + a + c;
-    y[1] = b + 2.0f * e;
-    y[2] = a + 4.0f * c;
-    y[3] = b + 8.0f * e + m[5];
-}
-
 // STREAM: the output tensor is far larger than the L2s (host: >= ND_W4_STREAM_MB, default 48 MB): its stores carry the non-temporal
 // system-scope policy bits, so the L2s stream them out instead of allocating lines for them.  With the default policy a 64 -> 64 layer at
 // 256 x 256 spends 2.3 k cycles more in the K chunk that follows an epilogue (its halo reads queue behind the output's write-back) and
@@ -471,18 +455,21 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 
     // accumulators are read in program order through volatile asm: left to itself hipcc hoists ~200 v_accvgpr_read to the top of
     // the epilogue and spills what they produce
-    auto read_acc = [&](int idx) -> f32x4 {
+    auto read_acc2 = [&](int idx, int h) -> f32x2 {                     // registers (2 h, 2 h + 1) of an accumulator
         if (idx >= ACC_AGPR) {
             // an accumulator in ordinary registers: the empty volatile asm keeps hipcc from scheduling its (plain VALU) readers above
             // W4_MFMA_DRAIN -- it does not know the asm statements that produced it are MFMAs still in flight
             asm volatile("" : "+v"(acc[idx]));
-            return acc[idx];
+            return h ? f32x2{acc[idx].z, acc[idx].w} : f32x2{acc[idx].x, acc[idx].y};
         }
-        f32x4 r;
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.x) : "a"(acc[idx].x));
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.y) : "a"(acc[idx].y));
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.z) : "a"(acc[idx].z));
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.w) : "a"(acc[idx].w));
+        f32x2 r;
+        if (h == 0) {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.x) : "a"(acc[idx].x));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.y) : "a"(acc[idx].y));
+        } else {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.x) : "a"(acc[idx].z));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r.y) : "a"(acc[idx].w));
+        }
         return r;
     };
 
@@ -636,60 +623,67 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 const bool cok = co < Cout;
                 float z0 = 0.0f;
                 asm volatile("" : "+v"(z0));                               // a fresh zero per tile: hipcc otherwise keeps one zero float4 alive (and spilled) for the whole kernel
-                float neg1 = -1.0f;
-                asm volatile("" : "+v"(neg1));                             // (see w4_sub4)
                 const float* const bias_p = bias_lds + co;                 // read where it is used (an LDS load: held in registers it gets spilled)
                 const int py0 = ty * 16 + 4 * kq, px0 = tx * 16;           // the lane's tile row; register r covers columns px0 + 4 r .. + 3
-                f32x4 sum4 = {z0, z0, z0, z0}, sq4 = {z0, z0, z0, z0}, cnt4 = {z0, z0, z0, z0};
+                f32x2 sum2 = {z0, z0}, sq2 = {z0, z0}, cnt2 = {z0, z0};
                 float pivot = z0;
                 const bool full = ty * 16 + 16 <= H && tx * 16 + 16 <= W && cg * 16 + 16 <= Cout;      // wave-uniform
                 const bool want_stats = a.d.stats != nullptr;
                 // stores: buffer addressing -- one 32-bit lane offset per tile, the pixel's offset (uniform) in the scalar offset
                 // field (the output stays below 4 GiB, host check)
                 const unsigned lane_off = (unsigned)((((unsigned)b * H + py0) * Wt + px0) * ldot + co) * 4u;
-                // two output rows at a time (Z[2][6]: the full Z[4][6] next to the live weight ring and the accumulators that sit in
-                // ordinary registers does not fit the 256 registers VALU instructions can address)
+                // two of the lane's four tiles at a time (Z[4][6] of float2 = 48 registers): every accumulator register is read ONCE
+                // (v_accvgpr_read_b32 issues every 8 cycles: 288 instead of the 480 of a float4 pass over two output rows at a time)
                 auto emit = [&](auto full_c, auto stats_c) {
                     constexpr bool FULL = decltype(full_c)::value, STATS = decltype(stats_c)::value;
-                    int soff = 0, step4 = ldot * 16, back11 = ldot * -44, rowadv = (Wt - 15) * ldot * 4;   // pixel (i, 4 r + jj): r -> r + 1, jj -> jj + 1, next row
-                    asm volatile("" : "+s"(soff), "+s"(step4), "+s"(back11), "+s"(rowadv));
+                    int step4 = ldot * 16, back3 = ldot * -12, rowadv = (Wt - 7) * ldot * 4;   // pixel (i, 4 r + jj): r -> r + 1, (jj, r + 1) -> (jj + 1, r), next row
+                    asm volatile("" : "+s"(step4), "+s"(back3), "+s"(rowadv));
+                    const f32x2 c2 = {2.0f, 2.0f}, c4 = {4.0f, 4.0f}, c8 = {8.0f, 8.0f};
 #pragma unroll
-                    for (int ih = 0; ih < 2; ++ih) {
-                        f32x4 Z[2][6];
+                    for (int h = 0; h < 2; ++h) {                        // tiles (2 h, 2 h + 1) of the lane's tile row = registers 2 h, 2 h + 1 of every accumulator
+                        int soff = h * 32 * ldot;                        // byte offset of pixel (0, 8 h): one running scalar, see below
+                        asm volatile("" : "+s"(soff));
+                        f32x2 Z[4][6];
 #pragma unroll
-                        for (int nu = 0; nu < 6; ++nu) {
-                            auto M = [&](int xi) { return read_acc(2 * (xi * 6 + nu) + j); };
-                            f32x4 m1 = M(1);
-                            const f32x4 m2 = M(2);
+                        for (int nu = 0; nu < 6; ++nu) {                 // Z = A^T M, one column of positions at a time: short live ranges
+                            auto M = [&](int xi) { return read_acc2(2 * (xi * 6 + nu) + j, h); };
+                            f32x2 m1 = M(1);
+                            const f32x2 m2 = M(2);
                             if (nu == 1) m1 += *bias_p;                   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
-                            const f32x4 p = m1 + m2, q = w4_sub4(m1, m2, neg1);
-                            const f32x4 m3 = M(3), m4 = M(4);
-                            const f32x4 r = m3 + m4, u = w4_sub4(m3, m4, neg1);
-                            if (ih == 0) { Z[0][nu] = M(0) + p + r;  Z[1][nu] = q + 2.0f * u; }
-                            else         { Z[0][nu] = p + 4.0f * r;  Z[1][nu] = q + 8.0f * u + M(5); }
-                            __builtin_amdgcn_sched_barrier(0);            // one column at a time: short live ranges
+                            const f32x2 p = m1 + m2, q = m1 - m2;
+                            const f32x2 m3 = M(3), m4 = M(4);
+                            const f32x2 r = m3 + m4, u = m3 - m4;
+                            Z[0][nu] = M(0) + p + r;
+                            Z[1][nu] = __builtin_elementwise_fma(c2, u, q);
+                            Z[2][nu] = __builtin_elementwise_fma(c4, r, p);
+                            Z[3][nu] = __builtin_elementwise_fma(c8, u, q) + M(5);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
 #pragma unroll
-                        for (int i2 = 0; i2 < 2; ++i2) {
-                            const int i = 2 * ih + i2;
-                            f32x4 y[4];
-                            w4_at(Z[i2], y, neg1);
+                        for (int i = 0; i < 4; ++i) {                    // Y = Z A, one output row at a time
+                            const f32x2 (&z)[6] = Z[i];
+                            const f32x2 ta = z[1] + z[2], tb = z[1] - z[2], tc = z[3] + z[4], te = z[3] - z[4];
+                            f32x2 y[4];
+                            y[0] = z[0] + ta + tc;
+                            y[1] = __builtin_elementwise_fma(c2, te, tb);
+                            y[2] = __builtin_elementwise_fma(c4, tc, ta);
+                            y[3] = __builtin_elementwise_fma(c8, te, tb) + z[5];
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
-                                const f32x4 v = y[jj];                   // pixel (4 kq + i, 4 r + jj) of the tile, r = component
-                                if (STATS && i == 0 && jj == 0)          // one pivot per cout for the whole 16x16 tile: its first pixel (lane l & 15, r = 0)
+                                const f32x2 v = y[jj];                   // pixels (4 kq + i, 4 (2 h + e) + jj) of the tile, e = component
+                                if (STATS && h == 0 && i == 0 && jj == 0)   // one pivot per cout for the whole 16x16 tile: its first pixel (lane l & 15, register 0)
                                     pivot = __shfl(v.x, l15);
-                                f32x4 in4 = {1.0f, 1.0f, 1.0f, 1.0f};    // !FULL: which of the four pixels are inside the image
+                                f32x2 in2 = {1.0f, 1.0f};                // !FULL: which of the two pixels are inside the image
                                 if (!FULL) {
                                     const bool row_in = py0 + i < H;
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) in4[r] = (row_in && px0 + 4 * r + jj < W) ? 1.0f : 0.0f;
+                                    in2.x = (row_in && px0 + 8 * h + jj < W) ? 1.0f : 0.0f;
+                                    in2.y = (row_in && px0 + 8 * h + 4 + jj < W) ? 1.0f : 0.0f;
                                 }
                                 if (STATS) {
-                                    f32x4 dv = w4_sub4(v, f32x4{pivot, pivot, pivot, pivot}, neg1);
-                                    if (!FULL) { dv *= in4;  cnt4 += in4; }
-                                    sum4 += dv;
-                                    sq4 += dv * dv;
+                                    f32x2 dv = v - f32x2{pivot, pivot};
+                                    if (!FULL) { dv *= in2;  cnt2 += in2; }
+                                    sum2 += dv;
+                                    sq2 += dv * dv;
                                 }
 #if !(W4_ABLATE & 8)
                                 // EVERY path issues the same store instructions: a pixel / cout outside the tensor gets an offset beyond the
@@ -697,16 +691,16 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                                 // and stores in one in-order queue; with a store-free path through the epilogue hipcc sizes the next tile's first
                                 // weight-fragment waits as if NO store were in flight.
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float vr = v[r];               // (by value: hipcc 7.2 evaluates __builtin_bit_cast(unsigned, v[r]) on the element
-                                                                         //  reference as element 0 for every r -- four stores of the same register)
+                                for (int e = 0; e < 2; ++e) {
+                                    const float vr = e ? v.y : v.x;      // (by value: hipcc 7.2 evaluates __builtin_bit_cast(unsigned, v[e]) on an element
+                                                                         //  reference as element 0 for every e -- stores of the same register)
                                     unsigned off = lane_off;
-                                    if (!FULL) off = (in4[r] != 0.0f && cok) ? off : 0xFFFFFFF0u;
+                                    if (!FULL) off = ((e ? in2.y : in2.x) != 0.0f && cok) ? off : 0xFFFFFFF0u;
                                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vr), orsrc, off, soff, STREAM ? W4_STORE_AUX : 0);
                                     // the pixel's offset ((i W + 4 r + jj) ldo 4 bytes, uniform) is ONE running scalar, advanced by a scalar add behind
                                     // every store.  Written as 64 expressions of W and ldo, hipcc computes them all at the kernel's start, spills them
                                     // to VGPR lanes and reloads one with v_readlane_b32 (+ the VALU-writes-SGPR -> VMEM wait states) in front of every store
-                                    asm volatile("s_add_i32 %0, %0, %1" : "+s"(soff) : "s"(r < 3 ? step4 : jj < 3 ? back11 : rowadv) : "scc");
+                                    asm volatile("s_add_i32 %0, %0, %1" : "+s"(soff) : "s"(e == 0 ? step4 : jj < 3 ? back3 : rowadv) : "scc");
                                 }
 #else
                                 asm volatile("" :: "v"(v));              // (the output transform stays: only the stores are gone)
@@ -719,8 +713,8 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 else { if (want_stats) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
                 if (a.d.stats) {
                     // pool the lane's four tiles, then the four tile rows (lanes l, l + 16, l + 32, l + 48 share the cout): sum = S + n p, M2 = Q - S^2 / n
-                    float fc = full ? 64.0f : cnt4.x + cnt4.y + cnt4.z + cnt4.w;
-                    float S = (sum4.x + sum4.y) + (sum4.z + sum4.w), Q = (sq4.x + sq4.y) + (sq4.z + sq4.w);
+                    float fc = full ? 64.0f : cnt2.x + cnt2.y;
+                    float S = sum2.x + sum2.y, Q = sq2.x + sq2.y;
                     fc += __shfl_xor(fc, 16);  S += __shfl_xor(S, 16);  Q += __shfl_xor(Q, 16);
                     fc += __shfl_xor(fc, 32);  S += __shfl_xor(S, 32);  Q += __shfl_xor(Q, 32);
                     const int slot = (ty * a.tiles_x + tx) * 2;
