@@ -90,6 +90,9 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
 #ifndef W4_STAGGER
 #define W4_STAGGER 12        // s_sleep units (64 cycles) between the 16 start phases of the workgroups; 0 = all start together
 #endif
+#ifndef W4_XF_SPLIT
+#define W4_XF_SPLIT 1        // the "every wave has read its V operands" barrier between the input transform's two passes (0: behind both)
+#endif
 #ifndef W4_ABLATE
 #define W4_ABLATE 0          // diagnostic builds only: 1 no staging, 2 no weight loads, 4 no transform, 8 no epilogue stores,
                              // 16 halo loaded but not written to LDS, 32 written but not loaded, 64 every halo load from the same pixels
@@ -366,19 +369,31 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #pragma unroll
             for (int xi = 0; xi < 6; ++xi) T[xi][bx] = t[xi];
         }
+#if W4_XF_SPLIT
+        before_write();                                                  // between the passes: the 18 writes below leave row by row, under the second pass' VALU
+#endif                                                                   // (the LDS takes 16-byte writes at ~77 B/clk: the 72 KB of a chunk's V images are ~940 cycles)
 #pragma unroll
         for (int xi = 0; xi < 6; ++xi) {                                 // V[xi] = T[xi] B
             f32x2 v[6];
             w4_bt(T[xi], v);
+#if W4_XF_SPLIT
+#pragma unroll
+            for (int h = 0; h < 3; ++h)                                  // 16 bytes = positions (xi, 2h), (xi, 2h + 1) of this lane's channel pair
+                *reinterpret_cast<f32x4*>(base + (xi * 3 + h) * 2048) = f32x4{v[2 * h].x, v[2 * h].y, v[2 * h + 1].x, v[2 * h + 1].y};
+            __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
             for (int bx = 0; bx < 6; ++bx) T[xi][bx] = v[bx];
+#endif
         }
+#if !W4_XF_SPLIT
         before_write();
 #pragma unroll
         for (int xi = 0; xi < 6; ++xi)
 #pragma unroll
-            for (int h = 0; h < 3; ++h)                                  // 16 bytes = positions (xi, 2h), (xi, 2h + 1) of this lane's channel pair
+            for (int h = 0; h < 3; ++h)
                 *reinterpret_cast<f32x4*>(base + (xi * 3 + h) * 2048) = f32x4{T[xi][2 * h].x, T[xi][2 * h].y, T[xi][2 * h + 1].x, T[xi][2 * h + 1].y};
+#endif
 #else
         before_write();
 #endif
