@@ -289,6 +289,14 @@ int nd_sinusoidal_time_emb_f32(const int64_t* time, const float* freqs, float* e
 int64_t nd_cond_step_lds_bytes(int B, int dim);
 int nd_cond_step_f32(const int64_t* time, const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2,
                      const float* Wp, const float* bp, float* out, int ld_out, int B, int dim, int J, void* stream);
+/* The same step with the head (emb -> time_mlp -> SiLU) looked up instead of computed: `table` (table_rows x 4 dim) holds the head's result for
+ * timestep = row index, built once per weight set by nd_cond_table_build_f32 (same kernel code: the very same bits).  A timestep outside the
+ * table falls back to computing the head.  Replaces the same ATen call sites as nd_cond_step_f32 (Diffusion_arch.py:100-107, 502-507, 149-152). */
+int nd_cond_table_build_f32(const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2, float* table, int rows, int dim,
+                            void* stream);
+int nd_cond_step_table_f32(const int64_t* time, const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2,
+                           const float* Wp, const float* bp, float* out, int ld_out, int B, int dim, int J, const float* table, int table_rows,
+                           void* stream);
 /* nn.Embedding lookup (:591): out[b] = table[idx[b]], idx int64. */
 int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, int B, int rows, int dim, void* stream);
 

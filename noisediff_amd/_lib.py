@@ -107,6 +107,8 @@ SIGNATURES = {
     "nd_sinusoidal_time_emb_f32": (i32, [vp, vp, vp, i32, i32, vp]),
     "nd_cond_step_lds_bytes": (i64, [i32, i32]),
     "nd_cond_step_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "nd_cond_table_build_f32": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "nd_cond_step_table_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "nd_embedding_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_pack_conv7x7_weight": (i32, [vp, vp, i32, vp]),

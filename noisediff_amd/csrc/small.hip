@@ -227,15 +227,32 @@ __global__ __launch_bounds__(1024) void cond_step_kernel(const int64_t* __restri
                                                          const float* __restrict__ W1, const float* __restrict__ b1,
                                                          const float* __restrict__ W2, const float* __restrict__ b2,
                                                          const float* __restrict__ Wp, const float* __restrict__ bp,
-                                                         float* __restrict__ out, int ld_out, int B, int d, int J) {
+                                                         float* __restrict__ out, int ld_out, int B, int d, int J,
+                                                         const float* __restrict__ table, int table_rows, float* __restrict__ table_out) {
+    // `table` (rows x 4d): the head's result st for timestep = row index, built once per weight set by this kernel itself (`table_out`
+    // mode: workgroup w computes the head for timesteps 16 w .. 16 w + 15 and writes it instead of projecting).  With a table whose rows
+    // cover every sample's timestep the head -- two dependent small Linears behind barriers, ~50 us of latency at the start of EVERY diffusion
+    // step -- is a lookup of the very same bits.
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D4 = 4 * d, half = d / 2, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     float* emb = sm;                    // [B][d]
     float* t1 = emb + B * d;            // [B][4d]
     float* st = t1 + B * D4;            // [B][4d]
+    const int t_first = table_out ? (int)blockIdx.x * B : 0;             // build mode: this workgroup's timesteps
+    if (table_out) { if (t_first >= table_rows) return;  B = min(B, table_rows - t_first); }
+    bool lookup = table != nullptr && !table_out;
+    if (lookup)
+        for (int b = 0; b < B; ++b) lookup = lookup && time[b] >= 0 && time[b] < table_rows;     // (uniform: every thread reads the same B values)
+    if (lookup) {
+        for (int i = tid; i < B * D4; i += blockDim.x) {
+            const int b = i / D4;
+            st[i] = table[(size_t)time[b] * D4 + (i - b * D4)];
+        }
+        __syncthreads();
+    } else {
     for (int i = tid; i < B * half; i += blockDim.x) {
         const int b = i / half, j = i - b * half;
-        const float ang = (float)time[b] * freqs[j];
+        const float ang = (float)(table_out ? (int64_t)(t_first + b) : time[b]) * freqs[j];
         emb[b * d + j] = sinf(ang);
         emb[b * d + half + j] = cosf(ang);
     }
@@ -272,6 +289,11 @@ __global__ __launch_bounds__(1024) void cond_step_kernel(const int64_t* __restri
     __syncthreads();
     linear(t1, D4, W2, b2, st, ND_ACT_SILU);
     __syncthreads();
+    }
+    if (table_out) {
+        for (int i = tid; i < B * D4; i += blockDim.x) table_out[(size_t)t_first * D4 + i] = st[i];
+        return;
+    }
     // this workgroup's rows of the stacked projection: one wave per row, the weight row in registers (4d <= 2048)
     for (int n = blockIdx.x * nwaves + wave; n < J; n += gridDim.x * nwaves) {
         float w[32];
@@ -320,8 +342,41 @@ extern "C" int nd_cond_step_f32(const int64_t* time, const float* freqs, const f
         if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(cond_step_kernel), 160 * 1024, "nd_cond_step")) return e;
     const int rows16 = nd_cdiv(J, 16), cus = nd_device_cus();
     hipLaunchKernelGGL(cond_step_kernel, dim3(rows16 < cus ? rows16 : cus), dim3(1024), (size_t)lds, (hipStream_t)stream, time, freqs, W1, b1, W2, b2, Wp, bp,
-                       out, ld_out, B, dim, J);
+                       out, ld_out, B, dim, J, (const float*)nullptr, 0, (float*)nullptr);
     return nd_launch_status("nd_cond_step_f32");
+}
+
+extern "C" int nd_cond_table_build_f32(const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2, float* table, int rows,
+                                       int dim, void* stream) {
+    ND_REQUIRE(freqs && W1 && b1 && W2 && b2 && table, ND_E_BADARG, "nd_cond_table_build: null pointer");
+    ND_REQUIRE(rows > 0 && dim >= 8 && dim % 8 == 0 && 4 * dim <= 2048, ND_E_SHAPE, "nd_cond_table_build: rows=%d dim=%d", rows, dim);
+    ND_REQUIRE(nd_aligned16(W1) && nd_aligned16(W2), ND_E_ALIGN, "nd_cond_table_build: time_mlp weights must be 16-byte aligned");
+    const int Bc = 16;                                                   // timesteps per workgroup: the head's batch size in the step kernel
+    const int64_t lds = nd_cond_step_lds_bytes(Bc, dim);
+    static nd_device_once configured;
+    if (lds > 64 * 1024)
+        if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(cond_step_kernel), 160 * 1024, "nd_cond_table_build")) return e;
+    hipLaunchKernelGGL(cond_step_kernel, dim3(nd_cdiv(rows, Bc)), dim3(1024), (size_t)lds, (hipStream_t)stream, (const int64_t*)nullptr, freqs, W1, b1, W2, b2,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, Bc, dim, 0, (const float*)nullptr, rows, table);
+    return nd_launch_status("nd_cond_table_build_f32");
+}
+
+extern "C" int nd_cond_step_table_f32(const int64_t* time, const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2,
+                                      const float* Wp, const float* bp, float* out, int ld_out, int B, int dim, int J, const float* table, int table_rows,
+                                      void* stream) {
+    ND_REQUIRE(time && freqs && W1 && b1 && W2 && b2 && Wp && bp && out && table, ND_E_BADARG, "nd_cond_step_table: null pointer");
+    ND_REQUIRE(B > 0 && dim >= 8 && dim % 8 == 0 && 4 * dim <= 2048 && J > 0 && ld_out >= J && table_rows > 0, ND_E_SHAPE,
+               "nd_cond_step_table: B=%d dim=%d J=%d rows=%d (dim a multiple of 8, 4 dim <= 2048)", B, dim, J, table_rows);
+    ND_REQUIRE(nd_aligned16(W1) && nd_aligned16(W2), ND_E_ALIGN, "nd_cond_step_table: time_mlp weights must be 16-byte aligned");
+    const int64_t lds = nd_cond_step_lds_bytes(B, dim);
+    ND_REQUIRE(lds <= 160 * 1024, ND_E_SHAPE, "nd_cond_step_table: B * dim = %d needs %lld bytes of LDS", B * dim, (long long)lds);
+    static nd_device_once configured;
+    if (lds > 64 * 1024)
+        if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(cond_step_kernel), 160 * 1024, "nd_cond_step_table")) return e;
+    const int rows16 = nd_cdiv(J, 16), cus = nd_device_cus();
+    hipLaunchKernelGGL(cond_step_kernel, dim3(rows16 < cus ? rows16 : cus), dim3(1024), (size_t)lds, (hipStream_t)stream, time, freqs, W1, b1, W2, b2, Wp, bp,
+                       out, ld_out, B, dim, J, table, table_rows, (float*)nullptr);
+    return nd_launch_status("nd_cond_step_table_f32");
 }
 
 extern "C" int nd_sinusoidal_time_emb_f32(const int64_t* time, const float* freqs, float* emb, int B, int half, void* stream) {

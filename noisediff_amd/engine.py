@@ -44,6 +44,8 @@ MAP_BLOCKED = os.environ.get("ND_MAP_BLOCKED", "1") != "0"   # A-B knob: 0 = Res
 COND_STEP = os.environ.get("ND_COND_STEP", "1") != "0"   # A-B knob: 0 = time embedding / time_mlp / projections as four launches
 WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel (conv3x3_wino4.hip)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
+TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
+TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
 
 
 def _wino4_layer(cin: int, cout: int) -> bool:
@@ -169,6 +171,9 @@ class Engine:
         add("tproj.weight", j * 4 * self.dim, "derived", (j, 4 * self.dim))
         add("tproj.bias", j, "derived", (j,))
         add("time_freqs", self.dim // 2, "derived", (self.dim // 2,))
+        # time_mlp's result for every timestep 0 .. TIME_TABLE_ROWS - 1 (st = SiLU(time_mlp(emb(t))), Diffusion_arch.py:100-107,502-507,149): the
+        # step kernel looks the head up instead of running two dependent small Linears at the start of every diffusion step
+        add("time_table", TIME_TABLE_ROWS * 4 * self.dim, "derived", (TIME_TABLE_ROWS, 4 * self.dim))
         self.arena_floats = off
 
     def view(self, name: str) -> torch.Tensor:
@@ -234,6 +239,9 @@ class Engine:
             e = math.log(10000) / (half - 1)
             self.view("time_freqs").copy_(torch.exp(torch.arange(half) * -e).to(torch.float32))
             torch.cuda.synchronize(self.device)
+            L.call("nd_cond_table_build_f32", self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"), self.p("time_mlp.3.weight"),
+                   self.p("time_mlp.3.bias"), self.p("time_table"), TIME_TABLE_ROWS, self.dim, st)
+            L.call("nd_stream_sync", st)
         self.loaded, self.valid, self.used = True, None, used
 
     def broadcast_state_dict(self, sd: Optional[Dict[str, torch.Tensor]], src: int = 0, group=None) -> int:
@@ -642,9 +650,13 @@ class Plan:
         e, d = self.e, self.e.dim
         if COND_STEP and e.lib.nd_cond_step_lds_bytes(self.B, d) <= 160 * 1024:
             # one launch: time embedding, time_mlp, SiLU and every ResnetBlock.mlp projection (tproj)
-            self._add("nd_cond_step_f32", self.time.data_ptr(), e.p("time_freqs"), e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"),
-                      e.p("time_mlp.3.weight"), e.p("time_mlp.3.bias"), e.p("tproj.weight"), e.p("tproj.bias"), self.tproj.data_ptr(),
-                      e.tproj_rows, self.B, d, e.tproj_rows, e.stream)
+            args = (self.time.data_ptr(), e.p("time_freqs"), e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"),
+                    e.p("time_mlp.3.weight"), e.p("time_mlp.3.bias"), e.p("tproj.weight"), e.p("tproj.bias"), self.tproj.data_ptr(),
+                    e.tproj_rows, self.B, d, e.tproj_rows)
+            if TIME_TABLE:
+                self._add("nd_cond_step_table_f32", *args, e.p("time_table"), TIME_TABLE_ROWS, e.stream)
+            else:
+                self._add("nd_cond_step_f32", *args, e.stream)
             return
         self._add("nd_sinusoidal_time_emb_f32", self.time.data_ptr(), e.p("time_freqs"), self.emb.data_ptr(), self.B, d // 2, e.stream)
         self.linear_rows(self.emb, e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"), self.t1, d, 4 * d, act_out=L.ACT_GELU)

@@ -864,3 +864,19 @@ def test_cond_step_single_launch_matches_torch(ctx, dim, B):
     with pytest.raises(L.HipError, match="LDS"):
         L.call("nd_cond_step_f32", td.data_ptr(), fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
                dWp.data_ptr(), dbp.data_ptr(), out.data_ptr(), J + 3, 64, 128, J, ctx.stream)
+    # the head looked up in a per-timestep table (built once per weight set by the same kernel code): the very same bits as computing it,
+    # also for a batch with a timestep beyond the table (the whole batch then falls back to computing)
+    rows = 1000
+    table = hu.full((rows, 4 * dim))
+    L.call("nd_cond_table_build_f32", fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), table.data_ptr(), rows, dim, ctx.stream)
+    ctx.sync()
+    assert not torch.isnan(table).any()
+    for tt in (t, torch.where(torch.arange(B) == B - 1, torch.tensor(1234), t)):
+        tdev = hu.dev(tt)
+        a_, b_ = hu.full((B, J)), hu.full((B, J))
+        L.call("nd_cond_step_f32", tdev.data_ptr(), fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+               dWp.data_ptr(), dbp.data_ptr(), a_.data_ptr(), J, B, dim, J, ctx.stream)
+        L.call("nd_cond_step_table_f32", tdev.data_ptr(), fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+               dWp.data_ptr(), dbp.data_ptr(), b_.data_ptr(), J, B, dim, J, table.data_ptr(), rows, ctx.stream)
+        ctx.sync()
+        assert torch.equal(a_.cpu(), b_.cpu())
