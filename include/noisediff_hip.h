@@ -126,6 +126,8 @@ int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int c
  * and the GroupNorm-affine + SiLU prologue, no upsample addressing, no statistics epilogue.  `weight` from
  * nd_pack_conv3x3_wino4_weight (U = G g G^T in blocks [cin/8][coutP/16][18 position pairs][64 lanes][4]). */
 int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream);
+/* its statistics epilogue writes ONE slot per 16 x 16-pixel tile (the F(2x2) kernels: two) */
+int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 

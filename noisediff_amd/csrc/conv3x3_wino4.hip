@@ -732,17 +732,15 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                     float S = sum2.x + sum2.y, Q = sq2.x + sq2.y;
                     fc += __shfl_xor(fc, 16);  S += __shfl_xor(S, 16);  Q += __shfl_xor(Q, 16);
                     fc += __shfl_xor(fc, 32);  S += __shfl_xor(S, 32);  Q += __shfl_xor(Q, 32);
-                    const int slot = (ty * a.tiles_x + tx) * 2;
+                    const int slot = ty * a.tiles_x + tx;             // one statistics slot per 16 x 16 tile (nd_conv3x3_wino4_stat_slots)
                     if (kq == 0 && cok) {
                         fc = fmaxf(fc, 1.0f);
                         float* o = a.d.stats + (((size_t)b * a.slots + slot) * Cout + co) * 2;
                         *reinterpret_cast<f32x2*>(o) = f32x2{S + fc * pivot, fmaxf(Q - S * S / fc, 0.0f)};
-                        *reinterpret_cast<f32x2*>(o + (size_t)Cout * 2) = f32x2{0.0f, 0.0f};   // the second slot of the tile (F(2x2) kernels: lower half) stays empty
                     }
 #ifndef W4_STAMP
                     if (b == 0 && nt == 0 && wave == 0 && lane == 0) {
                         a.d.slot_count[slot] = (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
-                        a.d.slot_count[slot + 1] = 0.0f;
                     }
 #endif
                 }
@@ -837,6 +835,8 @@ extern "C" int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, in
     return nd_launch_status("nd_pack_conv3x3_wino4_weight");
 }
 
+extern "C" int nd_conv3x3_wino4_stat_slots(int H, int W) { return nd_cdiv(W, 16) * nd_cdiv(H, 16); }
+
 extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_conv3x3_wino4: null descriptor");
     const nd_src& s = d->src;
@@ -888,7 +888,7 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     a.n_tiles = nd_cdiv(d->cout, 64);
     a.n_cg = nd_round_up(d->cout, 64) / 16;
     a.n_c8 = nd_round_up(nd_cdiv(d->cin, 8), 2);
-    a.slots = a.tiles_x * a.tiles_y * 2;
+    a.slots = a.tiles_x * a.tiles_y;
     const long wg = (long)d->B * a.regions_x * a.tiles_y * a.n_tiles;
     ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4: grid too large");
     a.total_wg = (int)wg;

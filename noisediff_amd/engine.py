@@ -440,19 +440,20 @@ class Plan:
         d = L.Conv3x3()
         d.src, d.bias, d.out = src, e.p(name + ".bias"), out.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, H, W, cin, cout, cout
-        st = sc = None
-        slots = 0
-        if stats:
-            slots = e.lib.nd_conv3x3_wino_stat_slots(H, W) if wino else e.lib.nd_conv3x3_stat_slots(H, W, cout, self.B)
-            st = self._alloc(self.B, slots, cout, 2)
-            sc = self._alloc(slots)
-            d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
         # both Winograd kernels share weights, statistics slots and descriptor; wino2 (one resident wave per SIMD,
         # all 16 position accumulators in registers) is the default, wino covers what it does not take
         wino2 = (wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
                  and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
                  and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
         wino4 = wino and self._wino4_takes(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W)
+        st = sc = None
+        slots = 0
+        if stats:     # per-(slot, channel) {sum, M2} partials for nd_groupnorm_finalize_f32: F(4x4) one slot per 16 x 16 tile, F(2x2) two
+            slots = (e.lib.nd_conv3x3_wino4_stat_slots(H, W) if wino4 else e.lib.nd_conv3x3_wino_stat_slots(H, W) if wino
+                     else e.lib.nd_conv3x3_stat_slots(H, W, cout, self.B))
+            st = self._alloc(self.B, slots, cout, 2)
+            sc = self._alloc(slots)
+            d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
         if src.map_blocked and not wino4:
             raise L.HipError(f"{name}: the scale / shift map was produced in the blocked layout but the layer does not run on conv3x3_wino4")
         # ONE packing of the weight is read (and marked for the weight broadcast): F(4x4), F(2x2) or the direct form

@@ -636,7 +636,7 @@ def _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats=True):
     d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
     d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
     st = sc = None
-    slots = ctx.lib.nd_conv3x3_wino_stat_slots(H, W)
+    slots = ctx.lib.nd_conv3x3_wino4_stat_slots(H, W)            # one per 16 x 16 tile (the F(2x2) kernels: two)
     if stats:
         st, sc = hu.full((B, slots, cout, 2)), hu.full((slots,))
         d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()

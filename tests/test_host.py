@@ -64,7 +64,7 @@ def test_host_only_entry_points_validate_arguments():
     # Winograd weights: 128 KB blocks [cin/32][cout/64][16 positions][8 quads][64][4], zero padded
     assert lib.nd_pack_conv3x3_wino_weight_floats(64, 64) == 16 * 64 * 64
     assert lib.nd_pack_conv3x3_wino_weight_floats(48, 40) == 16 * 64 * 64
-    assert lib.nd_conv3x3_wino_stat_slots(256, 256) == 16 * 16 * 2
+    assert lib.nd_conv3x3_wino_stat_slots(256, 256) == 16 * 16 * 2 and lib.nd_conv3x3_wino4_stat_slots(256, 250) == 16 * 16
     assert lib.nd_conv3x3_wino2_nhwc_f32(None, None) == -1
     d.src.c0 = d.src.ld0 = d.cin = 48
     d.src.p1, d.src.c1, d.src.ld1, d.cin = 0x2000, 16, 16, 64

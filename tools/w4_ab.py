@@ -29,7 +29,7 @@ def worker(lib):
         b = hu.dev(torch.randn(cout, generator=g)); out = torch.empty(B, H, W, cout, device=hu.DEV)
         mad = hu.dev(torch.rand(B, 3, cin, generator=g) + 0.5)
         mp = hu.dev(torch.rand(B, H, W, 2 * cin, generator=g) - 0.5) if mode == 2 else None
-        slots = ctx.lib.nd_conv3x3_wino_stat_slots(H, W)
+        slots = ctx.lib.nd_conv3x3_wino4_stat_slots(H, W)
         st = torch.empty(B, slots, cout, 2, device=hu.DEV); sc = torch.empty(slots, device=hu.DEV)
         torch.cuda.synchronize()
         kw = {"mad": mad} if mode else {}

@@ -17,7 +17,7 @@ for (B, H, W, cin, cout) in SHAPES:
     L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream); ctx.sync()
     out = torch.empty(B, H, W, cout, device=hu.DEV)
     dbg = torch.zeros(16 * 256, dtype=torch.int64, device=hu.DEV)
-    st = torch.zeros(B * ctx.lib.nd_conv3x3_wino_stat_slots(H, W) * cout * 2, device=hu.DEV)
+    st = torch.zeros(B * ctx.lib.nd_conv3x3_wino4_stat_slots(H, W) * cout * 2, device=hu.DEV)
     torch.cuda.synchronize()
     d = L.Conv3x3(); d.src, d.weight, d.out = hu.src(x), wp.data_ptr(), out.data_ptr()
     d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
