@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void affine_silu_add_kernel(const float* __res
 
 // Per-pixel LayerNorm statistics of (x + vec[b]) over C channels.  A row's C/4 quads are spread over `lpr`
 // lanes (power of two <= 64, up to 4 quads per lane => C <= 1024); a wave handles 64/lpr rows per pass.
+template <int NJ>      // float4s of a row per lane: C = 4 * lpr * NJ exactly (host: C a multiple of 64 above 256, lpr = 64 there)
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ vec,
                                                        float* __restrict__ stats, int B, int HW, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -109,35 +110,46 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     const int rpp = 64 / lpr, sub = lane / lpr, ql = lane - sub * lpr;
     const size_t npix = (size_t)B * HW;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t r0 = wave * rpp; r0 < npix; r0 += nwaves * rpp) {
-        const size_t r = r0 + sub;
-        const size_t rs = r < npix ? r : npix - 1;
-        const int b = (int)(rs / HW);
-        f32x4 v[4];
+    constexpr int UN = NJ == 1 ? 4 : NJ == 2 ? 2 : 1;                // row groups per pass: four independent 16-byte loads in flight per lane
+    const float inv_c = 1.0f / (float)C;
+    for (size_t r0 = wave * (rpp * UN); r0 < npix; r0 += nwaves * (rpp * UN)) {
+        f32x4 v[UN][NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = (ql + j * lpr) * 4, cs = c < C ? c : 0;
-            v[j] = nd_ld4(x + rs * ldx + cs);
-            if (vec) v[j] += nd_ld4(vec + (size_t)b * C + cs);
-            const f32x4 zero = {0, 0, 0, 0};
-            v[j] = c < C ? v[j] : zero;
+        for (int u = 0; u < UN; ++u) {
+            const size_t r = r0 + u * rpp + sub, rs = r < npix ? r : npix - 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = (ql + j * lpr) * 4, cs = c < C ? c : 0;
+                v[u][j] = nd_ld4(x + rs * ldx + cs);
+            }
         }
-        float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sum += v[j].x + v[j].y + v[j].z + v[j].w;
-        for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float mean = sum / (float)C;
-        float m2 = 0.0f;
+        for (int u = 0; u < UN; ++u) {
+            const size_t r = r0 + u * rpp + sub, rs = r < npix ? r : npix - 1;
+            const int b = (int)(rs / HW);
+            float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = (ql + j * lpr) * 4;
-            const f32x4 dv = v[j] - mean;
-            m2 += c < C ? dv.x * dv.x + dv.y * dv.y + dv.z * dv.z + dv.w * dv.w : 0.0f;
-        }
-        for (int o = lpr >> 1; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
-        if (ql == 0 && r < npix) {
-            stats[2 * r] = mean;
-            stats[2 * r + 1] = rsqrtf(m2 / (float)C + eps);
+            for (int j = 0; j < NJ; ++j) {
+                const int c = (ql + j * lpr) * 4;
+                if (vec) v[u][j] += nd_ld4(vec + (size_t)b * C + (c < C ? c : 0));
+                const f32x4 zero = {0, 0, 0, 0};
+                v[u][j] = c < C ? v[u][j] : zero;
+                sum += (v[u][j].x + v[u][j].y) + (v[u][j].z + v[u][j].w);
+            }
+            for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * inv_c;
+            float m2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = (ql + j * lpr) * 4;
+                const f32x4 dv = v[u][j] - mean;
+                m2 += c < C ? (dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w) : 0.0f;
+            }
+            for (int o = lpr >> 1; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+            if (ql == 0 && r < npix) {
+                stats[2 * r] = mean;
+                stats[2 * r + 1] = rsqrtf(m2 * inv_c + eps);
+            }
         }
     }
 }
@@ -183,7 +195,10 @@ extern "C" int nd_layernorm_stats_f32(const float* x, int ldx, const float* vec,
     const size_t npix = (size_t)B * HW;
     const size_t want = (npix + 15) / 16;
     const int blocks = (int)(want < 4096 ? (want ? want : 1) : 4096);
-    hipLaunchKernelGGL(ln_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, vec, stats, B, HW, C, eps);
+    const int nj = C <= 256 ? 1 : (C + 255) / 256;                    // 16-byte loads of a row per lane (the row's quads over up to 64 lanes)
+    if (nj == 1) hipLaunchKernelGGL(ln_stats_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, vec, stats, B, HW, C, eps);
+    else if (nj == 2) hipLaunchKernelGGL(ln_stats_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, vec, stats, B, HW, C, eps);
+    else hipLaunchKernelGGL(ln_stats_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, vec, stats, B, HW, C, eps);
     return nd_launch_status("nd_layernorm_stats_f32");
 }
 
