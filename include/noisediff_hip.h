@@ -108,6 +108,10 @@ int nd_conv3x3_tiling_id(int B, int H, int W, int cout);
 /* OIHW (cout,cin,3,3) -> [tap][cin/4][coutP][4], coutP = cout rounded up to 64; zero padded. */
 int64_t nd_pack_conv3x3_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
+/* training: the same packing of the DATA-GRADIENT operator of a layer, read in place from the forward layer's OIHW weight
+ * `oihw_fwd` (cout x cin there = cin x cout here): g'[co][ci][r][s] = oihw_fwd[ci][co][2 - r][2 - s].  `cin`, `cout` are the
+ * data-gradient convolution's (cin = the forward layer's cout).  Likewise for the two Winograd packings below. */
+int nd_pack_conv3x3_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream);
 
 /* Same operator, same descriptor, computed with Winograd F(2x2,3x3) (2.25x fewer multiplies; fp32 transforms,
  * ~1e-6 relative difference to the direct form).  `weight` must come from nd_pack_conv3x3_wino_weight
@@ -120,16 +124,20 @@ int nd_conv3x3_wino2_nhwc_f32(const nd_conv3x3* d, void* stream);
 int nd_conv3x3_wino_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
+int nd_pack_conv3x3_wino_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream);
 
-/* EXPERIMENTAL (r1e): the same operator with Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (1.78x fewer multiplies than
- * F(2x2,3x3); ~1e-5 relative difference to the direct form).  Not selected by the engine; takes plain / two-source inputs
- * and the GroupNorm-affine + SiLU prologue, no upsample addressing, no statistics epilogue.  `weight` from
+/* The same operator with Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (1.78x fewer multiplies than F(2x2,3x3); ~1e-5 relative
+ * difference to the direct form): the kernel that carries the sampling path (conv3x3_wino4.hip).  Takes plain / two-source
+ * (concat on a 16-channel boundary) inputs, the GroupNorm-affine (+ per-pixel map) + SiLU and LeakyReLU prologues, nearest-x2
+ * upsample addressing of a single source and the statistics epilogue; needs cin > 16, cout <= 2048, W <= 2048, sources below
+ * 1 GiB / 2^24 pixels (rejected otherwise: the caller picks nd_conv3x3_wino2_nhwc_f32).  `weight` from
  * nd_pack_conv3x3_wino4_weight (U = G g G^T in blocks [cin/8][coutP/16][18 position pairs][64 lanes][4]). */
 int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream);
 /* its statistics epilogue writes ONE slot per 16 x 16-pixel tile (the F(2x2) kernels: two) */
 int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
+int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream);
 
 /* ------------------------------------------------------------------ conv 3x3, training */
 
@@ -137,11 +145,12 @@ int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int 
  * (zero padding), x and dy NHWC fp32, dw in the torch OIHW layout.  The backward of Block.proj and the resampling convs under
  * GaussianDiffusion.p_losses (models/denoising_diffusion_pytorch.py:481-531; loss.backward() at models/trainer_diffusion.py:187).
  * Exact-fp32 MFMA; the split over pixel tiles depends on the shape only and the partial sums are added in a fixed order, so the
- * result is bitwise repeatable.  `workspace`: nd_conv3x3_wgrad_workspace_floats(...) floats.
- * The DATA gradient of the same layer is the forward operator itself: nd_conv3x3_*_nhwc_f32 on weights packed from
- * w.flip(2, 3).transpose(0, 1) (taps flipped, channel roles swapped) -- see noisediff_amd/train.py. */
+ * result is bitwise repeatable.  `workspace`: nd_conv3x3_wgrad_workspace_floats(...) floats.  `dbias` (may be NULL): the bias
+ * gradient db[co] = sum_{b,y,x} dy[b][y][x][co], from the same staged dy tiles (same fixed order).
+ * The DATA gradient of the same layer is the forward operator itself: nd_conv3x3_*_nhwc_f32 on weights packed by
+ * nd_pack_conv3x3_*_weight_dgrad (taps flipped, channel roles swapped) -- see noisediff_amd/train.py. */
 int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout);
-int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* workspace,
+int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace,
                               int B, int H, int W, int cin, int cout, void* stream);
 
 /* nn.GroupNorm(groups, C) forward and backward on NHWC fp32 for training: Block.norm (Diffusion_arch.py:132,138) under

@@ -72,17 +72,20 @@ SIGNATURES = {
     "nd_conv3x3_tiling_id": (i32, [i32, i32, i32, i32]),
     "nd_pack_conv3x3_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_weight": (i32, [vp, vp, i32, i32, vp]),
+    "nd_pack_conv3x3_weight_dgrad": (i32, [vp, vp, i32, i32, vp]),
     "nd_conv3x3_wino_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_conv3x3_wino2_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_conv3x3_wino_stat_slots": (i32, [i32, i32]),
     "nd_conv3x3_wino4_stat_slots": (i32, [i32, i32]),
     "nd_pack_conv3x3_wino_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_wino_weight": (i32, [vp, vp, i32, i32, vp]),
+    "nd_pack_conv3x3_wino_weight_dgrad": (i32, [vp, vp, i32, i32, vp]),
     "nd_conv3x3_wino4_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_pack_conv3x3_wino4_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_wino4_weight": (i32, [vp, vp, i32, i32, vp]),
+    "nd_pack_conv3x3_wino4_weight_dgrad": (i32, [vp, vp, i32, i32, vp]),
     "nd_conv3x3_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
-    "nd_conv3x3_wgrad_nhwc_f32": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nd_conv3x3_wgrad_nhwc_f32": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_groupnorm_train_workspace_floats": (i64, [i32, i32, i32]),
     "nd_linear_wgrad_workspace_floats": (i64, [i64, i32, i32]),
     "nd_groupnorm_silu_train_workspace_floats": (i64, [i32, i32, i32]),

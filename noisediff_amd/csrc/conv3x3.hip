@@ -334,6 +334,8 @@ void launch(const ConvArgs& a, hipStream_t st) {
 }
 
 // OIHW -> [tap][cin/4][coutP][4], coutP = cout rounded up to 64
+// dgrad: `w` is the forward layer's weight; taps flipped, channel roles swapped, read in place.
+template <bool DGRAD>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int coutP) {
     const size_t total = (size_t)9 * cin * coutP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -343,7 +345,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
         const int q = r % (cin >> 2);
         const int tap = r / (cin >> 2);
         const int ci = q * 4 + e;
-        out[i] = n < cout ? w[((size_t)n * cin + ci) * 9 + tap] : 0.0f;
+        out[i] = n < cout ? (DGRAD ? w[((size_t)ci * cout + n) * 9 + 8 - tap] : w[((size_t)n * cin + ci) * 9 + tap]) : 0.0f;
     }
 }
 
@@ -371,14 +373,23 @@ extern "C" int64_t nd_pack_conv3x3_weight_floats(int cin, int cout) {
     return (int64_t)9 * cin * nd_round_up(cout, 64);
 }
 
-extern "C" int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
+static int pack_direct(const float* oihw, float* packed, int cin, int cout, int dgrad, void* stream) {
     ND_REQUIRE(oihw && packed, ND_E_BADARG, "nd_pack_conv3x3_weight: null pointer");
     ND_REQUIRE(cin > 0 && cout > 0 && cin % 8 == 0, ND_E_SHAPE, "nd_pack_conv3x3_weight: cin=%d must be a positive multiple of 8", cin);
     const int coutP = nd_round_up(cout, 64);
     const size_t total = (size_t)9 * cin * coutP;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cout, coutP);
+    if (dgrad) hipLaunchKernelGGL(pack_conv3x3_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cout, coutP);
+    else hipLaunchKernelGGL(pack_conv3x3_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cout, coutP);
     return nd_launch_status("nd_pack_conv3x3_weight");
+}
+
+extern "C" int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
+    return pack_direct(oihw, packed, cin, cout, 0, stream);
+}
+
+extern "C" int nd_pack_conv3x3_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream) {
+    return pack_direct(oihw_fwd, packed, cin, cout, 1, stream);
 }
 
 extern "C" int nd_conv3x3_nhwc_f32(const nd_conv3x3* d, void* stream) {

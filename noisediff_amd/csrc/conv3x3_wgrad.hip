@@ -12,7 +12,8 @@
 // of all nine taps -- 4 waves x 9 accumulators of 32 x 32 -- and walks its share of the 16 x 16-pixel tiles: per tile the dY tile
 // and the 18 x 18 X halo (zero padded) are staged in LDS (145 KB), then 128 pixel pairs x 9 MFMAs per wave with both operands
 // read as one conflict-free ds_read_b32 each.  The split over pixel tiles is fixed by the shape alone, partial sums go to a
-// workspace and a second kernel adds them in a fixed order: bitwise repeatable, no atomics.
+// workspace and a second kernel adds them in a fixed order: bitwise repeatable, no atomics.  The bias gradient (sum of dY over the
+// pixels) falls out of the staged dY tiles of the first cin block's workgroups.
 #include "nd_common.h"
 
 namespace {
@@ -24,7 +25,7 @@ constexpr int WG_TILE = 16, TILE_H = WG_TILE_ROWS, HALO = 18, HALO_H = TILE_H + 
 constexpr int WGRAD_TARGET_WGS = (WG_TILE_ROWS <= 8 ? 512 : 256);                                  // one workgroup per CU of an MI355X (LDS: one fits); fixed: the summation order must not depend on the device
 
 struct WgradArgs {
-    const float* x; const float* dy; float* ws;
+    const float* x; const float* dy; float* ws; float* wsb;          // wsb: bias-gradient partials [S][coP] (null: no bias gradient)
     int ldx, ldy, B, H, W, cin, cout;
     int n_co, n_ci, S, tiles_x, tiles_y, n_tiles, fast;
     unsigned dy_bytes, x_bytes;
@@ -45,6 +46,10 @@ __global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = nd_zero16();
+    // bias gradient db[co] = sum over the pixels of dY[.][co]: falls out of the staged dY tile in the workgroups of the first cin block
+    // (thread = cout tid & 63, pixel quarter tid >> 6) -- no second pass over dY (ATen's sum over a channels_last tensor took 30 us per layer)
+    float bsum = 0.0f;
+    const bool do_bias = a.wsb != nullptr && cib == 0;
 
     // Interior tiles (no image border inside the halo, whole channel blocks) take a path without per-item vector arithmetic: buffer loads
     // with the tile's base in the scalar offset and per-thread item offsets computed once -- every VALU instruction of the staging pass
@@ -182,6 +187,12 @@ __global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel
                 }
             }
         }
+        if (do_bias) {
+            constexpr int QR = WG_TILE * TILE_H / 4;
+            const float* cp = dYs + (tid >> 6) * QR * CB + (tid & 63);
+#pragma unroll 8
+            for (int r = 0; r < QR; ++r) bsum += cp[r * CB];
+        }
     }
     // ---- this workgroup's partial sums: ws[s][tap][co][ci], rows of 32 consecutive cins per lane group
     const int coP = a.n_co * CB, ciP = a.n_ci * CB;
@@ -192,29 +203,39 @@ __global__ __launch_bounds__(256, (WG_TILE_ROWS <= 8 ? 2 : 1)) void wgrad_kernel
             const int co = co0 + co_w + nd_acc_row(r, lane), ci = ci0 + ci_w + col;
             a.ws[(((size_t)s * 9 + t) * coP + co) * ciP + ci] = acc[t][r];
         }
+    if (do_bias) {                                                   // the four pixel quarters meet in a fixed order
+        __syncthreads();
+        dYs[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) a.wsb[(size_t)s * coP + co0 + tid] = dYs[tid] + dYs[64 + tid] + dYs[128 + tid] + dYs[192 + tid];
+    }
 }
 
 // dW (OIHW, torch layout) = sum over the S partials in a fixed order.  A thread owns one element (tap, co, ci) of the partial
 // blocks -- consecutive threads read consecutive cins, every load of the S-deep sum is coalesced -- and scatters its one result.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int cin, int cout, int coP, int ciP) {
-    const size_t block = (size_t)9 * coP * ciP;
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < block; j += (size_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw,
+                                                           float* __restrict__ db, int S, int cin, int cout, int coP, int ciP) {
+    const size_t block = (size_t)9 * coP * ciP, total = block + (db ? coP : 0);     // the bias partials follow the weight partials element-wise
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+        const bool bias = j >= block;
         const int ci = (int)(j % ciP);
-        const int co = (int)((j / ciP) % coP);
+        const int co = bias ? (int)(j - block) : (int)((j / ciP) % coP);
         const int t = (int)(j / ((size_t)ciP * coP));
-        if (co >= cout || ci >= cin) continue;
-        const float* p = ws + j;
+        if (co >= cout || (!bias && ci >= cin)) continue;
+        const float* p = bias ? wsb + co : ws + j;
+        const size_t stride = bias ? (size_t)coP : block;
         float sum = 0.0f;
         int s = 0;
         for (; s + 8 <= S; s += 8) {                                     // eight loads in flight, added in slot order
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s + k) * block];
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s + k) * stride];
 #pragma unroll
             for (int k = 0; k < 8; ++k) sum += v[k];
         }
-        for (; s < S; ++s) sum += p[(size_t)s * block];
-        dw[((size_t)co * cin + ci) * 9 + t] = sum;
+        for (; s < S; ++s) sum += p[(size_t)s * stride];
+        if (bias) db[co] = sum;
+        else dw[((size_t)co * cin + ci) * 9 + t] = sum;
     }
 }
 
@@ -238,10 +259,10 @@ extern "C" int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int ci
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return -1;
     WgradArgs a;
     plan(B, H, W, cin, cout, a);
-    return (int64_t)a.S * 9 * a.n_co * CB * a.n_ci * CB;
+    return (int64_t)a.S * a.n_co * CB * (9 * a.n_ci * CB + 1);           // weight partials, then the bias partials
 }
 
-extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* workspace,
+extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace,
                                          int B, int H, int W, int cin, int cout, void* stream) {
     ND_REQUIRE(x && dy && dw_oihw && workspace, ND_E_BADARG, "nd_conv3x3_wgrad: null pointer");
     ND_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, ND_E_BADARG, "nd_conv3x3_wgrad: non-positive size");
@@ -251,6 +272,7 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
     WgradArgs a;
     plan(B, H, W, cin, cout, a);
     a.x = x; a.dy = dy; a.ws = workspace; a.ldx = ldx; a.ldy = ldy;
+    a.wsb = dbias ? workspace + (size_t)a.S * 9 * a.n_co * CB * a.n_ci * CB : nullptr;
     {   // the interior-tile path addresses both tensors with 32-bit byte offsets
         const long xb = (long)B * H * W * ldx * 4, dyb = (long)B * H * W * ldy * 4;
         a.fast = xb < (1L << 31) && dyb < (1L << 31) && nd_aligned16(x) && nd_aligned16(dy);
@@ -265,8 +287,8 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wgs), dim3(256), lds, st, a);
     if (int e = nd_launch_status("nd_conv3x3_wgrad_nhwc_f32")) return e;
-    const size_t total = (size_t)9 * a.n_co * CB * a.n_ci * CB;
+    const size_t total = (size_t)a.n_co * CB * (9 * a.n_ci * CB + 1);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw_oihw, a.S, cin, cout, a.n_co * CB, a.n_ci * CB);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, a.wsb, dw_oihw, dbias, a.S, cin, cout, a.n_co * CB, a.n_ci * CB);
     return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (reduce)");
 }

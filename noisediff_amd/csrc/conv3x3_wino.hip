@@ -289,6 +289,8 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void wino_kernel(const WinoA
 // OIHW -> U = G g G^T, packed as 128 KB blocks [cinP/32][coutP/64] of [pos = xi*4 + nu][8 channel quads][64 n][4]:
 // everything one workgroup reads for one K chunk is contiguous and every fragment address is block base + a
 // compile-time offset.  coutP = cout rounded up to 64, cinP = cin rounded up to 32 (zero fill).
+// dgrad: `w` is the forward layer's weight (cout x cin there = cin x cout here); taps flipped, channel roles swapped, read in place.
+template <bool DGRAD>
 __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cinP, int cout, int coutP) {
     const float G[4][3] = {{1.0f, 0.0f, 0.0f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.0f, 0.0f, 1.0f}};
     const size_t total = (size_t)16 * cinP * coutP;
@@ -300,7 +302,10 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
         const int xi = pos >> 2, nu = pos & 3;
         float u = 0.0f;
         if (n < cout && ci < cin) {
-            const float* g = w + ((size_t)n * cin + ci) * 9;
+            const float* gp = w + (DGRAD ? (size_t)ci * cout + n : (size_t)n * cin + ci) * 9;
+            float g[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) g[j] = gp[DGRAD ? 8 - j : j];
             float tmp[3];                                   // row xi of G g
 #pragma unroll
             for (int j = 0; j < 3; ++j) tmp[j] = G[xi][0] * g[j] + G[xi][1] * g[3 + j] + G[xi][2] * g[6 + j];
@@ -354,14 +359,23 @@ extern "C" int64_t nd_pack_conv3x3_wino_weight_floats(int cin, int cout) {
     return (int64_t)16 * nd_round_up(cin, 32) * nd_round_up(cout, 64);
 }
 
-extern "C" int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
+static int pack_wino(const float* oihw, float* packed, int cin, int cout, int dgrad, void* stream) {
     ND_REQUIRE(oihw && packed, ND_E_BADARG, "nd_pack_conv3x3_wino_weight: null pointer");
     ND_REQUIRE(cin > 0 && cout > 0 && cin % 8 == 0, ND_E_SHAPE, "nd_pack_conv3x3_wino_weight: cin=%d must be a positive multiple of 8", cin);
     const int coutP = nd_round_up(cout, 64), cinP = nd_round_up(cin, 32);
     const size_t total = (size_t)16 * cinP * coutP;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cinP, cout, coutP);
+    if (dgrad) hipLaunchKernelGGL(pack_wino_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cinP, cout, coutP);
+    else hipLaunchKernelGGL(pack_wino_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cinP, cout, coutP);
     return nd_launch_status("nd_pack_conv3x3_wino_weight");
+}
+
+extern "C" int nd_pack_conv3x3_wino_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
+    return pack_wino(oihw, packed, cin, cout, 0, stream);
+}
+
+extern "C" int nd_pack_conv3x3_wino_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream) {
+    return pack_wino(oihw_fwd, packed, cin, cout, 1, stream);
 }
 
 extern "C" int nd_conv3x3_wino_nhwc_f32(const nd_conv3x3* d, void* stream) {

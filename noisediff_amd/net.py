@@ -9,8 +9,9 @@ wrapper's ``device_ids`` itself, and a replica made by ``nn.DataParallel.forward
 ``forward(x, time, condition)`` with NCHW tensors and the ``clean_img`` / ``position`` /
 ``iso_ratio_idx`` condition dict.
 
-The forward pass runs ONLY on the HIP library (engine.py).  There is no CPU or eager-PyTorch
-fallback: a CPU tensor, a missing library or an autograd call raises.
+Without autograd the forward pass runs ONLY on the fused HIP engine (engine.py); with autograd (training: ``p_losses``) the
+NoiseDiffNet graph runs on the differentiable HIP operators of train.py.  There is no CPU or eager-PyTorch fallback: a CPU
+tensor or a missing library raises.
 """
 from __future__ import annotations
 
@@ -148,9 +149,7 @@ class NoiseDiffNet(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, time: torch.Tensor, condition=None) -> torch.Tensor:
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                f"noisediff_amd.{self.ARCH} implements the inference (sampling) path only; call it under "
-                "torch.no_grad()/inference_mode().  Train noisediff_amd.TrainableNoiseDiffNet (or the reference network) -- its weights load here unchanged.")
+            return self._forward_autograd(x, time, condition)
         assert all(d % self.downsample_factor == 0 for d in x.shape[-2:]), \
             f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {self.downsample_factor}, given the unet"
         B, Cc, H, W = x.shape
@@ -158,6 +157,34 @@ class NoiseDiffNet(nn.Module):
         with plan.lock:            # nn.DataParallel.forward calls replicas from several threads: one device's plan serves one call at a time
             plan.set_condition(condition)
             return plan.forward(x, time)
+
+
+    def _forward_autograd(self, x: torch.Tensor, time: torch.Tensor, condition) -> torch.Tensor:
+        """The training entry (models/denoising_diffusion_pytorch.py:481-531 drives ``model(x, t, condition)`` with autograd on,
+        models/trainer_diffusion.py:179-190): the same module, the same parameters, on the differentiable operators of train.py --
+        3x3 convolutions, GroupNorm (+ modulation + SiLU) and LayerNorm forward and backward and the Linear / 1x1 weight gradients on
+        the HIP library -- over the reference graph of trainable.py.  The fused sampling engine has no backward, so this path does
+        not go through it; like it, it has no CPU fallback."""
+        if self.ARCH != "NoiseDiffNet" or self.has_mid_attn:
+            raise NotImplementedError(
+                f"noisediff_amd.{self.ARCH}{' with mid_attn' if self.has_mid_attn else ''} implements the inference (sampling) path only; "
+                "call it under torch.no_grad()/inference_mode().  Only the NoiseDiffNet graph has a differentiable HIP path.")
+        if x.device.type != "cuda":
+            raise L.HipError(f"{self.ARCH} runs on the HIP library only; tensor is on {x.device} and there is no CPU path")
+        L.load()
+        from .trainable import _Ops, _forward
+        return _forward(_Ops(self._parameter_table(), True), x, time, condition)
+
+    def _parameter_table(self) -> Dict[str, torch.Tensor]:
+        """name -> tensor for the differentiable forward.  An nn.DataParallel replica holds no Parameters: ``replicate`` leaves the
+        broadcast copies (autograd-connected to the owner's parameters, on the replica's device) in ``_former_parameters``."""
+        if self._dp_root is None:
+            return dict(self.named_parameters())
+        table = {}
+        for prefix, m in self.named_modules():
+            for k, v in getattr(m, "_former_parameters", {}).items():
+                table[f"{prefix}.{k}" if prefix else k] = v
+        return table
 
 
 class UNet_PosEmbV2(NoiseDiffNet):

@@ -9,9 +9,10 @@
   * forward      nd_conv3x3_{wino4, wino2, direct}_nhwc_f32 (the sampling path's kernels, same selection rule as the engine)
   * grad input   the SAME forward kernels on weights packed from ``w.flip(2, 3).transpose(0, 1)`` -- the data gradient of a
                  stride-1 "same" convolution is that convolution with the taps flipped and the channel roles swapped
+                 (nd_pack_conv3x3_*_weight_dgrad read the forward weight that way in place)
   * grad weight  nd_conv3x3_wgrad_nhwc_f32 (conv3x3_wgrad.hip: nine tap GEMMs over the pixels on the fp32 MFMA, fixed
                  summation order, no atomics)
-  * grad bias    a sum over pixels (torch)
+  * grad bias    falls out of the weight-gradient kernel's staged dY tiles
 Tensors stay what PyTorch hands over: NCHW-shaped, ``channels_last`` in memory (= the library's NHWC; other layouts are
 converted once per call), fp32, on the caller's CUDA stream -- so autograd's stream ordering holds without synchronisation.
 ``GroupNormFunction`` (second slice) does the same for nn.GroupNorm: nd_groupnorm_train_forward_f32 / _backward_f32 (norm_train.hip) stream
@@ -64,11 +65,15 @@ def _stream(device: Optional[torch.device] = None) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """y = conv2d(x, w, bias, padding=1) on the HIP library; x (B, cin, H, W) channels_last, returns (B, cout, H, W) channels_last."""
+def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], dgrad: bool = False) -> torch.Tensor:
+    """y = conv2d(x, w, bias, padding=1) on the HIP library; x (B, cin, H, W) channels_last, returns (B, cout, H, W) channels_last.
+    ``dgrad``: ``w_oihw`` is the FORWARD layer's weight and the operator is its data gradient, conv2d(x, w.flip(2, 3).transpose(0, 1),
+    padding=1) -- the pack kernels read the flipped / role-swapped weight in place (nd_pack_conv3x3_*_weight_dgrad)."""
     lib = L.load()
     B, cin, H, W = x.shape
-    cout = w_oihw.shape[0]
+    cout = w_oihw.shape[1 if dgrad else 0]
+    if w_oihw.shape[0 if dgrad else 1] != cin:
+        raise ValueError(f"conv3x3: x {tuple(x.shape)} does not match weight {tuple(w_oihw.shape)}" + (" (data gradient)" if dgrad else ""))
     if x.device.type != "cuda":
         raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {x.device} and there is no CPU path")
     if cin % 4 or cout % 4:
@@ -91,7 +96,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
             if cin % 8:
                 raise L.HipError(f"conv3x3 on the HIP library needs cin % 8 == 0 (cin={cin})")
         wp = torch.empty(int(getattr(lib, pack + "_floats")(cin, cout)), dtype=torch.float32, device=x.device)
-        L.call(pack, w_oihw.data_ptr(), wp.data_ptr(), cin, cout, st)
+        L.call(pack + ("_dgrad" if dgrad else ""), w_oihw.data_ptr(), wp.data_ptr(), cin, cout, st)
         d = L.Conv3x3()
         d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x.data_ptr(), cin, cin, L.PRO_NONE
         d.weight, d.out = wp.data_ptr(), out.data_ptr()
@@ -125,15 +130,17 @@ class Conv3x3Function(torch.autograd.Function):
         cout = weight.shape[0]
         grad_x = grad_w = grad_b = None
         if ctx.needs_input_grad[0]:
-            # dL/dx = conv(dL/dy, flip(w)^T): the forward operator itself
-            grad_x = _conv3x3_nhwc(g, weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None)
+            # dL/dx = conv(dL/dy, flip(w)^T): the forward operator itself, its weight packed straight from the forward layer's
+            grad_x = _conv3x3_nhwc(g, weight, None, dgrad=True)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             with _on(xn.device):
                 grad_w = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xn.device)
+                grad_b = torch.empty(cout, dtype=torch.float32, device=xn.device) if want_b else None     # falls out of the staged dY tiles
                 ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, cin, cout)), dtype=torch.float32, device=xn.device)
-                L.call("nd_conv3x3_wgrad_nhwc_f32", xn.data_ptr(), cin, g.data_ptr(), cout, grad_w.data_ptr(), ws.data_ptr(),
-                       B, H, W, cin, cout, _stream())
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                L.call("nd_conv3x3_wgrad_nhwc_f32", xn.data_ptr(), cin, g.data_ptr(), cout, grad_w.data_ptr(),
+                       grad_b.data_ptr() if want_b else None, ws.data_ptr(), B, H, W, cin, cout, _stream(xn.device))
+        elif want_b:
             grad_b = g.sum(dim=(0, 2, 3))
         return grad_x, grad_w, grad_b
 

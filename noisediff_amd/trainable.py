@@ -135,7 +135,7 @@ def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, 
     # condition embeddings: learned sinusoidal position features -> Mlp; ISO table row as a one-token context; time MLP
     w = o.conv("pos_enc.weights", condition["position"])
     pos = o.mlp("pos_mlp", torch.cat((w, (2 * math.pi * w).sin(), (2 * math.pi * w).cos()), dim=1))
-    iso = F.embedding(condition["iso_ratio_idx"].long(), p["iso_embed.weight"])[:, None]
+    iso = F.embedding(condition["iso_ratio_idx"].long().to(x.device), p["iso_embed.weight"])[:, None]      # (the trainer keeps the index on the CPU, trainer_diffusion.py:135)
     half = dim // 2
     freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000.0) / (half - 1)))
     ang = time[:, None] * freqs[None]

@@ -95,15 +95,18 @@ def test_net_forward_non_square_and_wrapped(golden):
     assert rel_err(got.cpu().numpy(), ref.numpy()) < NET_TOL
 
 
-def test_net_refuses_cpu_and_autograd():
+def test_net_refuses_cpu_and_variants_refuse_autograd():
     from noisediff_amd._lib import HipError
+    from noisediff_amd import UNet_PosEmbV2_NoPosition
     net = make_net(16)
     cond = synth.make_condition(1, 16, seed=1)
     x = torch.zeros(1, 4, 16, 16)
     with torch.no_grad(), pytest.raises(HipError):
         net(x, torch.zeros(1, dtype=torch.long), cond)                   # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):                             # autograd requested: only the NoiseDiffNet graph is differentiable
+        make_net(16, mid_attn=True)(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), to_dev(cond))
     with pytest.raises(NotImplementedError):
-        net(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), to_dev(cond))   # autograd requested
+        UNet_PosEmbV2_NoPosition(SimpleNamespace(dim=16, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False)).to(DEV)(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), x.to(DEV))
 
 
 def _sample(dim, B, H, T, S, eta=0.0, return_all=False, sched="sigmoid2", objective="pred_v", mid=False, preset=False):
@@ -475,7 +478,7 @@ def test_config3_batch16_at_256_matches_oracle_on_one_row():
 
 # --------------------------------------------------------------------------- multi-rank product path
 
-def _rank_worker(rank, world, port, q, mode):
+def _rank_worker(rank, world, port, q, mode, backend="gloo"):
     """One rank of the sharded HIP sampler: broadcast_weights (the one collective) + sample_sharded, everything on cuda:0
     (the GPU box has one card, so the process group is gloo; on an 8-GPU node the same code runs with backend nccl = RCCL)."""
     import os
@@ -483,7 +486,10 @@ def _rank_worker(rank, world, port, q, mode):
     from noisediff_amd.shard import broadcast_weights, sample_sharded
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                                          # RCCL, bound to the device like bench.py --gpus N does
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=DEV)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     dim, H, T, total = 16, 32, 6, 5
     args = SimpleNamespace(dim=dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False)
     net = NoiseDiffNet(args)                                       # every rank starts from its own random init ...
@@ -523,10 +529,48 @@ def _rank_worker(rank, world, port, q, mode):
             return gd.sample(batch_size=batch_size, condition=condition, noise=noise)
 
         out = sample_sharded(fn, total, make_cond, seed=2, set_offset=lambda lo: state.update(lo=lo), gather=True)
+    if backend == "nccl":          # a world of one skips sample_sharded's gather: run the collectives of the N > 1 path on device tensors anyway
+        parts = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(parts, out.contiguous())
+        cs = out.double().abs().sum().reshape(1)
+        lo_, hi_ = cs.clone(), cs.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        assert torch.equal(parts[rank], out) and lo_.item() == hi_.item() == cs.item()
+        assert dist.get_backend() == "nccl" and out.is_cuda
     if rank == 0:
         q.put(out.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["explicit", "philox"])
+def test_rccl_process_group_of_one_rank_runs_the_collectives_of_the_sharded_sampler(mode):
+    """The GPU box has one card and RCCL refuses two ranks on one device, so the N > 1 tests below run on gloo.  This one runs the SAME
+    worker on backend nccl (= RCCL) with a world of one rank: communicator creation bound to the device (``device_id``), the weight
+    broadcast (raw weights / packed plan slices), the barrier and the all-gather of the patches all execute inside librccl, with device
+    tensors -- what bench.py --gpus N and shard.py call on an 8-GPU node, minus the peer transport."""
+    import os
+    import torch.multiprocessing as mp
+    dim, H, T, total = 16, 32, 6, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31600 + (os.getpid() + (0 if mode == "explicit" else 1)) % 2000
+    p = ctx.Process(target=_rank_worker, args=(0, 1, port, q, mode, "nccl"))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    net = make_net(dim)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    cond = synth.make_condition(total, H, seed=1)
+    if mode == "philox":
+        one = gd.sample(batch_size=total, condition=to_dev(cond), seed=21).cpu().numpy()
+    else:
+        x_T = synth.make_noise(2, "x_T", total, 4, H)
+        steps = torch.stack([synth.make_noise(2, f"noise.{i}", total, 4, H) for i in range(T - 1)])
+        one = gd.sample(batch_size=total, condition=to_dev(cond), noise={"x_T": x_T, "steps": steps}).cpu().numpy()
+    assert np.isfinite(got).all() and rel_err(got, one) < 1e-5
 
 
 @pytest.mark.parametrize("mode", ["explicit", "philox"])

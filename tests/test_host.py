@@ -137,7 +137,7 @@ def test_product_refuses_to_run_without_a_gpu():
     cond = synth.make_condition(1, 16, seed=1)
     with pytest.raises(L.HipError, match="no CPU path"):
         gd.sample(batch_size=1, condition=cond)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(L.HipError, match="no CPU path"):               # training entry (p_losses, autograd on): no CPU path either
         gd(torch.zeros(1, 4, 16, 16), cond)
 
 

@@ -51,20 +51,40 @@ def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum():
     x = U("wg.x", (B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
     gy = U("wg.gy", (B, cout, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
     ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, cin, cout)), device=DEV)
-    outs = []
-    for _ in range(3):
+    outs, bouts = [], []
+    for it in range(3):
         dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        db = torch.full((cout,), float("nan"), device=DEV)
         torch.cuda.synchronize()
-        L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), ws.data_ptr(), B, H, W, cin, cout,
-               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), db.data_ptr() if it else None, ws.data_ptr(),
+               B, H, W, cin, cout, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         outs.append(dw.cpu())
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        bouts.append(db.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])            # with and without the bias gradient: the same bits
+    assert bool(bouts[0].isnan().all()) and torch.equal(bouts[1], bouts[2])           # NULL dbias: untouched
     ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (cout, cin, 3, 3), gy.double().cpu(), padding=1)
     assert rel_err(outs[0].numpy(), ref.numpy()) < 2e-5
+    assert rel_err(bouts[1].numpy(), gy.double().cpu().sum(dim=(0, 2, 3)).numpy()) < 2e-6
     assert lib.nd_conv3x3_wgrad_workspace_floats(0, 8, 8, 8, 8) == -1
     with pytest.raises(L.HipError):
-        L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), ws.data_ptr(), B, H, W, 6, cout, None)
+        L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), None, ws.data_ptr(), B, H, W, 6, cout, None)
+
+
+@pytest.mark.parametrize("kind", ["", "_wino", "_wino4"])
+def test_dgrad_packing_equals_packing_the_flipped_transposed_weight(kind):
+    """nd_pack_conv3x3*_weight_dgrad(w) == nd_pack_conv3x3*_weight(w.flip(2, 3).transpose(0, 1)) bit for bit, ragged channel counts included."""
+    lib = L.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cout_f, cin_f in ((64, 128), (40, 72), (8, 24)):                              # forward layer: cin_f -> cout_f; its data gradient: cout_f -> cin_f
+        w = U(f"dg.{kind}.{cout_f}", (cout_f, cin_f, 3, 3)).to(DEV)
+        wt = w.flip(2, 3).transpose(0, 1).contiguous()
+        n = int(getattr(lib, f"nd_pack_conv3x3{kind}_weight_floats")(cout_f, cin_f))
+        a, b = torch.full((n,), float("nan"), device=DEV), torch.full((n,), float("nan"), device=DEV)
+        L.call(f"nd_pack_conv3x3{kind}_weight", wt.data_ptr(), a.data_ptr(), cout_f, cin_f, st)
+        L.call(f"nd_pack_conv3x3{kind}_weight_dgrad", w.data_ptr(), b.data_ptr(), cout_f, cin_f, st)
+        torch.cuda.synchronize()
+        assert torch.equal(a.cpu(), b.cpu()) and not bool(a.isnan().any()), (kind, cout_f, cin_f)
 
 
 class _Block(nn.Module):

@@ -127,6 +127,44 @@ def test_hip_convs_and_norms_keep_loss_and_gradients_and_weights_load_into_the_s
 
 
 @pytest.mark.gpu
+def test_the_drop_in_network_trains_under_autograd(golden):
+    """``noisediff_amd.NoiseDiffNet`` itself under ``p_losses`` (models/denoising_diffusion_pytorch.py:481-531 through the nn.DataParallel
+    wrapper of models/modules.py:81): loss and parameter gradients equal the reference's (tests/golden/training.npz); after an optimizer
+    step the SAME module samples on the fused engine with the updated weights (the engine repacks when parameter versions change)."""
+    from noisediff_amd import NoiseDiffNet
+    dev = torch.device("cuda", 0)
+    x0, noise, t, cond = _inputs()
+    x0, noise, t = x0.to(dev), noise.to(dev), t.to(dev)
+    cond_dev = {k: (v if k == "iso_ratio_idx" else v.to(dev)) for k, v in cond.items()}       # the trainer keeps iso_ratio_idx on the CPU
+    net = NoiseDiffNet(SimpleNamespace(dim=DIM, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, phase="train"))
+    net.load_state_dict(state_dict(DIM), strict=True)
+    net = net.to(dev).train()
+    gd = GaussianDiffusion(nn.DataParallel(net, device_ids=[0]), image_size=H, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+    with torch.no_grad():
+        before = net(x0, t, cond_dev).clone()                                  # fused engine
+    loss = gd.p_losses(x0, t, cond_dev, noise=noise.clone())
+    assert float(loss.detach()) == pytest.approx(float(golden("training", "train.loss.pred_v")), rel=5e-5)
+    loss.backward()
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    assert all(g is not None for g in grads.values())
+    for k in GRAD_KEYS:
+        ref = golden("training", f"train.grad.{k}")
+        assert np.abs(sub(grads[k].cpu(), 2048) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), k
+    sq = sum(float((g.double() ** 2).sum()) for g in grads.values())
+    assert sq == pytest.approx(float(golden("training", "train.grad_sq_norm")), rel=1e-3)
+    # the differentiable forward and the fused engine are the same function of the same parameters
+    with torch.enable_grad():
+        y_train = net(x0, t, cond_dev)
+    assert y_train.requires_grad and rel_err(y_train.detach().cpu().numpy(), before.cpu().numpy()) < 2e-4
+    torch.optim.Adam(net.parameters(), lr=1e-3).step()
+    with torch.no_grad():
+        after = net(x0, t, cond_dev)                                           # engine repacked from the updated parameters
+        ref_after = net._forward_autograd(x0, t, cond_dev)
+    assert not torch.equal(after, before)
+    assert rel_err(after.cpu().numpy(), ref_after.cpu().numpy()) < 2e-4
+
+
+@pytest.mark.gpu
 def test_a_whole_training_step_captures_into_one_graph():
     """forward + backward + Adam of the .hip() network as one torch.cuda.CUDAGraph: the library launches on torch's capture stream.
     Replays keep training: the loss of a fixed batch goes down and the weights move."""
