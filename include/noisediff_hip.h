@@ -230,6 +230,9 @@ int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream);
  * permutes K from (c p1 p2) to (p1 p2 c) for a pixel-unshuffled input with c = unshuffle_c. */
 int64_t nd_pack_pointwise_weight_floats(int cin, int cout);
 int nd_pack_pointwise_weight(const float* w, float* packed, int cin, int cout, int unshuffle_c, void* stream);
+/* training: the packing of the DATA-GRADIENT operator dx = dy @ W of a Linear / 1x1 convolution, read in place from its forward weight
+ * `w_t` ((cin, cout) row-major here = torch's (out_features, in_features) of the forward layer; cin = the forward layer's cout). */
+int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cout, void* stream);
 
 /* ------------------------------------------------------------------ chained pointwise layers
  * Two or three per-pixel Linear layers in one kernel, the intermediate activations never leaving registers:

@@ -659,8 +659,9 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
 }
 
 // (cout, cin) -> [cinP/4][coutP][4], optional K permutation for pixel-unshuffled inputs
+// transposed: `w` is (cin, cout) row-major -- the forward weight of the Linear whose DATA gradient dx = dy @ W this packing serves
 __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                      int cin, int cout, int cinP, int coutP, int unshuffle_c) {
+                                      int cin, int cout, int cinP, int coutP, int unshuffle_c, int transposed) {
     const size_t total = (size_t)cinP * coutP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int e = i & 3;
@@ -675,7 +676,7 @@ __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __rest
                 const int sub = kp / unshuffle_c, c = kp - sub * unshuffle_c;
                 k = c * 4 + sub;
             }
-            v = w[(size_t)n * cin + k];
+            v = transposed ? w[(size_t)k * cout + n] : w[(size_t)n * cin + k];
         }
         out[i] = v;
     }
@@ -740,8 +741,18 @@ extern "C" int nd_pack_pointwise_weight(const float* w, float* packed, int cin, 
     const int cinP = nd_round_up(cin, 8), coutP = nd_round_up(cout, 64);
     const size_t total = (size_t)cinP * coutP;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_pointwise_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, cinP, coutP, unshuffle_c);
+    hipLaunchKernelGGL(pack_pointwise_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, cinP, coutP, unshuffle_c, 0);
     return nd_launch_status("nd_pack_pointwise_weight");
+}
+
+extern "C" int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cout, void* stream) {
+    ND_REQUIRE(w_t && packed, ND_E_BADARG, "nd_pack_pointwise_weight_t: null pointer");
+    ND_REQUIRE(cin > 0 && cout > 0, ND_E_BADARG, "nd_pack_pointwise_weight_t: non-positive size");
+    const int cinP = nd_round_up(cin, 8), coutP = nd_round_up(cout, 64);
+    const size_t total = (size_t)cinP * coutP;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_pointwise_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_t, packed, cin, cout, cinP, coutP, 0, 1);
+    return nd_launch_status("nd_pack_pointwise_weight_t");
 }
 
 extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) {

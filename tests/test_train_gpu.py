@@ -71,6 +71,29 @@ def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum():
         L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), None, ws.data_ptr(), B, H, W, 6, cout, None)
 
 
+def test_linear_on_the_pointwise_kernels_matches_the_library_gemm():
+    """ND_TRAIN_PW=1: output and data gradient of a token Linear on nd_pointwise_gemm_nhwc_f32 (data-gradient weight packed in place by
+    nd_pack_pointwise_weight_t) against torch, ragged token counts and channel counts that are not multiples of the tiles included."""
+    old = train._PW_GEMM
+    train._PW_GEMM = True
+    try:
+        for (shape, cin, cout) in (((2, 1000, 64), 64, 128), ((4100, 72), 72, 40), ((3, 16), 16, 64), ((1, 8192, 256), 256, 256)):
+            x = U(f"pwl.x.{cin}", shape).to(DEV)
+            w = (U(f"pwl.w.{cin}", (cout, cin)) / cin ** 0.5).to(DEV)
+            b = U(f"pwl.b.{cin}", (cout,)).to(DEV)
+            gy = U(f"pwl.g.{cin}", shape[:-1] + (cout,)).to(DEV)
+            outs = []
+            for fn in (F.linear, train.linear):
+                xa, wa, ba = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+                y = fn(xa, wa, ba)
+                y.backward(gy)
+                outs.append([t.detach().cpu() for t in (y, xa.grad, wa.grad, ba.grad)])
+            for name, ref, got in zip(("y", "grad_x", "grad_w", "grad_b"), *outs):
+                assert got.shape == ref.shape and rel_err(got.numpy(), ref.numpy()) < 2e-5, (shape, name)
+    finally:
+        train._PW_GEMM = old
+
+
 @pytest.mark.parametrize("kind", ["", "_wino", "_wino4"])
 def test_dgrad_packing_equals_packing_the_flipped_transposed_weight(kind):
     """nd_pack_conv3x3*_weight_dgrad(w) == nd_pack_conv3x3*_weight(w.flip(2, 3).transpose(0, 1)) bit for bit, ragged channel counts included."""

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Family table of a rocprofv3 --kernel-trace --stats run of tools/train_step_profile.py: python tools/train_kernel_table.py <..._kernel_stats.csv> [steps]"""
+import csv, sys
+
+
+def family(n):
+    if "linear_wgrad" in n: return "Linear / 1x1 weight gradient (HIP)"
+    if "wgrad" in n: return "conv3x3 weight gradient (HIP)"
+    if any(k in n for k in ("wino4_kernel", "wino2_kernel", "conv3x3_kernel", "wino_kernel")) and "pack" not in n: return "conv3x3 forward + data gradient (HIP)"
+    if "pointwise" in n and "pack" not in n: return "Linear / 1x1 forward + data gradient (HIP pointwise)"
+    if n.startswith("Cijk"): return "library GEMM (rocBLAS / hipBLASLt)"
+    if any(k in n for k in ("gs_", "gn_", "ln_")): return "GroupNorm / LayerNorm forward + backward (HIP)"
+    if "pack_" in n: return "weight packing (HIP)"
+    if "multi_tensor" in n: return "Adam (ATen foreach)"
+    if "CUDAFunctor_add" in n: return "ATen add"
+    if "direct_copy" in n: return "ATen copy"
+    if "reduce_kernel" in n: return "ATen reduce"
+    if "Cat" in n: return "ATen cat"
+    if "at::native" in n: return "ATen other"
+    return "other"
+
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+fam = {}
+for r in rows:
+    f = fam.setdefault(family(r["Name"]), [0.0, 0.0])
+    f[0] += float(r["TotalDurationNs"]) / 1e6 / steps
+    f[1] += int(r["Calls"]) / steps
+print(f"GPU busy {sum(v[0] for v in fam.values()):.2f} ms per step, {sum(v[1] for v in fam.values()):.0f} launches per step ({steps} steps in the trace)")
+for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {k:55s} {v[0]:7.3f} ms  {v[1]:7.1f} launches")
