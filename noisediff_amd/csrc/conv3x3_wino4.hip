@@ -101,6 +101,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
 struct Wino4Args {
     nd_conv3x3 d;
     int tiles_x, tiles_y, regions_x, n_tiles, n_cg, n_c8, slots, total_wg;
+    int splits, chunks_per_split;            // SPLIT instances: K (cin) in `splits` ranges of `chunks_per_split` 16-channel chunks, partial outputs [split][B][H][W][ldo]
 };
 
 // MFMAs through inline asm: the constraint pins each accumulator to its half of the register file for the whole kernel
@@ -140,7 +141,11 @@ __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
 // 256 x 256 spends 2.3 k cycles more in the K chunk that follows an epilogue (its halo reads queue behind the output's write-back) and
 // 4.6 k more per workgroup in the prologue: -4 % per region tile (profiles/r3_w4_store_policy.txt); small outputs keep the default (the next
 // kernel finds them in the L2 / Infinity Cache).
-template <int MODE, bool STREAM>
+// SPLIT (split-K, plain sources without statistics only): layers whose (sample, region, cout tile) items fill a fraction of the chip -- 512 -> 512 at
+// 32 x 32 with 4 samples: 64 items for 256 CUs, each walking 32 K chunks -- are cut along cin: item (split, sample, region, cout tile) walks
+// `chunks_per_split` chunks starting at chunk split * chunks_per_split and writes its partial sums to out[split] (the host passes a workspace
+// and no bias); w4_splitk_reduce_kernel adds the partials in split order and the bias.  The split count is fixed by the shape alone.
+template <int MODE, bool STREAM, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     constexpr bool MAP = MODE == ND_PRO_AFFINE_MAP_SILU;                  // + per-pixel scale / shift maps (ResnetBlock2)
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAP;               // GroupNorm-affine + SiLU applied while the halo is written to LDS
@@ -179,14 +184,16 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     const int up = s.upsample ? 1 : 0;
     const int sH = H >> up, sW = W >> up;
     const int Ctot = s.c0 + s.c1;
-    const int n_chunks = (Cin + KC4 - 1) / KC4;
+    const int n_chunks = SPLIT ? a.chunks_per_split : (Cin + KC4 - 1) / KC4;   // chunks an item walks
 
-    auto decode = [&](int t, int& b_, int& ty_, int& rx_, int& nt_) {
+    auto decode = [&](int t, int& b_, int& ty_, int& rx_, int& nt_, int& sp_) {
         int lid = t;
         nt_ = lid % a.n_tiles;  lid /= a.n_tiles;
         rx_ = lid % a.regions_x;  lid /= a.regions_x;
         ty_ = lid % a.tiles_y;
         b_ = lid / a.tiles_y;
+        sp_ = 0;
+        if (SPLIT) { sp_ = b_ / a.d.B;  b_ -= sp_ * a.d.B; }             // the split is the slowest index: neighbouring workgroups share a K range's weights
     };
 
     // ---- staging.  The 18 x 34 pixel halo of the region (both tile groups) x 16 channels is fetched ONCE per chunk: item
@@ -489,15 +496,15 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     };
 
     // ---- prologue: first item staged and transformed synchronously, weight ring primed
-    int b, ty, rx, nt;
-    decode(t_begin, b, ty, rx, nt);
-    int b1 = b, ty1 = ty, rx1 = rx, nt1 = nt;
+    int b, ty, rx, nt, sp;
+    decode(t_begin, b, ty, rx, nt, sp);
+    int b1 = b, ty1 = ty, rx1 = rx, nt1 = nt, sp1 = sp;
     stage_tile(b, ty, rx);
-    stage_issue_begin(0);
+    stage_issue_begin(SPLIT ? sp * n_chunks * KC4 : 0);
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k, ptab[k * 256]);
     {
-        const int wb = wblock(0, nt * 4 + wave);
+        const int wb = wblock(SPLIT ? 2 * sp * n_chunks : 0, nt * 4 + wave);
 #pragma unroll
         for (int q = 0; q < UR_EPI; ++q) load_u(q, q, wb);
     }
@@ -523,18 +530,19 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         const bool more = t + 1 < t_end;
         W4_T0();
         if (more) {                                                      // the next item: decode(t + 1) without the divisions
-            nt1 = nt + 1;  rx1 = rx;  ty1 = ty;  b1 = b;
-            if (nt1 == a.n_tiles) { nt1 = 0;  if (++rx1 == a.regions_x) { rx1 = 0;  if (++ty1 == a.tiles_y) { ty1 = 0;  ++b1; } } }
+            nt1 = nt + 1;  rx1 = rx;  ty1 = ty;  b1 = b;  sp1 = sp;
+            if (nt1 == a.n_tiles) { nt1 = 0;  if (++rx1 == a.regions_x) { rx1 = 0;  if (++ty1 == a.tiles_y) { ty1 = 0;  ++b1;  if (SPLIT && b1 == a.d.B) { b1 = 0;  ++sp1; } } } }
         }
+        const int ch0 = SPLIT ? sp * n_chunks : 0, ch0n = SPLIT ? sp1 * n_chunks : 0;      // first chunk of this item's / the next item's K range
         const int cg = nt * 4 + wave, cg_next = (more ? nt1 : nt) * 4 + wave;          // this wave's 16 output channels
 
         auto chunk = [&](int ch, auto first_c, auto last_c) {
             const char* v0cur = reinterpret_cast<const char*>(Vd) + d_lds;                                       // tile group 0 / 1: V images
             const char* v1cur = reinterpret_cast<const char*>(Vd + VD_FLOATS) + d_lds;
             constexpr bool last = decltype(last_c)::value;               // last chunk of the tile (n_chunks >= 2: never also the first)
-            const int c8 = 2 * ch;
+            const int c8 = 2 * (ch0 + ch);
             // weight blocks: this chunk's two stages, then the next item's first stage (after the very last item: a harmless reload)
-            const int w0 = wblock(c8, cg), w1 = wblock(c8 + 1, cg), wn = last ? wblock(0, cg_next) : wblock(c8 + 2, cg);
+            const int w0 = wblock(c8, cg), w1 = wblock(c8 + 1, cg), wn = last ? wblock(2 * ch0n, cg_next) : wblock(c8 + 2, cg);
 #ifdef W4_STAMP
             if (decltype(first_c)::value) W4_ACC(stamp_top);
             W4_T0();
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             unsigned tabd[(AFF || LEAKY) ? RAW_IT : 1], tabp[PRE_P ? RAW_IT : 1];   // AFF / LEAKY: the clump's ten items
             auto issue_pre = [&](int pp) { if (pp < RAW_IT) tab1 = ptab[pp * 256]; };
             auto issue = [&](int pp) {
-                if (pp == 0) stage_issue_begin(last ? 0 : (ch + 1) * KC4);
+                if (pp == 0) stage_issue_begin(last ? ch0n * KC4 : (ch0 + ch + 1) * KC4);
                 if (pp < RAW_IT) stage_issue_one(pp, tab1);
             };
             auto commit_pre = [&](int pp) {
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         W4_T0();
         W4_MFMA_DRAIN();
 
-        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d.out, 0, (int)((unsigned)a.d.B * H * W * a.d.ldo * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d.out, 0, (int)((unsigned)(SPLIT ? a.splits : 1) * a.d.B * H * W * a.d.ldo * 4u), 0x00020000);
         int Wt = __builtin_amdgcn_readfirstlane(W), ldot = __builtin_amdgcn_readfirstlane(a.d.ldo);
         asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the store offsets from being hoisted into (spilled) SGPRs
 #pragma unroll
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 const bool want_stats = a.d.stats != nullptr;
                 // stores: buffer addressing -- one 32-bit lane offset per tile, the pixel's offset (uniform) in the scalar offset
                 // field (the output stays below 4 GiB, host check)
-                const unsigned lane_off = (unsigned)((((unsigned)b * H + py0) * Wt + px0) * ldot + co) * 4u;
+                const unsigned lane_off = (unsigned)((((unsigned)(SPLIT ? sp * a.d.B + b : b) * H + py0) * Wt + px0) * ldot + co) * 4u;   // (SPLIT: the split's partial tensor)
                 // two of the lane's four tiles at a time (Z[4][6] of float2 = 48 registers): every accumulator register is read ONCE
                 // (v_accvgpr_read_b32 issues every 8 cycles: 288 instead of the 480 of a float4 pass over two output rows at a time)
                 auto emit = [&](auto full_c, auto stats_c) {
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W4_ACC(stamp_drain);
 #endif
-        b = b1; ty = ty1; rx = rx1; nt = nt1;
+        b = b1; ty = ty1; rx = rx1; nt = nt1; sp = sp1;
     }
 #ifdef W4_STAMP
     if (tid == 0) {
@@ -830,6 +838,29 @@ int launch4s(const Wino4Args& a, hipStream_t st) {
     return 0;
 }
 
+// out[n][c] = sum over the splits (in split order) of part[s][n][c] + bias[c]; n = pixel (B * H * W), float4 per thread
+__global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                               int splits, long npix, int cout, int ldo) {
+    const int cq = cout >> 2;
+    const long total = npix * cq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / cq;
+        const int c = (int)(i - n * cq) * 4;
+        f32x4 acc = nd_ld4(part + n * cout + c);
+        for (int s = 1; s < splits; ++s) acc += nd_ld4(part + ((long)s * npix + n) * cout + c);
+        if (bias) acc += nd_ld4(bias + c);
+        nd_st4(out + n * ldo + c, acc);
+    }
+}
+
+int launch4_split(const Wino4Args& a, hipStream_t st) {
+    static nd_device_once configured;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<ND_PRO_NONE, false, true>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
+    const long resident = nd_device_cus();
+    hipLaunchKernelGGL((wino4_kernel<ND_PRO_NONE, false, true>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    return 0;
+}
+
 template <int MODE>
 int launch4(const Wino4Args& a, hipStream_t st) {
     static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;     // A/B knob (tools/ only)
@@ -866,7 +897,8 @@ extern "C" int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* 
 
 extern "C" int nd_conv3x3_wino4_stat_slots(int H, int W) { return nd_cdiv(W, 16) * nd_cdiv(H, 16); }
 
-extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
+// descriptor checks shared by the entry points; fills the launch arguments
+static int w4_prepare(const nd_conv3x3* d, Wino4Args& a) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_conv3x3_wino4: null descriptor");
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3_wino4: null tensor pointer");
@@ -909,7 +941,6 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
 
     ND_REQUIRE((long)d->B * d->H * d->W * d->ldo * 4 < (1L << 32) - 65536, ND_E_SHAPE, "nd_conv3x3_wino4: an output tensor of 4 GiB or more");
 
-    Wino4Args a;
     a.d = *d;
     a.tiles_x = nd_cdiv(d->W, 16);
     a.tiles_y = nd_cdiv(d->H, 16);
@@ -921,6 +952,15 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     const long wg = (long)d->B * a.regions_x * a.tiles_y * a.n_tiles;
     ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4: grid too large");
     a.total_wg = (int)wg;
+    a.splits = 1;
+    a.chunks_per_split = nd_cdiv(d->cin, KC4);
+    return 0;
+}
+
+extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
+    Wino4Args a;
+    if (int e = w4_prepare(d, a)) return e;
+    const nd_src& s = d->src;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (s.mode) {
@@ -932,4 +972,54 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     }
     if (rc) return rc;
     return nd_launch_status("nd_conv3x3_wino4_nhwc_f32");
+}
+
+// ---- split-K (training at small batch, and any plain layer without a statistics epilogue whose items fill a fraction of the chip)
+//
+// The layer's items are (sample, 16 x 32-pixel region, 64-cout tile): 512 -> 512 at 32 x 32 with 4 samples has 64 of them for 256 CUs, each
+// walking 32 K chunks.  nd_conv3x3_wino4_splitk_plan picks -- from the shape alone, so that the summation order never depends on the device --
+// the number of K ranges (1, 2, 4 or 8) that brings the item count to about one per CU while leaving every range at least four chunks.
+static int w4_splits(long items, int cin) {
+    const int n_chunks = nd_cdiv(cin, KC4);
+    if (cin % KC4) return 1;
+    int splits = 1;
+    while (splits < 8 && items * splits * 2 <= 256 && n_chunks % (splits * 2) == 0 && n_chunks / (splits * 2) >= 4) splits *= 2;
+    return splits;
+}
+
+extern "C" int nd_conv3x3_wino4_splitk_plan(int B, int H, int W, int cin, int cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 1;
+    return w4_splits((long)B * nd_cdiv(W, 32) * nd_cdiv(H, 16) * nd_cdiv(cout, 64), cin);
+}
+
+extern "C" int64_t nd_conv3x3_wino4_splitk_workspace_floats(int B, int H, int W, int cout, int splits) {
+    if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || splits <= 0) return -1;
+    return (int64_t)splits * B * H * W * cout;
+}
+
+extern "C" int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {
+    Wino4Args a;
+    if (int e = w4_prepare(d, a)) return e;
+    ND_REQUIRE(workspace && nd_aligned16(workspace), ND_E_BADARG, "nd_conv3x3_wino4_splitk: the workspace must be a 16-byte aligned pointer");
+    ND_REQUIRE(d->src.mode == ND_PRO_NONE && !d->stats, ND_E_BADARG, "nd_conv3x3_wino4_splitk: plain sources, no statistics epilogue");
+    const int n_chunks = nd_cdiv(d->cin, KC4);
+    ND_REQUIRE((splits == 2 || splits == 4 || splits == 8) && d->cin % KC4 == 0 && n_chunks % splits == 0 && n_chunks / splits >= 2, ND_E_SHAPE,
+               "nd_conv3x3_wino4_splitk: splits=%d must be 2, 4 or 8 and divide cin=%d into ranges of at least two whole 16-channel chunks", splits, d->cin);
+    const long npix = (long)d->B * d->H * d->W;
+    ND_REQUIRE((long)splits * npix * d->cout * 4 < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4_splitk: partial sums of 2 GiB or more");
+    ND_REQUIRE(d->cout % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4_splitk: cout must be a multiple of 4");
+    const float* bias = d->bias;
+    float* out = d->out;
+    const int ldo = d->ldo;
+    a.d.out = workspace;  a.d.ldo = d->cout;  a.d.bias = nullptr;       // partial sums [split][B][H][W][cout]; the bias joins in the reduction
+    a.splits = splits;
+    a.chunks_per_split = n_chunks / splits;
+    a.total_wg *= splits;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = launch4_split(a, st)) return rc;
+    if (int e = nd_launch_status("nd_conv3x3_wino4_splitk_nhwc_f32")) return e;
+    const long total = npix * (d->cout / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, bias, out, splits, npix, d->cout, ldo);
+    return nd_launch_status("nd_conv3x3_wino4_splitk_nhwc_f32 (reduce)");
 }

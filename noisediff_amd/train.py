@@ -65,6 +65,9 @@ def _stream(device: Optional[torch.device] = None) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_SPLIT_K = __import__("os").environ.get("ND_TRAIN_SPLITK", "1") != "0"      # A/B knob (tools/): 0 = never the split-K form of conv3x3_wino4
+
+
 def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], dgrad: bool = False) -> torch.Tensor:
     """y = conv2d(x, w, bias, padding=1) on the HIP library; x (B, cin, H, W) channels_last, returns (B, cout, H, W) channels_last.
     ``dgrad``: ``w_oihw`` is the FORWARD layer's weight and the operator is its data gradient, conv2d(x, w.flip(2, 3).transpose(0, 1),
@@ -104,7 +107,12 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
             b = bias.detach().to(torch.float32).contiguous()
             d.bias = b.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
-        L.call(entry, C.byref(d), st)
+        splits = int(lib.nd_conv3x3_wino4_splitk_plan(B, H, W, cin, cout)) if wino4 and _SPLIT_K else 1
+        if splits > 1:      # few (sample, region, cout tile) items for 256 CUs (the deep layers at training batch sizes): cut along cin
+            ws = torch.empty(int(lib.nd_conv3x3_wino4_splitk_workspace_floats(B, H, W, cout, splits)), dtype=torch.float32, device=x.device)
+            L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), splits, st)
+        else:
+            L.call(entry, C.byref(d), st)
         # wp / b are dropped on return: safe, because the kernels were enqueued on torch's CURRENT stream and the caching
         # allocator reuses a block only for work that is enqueued later on that same stream
     return out

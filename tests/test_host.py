@@ -266,3 +266,15 @@ def test_accelerate_retargets_the_class_so_replicas_and_copies_resolve_forward_t
     assert isinstance(clone, nn.Conv2d)
     with pytest.raises(Exception, match="HIP library only|no CPU path"):
         conv(torch.zeros(1, 8, 16, 16))                                          # still no CPU fallback
+
+
+def test_split_k_plan_is_a_function_of_the_shape():
+    """nd_conv3x3_wino4_splitk_plan (host code, no GPU): 1 where the layer's (sample, region, cout tile) items fill the chip or cin leaves
+    no room, else the power of two that brings them to about 256 with at least four 16-channel chunks per range."""
+    lib = L.load()
+    plan = lib.nd_conv3x3_wino4_splitk_plan
+    assert plan(16, 256, 256, 64, 64) == 1 and plan(16, 32, 32, 512, 512) == 1          # the bench workload's layers: never split
+    assert plan(4, 32, 32, 512, 512) == 4 and plan(4, 64, 64, 256, 256) == 2 and plan(4, 32, 32, 1536, 512) == 4
+    assert plan(1, 32, 32, 1536, 64) == 8 and plan(1, 32, 32, 64, 64) == 1 and plan(1, 32, 32, 72, 64) == 1
+    assert plan(4, 256, 256, 64, 64) == 1 and plan(0, 1, 1, 1, 1) == 1
+    assert lib.nd_conv3x3_wino4_splitk_workspace_floats(2, 8, 8, 16, 4) == 2 * 8 * 8 * 16 * 4

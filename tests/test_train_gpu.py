@@ -71,6 +71,55 @@ def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum():
         L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), None, ws.data_ptr(), B, H, W, 6, cout, None)
 
 
+@pytest.mark.parametrize("case", [
+    # B, H, W, cin (first source), cin of a second concat source, cout, ldo, expected splits
+    (4, 32, 32, 512, 0, 512, 512, 4), (2, 32, 32, 256, 0, 256, 256, 4), (4, 64, 64, 256, 0, 256, 260, 2), (1, 48, 40, 128, 128, 192, 192, 4),
+    (1, 32, 32, 1024, 512, 64, 64, 8), (3, 20, 36, 128, 0, 100, 100, 2)])
+def test_wino4_split_k_equals_the_plain_kernel_and_torch(case):
+    """nd_conv3x3_wino4_splitk_nhwc_f32 (cin cut into 2 / 4 / 8 ranges, partial sums added in range order, bias in the reduction) against
+    nd_conv3x3_wino4_nhwc_f32 on the same packed weights and against torch's fp32 convolution: ragged images, a concat source, a padded
+    output stride, cout that is not a multiple of the 64-cout tile; bitwise repeatable; the plan is a function of the shape alone."""
+    lib = L.load()
+    B, H, W, c0, c1, cout, ldo, want = case
+    cin = c0 + c1
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.nd_conv3x3_wino4_splitk_plan(B, H, W, cin, cout) == want
+    x = U(f"sk.x.{case}", (B, H, W, cin)).to(DEV)
+    xa, xb = (x[..., :c0].contiguous(), x[..., c0:].contiguous()) if c1 else (x, None)
+    w = (U(f"sk.w.{case}", (cout, cin, 3, 3)) / (9 * cin) ** 0.5).to(DEV)
+    b = U(f"sk.b.{case}", (cout,)).to(DEV)
+    wp = torch.empty(int(lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout)), device=DEV)
+    L.call("nd_pack_conv3x3_wino4_weight", w.data_ptr(), wp.data_ptr(), cin, cout, st)
+    d = L.Conv3x3()
+    d.src.p0, d.src.c0, d.src.ld0, d.src.mode = xa.data_ptr(), c0, c0, L.PRO_NONE
+    if c1:
+        d.src.p1, d.src.c1, d.src.ld1 = xb.data_ptr(), c1, c1
+    d.weight, d.bias = wp.data_ptr(), b.data_ptr()
+    d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, ldo
+    outs = []
+    for split in (0, want, want):
+        out = torch.full((B, H, W, ldo), float("nan"), device=DEV)
+        d.out = out.data_ptr()
+        if split:
+            ws = torch.full((int(lib.nd_conv3x3_wino4_splitk_workspace_floats(B, H, W, cout, split)),), float("nan"), device=DEV)
+            L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), split, st)
+        else:
+            L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), st)
+        torch.cuda.synchronize()
+        assert bool(out[..., cout:].isnan().all())                                   # the padding of the output stride is not touched
+        outs.append(out[..., :cout].cpu())
+    assert torch.equal(outs[1], outs[2])
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 1).float()
+    assert rel_err(outs[0].numpy(), ref.numpy()) < 5e-5 and rel_err(outs[1].numpy(), ref.numpy()) < 5e-5
+    assert rel_err(outs[1].numpy(), outs[0].numpy()) < 5e-5                          # the same products, another summation order over cin
+    # rejected: statistics epilogue, prologues, split counts that do not divide the K chunks
+    with pytest.raises(L.HipError):
+        L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), 3, st)
+    d.src.mode = L.PRO_LEAKY
+    with pytest.raises(L.HipError):
+        L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), want, st)
+
+
 def test_linear_on_the_pointwise_kernels_matches_the_library_gemm():
     """ND_TRAIN_PW=1: output and data gradient of a token Linear on nd_pointwise_gemm_nhwc_f32 (data-gradient weight packed in place by
     nd_pack_pointwise_weight_t) against torch, ragged token counts and channel counts that are not multiples of the tiles included."""

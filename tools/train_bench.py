@@ -22,7 +22,8 @@ def run(fn, x, w, b, gy, reps=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps, (xa.grad, wa.grad)
 
-for (B, H, W, cin, cout) in [(16, 256, 256, 64, 64), (16, 256, 256, 128, 64), (16, 64, 64, 256, 256), (16, 32, 32, 512, 512)]:
+for (B, H, W, cin, cout) in [(16, 256, 256, 64, 64), (16, 256, 256, 128, 64), (16, 64, 64, 256, 256), (16, 32, 32, 512, 512),
+                           (4, 64, 64, 256, 256), (4, 32, 32, 512, 512), (4, 32, 32, 1024, 512)]:      # B = 4: the deep layers run on the split-K form
     x = torch.randn(B, cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     w = torch.randn(cout, cin, 3, 3, device=dev) / (9 * cin) ** 0.5
     b = torch.randn(cout, device=dev)
