@@ -395,6 +395,8 @@ int nd_linear_attention_f32(const float* qkv, int ld_qkv, float* out, int ld_out
 /* RMSNorm.forward (:89-90) over channels: out = x / max(||x||, 1e-12) * g * sqrt(C). */
 int nd_rmsnorm_nhwc_f32(const float* x, int ldx, const float* g, float* out, int ldo,
                         int B, int HW, int C, void* stream);
+/* out = RMSNorm(x) * g + res: LinearAttention's closing RMSNorm (Diffusion_arch.py:213-216) with the residual of the per-stage wiring */
+int nd_rmsnorm_add_nhwc_f32(const float* x, int ldx, const float* g, const float* res, int ldr, float* out, int ldo, int B, int HW, int C, void* stream);
 
 /* ------------------------------------------------------------------ HIP graph helpers */
 int nd_stream_create(void** stream);

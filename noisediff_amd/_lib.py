@@ -134,6 +134,7 @@ SIGNATURES = {
     "nd_linear_attention_workspace_floats": (i64, [i32, i32, i32]),
     "nd_linear_attention_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "nd_rmsnorm_nhwc_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "nd_rmsnorm_add_nhwc_f32": (i32, [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp]),
     "nd_stream_create": (i32, [C.POINTER(vp)]),
     "nd_stream_destroy": (i32, [vp]),
     "nd_stream_sync": (i32, [vp]),

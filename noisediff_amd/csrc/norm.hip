@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 }
 
 // RMSNorm.forward (Diffusion_arch.py:89-90): F.normalize(x, dim=channel) * g * sqrt(C); one wave per pixel.
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+// res != null: out = RMSNorm(x) + res (the residual around LinearAttention, whose last layer is an RMSNorm: Diffusion_arch.py:213-216).
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g, const float* __restrict__ res, int ldr,
                                                       float* __restrict__ out, int ldo, size_t npix, int C) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
@@ -171,7 +172,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o);
         const float inv = rootc / fmaxf(sqrtf(ssq), 1e-12f);
-        for (int c = lane * 4; c < C; c += 256) nd_st4(out + p * ldo + c, nd_ld4(row + c) * inv * nd_ld4(g + c));
+        for (int c = lane * 4; c < C; c += 256) {
+            f32x4 v = nd_ld4(row + c) * inv * nd_ld4(g + c);
+            if (res) v += nd_ld4(res + p * ldr + c);
+            nd_st4(out + p * ldo + c, v);
+        }
     }
 }
 
@@ -225,6 +230,18 @@ extern "C" int nd_rmsnorm_nhwc_f32(const float* x, int ldx, const float* g, floa
     ND_REQUIRE(nd_aligned16(x) && nd_aligned16(g) && nd_aligned16(out), ND_E_ALIGN, "nd_rmsnorm: alignment");
     const size_t npix = (size_t)B * HW;
     const int blocks = (int)((npix + 3) / 4 < 4096 ? (npix + 3) / 4 : 4096);
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, g, out, ldo, npix, C);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, g, (const float*)nullptr, 0, out, ldo, npix, C);
     return nd_launch_status("nd_rmsnorm_nhwc_f32");
+}
+
+extern "C" int nd_rmsnorm_add_nhwc_f32(const float* x, int ldx, const float* g, const float* res, int ldr, float* out, int ldo, int B, int HW, int C,
+                                       void* stream) {
+    ND_REQUIRE(x && g && res && out, ND_E_BADARG, "nd_rmsnorm_add: null pointer");
+    ND_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldr % 4 == 0 && ldx >= C && ldo >= C && ldr >= C, ND_E_SHAPE,
+               "nd_rmsnorm_add: C and strides must be multiples of 4, strides >= C");
+    ND_REQUIRE(nd_aligned16(x) && nd_aligned16(g) && nd_aligned16(res) && nd_aligned16(out), ND_E_ALIGN, "nd_rmsnorm_add: alignment");
+    const size_t npix = (size_t)B * HW;
+    const int blocks = (int)((npix + 3) / 4 < 4096 ? (npix + 3) / 4 : 4096);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, g, res, ldr, out, ldo, npix, C);
+    return nd_launch_status("nd_rmsnorm_add_nhwc_f32");
 }

@@ -29,7 +29,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from .spec import (ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, POS_GROUPS, RESNET_GROUPS, SHOT_GROUPS,
+from .spec import (normalize_stage_attn, stage_attention_param_spec, ATTN_DIM_HEAD, ATTN_HEADS, ISO_DIM, ISO_TABLE_ROWS, POS_DIM, POS_GROUPS, RESNET_GROUPS, SHOT_GROUPS,
                    arch_param_spec, arch_traits, attention_param_spec, stage_dims)
 
 GN_EPS = 1e-5
@@ -95,7 +95,7 @@ class Slot:
 class Engine:
     """Packed weights of one U-Net (NoiseDiffNet or one of the UNet_PosEmbV2* ablation nets) on one GPU."""
 
-    def __init__(self, dim: int, device: torch.device, mid_attn: bool = False, inp_dim: int = 4, arch: str = "NoiseDiffNet"):
+    def __init__(self, dim: int, device: torch.device, mid_attn: bool = False, inp_dim: int = 4, arch: str = "NoiseDiffNet", stage_attn=None):
         if device.type != "cuda":
             raise L.HipError("noisediff_amd runs on MI355X only: got device %r (there is no CPU path)" % (device,))
         self.lib = L.load()
@@ -104,6 +104,9 @@ class Engine:
         self.spec = list(arch_param_spec(arch, dim, inp_dim))
         if mid_attn:
             self.spec += attention_param_spec("mid_attn", 8 * dim)
+        self.stage_attn = normalize_stage_attn(stage_attn)         # per-stage LinearAttention / Attention (upstream's wiring; spec.py)
+        if self.stage_attn:
+            self.spec += stage_attention_param_spec(dim, self.stage_attn)
         self.resnet_names = [p.name[:-len(".mlp.1.weight")] for p in self.spec
                              if p.name.endswith(".mlp.1.weight") and len(p.shape) == 2]
         self.tproj_off: Dict[str, int] = {}
@@ -700,6 +703,8 @@ class Plan:
             x1 = self.resnet(p + ".0", x, None, cin, h, w, G)
             self._release(x)
             x2 = self.resnet(p + ".1", x1, None, cin, h, w, G)
+            if e.stage_attn and e.stage_attn[i]:
+                x2 = self._stage_attention(f"down_attns.{i}", e.stage_attn[i], x2, h, w)
             hs += [x1, x2]
             xa = self.attn_block(p + ".2", x2, h, w) if tr.iso_attn else x2
             self._tap(p + ".0", x1); self._tap(p + ".1", x2); self._tap(p + ".2", xa)
@@ -727,6 +732,8 @@ class Plan:
             sk = hs.pop()
             x2 = self.resnet(p + ".1", x1, sk, cout, h, w, G)
             self._release(x1, sk)
+            if e.stage_attn and e.stage_attn[3 - i]:
+                x2 = self._stage_attention(f"up_attns.{i}", e.stage_attn[3 - i], x2, h, w)
             xa = self.attn_block(p + ".2", x2, h, w) if tr.iso_attn else x2
             if xa is not x2:
                 self._release(x2)
@@ -747,17 +754,37 @@ class Plan:
         if shot_noise is not None:
             self._release(shot_noise)
 
-    def _mid_attention(self, x: torch.Tensor, h: int, w: int) -> torch.Tensor:
-        """x = Attention(x) + x between the mid blocks (Diffusion_arch.py:237-266; BASELINE config 4)."""
+    def _mid_attention(self, x: torch.Tensor, h: int, w: int, prefix: str = "mid_attn") -> torch.Tensor:
+        """x = Attention(x) + x (Diffusion_arch.py:237-266): between the mid blocks (BASELINE config 4) or as a stage's full attention."""
         e, B, Cc, N = self.e, self.B, x.shape[-1], h * w
         hid = ATTN_HEADS * ATTN_DIM_HEAD
         xn = self._alloc(B, N, Cc)
-        self._add("nd_rmsnorm_nhwc_f32", x.data_ptr(), Cc, e.p("mid_attn.norm.g"), xn.data_ptr(), Cc, B, N, Cc, e.stream)
-        qkv = self.pw("mid_attn.to_qkv", self._src(xn), Cc, 3 * hid, N, w, bias=False)
+        self._add("nd_rmsnorm_nhwc_f32", x.data_ptr(), Cc, e.p(prefix + ".norm.g"), xn.data_ptr(), Cc, B, N, Cc, e.stream)
+        qkv = self.pw(prefix + ".to_qkv", self._src(xn), Cc, 3 * hid, N, w, bias=False)
         att = self._alloc(B, N, hid)
         self._add("nd_attention_mfma_f32", qkv.data_ptr(), 3 * hid, att.data_ptr(), hid, B, N, ATTN_HEADS, ATTN_DIM_HEAD, e.stream)
-        y = self.pw("mid_attn.to_out", self._src(att), hid, Cc, N, w, res0=x)
+        y = self.pw(prefix + ".to_out", self._src(att), hid, Cc, N, w, res0=x)
         self._release(xn, qkv, att, x)
+        return y.view(B, h, w, Cc)
+
+    def _stage_attention(self, prefix: str, kind: str, x: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """x = attn(x) + x behind a stage's second ResnetBlock -- upstream's per-stage wiring of the classes the reference defines and drops
+        (Diffusion_arch.py:198-266,509-518): 'full' = Attention (as _mid_attention), 'linear' = LinearAttention: RMSNorm ->
+        to_qkv -> softmax(q over d), softmax(k over n), (k v^T)^T q (nd_linear_attention_f32) -> to_out.0 -> RMSNorm (+ x)."""
+        if kind == "full":
+            return self._mid_attention(x, h, w, prefix)
+        e, B, Cc, N = self.e, self.B, x.shape[-1], h * w
+        hid = ATTN_HEADS * ATTN_DIM_HEAD
+        xn = self._alloc(B, N, Cc)
+        self._add("nd_rmsnorm_nhwc_f32", x.data_ptr(), Cc, e.p(prefix + ".norm.g"), xn.data_ptr(), Cc, B, N, Cc, e.stream)
+        qkv = self.pw(prefix + ".to_qkv", self._src(xn), Cc, 3 * hid, N, w, bias=False)
+        att = self._alloc(B, N, hid)
+        ws = self._alloc(int(e.lib.nd_linear_attention_workspace_floats(B, N, ATTN_HEADS)))
+        self._add("nd_linear_attention_f32", qkv.data_ptr(), 3 * hid, att.data_ptr(), hid, ws.data_ptr(), B, N, ATTN_HEADS, ATTN_DIM_HEAD, e.stream)
+        o = self.pw(prefix + ".to_out.0", self._src(att), hid, Cc, N, w)
+        y = self._alloc(B, N, Cc)
+        self._add("nd_rmsnorm_add_nhwc_f32", o.data_ptr(), Cc, e.p(prefix + ".to_out.1.g"), x.data_ptr(), Cc, y.data_ptr(), Cc, B, N, Cc, e.stream)
+        self._release(xn, qkv, att, ws, o, x)
         return y.view(B, h, w, Cc)
 
     # ------------------------------------------------------------------ execution

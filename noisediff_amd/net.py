@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .spec import arch_param_spec, arch_traits, attention_param_spec
+from .spec import arch_param_spec, arch_traits, attention_param_spec, normalize_stage_attn, stage_attention_param_spec
 
 
 class _Node(nn.Module):
@@ -54,7 +54,7 @@ def _init(p, gen: Optional[torch.Generator] = None) -> torch.Tensor:
 class NoiseDiffNet(nn.Module):
     ARCH = "NoiseDiffNet"          # subclasses below: the UNet_PosEmbV2* ablation nets of models/archs/others_arch.py
 
-    def __init__(self, args, mid_attn: Optional[bool] = None):
+    def __init__(self, args, mid_attn: Optional[bool] = None, stage_attn=None):
         super().__init__()
         self.dim = int(args.dim)
         if self.dim % 8 or self.dim < 16:
@@ -73,6 +73,13 @@ class NoiseDiffNet(nn.Module):
         spec = list(arch_param_spec(self.ARCH, self.dim, self.channels))
         if self.has_mid_attn:
             spec += attention_param_spec("mid_attn", 8 * self.dim)
+        # SURVEY 8f-3, second half: upstream's per-stage attention (the classes the reference defines, computes the flags for and drops,
+        # Diffusion_arch.py:467-468,509-518): ``args.stage_attn = True`` wires LinearAttention x3 + Attention as the reference's full_attn says
+        self.stage_attn = normalize_stage_attn(getattr(args, "stage_attn", None) if stage_attn is None else stage_attn)
+        if self.stage_attn:
+            if self.ARCH != "NoiseDiffNet":
+                raise ValueError("stage_attn is wired for NoiseDiffNet only")
+            spec += stage_attention_param_spec(self.dim, self.stage_attn)
         for p in spec:
             _attach(self, p.name, nn.Parameter(_init(p)))
         self._engines: Dict[int, object] = {}
@@ -122,7 +129,7 @@ class NoiseDiffNet(nn.Module):
             sig = self._signature()
             eng = self._engines.get(idx)
             if eng is None:
-                eng = Engine(self.dim, device, mid_attn=self.has_mid_attn, inp_dim=self.channels, arch=self.ARCH)
+                eng = Engine(self.dim, device, mid_attn=self.has_mid_attn, inp_dim=self.channels, arch=self.ARCH, stage_attn=self.stage_attn)
                 self._engines[idx] = eng
                 self._engine_sig[idx] = None
             if self._engine_sig[idx] != sig:
@@ -165,9 +172,9 @@ class NoiseDiffNet(nn.Module):
         3x3 convolutions, GroupNorm (+ modulation + SiLU) and LayerNorm forward and backward and the Linear / 1x1 weight gradients on
         the HIP library -- over the reference graph of trainable.py.  The fused sampling engine has no backward, so this path does
         not go through it; like it, it has no CPU fallback."""
-        if self.ARCH != "NoiseDiffNet" or self.has_mid_attn:
+        if self.ARCH != "NoiseDiffNet" or self.has_mid_attn or self.stage_attn:
             raise NotImplementedError(
-                f"noisediff_amd.{self.ARCH}{' with mid_attn' if self.has_mid_attn else ''} implements the inference (sampling) path only; "
+                f"noisediff_amd.{self.ARCH}{' with mid_attn / stage_attn' if self.has_mid_attn or self.stage_attn else ''} implements the inference (sampling) path only; "
                 "call it under torch.no_grad()/inference_mode().  Only the NoiseDiffNet graph has a differentiable HIP path.")
         if x.device.type != "cuda":
             raise L.HipError(f"{self.ARCH} runs on the HIP library only; tensor is on {x.device} and there is no CPU path")

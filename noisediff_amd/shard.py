@@ -34,7 +34,8 @@ def broadcast_weights(net, device: torch.device, src: int = 0, group=None, shape
     packings of every 3x3 weight); with ``shapes`` -- the (batch, height, width) problems this job will run -- only the slices
     those plans read (0.5 GB), and another problem size on a receiving rank then raises instead of reading weights that never arrived."""
     from .engine import Engine
-    eng = Engine(net.dim, device, mid_attn=net.has_mid_attn, inp_dim=net.channels, arch=getattr(net, "ARCH", "NoiseDiffNet"))
+    eng = Engine(net.dim, device, mid_attn=net.has_mid_attn, inp_dim=net.channels, arch=getattr(net, "ARCH", "NoiseDiffNet"),
+                 stage_attn=getattr(net, "stage_attn", None))
     is_src = dist.get_rank(group) == src
     if not packed:
         eng.last_broadcast_bytes = eng.broadcast_state_dict(net.state_dict() if is_src else None, src=src, group=group)

@@ -13,7 +13,7 @@ the reference) pins the list.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Tuple
+from typing import List, Tuple, Optional, Sequence
 
 ISO_TABLE_ROWS = 100      # nn.Embedding(100, 16)      Diffusion_arch.py:486-487
 ISO_DIM = 16
@@ -238,6 +238,52 @@ def attention_param_spec(prefix: str, dim: int, heads: int = 4, dim_head: int = 
         ParamSpec(f"{prefix}.to_out.weight", (dim, hidden, 1, 1), "uniform_fan_in", hidden),
         ParamSpec(f"{prefix}.to_out.bias", (dim,), "uniform_fan_in", hidden),
     ]
+
+
+def linear_attention_param_spec(prefix: str, dim: int, heads: int = 4, dim_head: int = 32) -> List[ParamSpec]:
+    """Standalone ``LinearAttention`` block (Diffusion_arch.py:198-216): RMSNorm, to_qkv (no bias), to_out = conv1x1 + RMSNorm."""
+    hidden = heads * dim_head
+    return [
+        ParamSpec(f"{prefix}.norm.g", (1, dim, 1, 1), "ones"),
+        ParamSpec(f"{prefix}.to_qkv.weight", (hidden * 3, dim, 1, 1), "uniform_fan_in", dim),
+        ParamSpec(f"{prefix}.to_out.0.weight", (dim, hidden, 1, 1), "uniform_fan_in", hidden),
+        ParamSpec(f"{prefix}.to_out.0.bias", (dim,), "uniform_fan_in", hidden),
+        ParamSpec(f"{prefix}.to_out.1.g", (1, dim, 1, 1), "ones"),
+    ]
+
+
+# The reference computes ``full_attn = (False, False, False, True)`` and ``FullAttention`` per stage (Diffusion_arch.py:467-468,509-518) and then
+# drops them; upstream (lucidrains' Unet) wires ``attn_klass = FullAttention if full_attn else LinearAttention`` as the third module of every
+# down and up stage, applied as ``x = attn(x) + x`` behind the stage's second ResnetBlock and in front of the skip.  ``stage_attn`` switches that
+# wiring on (SURVEY 8f-3, second half): None = the reference network as it runs; True = the reference's own tuple.
+STAGE_ATTN_REFERENCE = ("linear", "linear", "linear", "full")
+
+
+def normalize_stage_attn(value) -> Optional[Tuple[Optional[str], ...]]:
+    """None / False -> None; True -> the reference's ``full_attn`` tuple; a 4-tuple of 'linear' / 'full' / None, or of bools with upstream's
+    meaning (False = LinearAttention, True = full Attention)."""
+    if value is None or value is False:
+        return None
+    if value is True:
+        return STAGE_ATTN_REFERENCE
+    kinds = tuple(("full" if v else "linear") if isinstance(v, bool) else v for v in value)
+    if len(kinds) != len(DIM_MULTS) or any(k not in (None, "linear", "full") for k in kinds):
+        raise ValueError(f"stage_attn={value!r}: expected True or {len(DIM_MULTS)} entries of 'linear' / 'full' / None (or upstream's full_attn booleans)")
+    return kinds if any(kinds) else None
+
+
+def stage_attention_param_spec(dim: int, kinds: Sequence[Optional[str]]) -> List[ParamSpec]:
+    """Parameters of the per-stage attention modules: ``down_attns.{i}`` at the stage's input width, ``up_attns.{i}`` (i = 0 the deepest) at
+    its ResnetBlocks' output width -- upstream's ``attn_klass(dim_in)`` / ``attn_klass(dim_out)``."""
+    items: List[ParamSpec] = []
+    dims = stage_dims(dim)
+    for i, k in enumerate(kinds):
+        if k:
+            items += (attention_param_spec if k == "full" else linear_attention_param_spec)(f"down_attns.{i}", dims[i][0])
+    for i, (k, (_, cout)) in enumerate(zip(reversed(tuple(kinds)), reversed(dims))):
+        if k:
+            items += (attention_param_spec if k == "full" else linear_attention_param_spec)(f"up_attns.{i}", cout)
+    return items
 
 
 LSID_STAGES = (32, 64, 128, 256, 512)      # models/archs/SID_arch.py:57-75

@@ -251,15 +251,26 @@ def net_dim(sd: SD) -> int:
 
 def noisediff_forward(sd: SD, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, torch.Tensor],
                       mid_attention: Optional[str] = None,
-                      taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                      taps: Optional[Dict[str, torch.Tensor]] = None, stage_attention=None) -> torch.Tensor:
     """NoiseDiffNet.forward  models/archs/Diffusion_arch.py:577-646.
 
     ``mid_attention``: state-dict prefix of an ``Attention`` block applied as
     ``x = attn(x) + x`` between mid_block1 and mid_block2 (BASELINE config 4; the
     reference computes ``FullAttention`` at :518 but never wires it).
     ``taps``: optional dict that receives named intermediates for module-level tests.
+    ``stage_attention``: four entries 'linear' / 'full' / None -- upstream's per-stage wiring of the ``LinearAttention`` / ``Attention``
+    classes the reference defines and drops (:198-266; flags computed at :467-468,509-518): ``x = attn(x) + x`` behind a stage's second
+    ResnetBlock (in front of the skip), modules ``down_attns.{i}`` / ``up_attns.{i}`` (up stage i uses entry 3 - i).  Pinned by
+    tests/golden/stage_attn.npz (tests/golden/capture_stage_attn.py: forward hooks on the reference net's blocks).
     """
     dim = net_dim(sd)
+
+    def stage_attn(prefix: str, kind, v: torch.Tensor) -> torch.Tensor:
+        if not kind:
+            return v
+        return (attention(sd, prefix, v) if kind == "full" else linear_attention(sd, prefix, v)) + v
+
+    kinds = tuple(stage_attention) if stage_attention else (None,) * 4
     assert x.shape[-1] % 8 == 0 and x.shape[-2] % 8 == 0                      # :578
     clean, position = condition["clean_img"], condition["position"]
     G = 8
@@ -290,7 +301,7 @@ def noisediff_forward(sd: SD, x: torch.Tensor, time: torch.Tensor, condition: Di
     for i in range(4):                                                         # :613-622
         p = f"downs.{i}"
         x = resnet_block(sd, p + ".0", x, t, G); hs.append(x)
-        x = resnet_block(sd, p + ".1", x, t, G); hs.append(x)
+        x = stage_attn(f"down_attns.{i}", kinds[i], resnet_block(sd, p + ".1", x, t, G)); hs.append(x)
         x = attn_block(sd, p + ".2", x, iso)
         x = conv(sd, p + ".3", x, padding=1) if i == 3 else pixel_unshuffle_conv(sd, p + ".3", x)
         tap(f"down{i}", x)
@@ -303,7 +314,7 @@ def noisediff_forward(sd: SD, x: torch.Tensor, time: torch.Tensor, condition: Di
     for i in range(4):                                                         # :627-636
         p = f"ups.{i}"
         x = resnet_block(sd, p + ".0", torch.cat((x, hs.pop()), dim=1), t, G)
-        x = resnet_block(sd, p + ".1", torch.cat((x, hs.pop()), dim=1), t, G)
+        x = stage_attn(f"up_attns.{i}", kinds[3 - i], resnet_block(sd, p + ".1", torch.cat((x, hs.pop()), dim=1), t, G))
         x = attn_block(sd, p + ".2", x, iso)
         x = conv(sd, p + ".3", x, padding=1) if i == 3 else upsample_conv(sd, p + ".3", x)
         tap(f"up{i}", x)
@@ -459,7 +470,7 @@ def sample(sd: SD, condition: Dict[str, torch.Tensor], *, image_size: int, batch
            timesteps: int = 1000, sampling_timesteps: Optional[int] = None,
            beta_schedule_name: str = "sigmoid2", objective: str = "pred_v", eta: float = 0.0,
            x_T: torch.Tensor, noise: NoiseFn, return_all: bool = False,
-           mid_attention: Optional[str] = None, on_step=None) -> torch.Tensor:
+           mid_attention: Optional[str] = None, on_step=None, stage_attention=None) -> torch.Tensor:
     """GaussianDiffusion.sample :446-451 (auto_normalize=False => unnormalize is identity :290-291)."""
     buf = schedule_buffers(beta_schedule_name, timesteps, objective)
     S = timesteps if sampling_timesteps is None else sampling_timesteps
@@ -467,7 +478,7 @@ def sample(sd: SD, condition: Dict[str, torch.Tensor], *, image_size: int, batch
     assert tuple(x_T.shape) == (batch_size, sd["init_conv.weight"].shape[1], image_size, image_size)
 
     def net(x, t):
-        return noisediff_forward(sd, x, t, condition, mid_attention=mid_attention)
+        return noisediff_forward(sd, x, t, condition, mid_attention=mid_attention, stage_attention=stage_attention)
 
     with torch.no_grad():
         if S < timesteps:                                                             # :235,449
