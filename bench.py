@@ -311,7 +311,7 @@ def roofline(a, loop, plan, L, per_step):
     tot_ms = sum(d["ms"] for d in per.values())
     tot_flop = sum(d["flop"] for d in per.values())
     tot_exec = sum(d["flop"] / WINO_FACTOR.get(k[0], 1.0) for k, d in per.items())
-    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}>" if k[0] == 9004 else
+    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, false>" if k[0] == 9004 else
                        f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
                        f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
     tid, d = max(per.items(), key=lambda kv: kv[1]["ms"])
