@@ -108,7 +108,8 @@ int nd_conv3x3_tiling_id(int B, int H, int W, int cout);
 /* OIHW (cout,cin,3,3) -> [tap][cin/4][coutP][4], coutP = cout rounded up to 64; zero padded. */
 int64_t nd_pack_conv3x3_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
-/* training: the same packing of the DATA-GRADIENT operator of a layer, read in place from the forward layer's OIHW weight
+/* training (loss.backward() of p_losses, models/trainer_diffusion.py:187): the same packing of the DATA-GRADIENT operator of a layer
+ * (nn.Conv2d(cin, cout, 3, padding=1), Diffusion_arch.py:131), read in place from the forward layer's OIHW weight
  * `oihw_fwd` (cout x cin there = cin x cout here): g'[co][ci][r][s] = oihw_fwd[ci][co][2 - r][2 - s].  `cin`, `cout` are the
  * data-gradient convolution's (cin = the forward layer's cout).  Likewise for the two Winograd packings below. */
 int nd_pack_conv3x3_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream);
@@ -138,7 +139,9 @@ int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream);
-/* Split-K form of nd_conv3x3_wino4_nhwc_f32 for plain sources without a statistics epilogue (training at small batch: 512 -> 512 at
+/* Split-K form of nd_conv3x3_wino4_nhwc_f32 for plain sources without a statistics epilogue -- the forward and data-gradient convolutions of
+ * Block.proj under GaussianDiffusion.p_losses (models/archs/Diffusion_arch.py:128-144; models/denoising_diffusion_pytorch.py:481-531) at
+ * training batch sizes (512 -> 512 at
  * 32 x 32 with 4 samples is 64 workgroup items for 256 CUs, each walking 32 K chunks): cin is cut into `splits` ranges (2, 4 or 8; whole
  * 16-channel chunks, at least two per range), every (range, sample, region, cout tile) is a workgroup item that writes partial sums to
  * `workspace` ([splits][B][H][W][cout] floats), and a second kernel adds them in range order and the bias into d->out.  _plan returns the
@@ -238,7 +241,8 @@ int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream);
  * permutes K from (c p1 p2) to (p1 p2 c) for a pixel-unshuffled input with c = unshuffle_c. */
 int64_t nd_pack_pointwise_weight_floats(int cin, int cout);
 int nd_pack_pointwise_weight(const float* w, float* packed, int cin, int cout, int unshuffle_c, void* stream);
-/* training: the packing of the DATA-GRADIENT operator dx = dy @ W of a Linear / 1x1 convolution, read in place from its forward weight
+/* training: the packing of the DATA-GRADIENT operator dx = dy @ W of a Linear / 1x1 convolution (res_conv, Mlp.fc1 / fc2, FeedForward:
+ * Diffusion_arch.py:156,345-347,410-419), read in place from its forward weight
  * `w_t` ((cin, cout) row-major here = torch's (out_features, in_features) of the forward layer; cin = the forward layer's cout). */
 int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cout, void* stream);
 
