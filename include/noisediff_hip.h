@@ -183,12 +183,25 @@ int nd_groupnorm_train_backward_f32(const float* dy, int lddy, const float* x, i
  * `dscale_shift` [B][2C] (NULL iff scale_shift is NULL).  Two passes over the tensor per direction (the separate ops take four and seven).
  * `workspace`: nd_groupnorm_silu_train_workspace_floats(B, HW, C) floats. */
 int64_t nd_groupnorm_silu_train_workspace_floats(int B, int HW, int C);
-int nd_groupnorm_silu_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, const float* scale_shift, float* y, int ldy,
-                                        float* mean_rstd, float* mad, float* workspace, int B, int HW, int C, int groups, float eps, void* stream);
+int nd_groupnorm_silu_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, const float* scale_shift, const float* res, int ldr,
+                                        float* y, int ldy, float* mean_rstd, float* mad, float* workspace, int B, int HW, int C, int groups, float eps,
+                                        void* stream);   /* res (may be NULL): + the ResnetBlock's shortcut, h + res_conv(x) (Diffusion_arch.py:170), in the same pass */
 int nd_groupnorm_silu_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
                                          const float* scale_shift, const float* mean_rstd, const float* mad, float* dx, int lddx,
                                          float* dgamma, float* dbeta, float* dscale_shift, float* workspace, int B, int HW, int C, int groups,
                                          void* stream);
+
+/* ResnetBlock2's modulation + activation for training (Diffusion_arch.py:173-196: scale / shift are per-pixel MAPS from the position
+ * embedding): y = silu(n * (scale + 1) + shift), n [N][>= C] the GroupNorm's output, map [N][>= 2C] = scale | shift as ResnetBlock2.mlp emits it.
+ * Backward: dn, and dmap [N][2C] = d scale | d shift, one pass each (the separate ops take four and five). */
+int nd_modulate_silu_forward_f32(const float* n, int ldn, const float* map, int ldm, float* y, int ldy, int64_t N, int C, void* stream);
+int nd_modulate_silu_backward_f32(const float* dy, int lddy, const float* n, int ldn, const float* map, int ldm, float* dn, int lddn, float* dmap, int lddm,
+                                  int64_t N, int C, void* stream);
+
+/* out[b][c] = sum over the HW tokens of x[b][p][c]: the gradient of a per-sample vector broadcast over the tokens -- AttnBlock's one-token ISO
+ * cross attention adds to_out(to_v(ctx)) to every token (Diffusion_arch.py:435-437).  Fixed order; workspace: nd_token_sum_workspace_floats. */
+int64_t nd_token_sum_workspace_floats(int B, int HW, int C);
+int nd_token_sum_f32(const float* x, int ldx, float* out, float* workspace, int B, int HW, int C, void* stream);
 
 /* nn.LayerNorm(C) over the channels of NHWC tokens for training (AttnBlock.norm1 / norm2, Diffusion_arch.py:427-428): forward
  * y = (x - mean) rstd gamma + beta with `stats` [N][2] = {mean, rstd} per token saved for the backward; backward dx, dgamma [C],

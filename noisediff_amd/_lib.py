@@ -92,7 +92,11 @@ SIGNATURES = {
     "nd_groupnorm_train_workspace_floats": (i64, [i32, i32, i32]),
     "nd_linear_wgrad_workspace_floats": (i64, [i64, i32, i32]),
     "nd_groupnorm_silu_train_workspace_floats": (i64, [i32, i32, i32]),
-    "nd_groupnorm_silu_train_forward_f32": (i32, [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]),
+    "nd_groupnorm_silu_train_forward_f32": (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]),
+    "nd_token_sum_workspace_floats": (i64, [i32, i32, i32]),
+    "nd_token_sum_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
+    "nd_modulate_silu_forward_f32": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, vp]),
+    "nd_modulate_silu_backward_f32": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]),
     "nd_groupnorm_silu_train_backward_f32": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_layernorm_train_workspace_floats": (i64, [i64, i32]),
     "nd_layernorm_train_forward_f32": (i32, [vp, i32, vp, vp, vp, i32, vp, i64, i32, C.c_float, vp]),
@@ -150,7 +154,7 @@ SIGNATURES = {
 
 _UNCHECKED = {"nd_version", "nd_last_error", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
               "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats", "nd_conv3x3_wino_stat_slots", "nd_conv3x3_wino4_stat_slots",
-              "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
+              "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_token_sum_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
               "nd_groupnorm_train_workspace_floats", "nd_linear_wgrad_workspace_floats",
               "nd_layernorm_train_workspace_floats", "nd_groupnorm_silu_train_workspace_floats"}
 

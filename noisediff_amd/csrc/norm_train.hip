@@ -18,7 +18,10 @@
 
 namespace {
 
-constexpr int GT_SLOTS_MAX = 64;
+#ifndef GT_SLOTS_MAX_N
+#define GT_SLOTS_MAX_N 256       // pixel slots per sample of the partial-sum passes (64 in r2: 4 x 64 workgroups at B = 4 streamed a 256 x 256 x 64 tensor at 1.7 TB/s)
+#endif
+constexpr int GT_SLOTS_MAX = GT_SLOTS_MAX_N;
 
 __host__ __device__ inline int gt_slots(int HW) { return HW >= 64 * GT_SLOTS_MAX ? GT_SLOTS_MAX : (HW + 63) / 64; }
 
@@ -102,9 +105,11 @@ __device__ __forceinline__ void gt_channel_totals(const float* __restrict__ part
 }
 
 // one workgroup per (sample, group)
+// (ss != null: the time embedding's per-(sample, channel) scale | shift folded into A and D: what gs_mad_kernel computed in a launch of its own)
 __global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const float* __restrict__ part, int slots, int HW, const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float* __restrict__ mean_rstd, float* __restrict__ mad, int C, int G, float eps) {
+                                                             float* __restrict__ mean_rstd, float* __restrict__ mad, int C, int G, float eps,
+                                                             const float* __restrict__ ss = nullptr) {
     __shared__ double tot[2][512], red[2][256], stat[2];
     const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G, tid = threadIdx.x;
     gt_channel_totals(part, slots, C, b, g, cpg, tot, red);
@@ -128,7 +133,8 @@ __global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const float* __res
     for (int i = tid; i < cpg; i += 256) {
         const int c = g * cpg + i;
         float* o = mad + (size_t)b * 3 * C + c;
-        o[0] = fmean;  o[C] = rstd * gamma[c];  o[2 * C] = beta[c];
+        const float s1 = ss ? ss[(size_t)b * 2 * C + c] + 1.0f : 1.0f, h = ss ? ss[(size_t)b * 2 * C + C + c] : 0.0f;
+        o[0] = fmean;  o[C] = rstd * gamma[c] * s1;  o[2 * C] = beta[c] * s1 + h;
     }
 }
 
@@ -540,9 +546,10 @@ __global__ __launch_bounds__(256) void gs_bwd_finalize_kernel(const float* __res
     }
 }
 
-// mode 0: y = silu((x - M) A + D);  mode 1: dx = dm A + x c1 + c2 with dm recomputed from (dy, x)
+// mode 0: y = silu((x - M) A + D) (+ res: the ResnetBlock's shortcut, Diffusion_arch.py:170);  mode 1: dx = dm A + x c1 + c2 with dm recomputed from (dy, x)
 __global__ __launch_bounds__(256) void gs_apply_kernel(const float* __restrict__ u, int ldu, const float* __restrict__ x, int ldx, const float* __restrict__ mad,
-                                                      const float* __restrict__ coef, float* __restrict__ out, int ldo, int B, int HW, int C, int mode) {
+                                                      const float* __restrict__ coef, float* __restrict__ out, int ldo, int B, int HW, int C, int mode,
+                                                      const float* __restrict__ res = nullptr, int ldr = 0) {
     const int cq = C >> 2;
     const size_t total = (size_t)B * HW * cq;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -553,8 +560,10 @@ __global__ __launch_bounds__(256) void gs_apply_kernel(const float* __restrict__
         const f32x4 M = nd_ld4(m), A = nd_ld4(m + C), D = nd_ld4(m + 2 * C);
         const f32x4 xv = nd_ld4(x + pix * ldx + 4 * q), xc = xv - M, mm = xc * A + D;
         f32x4 r;
-        if (mode == 0) r = nd_silu4(mm);
-        else {
+        if (mode == 0) {
+            r = nd_silu4(mm);
+            if (res) r += nd_ld4(res + pix * ldr + 4 * q);
+        } else {
             const float* cf = coef + (size_t)b * 2 * C + 4 * q;
             r = gs_dsilu(nd_ld4(u + pix * ldu + 4 * q), mm) * A + xv * nd_ld4(cf) + nd_ld4(cf + C);
         }
@@ -575,22 +584,22 @@ extern "C" int64_t nd_groupnorm_silu_train_workspace_floats(int B, int HW, int C
     return (int64_t)B * gt_slots(HW) * C * 2 + (int64_t)B * 3 * C + (int64_t)B * 2 * C + (int64_t)B * C * 2;
 }
 
-extern "C" int nd_groupnorm_silu_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, const float* scale_shift, float* y, int ldy,
-                                                   float* mean_rstd, float* mad, float* workspace, int B, int HW, int C, int groups, float eps, void* stream) {
+extern "C" int nd_groupnorm_silu_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, const float* scale_shift, const float* res, int ldr,
+                                                   float* y, int ldy, float* mean_rstd, float* mad, float* workspace, int B, int HW, int C, int groups, float eps,
+                                                   void* stream) {
     ND_REQUIRE(x && gamma && beta && y && mean_rstd && mad && workspace, ND_E_BADARG, "nd_groupnorm_silu_train_forward: null pointer");
     if (int e = gs_check("nd_groupnorm_silu_train_forward", B, HW, C, groups)) return e;
     ND_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && nd_aligned16(x) && nd_aligned16(y) && nd_aligned16(workspace) && nd_aligned16(mad),
                ND_E_ALIGN, "nd_groupnorm_silu_train_forward: strides must be multiples of 4 floats >= C, pointers 16-byte aligned");
+    ND_REQUIRE(!res || (ldr >= C && ldr % 4 == 0 && nd_aligned16(res)), ND_E_ALIGN, "nd_groupnorm_silu_train_forward: the residual's stride / alignment");
     const int slots = gt_slots(HW);
     float* part = workspace;
-    float* mad0 = workspace + (size_t)B * slots * C * 2;          // the plain norm's coefficients (scratch)
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partials_kernel, dim3(B * slots), dim3(256), 0, st, x, ldx, x, ldx, 0, part, HW, C, slots);
-    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, part, slots, HW, x, ldx, gamma, beta, mean_rstd, mad0, C, groups, eps);
-    hipLaunchKernelGGL(gs_mad_kernel, dim3(nd_cdiv(B * C, 256)), dim3(256), 0, st, mean_rstd, gamma, beta, scale_shift, mad, B, C, groups);
+    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, part, slots, HW, x, ldx, gamma, beta, mean_rstd, mad, C, groups, eps, scale_shift);
     const size_t total = (size_t)B * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(gs_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, x, ldx, mad, mad, y, ldy, B, HW, C, 0);
+    hipLaunchKernelGGL(gs_apply_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, x, ldx, mad, mad, y, ldy, B, HW, C, 0, res, ldr);
     return nd_launch_status("nd_groupnorm_silu_train_forward_f32");
 }
 
@@ -617,4 +626,94 @@ extern "C" int nd_groupnorm_silu_train_backward_f32(const float* dy, int lddy, c
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(gs_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mad, coef, dx, lddx, B, HW, C, 1);
     return nd_launch_status("nd_groupnorm_silu_train_backward_f32");
+}
+
+
+// ---- per-pixel modulation + SiLU (ResnetBlock2, Diffusion_arch.py:173-196: scale / shift are MAPS from the position embedding):
+//      y = silu(n (s + 1) + t) with n [N][C] (the GroupNorm's output) and map [N][2C] = s | t.  Backward: g = dy dsilu(m), dn = g (s + 1), ds = g n, dt = g.
+namespace {
+
+__global__ __launch_bounds__(256) void modsilu_kernel(const float* __restrict__ n, int ldn, const float* __restrict__ map, int ldm, const float* __restrict__ dy, int lddy,
+                                                     float* __restrict__ out, int ldo, float* __restrict__ dmap, int lddm, size_t N, int C) {
+    const int cq = C >> 2;
+    const size_t total = N * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const size_t p = i / cq;
+        const f32x4 nv = nd_ld4(n + p * ldn + 4 * q), s1 = nd_ld4(map + p * ldm + 4 * q) + 1.0f, t = nd_ld4(map + p * ldm + C + 4 * q);
+        const f32x4 m = nv * s1 + t;
+        if (!dy) nd_st4(out + p * ldo + 4 * q, nd_silu4(m));
+        else {
+            const f32x4 g = gs_dsilu(nd_ld4(dy + p * lddy + 4 * q), m);
+            nd_st4(out + p * ldo + 4 * q, g * s1);
+            nd_st4(dmap + p * lddm + 4 * q, g * nv);
+            nd_st4(dmap + p * lddm + C + 4 * q, g);
+        }
+    }
+}
+
+int modsilu_check(const char* who, const void* a, const void* b, const void* c, int ld0, int ld1, int ld2, int64_t N, int C) {
+    ND_REQUIRE(a && b && c, ND_E_BADARG, "%s: null pointer", who);
+    ND_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && ld0 >= C && ld2 >= C && ld1 >= 2 * C && ld0 % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0, ND_E_SHAPE,
+               "%s: C=%d (multiple of 4), strides multiples of 4 (tensor >= C, map >= 2C)", who, C);
+    ND_REQUIRE(nd_aligned16(a) && nd_aligned16(b) && nd_aligned16(c), ND_E_ALIGN, "%s: pointers must be 16-byte aligned", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int nd_modulate_silu_forward_f32(const float* n, int ldn, const float* map, int ldm, float* y, int ldy, int64_t N, int C, void* stream) {
+    if (int e = modsilu_check("nd_modulate_silu_forward", n, map, y, ldn, ldm, ldy, N, C)) return e;
+    const size_t total = (size_t)N * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(modsilu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, ldn, map, ldm, (const float*)nullptr, 0, y, ldy, (float*)nullptr, 0, (size_t)N, C);
+    return nd_launch_status("nd_modulate_silu_forward_f32");
+}
+
+extern "C" int nd_modulate_silu_backward_f32(const float* dy, int lddy, const float* n, int ldn, const float* map, int ldm, float* dn, int lddn, float* dmap, int lddm,
+                                             int64_t N, int C, void* stream) {
+    if (int e = modsilu_check("nd_modulate_silu_backward", n, map, dn, ldn, ldm, lddn, N, C)) return e;
+    ND_REQUIRE(dy && dmap && lddy >= C && lddy % 4 == 0 && lddm >= 2 * C && lddm % 4 == 0 && nd_aligned16(dy) && nd_aligned16(dmap), ND_E_BADARG,
+               "nd_modulate_silu_backward: dy / dmap pointer, stride or alignment");
+    const size_t total = (size_t)N * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(modsilu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, ldn, map, ldm, dy, lddy, dn, lddn, dmap, lddm, (size_t)N, C);
+    return nd_launch_status("nd_modulate_silu_backward_f32");
+}
+
+// ---- out[b][c] = sum over the HW tokens of x[b][p][c]: the gradient of a per-sample vector that was broadcast over the tokens (the one-token ISO
+//      cross attention's output, AttnBlock: Diffusion_arch.py:435-437).  gn_partials_kernel's sum (mode 1, second component) per (sample, slot, channel),
+//      then the slots in order (fp64): bitwise repeatable.  ATen's reduction of a (4, 65536, 64) tensor over its middle dimension takes 93 us.
+namespace {
+// block = 16 channels of a sample x 16 stripes of slots; the stripes meet in order (one thread per output and all slots: 40 us of dependent loads)
+__global__ __launch_bounds__(256) void token_sum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int slots, int B, int C) {
+    __shared__ double red[16][16];
+    const int cl = threadIdx.x & 15, stripe = threadIdx.x >> 4;
+    const int per = (C + 15) / 16, b = blockIdx.x / per, c = (blockIdx.x % per) * 16 + cl;
+    double acc = 0.0;
+    if (c < C)
+        for (int s = stripe; s < slots; s += 16) acc += (double)part[(((size_t)b * slots + s) * C + c) * 2 + 1];
+    red[stripe][cl] = acc;
+    __syncthreads();
+    if (stripe == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) acc += red[k][cl];
+        out[(size_t)b * C + c] = (float)acc;
+    }
+}
+}  // namespace
+
+extern "C" int64_t nd_token_sum_workspace_floats(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return -1;
+    return (int64_t)B * gt_slots(HW) * C * 2;
+}
+
+extern "C" int nd_token_sum_f32(const float* x, int ldx, float* out, float* workspace, int B, int HW, int C, void* stream) {
+    ND_REQUIRE(x && out && workspace, ND_E_BADARG, "nd_token_sum: null pointer");
+    ND_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx >= C && ldx % 4 == 0, ND_E_SHAPE, "nd_token_sum: C=%d (multiple of 4, <= 1024), stride", C);
+    ND_REQUIRE(nd_aligned16(x) && nd_aligned16(workspace), ND_E_ALIGN, "nd_token_sum: x and the workspace must be 16-byte aligned");
+    const int slots = gt_slots(HW);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partials_kernel, dim3(B * slots), dim3(256), 0, st, x, ldx, x, ldx, 1, workspace, HW, C, slots);
+    hipLaunchKernelGGL(token_sum_reduce_kernel, dim3(B * nd_cdiv(C, 16)), dim3(256), 0, st, workspace, out, slots, B, C);
+    return nd_launch_status("nd_token_sum_f32");
 }

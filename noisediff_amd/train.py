@@ -212,9 +212,10 @@ class GroupNormSiLUFunction(torch.autograd.Function):
     (norm_train.hip); ``scale_shift`` is the (B, 2C) output of ResnetBlock.mlp (scale | shift) or None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale_shift, groups, eps):
+    def forward(ctx, x, weight, bias, scale_shift, res, groups, eps):
         lib = L.load()
         xn = _nhwc(x)
+        rn = None if res is None else _nhwc(res)
         if xn.device.type != "cuda":
             raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {xn.device} and there is no CPU path")
         B, C_, H, W = xn.shape
@@ -226,9 +227,10 @@ class GroupNormSiLUFunction(torch.autograd.Function):
             ws = torch.empty(int(lib.nd_groupnorm_silu_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
             w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
             L.call("nd_groupnorm_silu_train_forward_f32", xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), None if ss is None else ss.data_ptr(),
-                   y.data_ptr(), C_, mean_rstd.data_ptr(), mad.data_ptr(), ws.data_ptr(), B, H * W, C_, groups, float(eps), _stream())
+                   None if rn is None else rn.data_ptr(), C_, y.data_ptr(), C_, mean_rstd.data_ptr(), mad.data_ptr(), ws.data_ptr(), B, H * W, C_, groups, float(eps), _stream())
         ctx.save_for_backward(xn, weight, bias, mean_rstd, mad, ss if ss is not None else mean_rstd.new_empty(0))
         ctx.groups, ctx.has_ss, ctx.ss_shape = groups, ss is not None, None if scale_shift is None else scale_shift.shape
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -248,18 +250,89 @@ class GroupNormSiLUFunction(torch.autograd.Function):
             L.call("nd_groupnorm_silu_train_backward_f32", g.data_ptr(), C_, xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(),
                    ss.data_ptr() if ctx.has_ss else None, mean_rstd.data_ptr(), mad.data_ptr(), dx.data_ptr(), C_, dgamma.data_ptr(), dbeta.data_ptr(),
                    dss.data_ptr() if ctx.has_ss else None, ws.data_ptr(), B, H * W, C_, ctx.groups, _stream())
-        return dx, dgamma, dbeta, (dss.view(ctx.ss_shape) if ctx.has_ss else None), None, None
+        return dx, dgamma, dbeta, (dss.view(ctx.ss_shape) if ctx.has_ss else None), (grad_out if ctx.has_res else None), None, None
 
 
 def group_norm_silu(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.Tensor, scale_shift: Optional[torch.Tensor] = None,
-                    eps: float = 1e-5) -> torch.Tensor:
-    """Differentiable silu(F.group_norm(x, groups, weight, bias, eps) * (scale + 1) + shift), scale | shift = the halves of ``scale_shift``
-    ((B, 2C) or (B, 2C, 1, 1)), on the HIP library."""
+                    eps: float = 1e-5, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable silu(F.group_norm(x, groups, weight, bias, eps) * (scale + 1) + shift) (+ res), scale | shift = the halves of ``scale_shift``
+    ((B, 2C) or (B, 2C, 1, 1)), on the HIP library; ``res`` (x's shape): the ResnetBlock's shortcut added in the same pass (Diffusion_arch.py:170)."""
     if x.dim() != 4 or x.shape[1] % groups or x.shape[1] % 4 or x.shape[1] > 1024 or weight is None or bias is None:
         raise ValueError(f"group_norm_silu: x {tuple(x.shape)}, groups {groups}: needs a 4-D input, C a multiple of 4 and of groups (<= 1024), affine parameters")
     if scale_shift is not None and scale_shift.numel() != x.shape[0] * 2 * x.shape[1]:
         raise ValueError(f"group_norm_silu: scale_shift {tuple(scale_shift.shape)} is not (B, 2C) for x {tuple(x.shape)}")
-    return GroupNormSiLUFunction.apply(x, weight, bias, scale_shift, groups, eps)
+    if res is not None and res.shape != x.shape:
+        raise ValueError(f"group_norm_silu: res {tuple(res.shape)} does not match x {tuple(x.shape)}")
+    return GroupNormSiLUFunction.apply(x, weight, bias, scale_shift, res, groups, eps)
+
+
+class BroadcastAddFunction(torch.autograd.Function):
+    """tokens (B, N, C) + vec (B, 1, C): AttnBlock's one-token cross attention adds the same vector to every token (Diffusion_arch.py:435-437).  The
+    gradient of ``vec`` is a sum over the tokens: nd_token_sum_f32 (fixed order) instead of ATen's reduction over a middle dimension."""
+
+    @staticmethod
+    def forward(ctx, tokens, vec):
+        ctx.vec_shape = vec.shape
+        return tokens + vec
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        lib = L.load()
+        B, N, C_ = grad_out.shape
+        g = grad_out if grad_out.is_contiguous() and grad_out.dtype == torch.float32 else grad_out.float().contiguous()
+        grad_vec = None
+        if ctx.needs_input_grad[1]:
+            with _on(g.device):
+                grad_vec = torch.empty((B, C_), dtype=torch.float32, device=g.device)
+                ws = torch.empty(int(lib.nd_token_sum_workspace_floats(B, N, C_)), dtype=torch.float32, device=g.device)
+                L.call("nd_token_sum_f32", g.data_ptr(), C_, grad_vec.data_ptr(), ws.data_ptr(), B, N, C_, _stream(g.device))
+            grad_vec = grad_vec.view(ctx.vec_shape)
+        return grad_out, grad_vec
+
+
+def broadcast_add(tokens: torch.Tensor, vec: torch.Tensor) -> torch.Tensor:
+    """tokens (B, N, C) + vec (B, 1, C) with the token sum of the backward on the HIP library (C a multiple of 4, <= 1024; CUDA tensors)."""
+    if tokens.dim() != 3 or vec.shape != (tokens.shape[0], 1, tokens.shape[2]) or tokens.shape[2] % 4 or tokens.shape[2] > 1024 or not tokens.is_cuda:
+        return tokens + vec
+    return BroadcastAddFunction.apply(tokens, vec)
+
+
+class ModulateSiLUFunction(torch.autograd.Function):
+    """y = silu(n * (scale + 1) + shift) with per-pixel maps (ResnetBlock2, Diffusion_arch.py:188-192): ``n`` (B, C, H, W) the GroupNorm's output,
+    ``ss`` (B, 2C, H, W) = scale | shift as ResnetBlock2.mlp emits it; one pass forward, one backward (nd_modulate_silu_*_f32)."""
+
+    @staticmethod
+    def forward(ctx, n, ss):
+        nn_, sn = _nhwc(n), _nhwc(ss)
+        if nn_.device.type != "cuda":
+            raise L.HipError(f"noisediff_amd.train runs on the HIP library only; tensor is on {nn_.device} and there is no CPU path")
+        B, C_, H, W = nn_.shape
+        with _on(nn_.device):
+            y = torch.empty_like(nn_, memory_format=torch.channels_last)
+            L.call("nd_modulate_silu_forward_f32", nn_.data_ptr(), C_, sn.data_ptr(), 2 * C_, y.data_ptr(), C_, B * H * W, C_, _stream(nn_.device))
+        ctx.save_for_backward(nn_, sn)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        nn_, sn = ctx.saved_tensors
+        g = _nhwc(grad_out)
+        B, C_, H, W = nn_.shape
+        with _on(nn_.device):
+            dn = torch.empty_like(nn_, memory_format=torch.channels_last)
+            dss = torch.empty_like(sn, memory_format=torch.channels_last)
+            L.call("nd_modulate_silu_backward_f32", g.data_ptr(), C_, nn_.data_ptr(), C_, sn.data_ptr(), 2 * C_, dn.data_ptr(), C_, dss.data_ptr(), 2 * C_,
+                   B * H * W, C_, _stream(nn_.device))
+        return dn, dss
+
+
+def modulate_silu(n: torch.Tensor, scale_shift: torch.Tensor) -> torch.Tensor:
+    """Differentiable silu(n * (scale + 1) + shift), scale | shift = the channel halves of the per-pixel map ``scale_shift`` (B, 2C, H, W)."""
+    if n.dim() != 4 or scale_shift.dim() != 4 or scale_shift.shape != (n.shape[0], 2 * n.shape[1], n.shape[2], n.shape[3]) or n.shape[1] % 4:
+        raise ValueError(f"modulate_silu: n {tuple(n.shape)} / scale_shift {tuple(scale_shift.shape)}: needs (B, C, H, W) and (B, 2C, H, W), C a multiple of 4")
+    return ModulateSiLUFunction.apply(n, scale_shift)
 
 
 def _group_norm_ok(channels: int, groups: int) -> bool:
@@ -475,7 +548,7 @@ def _hip_block_forward(self, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
     scale, shift = scale_shift
     if scale.numel() == x.shape[0] * x.shape[1] and shift.numel() == scale.numel():              # (B, C, 1, 1): the time embedding's
         return group_norm_silu(x, n.num_groups, n.weight, n.bias, torch.cat((scale.reshape(x.shape[0], -1), shift.reshape(x.shape[0], -1)), 1), n.eps)
-    return self.act(self.norm(x) * (scale + 1) + shift)                                           # per-pixel maps (ResnetBlock2): unfused
+    return self.act(self.norm(x) * (scale + 1) + shift)                                           # per-pixel maps (ResnetBlock2): unfused here; trainable.py fuses them (modulate_silu)
 
 
 def _eligible(m: nn.Module) -> bool:

@@ -67,19 +67,23 @@ class _Ops:
         return F.layer_norm(x, x.shape[-1:], w, b, eps=1e-5)
 
     # ---- composite layers ------------------------------------------------------------------------------------------
-    def block(self, name: str, x, groups: int, ss=None):
+    def block(self, name: str, x, groups: int, ss=None, res=None):
         """Block: conv3x3 -> GroupNorm -> optional x (scale + 1) + shift -> SiLU   (Diffusion_arch.py:128-144); ``ss`` = scale | shift
         along dim 1: (B, 2C, 1, 1) from the time embedding or (B, 2C, H, W) per-pixel maps."""
         x = self.conv(name + ".proj", x, 1)
         from . import train
         if (self.hip and x.is_cuda and train._group_norm_ok(x.shape[1], groups)
-                and (ss is None or ss.numel() == x.shape[0] * 2 * x.shape[1])):  # norm, per-sample modulation and SiLU as one operator
-            return train.group_norm_silu(x, groups, self.p[name + ".norm.weight"], self.p[name + ".norm.bias"], ss, 1e-5)
+                and (ss is None or ss.numel() == x.shape[0] * 2 * x.shape[1])):  # norm, per-sample modulation, SiLU (and the block's shortcut) as one operator
+            return train.group_norm_silu(x, groups, self.p[name + ".norm.weight"], self.p[name + ".norm.bias"], ss, 1e-5, res=res)
         x = self.group_norm(name + ".norm", x, groups)
-        if ss is not None:
-            scale, shift = ss.chunk(2, dim=1)
-            x = x * (scale + 1) + shift
-        return F.silu(x)
+        if ss is not None and self.hip and x.is_cuda and x.shape[1] % 4 == 0 and ss.shape == (x.shape[0], 2 * x.shape[1]) + tuple(x.shape[2:]):
+            x = train.modulate_silu(x, ss)                                      # per-pixel maps (ResnetBlock2): modulation + SiLU as one operator
+        else:
+            if ss is not None:
+                scale, shift = ss.chunk(2, dim=1)
+                x = x * (scale + 1) + shift
+            x = F.silu(x)
+        return x if res is None else x + res
 
     def resnet(self, name: str, x, emb, groups: int, per_pixel: bool = False):
         """ResnetBlock (per-sample scale / shift from the time embedding, :146-170) and ResnetBlock2 (per-pixel maps from the
@@ -87,8 +91,8 @@ class _Ops:
         ss = None
         if emb is not None:
             ss = self.conv(name + ".mlp.1", F.silu(emb)) if per_pixel else self.linear(name + ".mlp.1", F.silu(emb))[:, :, None, None]
-        h = self.block(name + ".block2", self.block(name + ".block1", x, groups, ss), groups)
-        return h + (self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x)
+        res = self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x
+        return self.block(name + ".block2", self.block(name + ".block1", x, groups, ss), groups, res=res)      # block2(...) + res, the add inside block2's fused tail
 
     def mlp(self, name: str, x):
         """Mlp: conv1x1 -> GELU -> conv1x1   (:340-356)."""
@@ -118,7 +122,12 @@ class _Ops:
         t = x.flatten(2).transpose(1, 2)
         if ctx.shape[1] == 1:                                                # norm1 feeds only the (dead) queries: skipped, its gradient is zero
             dead = (self.p[name + ".norm1.weight"].sum() + self.p[name + ".norm1.bias"].sum()) * 0.0
-            t = self.cross_attention(name + ".attn", t, ctx) + dead + t
+            vec = self.cross_attention(name + ".attn", t, ctx) + dead                  # (b, 1, C): the same vector for every token
+            if self.hip and t.is_cuda:
+                from . import train
+                t = train.broadcast_add(t, vec)                                     # its gradient: a token sum on the library (fixed order)
+            else:
+                t = vec + t
         else:
             t = self.cross_attention(name + ".attn", self.layer_norm(name + ".norm1", t), ctx) + t
         t = self.linear(name + ".ff.net.2", F.gelu(self.linear(name + ".ff.net.0.0", self.layer_norm(name + ".norm2", t)))) + t
@@ -146,6 +155,8 @@ def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, 
     shot = o.mlp("shot_mlp3", o.resnet("shot_time", s, t, POS_GROUPS) + s0)
 
     x = o.conv("init_conv", x, 3)
+    if o.hip and x.is_cuda:                     # MIOpen answers the 4-channel NCHW input in NCHW: one conversion here instead of one in every consumer of the stem
+        x = x.contiguous(memory_format=torch.channels_last)       # (pos_block1's conv, its shortcut, the final concat and both of that concat's readers)
     stem = x
     x = o.resnet("pos_block1", x, pos, POS_GROUPS, per_pixel=True)
     skips: List[torch.Tensor] = []

@@ -120,6 +120,58 @@ def test_wino4_split_k_equals_the_plain_kernel_and_torch(case):
         L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), want, st)
 
 
+def test_modulate_silu_and_the_fused_shortcut_match_torch():
+    """train.modulate_silu (ResnetBlock2's per-pixel modulation + SiLU, forward and backward) and group_norm_silu(..., res=) against the same
+    expressions in torch (float64 reference)."""
+    B, C_, H, W = 2, 64, 24, 20
+    n = U("ms.n", (B, C_, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
+    ss = U("ms.ss", (B, 2 * C_, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = U("ms.g", (B, C_, H, W)).to(DEV)
+    na, sa = n.clone().requires_grad_(), ss.clone().requires_grad_()
+    y = train.modulate_silu(na, sa)
+    y.backward(gy)
+    nd, sd = n.double().requires_grad_(), ss.double().requires_grad_()
+    sc, sh = sd.chunk(2, dim=1)
+    yr = F.silu(nd * (sc + 1) + sh)
+    yr.backward(gy.double())
+    for name, got, ref in (("y", y, yr), ("dn", na.grad, nd.grad), ("dss", sa.grad, sd.grad)):
+        assert rel_err(got.detach().cpu().numpy(), ref.detach().float().cpu().numpy()) < 2e-6, name
+    with pytest.raises(ValueError):
+        train.modulate_silu(n, ss[:, :C_])
+    # the ResnetBlock's shortcut inside the fused norm + SiLU operator
+    x = U("ms.x", (B, C_, H, W)).to(DEV)
+    res = U("ms.res", (B, C_, H, W)).to(DEV)
+    gam, bet = U("ms.gam", (C_,), 0.5, 1.5).to(DEV), U("ms.bet", (C_,)).to(DEV)
+    tss = U("ms.tss", (B, 2 * C_)).to(DEV)
+    xa, ra, ga, ba, ta = (t.clone().requires_grad_() for t in (x, res, gam, bet, tss))
+    y = train.group_norm_silu(xa, 8, ga, ba, ta, 1e-5, res=ra)
+    y.backward(gy)
+    xd, rd, gd_, bd, td = (t.double().requires_grad_() for t in (x, res, gam, bet, tss))
+    sc, sh = td[:, :, None, None].chunk(2, dim=1)
+    yr = F.silu(F.group_norm(xd, 8, gd_, bd, 1e-5) * (sc + 1) + sh) + rd
+    yr.backward(gy.double())
+    for name, got, ref in (("y", y, yr), ("dx", xa.grad, xd.grad), ("dres", ra.grad, rd.grad), ("dgamma", ga.grad, gd_.grad), ("dbeta", ba.grad, bd.grad),
+                           ("dss", ta.grad, td.grad)):
+        assert rel_err(got.detach().cpu().numpy(), ref.detach().float().cpu().numpy()) < 2e-5, name
+
+
+def test_broadcast_add_token_sum_matches_a_float64_sum():
+    """train.broadcast_add: tokens + a per-sample vector, the vector's gradient = nd_token_sum_f32 over the tokens (fixed order, repeatable)."""
+    for (B, N, C_) in ((4, 65536, 64), (2, 1000, 128), (3, 50, 512)):
+        t = U(f"ba.t.{N}", (B, N, C_)).to(DEV)
+        v = U(f"ba.v.{N}", (B, 1, C_)).to(DEV)
+        gy = U(f"ba.g.{N}", (B, N, C_)).to(DEV)
+        outs = []
+        for _ in range(2):
+            ta, va = t.clone().requires_grad_(), v.clone().requires_grad_()
+            y = train.broadcast_add(ta, va)
+            y.backward(gy)
+            outs.append((y.detach().cpu(), ta.grad.cpu(), va.grad.cpu()))
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
+        assert torch.equal(outs[0][0], (t + v).cpu()) and torch.equal(outs[0][1], gy.cpu())
+        assert rel_err(outs[0][2].numpy(), gy.double().sum(dim=1, keepdim=True).float().cpu().numpy()) < 2e-6
+
+
 def test_linear_on_the_pointwise_kernels_matches_the_library_gemm():
     """ND_TRAIN_PW=1: output and data gradient of a token Linear on nd_pointwise_gemm_nhwc_f32 (data-gradient weight packed in place by
     nd_pack_pointwise_weight_t) against torch, ragged token counts and channel counts that are not multiples of the tiles included."""

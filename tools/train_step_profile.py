@@ -46,4 +46,11 @@ if os.environ.get("PROFILE", "0") != "0":          # where do the ATen copies / 
         for _ in range(2):
             one()
         torch.cuda.synchronize()
-    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=48, max_shapes_column_width=90))
+    ka = prof.key_averages(group_by_input_shape=True)
+    if os.environ.get("PROFILE") == "2":                 # ATen / autograd-function rows only, per step
+        rows = sorted(((e.self_device_time_total / 2, e.key, e.count // 2, str(e.input_shapes)[:110]) for e in ka if e.key.startswith(("aten::", "Optimizer"))
+                       and e.self_device_time_total > 0), reverse=True)
+        for us, key, cnt, shp in rows[:60]:
+            print(f"{us:9.1f} us/step  {key:32s} x{cnt:4d}  {shp}")
+    else:
+        print(ka.table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=48, max_shapes_column_width=90))
