@@ -982,8 +982,10 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
 static int w4_splits(long items, int cin) {
     const int n_chunks = nd_cdiv(cin, KC4);
     if (cin % KC4) return 1;
+    static const long cap = getenv("ND_W4_SPLIT_ITEMS") ? atol(getenv("ND_W4_SPLIT_ITEMS")) : 256;      // A/B knob (tools/ only)
+    static const int min_chunks = getenv("ND_W4_SPLIT_MIN_CHUNKS") ? atoi(getenv("ND_W4_SPLIT_MIN_CHUNKS")) : 4;
     int splits = 1;
-    while (splits < 8 && items * splits * 2 <= 256 && n_chunks % (splits * 2) == 0 && n_chunks / (splits * 2) >= 4) splits *= 2;
+    while (splits < 8 && items * splits * 2 <= cap && n_chunks % (splits * 2) == 0 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     return splits;
 }
 

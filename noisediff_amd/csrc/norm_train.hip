@@ -549,7 +549,15 @@ __global__ __launch_bounds__(256) void gs_bwd_finalize_kernel(const float* __res
 // mode 0: y = silu((x - M) A + D) (+ res: the ResnetBlock's shortcut, Diffusion_arch.py:170);  mode 1: dx = dm A + x c1 + c2 with dm recomputed from (dy, x)
 __global__ __launch_bounds__(256) void gs_apply_kernel(const float* __restrict__ u, int ldu, const float* __restrict__ x, int ldx, const float* __restrict__ mad,
                                                       const float* __restrict__ coef, float* __restrict__ out, int ldo, int B, int HW, int C, int mode,
-                                                      const float* __restrict__ res = nullptr, int ldr = 0) {
+                                                      const float* __restrict__ res = nullptr, int ldr = 0, const float* __restrict__ ab = nullptr,
+                                                      float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
+    if (ab && blockIdx.x == 0) {      // dgamma / dbeta = the per-sample terms added in sample order (gn_dparam_kernel's work, without its launch)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            double dg = 0.0, db = 0.0;
+            for (int b = 0; b < B; ++b) { dg += (double)ab[((size_t)b * C + c) * 2]; db += (double)ab[((size_t)b * C + c) * 2 + 1]; }
+            dgamma[c] = (float)dg;  dbeta[c] = (float)db;
+        }
+    }
     const int cq = C >> 2;
     const size_t total = (size_t)B * HW * cq;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -621,10 +629,10 @@ extern "C" int nd_groupnorm_silu_train_backward_f32(const float* dy, int lddy, c
     hipLaunchKernelGGL(gs_partials_kernel, dim3(B * slots), dim3(256), 0, st, dy, lddy, x, ldx, mad, part, HW, C, slots);
     hipLaunchKernelGGL(gs_bwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, part, slots, HW, mean_rstd, gamma, beta, scale_shift, coef, ab, dscale_shift,
                        C, groups);
-    hipLaunchKernelGGL(gn_dparam_kernel, dim3(nd_cdiv(C, 256)), dim3(256), 0, st, ab, dgamma, dbeta, B, C);
     const size_t total = (size_t)B * HW * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(gs_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mad, coef, dx, lddx, B, HW, C, 1);
+    hipLaunchKernelGGL(gs_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mad, coef, dx, lddx, B, HW, C, 1, (const float*)nullptr, 0, ab, dgamma,
+                       dbeta);
     return nd_launch_status("nd_groupnorm_silu_train_backward_f32");
 }
 

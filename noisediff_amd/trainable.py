@@ -89,8 +89,8 @@ class _Ops:
         """ResnetBlock (per-sample scale / shift from the time embedding, :146-170) and ResnetBlock2 (per-pixel maps from the
         position embedding, :173-196); the shortcut is a 1x1 conv iff the channel count changes."""
         ss = None
-        if emb is not None:
-            ss = self.conv(name + ".mlp.1", F.silu(emb)) if per_pixel else self.linear(name + ".mlp.1", F.silu(emb))[:, :, None, None]
+        if emb is not None:      # ``emb`` arrives ACTIVATED: every block's mlp starts with the same SiLU of the same embedding (:149,176) -- computed once in _forward
+            ss = self.conv(name + ".mlp.1", emb) if per_pixel else self.linear(name + ".mlp.1", emb)[:, :, None, None]
         res = self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x
         return self.block(name + ".block2", self.block(name + ".block1", x, groups, ss), groups, res=res)      # block2(...) + res, the add inside block2's fused tail
 
@@ -150,6 +150,9 @@ def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, 
     ang = time[:, None] * freqs[None]
     t = o.linear("time_mlp.3", F.gelu(o.linear("time_mlp.1", torch.cat((ang.sin(), ang.cos()), dim=-1))))
 
+    # ResnetBlock.mlp / ResnetBlock2.mlp = Sequential(SiLU, Linear / Conv2d) of the SAME embedding in all 20 (2) blocks: one activation each, not 20
+    # forward + 20 backward + 19 gradient accumulations of launch-bound (4, 256) kernels (and two full-resolution SiLUs of the position embedding)
+    t, pos = F.silu(t), F.silu(pos)
     s0 = o.mlp("shot_mlp1", torch.cat((clean, x), dim=1))
     s = o.mlp("shot_mlp2", o.attn_block("shot_attn", s0, iso))
     shot = o.mlp("shot_mlp3", o.resnet("shot_time", s, t, POS_GROUPS) + s0)
