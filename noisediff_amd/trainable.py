@@ -32,6 +32,25 @@ class _Ops:
 
     def __init__(self, params: P, hip: bool):
         self.p, self.hip = params, hip
+        self.ss: Dict[str, torch.Tensor] = {}            # ResnetBlock name -> its (B, 2C) scale | shift rows (time_projections)
+
+    def time_projections(self, t_act: torch.Tensor) -> None:
+        """All ResnetBlock.mlp[1] Linears (Diffusion_arch.py:149-152; 20 of them, each a (B, 4 dim) x (4 dim, 2C) product of a few microseconds) as ONE
+        Linear over the stacked weights -- what the sampling engine's ``tproj`` does: 1 + 2 GEMMs per step instead of 20 + 40 launch-bound ones.
+        The stacked weight is a torch.cat of the parameters, so their gradients arrive as slices of one weight gradient."""
+        names = [k[:-len(".mlp.1.weight")] for k, v in self.p.items() if k.endswith(".mlp.1.weight") and v.dim() == 2]
+        if not names:
+            return
+        w = torch.cat([self.p[n + ".mlp.1.weight"] for n in names])
+        b = torch.cat([self.p[n + ".mlp.1.bias"] for n in names])
+        if self.hip and t_act.is_cuda:
+            from . import train
+            ss_all = train.linear(t_act, w, b)
+        else:
+            ss_all = F.linear(t_act, w, b)
+        # one split (its backward is one cat of the 20 gradients; 20 slices would each zero-fill and accumulate a full-width gradient)
+        for n, part in zip(names, ss_all.split([self.p[n + ".mlp.1.weight"].shape[0] for n in names], dim=1)):
+            self.ss[n] = part
 
     def conv(self, name: str, x: torch.Tensor, padding: int = 0) -> torch.Tensor:
         w, b = self.p[name + ".weight"], self.p.get(name + ".bias")
@@ -90,7 +109,12 @@ class _Ops:
         position embedding, :173-196); the shortcut is a 1x1 conv iff the channel count changes."""
         ss = None
         if emb is not None:      # ``emb`` arrives ACTIVATED: every block's mlp starts with the same SiLU of the same embedding (:149,176) -- computed once in _forward
-            ss = self.conv(name + ".mlp.1", emb) if per_pixel else self.linear(name + ".mlp.1", emb)[:, :, None, None]
+            if per_pixel:
+                ss = self.conv(name + ".mlp.1", emb)
+            elif name in self.ss:                                # the block's rows of the one stacked projection (time_projections)
+                ss = self.ss[name][:, :, None, None]
+            else:
+                ss = self.linear(name + ".mlp.1", emb)[:, :, None, None]
         res = self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x
         return self.block(name + ".block2", self.block(name + ".block1", x, groups, ss), groups, res=res)      # block2(...) + res, the add inside block2's fused tail
 
@@ -153,6 +177,7 @@ def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, 
     # ResnetBlock.mlp / ResnetBlock2.mlp = Sequential(SiLU, Linear / Conv2d) of the SAME embedding in all 20 (2) blocks: one activation each, not 20
     # forward + 20 backward + 19 gradient accumulations of launch-bound (4, 256) kernels (and two full-resolution SiLUs of the position embedding)
     t, pos = F.silu(t), F.silu(pos)
+    o.time_projections(t)
     s0 = o.mlp("shot_mlp1", torch.cat((clean, x), dim=1))
     s = o.mlp("shot_mlp2", o.attn_block("shot_attn", s0, iso))
     shot = o.mlp("shot_mlp3", o.resnet("shot_time", s, t, POS_GROUPS) + s0)
