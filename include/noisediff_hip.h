@@ -297,6 +297,12 @@ int nd_groupnorm_finalize_f32(const float* stats, const float* slot_count, int s
                               const float* gamma, const float* beta,
                               const float* scale_shift, int ld_ss,
                               float* mad, int B, int C, int groups, float eps, void* stream);
+/* training (Block.forward under p_losses): the same finalize, which also saves `mean_rstd` [B][groups][2] for the backward pass
+ * (nd_groupnorm_silu_train_backward_f32) -- the convolution's statistics epilogue then feeds the norm in training as it does in sampling,
+ * and the forward tail is nd_affine_silu_add_f32. */
+int nd_groupnorm_finalize_train_f32(const float* stats, const float* slot_count, int slots, const float* gamma, const float* beta,
+                                    const float* scale_shift, int ld_ss, float* mad, float* mean_rstd, int B, int C, int groups, float eps,
+                                    void* stream);
 
 /* Per-pixel LayerNorm statistics over channels of (x + vec[b]): stats[p] = {mean, 1/sqrt(var + eps)}
  * (nn.LayerNorm: biased variance; AttnBlock.norm2, Diffusion_arch.py:430,439).  vec may be NULL. */

@@ -113,6 +113,7 @@ SIGNATURES = {
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
+    "nd_groupnorm_finalize_train_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_affine_silu_add_f32": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "nd_linear_rows_f32": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -19,7 +19,7 @@ constexpr int GNF_THREADS = 64 * GNF_WAVES;
 __global__ __launch_bounds__(GNF_THREADS) void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ slot_count,
                                                           int slots, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ ss, int ld_ss, float* __restrict__ mad,
-                                                          int C, int G, float eps) {
+                                                          int C, int G, float eps, float* __restrict__ mean_rstd = nullptr) {
     __shared__ double part[GNF_WAVES][3];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,6 +69,10 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_finalize_kernel(const float* _
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
+    if (mean_rstd && tid == 0) {                                // training: the group's moments, saved for the backward pass
+        mean_rstd[((size_t)b * G + g) * 2] = fmean;
+        mean_rstd[((size_t)b * G + g) * 2 + 1] = rstd;
+    }
     for (int i = tid; i < cpg; i += GNF_THREADS) {
         const int ch = g * cpg + i;
         const float sc = ss ? ss[(size_t)b * ld_ss + ch] : 0.0f;
@@ -191,6 +195,17 @@ extern "C" int nd_groupnorm_finalize_f32(const float* stats, const float* slot_c
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(GNF_THREADS), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
                        beta, scale_shift, ld_ss, mad, C, groups, eps);
     return nd_launch_status("nd_groupnorm_finalize_f32");
+}
+
+extern "C" int nd_groupnorm_finalize_train_f32(const float* stats, const float* slot_count, int slots, const float* gamma, const float* beta,
+                                               const float* scale_shift, int ld_ss, float* mad, float* mean_rstd, int B, int C, int groups, float eps,
+                                               void* stream) {
+    ND_REQUIRE(stats && slot_count && gamma && beta && mad && mean_rstd, ND_E_BADARG, "nd_groupnorm_finalize_train: null pointer");
+    ND_REQUIRE(B > 0 && C > 0 && groups > 0 && slots > 0 && C % groups == 0, ND_E_SHAPE, "nd_groupnorm_finalize_train: C=%d groups=%d", C, groups);
+    ND_REQUIRE(!scale_shift || ld_ss >= 2 * C, ND_E_SHAPE, "nd_groupnorm_finalize_train: ld_ss < 2C");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(GNF_THREADS), 0, (hipStream_t)stream, stats, slot_count, slots, gamma,
+                       beta, scale_shift, ld_ss, mad, C, groups, eps, mean_rstd);
+    return nd_launch_status("nd_groupnorm_finalize_train_f32");
 }
 
 extern "C" int nd_layernorm_stats_f32(const float* x, int ldx, const float* vec, float* stats, int B, int HW, int C, float eps, void* stream) {

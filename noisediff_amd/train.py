@@ -68,10 +68,12 @@ def _stream(device: Optional[torch.device] = None) -> C.c_void_p:
 _SPLIT_K = __import__("os").environ.get("ND_TRAIN_SPLITK", "1") != "0"      # A/B knob (tools/): 0 = never the split-K form of conv3x3_wino4
 
 
-def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], dgrad: bool = False) -> torch.Tensor:
+def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], dgrad: bool = False, stats: bool = False):
     """y = conv2d(x, w, bias, padding=1) on the HIP library; x (B, cin, H, W) channels_last, returns (B, cout, H, W) channels_last.
     ``dgrad``: ``w_oihw`` is the FORWARD layer's weight and the operator is its data gradient, conv2d(x, w.flip(2, 3).transpose(0, 1),
-    padding=1) -- the pack kernels read the flipped / role-swapped weight in place (nd_pack_conv3x3_*_weight_dgrad)."""
+    padding=1) -- the pack kernels read the flipped / role-swapped weight in place (nd_pack_conv3x3_*_weight_dgrad).
+    ``stats``: returns (y, st, sc) with the kernel's GroupNorm statistics epilogue -- per-(sample, slot, channel) {sum, M2} partials ``st`` and the
+    pixel counts ``sc`` of the slots, what nd_groupnorm_finalize*_f32 pools -- or (y, None, None) where the layer runs on the split-K form."""
     lib = L.load()
     B, cin, H, W = x.shape
     cout = w_oihw.shape[1 if dgrad else 0]
@@ -108,6 +110,13 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
             d.bias = b.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
         splits = int(lib.nd_conv3x3_wino4_splitk_plan(B, H, W, cin, cout)) if wino4 and _SPLIT_K else 1
+        st_t = sc_t = None
+        if stats and splits == 1:
+            slots = int(lib.nd_conv3x3_wino4_stat_slots(H, W) if wino4 else lib.nd_conv3x3_wino_stat_slots(H, W) if wino2
+                        else lib.nd_conv3x3_stat_slots(H, W, cout, B))
+            st_t = torch.empty((B, slots, cout, 2), dtype=torch.float32, device=x.device)
+            sc_t = torch.empty(slots, dtype=torch.float32, device=x.device)
+            d.stats, d.slot_count = st_t.data_ptr(), sc_t.data_ptr()
         if splits > 1:      # few (sample, region, cout tile) items for 256 CUs (the deep layers at training batch sizes): cut along cin
             ws = torch.empty(int(lib.nd_conv3x3_wino4_splitk_workspace_floats(B, H, W, cout, splits)), dtype=torch.float32, device=x.device)
             L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), splits, st)
@@ -115,22 +124,30 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
             L.call(entry, C.byref(d), st)
         # wp / b are dropped on return: safe, because the kernels were enqueued on torch's CURRENT stream and the caching
         # allocator reuses a block only for work that is enqueued later on that same stream
-    return out
+    return (out, st_t, sc_t) if stats else out
 
 
 class Conv3x3Function(torch.autograd.Function):
     """nn.Conv2d(cin, cout, 3, padding=1) forward and backward on libnoisediff_hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         xn = _nhwc(x)
         ctx.save_for_backward(xn, weight)
         ctx.has_bias = bias is not None
-        return _conv3x3_nhwc(xn, weight, bias)
+        ctx.n_out = 1
+        if not want_stats:
+            return _conv3x3_nhwc(xn, weight, bias)
+        y, st, sc = _conv3x3_nhwc(xn, weight, bias, stats=True)
+        if st is None:                                           # split-K layer: no statistics epilogue; empty placeholders keep the arity
+            st, sc = y.new_empty(0), y.new_empty(0)
+        ctx.mark_non_differentiable(st, sc)
+        ctx.n_out = 3
+        return y, st, sc
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, *unused):
         xn, weight = ctx.saved_tensors
         lib = L.load()
         g = _nhwc(grad_out)
@@ -150,7 +167,7 @@ class Conv3x3Function(torch.autograd.Function):
                        grad_b.data_ptr() if want_b else None, ws.data_ptr(), B, H, W, cin, cout, _stream(xn.device))
         elif want_b:
             grad_b = g.sum(dim=(0, 2, 3))
-        return grad_x, grad_w, grad_b
+        return grad_x, grad_w, grad_b, None
 
 
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -158,6 +175,16 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     if tuple(weight.shape[2:]) != (3, 3) or x.dim() != 4 or x.shape[1] != weight.shape[1]:
         raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)} is not a 3x3 convolution")
     return Conv3x3Function.apply(x, weight, bias)
+
+
+def conv3x3_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """conv3x3 plus the kernel's GroupNorm statistics epilogue: (y, (st, sc)) for ``group_norm_silu(y, ..., conv_stats=)`` -- the norm then needs no
+    pass of its own over y for its moments, as in the sampling engine (Block: conv -> statistics -> finalize -> apply).  (y, None) where the layer
+    runs on the split-K form, which has no statistics epilogue."""
+    if tuple(weight.shape[2:]) != (3, 3) or x.dim() != 4 or x.shape[1] != weight.shape[1]:
+        raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)} is not a 3x3 convolution")
+    y, st, sc = Conv3x3Function.apply(x, weight, bias, True)
+    return y, ((st, sc) if st.numel() else None)
 
 
 class GroupNormFunction(torch.autograd.Function):
@@ -212,7 +239,7 @@ class GroupNormSiLUFunction(torch.autograd.Function):
     (norm_train.hip); ``scale_shift`` is the (B, 2C) output of ResnetBlock.mlp (scale | shift) or None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale_shift, res, groups, eps):
+    def forward(ctx, x, weight, bias, scale_shift, res, groups, eps, st=None, sc=None):
         lib = L.load()
         xn = _nhwc(x)
         rn = None if res is None else _nhwc(res)
@@ -226,8 +253,15 @@ class GroupNormSiLUFunction(torch.autograd.Function):
             mad = torch.empty((B, 3, C_), dtype=torch.float32, device=xn.device)
             ws = torch.empty(int(lib.nd_groupnorm_silu_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
             w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-            L.call("nd_groupnorm_silu_train_forward_f32", xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), None if ss is None else ss.data_ptr(),
-                   None if rn is None else rn.data_ptr(), C_, y.data_ptr(), C_, mean_rstd.data_ptr(), mad.data_ptr(), ws.data_ptr(), B, H * W, C_, groups, float(eps), _stream())
+            if st is not None:       # the convolution's statistics epilogue already holds the partial moments: finalize (saving mean / rstd) + one apply pass
+                stp = _stream(xn.device)
+                L.call("nd_groupnorm_finalize_train_f32", st.data_ptr(), sc.data_ptr(), st.shape[1], w32.data_ptr(), b32.data_ptr(),
+                       None if ss is None else ss.data_ptr(), 2 * C_, mad.data_ptr(), mean_rstd.data_ptr(), B, C_, groups, float(eps), stp)
+                L.call("nd_affine_silu_add_f32", xn.data_ptr(), C_, mad.data_ptr(), None if rn is None else rn.data_ptr(), C_, None, 0, y.data_ptr(), C_,
+                       B, H * W, C_, stp)
+            else:
+                L.call("nd_groupnorm_silu_train_forward_f32", xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), None if ss is None else ss.data_ptr(),
+                       None if rn is None else rn.data_ptr(), C_, y.data_ptr(), C_, mean_rstd.data_ptr(), mad.data_ptr(), ws.data_ptr(), B, H * W, C_, groups, float(eps), _stream())
         ctx.save_for_backward(xn, weight, bias, mean_rstd, mad, ss if ss is not None else mean_rstd.new_empty(0))
         ctx.groups, ctx.has_ss, ctx.ss_shape = groups, ss is not None, None if scale_shift is None else scale_shift.shape
         ctx.has_res = res is not None
@@ -250,11 +284,11 @@ class GroupNormSiLUFunction(torch.autograd.Function):
             L.call("nd_groupnorm_silu_train_backward_f32", g.data_ptr(), C_, xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(),
                    ss.data_ptr() if ctx.has_ss else None, mean_rstd.data_ptr(), mad.data_ptr(), dx.data_ptr(), C_, dgamma.data_ptr(), dbeta.data_ptr(),
                    dss.data_ptr() if ctx.has_ss else None, ws.data_ptr(), B, H * W, C_, ctx.groups, _stream())
-        return dx, dgamma, dbeta, (dss.view(ctx.ss_shape) if ctx.has_ss else None), (grad_out if ctx.has_res else None), None, None
+        return dx, dgamma, dbeta, (dss.view(ctx.ss_shape) if ctx.has_ss else None), (grad_out if ctx.has_res else None), None, None, None, None
 
 
 def group_norm_silu(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.Tensor, scale_shift: Optional[torch.Tensor] = None,
-                    eps: float = 1e-5, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    eps: float = 1e-5, res: Optional[torch.Tensor] = None, conv_stats=None) -> torch.Tensor:
     """Differentiable silu(F.group_norm(x, groups, weight, bias, eps) * (scale + 1) + shift) (+ res), scale | shift = the halves of ``scale_shift``
     ((B, 2C) or (B, 2C, 1, 1)), on the HIP library; ``res`` (x's shape): the ResnetBlock's shortcut added in the same pass (Diffusion_arch.py:170)."""
     if x.dim() != 4 or x.shape[1] % groups or x.shape[1] % 4 or x.shape[1] > 1024 or weight is None or bias is None:
@@ -263,6 +297,8 @@ def group_norm_silu(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: to
         raise ValueError(f"group_norm_silu: scale_shift {tuple(scale_shift.shape)} is not (B, 2C) for x {tuple(x.shape)}")
     if res is not None and res.shape != x.shape:
         raise ValueError(f"group_norm_silu: res {tuple(res.shape)} does not match x {tuple(x.shape)}")
+    if conv_stats is not None:       # (st, sc) of conv3x3_with_stats for THIS x: the partial moments of the producing convolution's epilogue
+        return GroupNormSiLUFunction.apply(x, weight, bias, scale_shift, res, groups, eps, conv_stats[0], conv_stats[1])
     return GroupNormSiLUFunction.apply(x, weight, bias, scale_shift, res, groups, eps)
 
 

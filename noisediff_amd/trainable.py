@@ -89,10 +89,16 @@ class _Ops:
     def block(self, name: str, x, groups: int, ss=None, res=None):
         """Block: conv3x3 -> GroupNorm -> optional x (scale + 1) + shift -> SiLU   (Diffusion_arch.py:128-144); ``ss`` = scale | shift
         along dim 1: (B, 2C, 1, 1) from the time embedding or (B, 2C, H, W) per-pixel maps."""
-        x = self.conv(name + ".proj", x, 1)
         from . import train
-        if (self.hip and x.is_cuda and train._group_norm_ok(x.shape[1], groups)
-                and (ss is None or ss.numel() == x.shape[0] * 2 * x.shape[1])):  # norm, per-sample modulation, SiLU (and the block's shortcut) as one operator
+        w = self.p[name + ".proj.weight"]
+        fused = (self.hip and x.is_cuda and train._group_norm_ok(w.shape[0], groups)
+                 and (ss is None or ss.numel() == x.shape[0] * 2 * w.shape[0]))   # norm, per-sample modulation, SiLU (and the block's shortcut) as one operator
+        if fused and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+            # ... fed by the convolution's statistics epilogue, as in the sampling engine: no pass of the norm's own over the conv output for its moments
+            x, cs = train.conv3x3_with_stats(x, w, self.p.get(name + ".proj.bias"))
+            return train.group_norm_silu(x, groups, self.p[name + ".norm.weight"], self.p[name + ".norm.bias"], ss, 1e-5, res=res, conv_stats=cs)
+        x = self.conv(name + ".proj", x, 1)
+        if fused:
             return train.group_norm_silu(x, groups, self.p[name + ".norm.weight"], self.p[name + ".norm.bias"], ss, 1e-5, res=res)
         x = self.group_norm(name + ".norm", x, groups)
         if ss is not None and self.hip and x.is_cuda and x.shape[1] % 4 == 0 and ss.shape == (x.shape[0], 2 * x.shape[1]) + tuple(x.shape[2:]):

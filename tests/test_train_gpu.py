@@ -155,6 +155,34 @@ def test_modulate_silu_and_the_fused_shortcut_match_torch():
         assert rel_err(got.detach().cpu().numpy(), ref.detach().float().cpu().numpy()) < 2e-5, name
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64, 8), (4, 32, 32, 512, 512, 8), (2, 16, 16, 32, 64, 2), (1, 8, 8, 16, 16, 8), (2, 40, 36, 24, 40, 8)])
+def test_block_with_the_convs_statistics_epilogue_matches_torch(case):
+    """conv3x3_with_stats + group_norm_silu(conv_stats=): Block (conv -> GroupNorm -> modulation -> SiLU (+ shortcut)) with the norm's moments taken from
+    the convolution kernel's statistics epilogue (all three forward kernels; the split-K layer falls back to the norm's own pass) against torch in
+    float64, forward and every gradient."""
+    B, H, W, cin, cout, groups = case
+    x = U(f"cs.x.{case}", (B, cin, H, W)).to(DEV)
+    w = (U(f"cs.w.{case}", (cout, cin, 3, 3)) / (9 * cin) ** 0.5).to(DEV)
+    b = U(f"cs.b.{case}", (cout,)).to(DEV)
+    gam, bet = U(f"cs.g.{case}", (cout,), 0.5, 1.5).to(DEV), U(f"cs.be.{case}", (cout,)).to(DEV)
+    ss = U(f"cs.ss.{case}", (B, 2 * cout)).to(DEV)
+    res = U(f"cs.r.{case}", (B, cout, H, W)).to(DEV)
+    gy = U(f"cs.gy.{case}", (B, cout, H, W)).to(DEV)
+    ts = [t.clone().requires_grad_() for t in (x, w, b, gam, bet, ss, res)]
+    y, cs = train.conv3x3_with_stats(ts[0], ts[1], ts[2])
+    split = L.load().nd_conv3x3_wino4_splitk_plan(B, H, W, cin, cout) > 1 and W >= 32 and cin > 16
+    assert (cs is None) == bool(split)
+    out = train.group_norm_silu(y, groups, ts[3], ts[4], ts[5], 1e-5, res=ts[6], conv_stats=cs)
+    out.backward(gy)
+    td = [t.double().requires_grad_() for t in (x, w, b, gam, bet, ss, res)]
+    sc, sh = td[5][:, :, None, None].chunk(2, dim=1)
+    ref = F.silu(F.group_norm(F.conv2d(td[0], td[1], td[2], padding=1), groups, td[3], td[4], 1e-5) * (sc + 1) + sh) + td[6]
+    ref.backward(gy.double())
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().float().cpu().numpy()) < 1e-4
+    for name, got, r in zip(("dx", "dw", "db", "dgamma", "dbeta", "dss", "dres"), ts, td):
+        assert rel_err(got.grad.cpu().numpy(), r.grad.float().cpu().numpy()) < 2e-4, (case, name)
+
+
 def test_broadcast_add_token_sum_matches_a_float64_sum():
     """train.broadcast_add: tokens + a per-sample vector, the vector's gradient = nd_token_sum_f32 over the tokens (fixed order, repeatable)."""
     for (B, N, C_) in ((4, 65536, 64), (2, 1000, 128), (3, 50, 512)):

@@ -10,7 +10,7 @@ def family(n):
     if any(k in n for k in ("wino4_kernel", "wino2_kernel", "conv3x3_kernel", "wino_kernel", "w4_splitk_reduce")) and "pack" not in n: return "conv3x3 forward + data gradient (HIP)"
     if "pointwise" in n and "pack" not in n: return "Linear / 1x1 forward + data gradient (HIP pointwise)"
     if n.startswith("Cijk"): return "library GEMM (rocBLAS / hipBLASLt)"
-    if any(k in n for k in ("gs_", "gn_", "ln_fwd", "ln_bwd", "ln_dparam", "token_sum", "modsilu", "affine3")): return "GroupNorm / LayerNorm / modulation forward + backward, token sums (HIP)"
+    if any(k in n for k in ("gs_", "gn_", "ln_fwd", "ln_bwd", "ln_dparam", "token_sum", "modsilu", "affine3", "affine_silu_add")): return "GroupNorm / LayerNorm / modulation forward + backward, token sums (HIP)"
     if "pack_" in n: return "weight packing (HIP)"
     if "multi_tensor" in n: return "Adam (ATen foreach)"
     if "CUDAFunctor_add" in n: return "ATen add"

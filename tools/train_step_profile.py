@@ -20,7 +20,7 @@ if os.environ.get("NET", "trainable") == "dropin":
 else:
     net = TrainableNoiseDiffNet(SimpleNamespace(dim=64)).to(dev).hip(HIP)
 gd = GaussianDiffusion(net, image_size=S, timesteps=1000, beta_schedule="sigmoid2", objective="pred_v").to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=os.environ.get("ADAM_FUSED", "0") != "0")     # ADAM_FUSED=1: PyTorch's single-kernel Adam
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, **({"fused": True} if os.environ.get("ADAM_FUSED", "0") != "0" else {}))   # ADAM_FUSED=1: PyTorch's single-kernel Adam (an explicit fused=False would also switch the foreach default off)
 
 
 def one():
