@@ -142,6 +142,7 @@ class Conv3x3Function(torch.autograd.Function):
         if st is None:                                           # split-K layer: no statistics epilogue; empty placeholders keep the arity
             st, sc = y.new_empty(0), y.new_empty(0)
         ctx.mark_non_differentiable(st, sc)
+        ctx.set_materialize_grads(False)                         # no zero tensors for the statistics outputs' (never used) gradients
         ctx.n_out = 3
         return y, st, sc
 
@@ -149,6 +150,8 @@ class Conv3x3Function(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_out, *unused):
         xn, weight = ctx.saved_tensors
+        if grad_out is None:                                     # (materialize_grads is off for the statistics variant)
+            return None, None, None, None
         lib = L.load()
         g = _nhwc(grad_out)
         B, cin, H, W = xn.shape
