@@ -226,7 +226,7 @@ class GroupNormFunction(torch.autograd.Function):
             ws = torch.empty(int(lib.nd_groupnorm_train_workspace_floats(B, H * W, C_)), dtype=torch.float32, device=xn.device)
             w32 = weight.detach().float().contiguous()
             L.call("nd_groupnorm_train_backward_f32", g.data_ptr(), C_, xn.data_ptr(), C_, w32.data_ptr(), mean_rstd.data_ptr(), dx.data_ptr(), C_,
-                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), B, H * W, C_, ctx.groups, _stream())
+                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), B, H * W, C_, ctx.groups, _stream(xn.device))
         return dx, dgamma, dbeta, None, None
 
 
@@ -264,7 +264,7 @@ class GroupNormSiLUFunction(torch.autograd.Function):
                        B, H * W, C_, stp)
             else:
                 L.call("nd_groupnorm_silu_train_forward_f32", xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), None if ss is None else ss.data_ptr(),
-                       None if rn is None else rn.data_ptr(), C_, y.data_ptr(), C_, mean_rstd.data_ptr(), mad.data_ptr(), ws.data_ptr(), B, H * W, C_, groups, float(eps), _stream())
+                       None if rn is None else rn.data_ptr(), C_, y.data_ptr(), C_, mean_rstd.data_ptr(), mad.data_ptr(), ws.data_ptr(), B, H * W, C_, groups, float(eps), _stream(xn.device))
         ctx.save_for_backward(xn, weight, bias, mean_rstd, mad, ss if ss is not None else mean_rstd.new_empty(0))
         ctx.groups, ctx.has_ss, ctx.ss_shape = groups, ss is not None, None if scale_shift is None else scale_shift.shape
         ctx.has_res = res is not None
@@ -286,7 +286,7 @@ class GroupNormSiLUFunction(torch.autograd.Function):
             w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
             L.call("nd_groupnorm_silu_train_backward_f32", g.data_ptr(), C_, xn.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(),
                    ss.data_ptr() if ctx.has_ss else None, mean_rstd.data_ptr(), mad.data_ptr(), dx.data_ptr(), C_, dgamma.data_ptr(), dbeta.data_ptr(),
-                   dss.data_ptr() if ctx.has_ss else None, ws.data_ptr(), B, H * W, C_, ctx.groups, _stream())
+                   dss.data_ptr() if ctx.has_ss else None, ws.data_ptr(), B, H * W, C_, ctx.groups, _stream(xn.device))
         return dx, dgamma, dbeta, (dss.view(ctx.ss_shape) if ctx.has_ss else None), (grad_out if ctx.has_res else None), None, None, None, None
 
 
@@ -529,7 +529,7 @@ class LayerNormFunction(torch.autograd.Function):
             stats = torch.empty((N, 2), dtype=torch.float32, device=x2.device)
             w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
             L.call("nd_layernorm_train_forward_f32", x2.data_ptr(), C_, w32.data_ptr(), b32.data_ptr(), y.data_ptr(), C_, stats.data_ptr(),
-                   N, C_, float(eps), _stream())
+                   N, C_, float(eps), _stream(x2.device))
         ctx.save_for_backward(x2, weight, stats)
         ctx.shape = x.shape
         return y.view(x.shape)
@@ -550,7 +550,7 @@ class LayerNormFunction(torch.autograd.Function):
             ws = torch.empty(int(lib.nd_layernorm_train_workspace_floats(N, C_)), dtype=torch.float32, device=x2.device)
             w32 = weight.detach().float().contiguous()
             L.call("nd_layernorm_train_backward_f32", g2.data_ptr(), C_, x2.data_ptr(), C_, w32.data_ptr(), stats.data_ptr(), dx.data_ptr(), C_,
-                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, C_, _stream())
+                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), N, C_, _stream(x2.device))
         return dx.view(ctx.shape), dgamma, dbeta, None
 
 
