@@ -18,6 +18,11 @@ from oracle import noisediff_oracle as O
 from util import rel_err, state_dict, sub
 
 DIM, B, H, T = 16, 2, 32, 1000
+
+
+def golden_value(key):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "training.npz"))[key]
 GRAD_KEYS = ["final_conv.weight", "downs.0.0.block1.proj.weight", "time_mlp.1.weight", "mid_block1.block2.norm.weight",
              "ups.3.2.ff.net.2.weight", "shot_mlp1.fc1.weight", "pos_block1.mlp.1.bias", "iso_embed.weight"]
 
@@ -162,6 +167,33 @@ def test_the_drop_in_network_trains_under_autograd(golden):
         ref_after = net._forward_autograd(x0, t, cond_dev)
     assert not torch.equal(after, before)
     assert rel_err(after.cpu().numpy(), ref_after.cpu().numpy()) < 2e-4
+
+
+@pytest.mark.gpu
+def test_data_parallel_replicas_train_through_their_broadcast_parameters():
+    """nn.DataParallel.forward over several device_ids (models/modules.py:81, the trainer's wrapper) replicates the module: a replica holds no
+    Parameters, only the broadcast copies ``replicate`` leaves in ``_former_parameters``.  Under autograd the replicas evaluate the graph over those
+    copies (net.py::_parameter_table), and the gradients that arrive at the owner's parameters equal the bare module's.  (Two logical replicas on
+    cuda:0: the box has one card.)"""
+    from noisediff_amd import NoiseDiffNet
+    dev = torch.device("cuda", 0)
+    x0, noise, t, cond = _inputs()
+    x0, noise, t = x0.to(dev), noise.to(dev), t.to(dev)
+    cond_dev = {k: v.to(dev) for k, v in cond.items()}
+    grads = []
+    for wrap in (False, True):
+        net = NoiseDiffNet(SimpleNamespace(dim=DIM, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, phase="train"))
+        net.load_state_dict(state_dict(DIM), strict=True)
+        net = net.to(dev).train()
+        model = nn.DataParallel(net, device_ids=[0, 0]) if wrap else net
+        gd = GaussianDiffusion(model, image_size=H, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+        loss = gd.p_losses(x0, t, cond_dev, noise=noise.clone())
+        loss.backward()
+        grads.append((float(loss.detach()), {k: p.grad.detach().cpu() for k, p in net.named_parameters()}))
+    assert grads[1][0] == pytest.approx(grads[0][0], rel=1e-5)
+    assert grads[1][0] == pytest.approx(float(golden_value("train.loss.pred_v")), rel=5e-5)
+    for k, g in grads[0][1].items():
+        assert rel_err(grads[1][1][k].numpy(), g.numpy()) < 5e-4, k
 
 
 @pytest.mark.gpu
