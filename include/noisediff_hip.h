@@ -139,12 +139,13 @@ int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream);
-/* Split-K form of nd_conv3x3_wino4_nhwc_f32 for plain sources without a statistics epilogue -- the forward and data-gradient convolutions of
+/* Split-K form of nd_conv3x3_wino4_nhwc_f32 for plain and GroupNorm-affine + SiLU sources -- the forward and data-gradient convolutions of
  * Block.proj under GaussianDiffusion.p_losses (models/archs/Diffusion_arch.py:128-144; models/denoising_diffusion_pytorch.py:481-531) at
  * training batch sizes (512 -> 512 at
  * 32 x 32 with 4 samples is 64 workgroup items for 256 CUs, each walking 32 K chunks): cin is cut into `splits` ranges (2, 4 or 8; whole
  * 16-channel chunks, at least two per range), every (range, sample, region, cout tile) is a workgroup item that writes partial sums to
- * `workspace` ([splits][B][H][W][cout] floats), and a second kernel adds them in range order and the bias into d->out.  _plan returns the
+ * `workspace` ([splits][B][H][W][cout] floats), and a second kernel adds them in range order and the bias into d->out -- and, when d->stats is
+ * set, leaves the statistics slots of the summed output as the plain kernel's epilogue does (one slot per 16 x 16 tile).  _plan returns the
  * split count for a shape (1 = use the plain entry) -- a function of the shape alone, so results never depend on the device. */
 int nd_conv3x3_wino4_splitk_plan(int B, int H, int W, int cin, int cout);
 int64_t nd_conv3x3_wino4_splitk_workspace_floats(int B, int H, int W, int cout, int splits);

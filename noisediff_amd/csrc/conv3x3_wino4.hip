@@ -141,7 +141,7 @@ __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
 // 256 x 256 spends 2.3 k cycles more in the K chunk that follows an epilogue (its halo reads queue behind the output's write-back) and
 // 4.6 k more per workgroup in the prologue: -4 % per region tile (profiles/r3_w4_store_policy.txt); small outputs keep the default (the next
 // kernel finds them in the L2 / Infinity Cache).
-// SPLIT (split-K, plain sources without statistics only): layers whose (sample, region, cout tile) items fill a fraction of the chip -- 512 -> 512 at
+// SPLIT (split-K, plain or affine + SiLU sources; a statistics epilogue moves into the reduction): layers whose (sample, region, cout tile) items fill a fraction of the chip -- 512 -> 512 at
 // 32 x 32 with 4 samples: 64 items for 256 CUs, each walking 32 K chunks -- are cut along cin: item (split, sample, region, cout tile) walks
 // `chunks_per_split` chunks starting at chunk split * chunks_per_split and writes its partial sums to out[split] (the host passes a workspace
 // and no bias); w4_splitk_reduce_kernel adds the partials in split order and the bias.  The split count is fixed by the shape alone.
@@ -853,11 +853,67 @@ __global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __re
     }
 }
 
+// The same reduction for layers with a statistics epilogue (Block.proj: the GroupNorm that follows pools them): one workgroup per (sample, 16 x 16-pixel
+// tile) -- the tile is one statistics slot of nd_conv3x3_wino4_stat_slots -- adds the partial tensors' tile (+ bias), stores it, and leaves the slot's
+// per-channel {sum, M2 about the tile's mean} in `stats` exactly as wino4_kernel's own epilogue does (pivot = the tile's first pixel; M2 = Q - S^2 / n).
+// Thread = (channel quad, pixel row group); the row groups meet through LDS in a fixed order.
+__global__ __launch_bounds__(256) void w4_splitk_reduce_stats_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                                     float* __restrict__ stats, float* __restrict__ slot_count, int splits, int B, int H, int W,
+                                                                     int cout, int ldo, int tiles_x, int tiles_y, int n_cgrp) {
+    __shared__ __attribute__((aligned(16))) float red[2][256][4];
+    int bid = blockIdx.x;
+    const int cgrp = bid % n_cgrp;  bid /= n_cgrp;                 // 64 couts (16 channel quads) per workgroup: small images still give the chip work
+    const int slot = bid % (tiles_x * tiles_y), b = bid / (tiles_x * tiles_y);
+    const int ty = slot / tiles_x, tx = slot % tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16, th = min(16, H - y0), tw = min(16, W - x0), npx = th * tw;
+    const long npix = (long)B * H * W;
+    const int q = cgrp * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;      // channel quad, pixel row group (16 of them)
+    const bool act = 4 * q < cout;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, pv = {0, 0, 0, 0};
+    if (act) {
+        const f32x4 bq = bias ? nd_ld4(bias + 4 * q) : f32x4{0, 0, 0, 0};
+        {   // pivot: the tile's first pixel, summed the same way
+            const long n0 = ((long)b * H + y0) * W + x0;
+            pv = nd_ld4(part + n0 * cout + 4 * q);
+            for (int sp = 1; sp < splits; ++sp) pv += nd_ld4(part + ((long)sp * npix + n0) * cout + 4 * q);
+            pv += bq;
+        }
+        for (int p = rg; p < npx; p += 16) {
+            const int py = p / tw, px = p - py * tw;
+            const long n = ((long)b * H + y0 + py) * W + x0 + px;
+            f32x4 v = nd_ld4(part + n * cout + 4 * q);
+            for (int sp = 1; sp < splits; ++sp) v += nd_ld4(part + ((long)sp * npix + n) * cout + 4 * q);
+            v += bq;
+            nd_st4(out + n * ldo + 4 * q, v);
+            const f32x4 dv = v - pv;
+            s1 += dv;  s2 += dv * dv;
+        }
+    }
+    *reinterpret_cast<f32x4*>(red[0][threadIdx.x]) = s1;
+    *reinterpret_cast<f32x4*>(red[1][threadIdx.x]) = s2;
+    __syncthreads();
+    if (act && rg == 0) {
+        for (int r = 1; r < 16; ++r) {
+            s1 += *reinterpret_cast<const f32x4*>(red[0][r * 16 + (threadIdx.x & 15)]);
+            s2 += *reinterpret_cast<const f32x4*>(red[1][r * 16 + (threadIdx.x & 15)]);
+        }
+        const float fn = (float)npx;
+        float* o = stats + (((size_t)b * tiles_x * tiles_y + slot) * cout + 4 * q) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = s1[i] + fn * pv[i];
+            o[2 * i + 1] = fmaxf(s2[i] - s1[i] * s1[i] / fn, 0.0f);
+        }
+    }
+    if (b == 0 && cgrp == 0 && threadIdx.x == 0) slot_count[slot] = (float)npx;
+}
+
+template <int MODE>
 int launch4_split(const Wino4Args& a, hipStream_t st) {
     static nd_device_once configured;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<ND_PRO_NONE, false, true>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, false, true>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
     const long resident = nd_device_cus();
-    hipLaunchKernelGGL((wino4_kernel<ND_PRO_NONE, false, true>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((wino4_kernel<MODE, false, true>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
     return 0;
 }
 
@@ -1003,7 +1059,8 @@ extern "C" int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* work
     Wino4Args a;
     if (int e = w4_prepare(d, a)) return e;
     ND_REQUIRE(workspace && nd_aligned16(workspace), ND_E_BADARG, "nd_conv3x3_wino4_splitk: the workspace must be a 16-byte aligned pointer");
-    ND_REQUIRE(d->src.mode == ND_PRO_NONE && !d->stats, ND_E_BADARG, "nd_conv3x3_wino4_splitk: plain sources, no statistics epilogue");
+    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
+               "nd_conv3x3_wino4_splitk: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)");
     const int n_chunks = nd_cdiv(d->cin, KC4);
     ND_REQUIRE((splits == 2 || splits == 4 || splits == 8) && d->cin % KC4 == 0 && n_chunks % splits == 0 && n_chunks / splits >= 2, ND_E_SHAPE,
                "nd_conv3x3_wino4_splitk: splits=%d must be 2, 4 or 8 and divide cin=%d into ranges of at least two whole 16-channel chunks", splits, d->cin);
@@ -1014,12 +1071,19 @@ extern "C" int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* work
     float* out = d->out;
     const int ldo = d->ldo;
     a.d.out = workspace;  a.d.ldo = d->cout;  a.d.bias = nullptr;       // partial sums [split][B][H][W][cout]; the bias joins in the reduction
+    a.d.stats = nullptr;  a.d.slot_count = nullptr;                      // ... and so do the statistics (of the SUMMED output)
     a.splits = splits;
     a.chunks_per_split = n_chunks / splits;
     a.total_wg *= splits;
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = launch4_split(a, st)) return rc;
+    if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4_split<ND_PRO_AFFINE_SILU>(a, st) : launch4_split<ND_PRO_NONE>(a, st)) return rc;
     if (int e = nd_launch_status("nd_conv3x3_wino4_splitk_nhwc_f32")) return e;
+    if (d->stats) {
+        const int n_cgrp = nd_cdiv(d->cout, 64);
+        hipLaunchKernelGGL(w4_splitk_reduce_stats_kernel, dim3((unsigned)(d->B * a.tiles_x * a.tiles_y * n_cgrp)), dim3(256), 0, st, workspace, bias, out,
+                           d->stats, d->slot_count, splits, d->B, d->H, d->W, d->cout, ldo, a.tiles_x, a.tiles_y, n_cgrp);
+        return nd_launch_status("nd_conv3x3_wino4_splitk_nhwc_f32 (reduce + statistics)");
+    }
     const long total = npix * (d->cout / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, bias, out, splits, npix, d->cout, ldo);

@@ -43,6 +43,12 @@ WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two
 MAP_BLOCKED = os.environ.get("ND_MAP_BLOCKED", "1") != "0"   # A-B knob: 0 = ResnetBlock2 scale / shift maps in the planar [scale C | shift C] layout
 COND_STEP = os.environ.get("ND_COND_STEP", "1") != "0"   # A-B knob: 0 = time embedding / time_mlp / projections as four launches
 WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel (conv3x3_wino4.hip)
+# Low-latency mode for SMALL batches (opt-in: ND_SPLIT_K=1 or engine.SPLIT_K = True before the plans are recorded): plain-source F(4x4) layers whose
+# (sample, region, cout tile) items fill a fraction of the chip run on the split-K form (nd_conv3x3_wino4_splitk_nhwc_f32: one sample at 256 x 256 has 16
+# items for the 512 -> 512 layers at 32 x 32).  Off by default: the split count depends on the batch size, and with it the summation order over cin --
+# a sample's bits would depend on the batch it is sharded into, which the default path rules out (see _wino4_takes).  16 patches per GPU never split.
+SPLIT_K = os.environ.get("ND_SPLIT_K", "0") != "0"
+EIGHT_TILES_RULE = os.environ.get("ND_W4_EIGHT_TILES", "1") != "0"     # A-B knob (tools/): 0 = F(4x4) also for layers with <= 8 workgroup tiles per sample
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -463,9 +469,16 @@ class Plan:
         d.weight = e.p(name + (".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
         entry = ("nd_conv3x3_wino4_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
                  "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32")
-        self._add(entry, C.byref(d), e.stream,
-                  meta={"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
-                        "tiling": 9004 if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)})
+        meta = {"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
+                "tiling": 9004 if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
+        splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and wino4 and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
+        if splits > 1 and splits * self.B * H * W * cout * 4 < (1 << 31):
+            ws = self._alloc(splits * self.B * H * W * cout)
+            meta["splits"] = splits
+            self._add("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), splits, e.stream, meta=meta)
+            self._release(ws)
+        else:
+            self._add(entry, C.byref(d), e.stream, meta=meta)
         self._keep.append(d)
         return out, st, sc, slots
 
@@ -477,7 +490,8 @@ class Plan:
         # Layers with at most eight F(4x4) workgroup tiles (16 x 32 pixels x 64 couts) per SAMPLE -- 256 -> 256 at 32 x 32 -- fill half of an
         # MI355X at the usual 16 patches per GPU; F(2x2)'s 16 x 16-pixel tiles fill it (84 vs 114 us per layer).  The rule looks at the
         # sample's geometry only: the kernel choice -- and with it the bits of a sample -- must not depend on the batch it is sharded into.
-        if (WINO2 and ((H + 15) // 16) * ((W + 31) // 32) * ((cout + 63) // 64) <= 8 and (c1 == 0 or c0 % 32 == 0)
+        # (The opt-in low-latency mode, SPLIT_K, gives that up anyway and cuts these layers along cin instead.)
+        if (WINO2 and not SPLIT_K and EIGHT_TILES_RULE and ((H + 15) // 16) * ((W + 31) // 32) * ((cout + 63) // 64) <= 8 and (c1 == 0 or c0 % 32 == 0)
                 and not (mode == L.PRO_AFFINE_MAP_SILU and up)):
             return False
         src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor

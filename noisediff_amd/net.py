@@ -113,7 +113,12 @@ class NoiseDiffNet(nn.Module):
 
     # ------------------------------------------------------------------ engine management
     def _signature(self) -> tuple:
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        def version(p):
+            try:
+                return p._version
+            except RuntimeError:                                 # parameters created under torch.inference_mode() have no version counter
+                return -1
+        return tuple((p.data_ptr(), version(p)) for p in self.parameters())
 
     def hip_engine(self, device: torch.device, like: Optional[torch.device] = None):
         """The packed-weight engine for ``device`` (rebuilt when parameters changed).  ``like``: another device whose engine is

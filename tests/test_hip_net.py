@@ -352,6 +352,46 @@ def test_data_parallel_forward_replicas_use_the_owners_engines():
     assert y.shape == ref.shape and torch.equal(y, ref)
 
 
+def test_low_latency_mode_split_k_for_small_batches_matches_oracle():
+    """engine.SPLIT_K (ND_SPLIT_K=1): one patch at the headline size (d=64, 256x256) -- the 512-channel layers at 32x32 have 16 workgroup items --
+    with the plain-source F(4x4) layers on the split-K form, statistics from its reduction kernel: the forward against the oracle and against the
+    default path, and the recorded plan really splits."""
+    from noisediff_amd import engine as E
+    _oracle_threads_early()
+    dim, H, B = 64, 256, 1
+    sd = state_dict(dim)
+    cond = synth.make_condition(B, H, seed=3)
+    x = synth.make_noise(4, "net.x", B, 4, H)
+    t = torch.tensor([640])
+    base_net = make_net(dim)
+    with torch.inference_mode():
+        base = base_net(x.to(DEV), t.to(DEV), to_dev(cond)).cpu()
+    old = E.SPLIT_K
+    E.SPLIT_K = True
+    try:
+        net = make_net(dim)
+        with torch.inference_mode():
+            y = net(x.to(DEV), t.to(DEV), to_dev(cond)).cpu()
+        plan = net.hip_engine(DEV).plan(B, H, H)
+        split_ops = [m for _f, _a, name, m in plan.step_ops if name == "nd_conv3x3_wino4_splitk_nhwc_f32"]
+    finally:
+        E.SPLIT_K = old
+    assert len(split_ops) >= 10 and max(m["splits"] for m in split_ops) == 8
+    with torch.no_grad():
+        ref = O.noisediff_forward(sd, x, t, cond)
+    assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
+    assert rel_err(y.numpy(), base.numpy()) < 1e-4 and not torch.equal(y, base)
+
+
+def _oracle_threads_early():
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    torch.set_num_threads(max(1, min(n, 32)))
+
+
 # --------------------------------------------------------------------------- the bench workload's own sizes, against the oracle
 
 def _oracle_threads():

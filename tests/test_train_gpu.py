@@ -120,6 +120,88 @@ def test_wino4_split_k_equals_the_plain_kernel_and_torch(case):
         L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), want, st)
 
 
+def test_wino4_split_k_with_the_affine_silu_prologue():
+    """The split-K instance of the GroupNorm-affine + SiLU prologue (block2's convolution in the engine's low-latency mode) against the plain kernel
+    and torch: conv(silu((x - M) A + D)) with per-(sample, channel) M, A, D, statistics on."""
+    lib = L.load()
+    B, H, W, cin, cout = 1, 32, 32, 512, 512
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    splits = lib.nd_conv3x3_wino4_splitk_plan(B, H, W, cin, cout)
+    x = U("ska.x", (B, H, W, cin)).to(DEV)
+    w = (U("ska.w", (cout, cin, 3, 3)) / (9 * cin) ** 0.5).to(DEV)
+    b = U("ska.b", (cout,)).to(DEV)
+    mad = torch.stack((U("ska.m", (B, cin)) * 0.2, U("ska.a", (B, cin), 0.5, 1.5), U("ska.d", (B, cin)) * 0.3), dim=1).contiguous().to(DEV)   # [B][3][cin]
+    wp = torch.empty(int(lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout)), device=DEV)
+    L.call("nd_pack_conv3x3_wino4_weight", w.data_ptr(), wp.data_ptr(), cin, cout, st)
+    slots = lib.nd_conv3x3_wino4_stat_slots(H, W)
+    outs = []
+    for split in (0, splits):
+        out = torch.full((B, H, W, cout), float("nan"), device=DEV)
+        stt, sc = torch.empty((B, slots, cout, 2), device=DEV), torch.empty((slots,), device=DEV)
+        d = L.Conv3x3()
+        d.src.p0, d.src.c0, d.src.ld0, d.src.mode, d.src.mad = x.data_ptr(), cin, cin, L.PRO_AFFINE_SILU, mad.data_ptr()
+        d.weight, d.bias, d.out, d.stats, d.slot_count = wp.data_ptr(), b.data_ptr(), out.data_ptr(), stt.data_ptr(), sc.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        if split:
+            ws = torch.empty((int(lib.nd_conv3x3_wino4_splitk_workspace_floats(B, H, W, cout, split)),), device=DEV)
+            L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), split, st)
+        else:
+            L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), st)
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), stt.cpu()))
+    assert splits == 8 and rel_err(outs[1][0].numpy(), outs[0][0].numpy()) < 5e-5
+    assert rel_err(outs[1][1][..., 0].numpy(), outs[0][1][..., 0].numpy()) < 1e-4
+    xin = F.silu((x.double().cpu() - mad[:, 0].double().cpu()[:, None, None, :]) * mad[:, 1].double().cpu()[:, None, None, :] + mad[:, 2].double().cpu()[:, None, None, :])
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), w.double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 1).float()
+    assert rel_err(outs[1][0].numpy(), ref.numpy()) < 5e-5
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 512, 512, 8), (2, 48, 40, 256, 192, 8), (1, 64, 64, 256, 100, 4)])
+def test_wino4_split_k_statistics_match_the_plain_epilogue(case):
+    """The split-K form with a statistics epilogue (the reduction kernel leaves the slots of the summed output) against nd_conv3x3_wino4_nhwc_f32's own
+    epilogue: same slot layout and counts, sums and centred second moments equal within rounding, and the GroupNorm coefficients pooled from them
+    (nd_groupnorm_finalize_f32) equal to 1e-5 -- ragged tiles, cout that is not a multiple of 64."""
+    lib = L.load()
+    B, H, W, cin, cout, groups = case
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    splits = lib.nd_conv3x3_wino4_splitk_plan(B, H, W, cin, cout)
+    assert splits > 1
+    x = U(f"sks.x.{case}", (B, H, W, cin)).to(DEV)
+    w = (U(f"sks.w.{case}", (cout, cin, 3, 3)) / (9 * cin) ** 0.5).to(DEV)
+    b = U(f"sks.b.{case}", (cout,)).to(DEV)
+    gam, bet = U(f"sks.g.{case}", (cout,), 0.5, 1.5).to(DEV), U(f"sks.be.{case}", (cout,)).to(DEV)
+    wp = torch.empty(int(lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout)), device=DEV)
+    L.call("nd_pack_conv3x3_wino4_weight", w.data_ptr(), wp.data_ptr(), cin, cout, st)
+    slots = lib.nd_conv3x3_wino4_stat_slots(H, W)
+    res = []
+    for split in (0, splits):
+        out = torch.full((B, H, W, cout), float("nan"), device=DEV)
+        stt = torch.full((B, slots, cout, 2), float("nan"), device=DEV)
+        sc = torch.full((slots,), float("nan"), device=DEV)
+        mad = torch.full((B, 3, cout), float("nan"), device=DEV)
+        d = L.Conv3x3()
+        d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x.data_ptr(), cin, cin, L.PRO_NONE
+        d.weight, d.bias, d.out, d.stats, d.slot_count = wp.data_ptr(), b.data_ptr(), out.data_ptr(), stt.data_ptr(), sc.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
+        if split:
+            ws = torch.full((int(lib.nd_conv3x3_wino4_splitk_workspace_floats(B, H, W, cout, split)),), float("nan"), device=DEV)
+            L.call("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), split, st)
+        else:
+            L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), st)
+        L.call("nd_groupnorm_finalize_f32", stt.data_ptr(), sc.data_ptr(), slots, gam.data_ptr(), bet.data_ptr(), None, 0, mad.data_ptr(), B, cout, groups, 1e-5, st)
+        torch.cuda.synchronize()
+        res.append((out.cpu(), stt.cpu(), sc.cpu(), mad.cpu()))
+    (o0, s0, c0, m0), (o1, s1, c1, m1) = res
+    assert not bool(o1.isnan().any()) and not bool(s1.isnan().any()) and torch.equal(c0, c1)
+    assert rel_err(o1.numpy(), o0.numpy()) < 5e-5
+    assert rel_err(s1[..., 0].numpy(), s0[..., 0].numpy()) < 1e-4 and rel_err(s1[..., 1].numpy(), s0[..., 1].numpy()) < 1e-3
+    assert rel_err(m1.numpy(), m0.numpy()) < 1e-5
+    xr = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    ref = F.group_norm(xr, groups, gam.double().cpu(), bet.double().cpu(), 1e-5).permute(0, 2, 3, 1)
+    got = (o1.double() - m1[:, 0].double()[:, None, None, :]) * m1[:, 1].double()[:, None, None, :] + m1[:, 2].double()[:, None, None, :]
+    assert rel_err(got.float().numpy(), ref.float().numpy()) < 1e-4
+
+
 def test_modulate_silu_and_the_fused_shortcut_match_torch():
     """train.modulate_silu (ResnetBlock2's per-pixel modulation + SiLU, forward and backward) and group_norm_silu(..., res=) against the same
     expressions in torch (float64 reference)."""
