@@ -73,7 +73,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
     ``dgrad``: ``w_oihw`` is the FORWARD layer's weight and the operator is its data gradient, conv2d(x, w.flip(2, 3).transpose(0, 1),
     padding=1) -- the pack kernels read the flipped / role-swapped weight in place (nd_pack_conv3x3_*_weight_dgrad).
     ``stats``: returns (y, st, sc) with the kernel's GroupNorm statistics epilogue -- per-(sample, slot, channel) {sum, M2} partials ``st`` and the
-    pixel counts ``sc`` of the slots, what nd_groupnorm_finalize*_f32 pools -- or (y, None, None) where the layer runs on the split-K form."""
+    pixel counts ``sc`` of the slots, what nd_groupnorm_finalize*_f32 pools."""
     lib = L.load()
     B, cin, H, W = x.shape
     cout = w_oihw.shape[1 if dgrad else 0]
@@ -111,7 +111,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
         splits = int(lib.nd_conv3x3_wino4_splitk_plan(B, H, W, cin, cout)) if wino4 and _SPLIT_K else 1
         st_t = sc_t = None
-        if stats and splits == 1:
+        if stats:                                                 # (the split-K form leaves the same slots from its reduction kernel)
             slots = int(lib.nd_conv3x3_wino4_stat_slots(H, W) if wino4 else lib.nd_conv3x3_wino_stat_slots(H, W) if wino2
                         else lib.nd_conv3x3_stat_slots(H, W, cout, B))
             st_t = torch.empty((B, slots, cout, 2), dtype=torch.float32, device=x.device)
@@ -139,8 +139,6 @@ class Conv3x3Function(torch.autograd.Function):
         if not want_stats:
             return _conv3x3_nhwc(xn, weight, bias)
         y, st, sc = _conv3x3_nhwc(xn, weight, bias, stats=True)
-        if st is None:                                           # split-K layer: no statistics epilogue; empty placeholders keep the arity
-            st, sc = y.new_empty(0), y.new_empty(0)
         ctx.mark_non_differentiable(st, sc)
         ctx.set_materialize_grads(False)                         # no zero tensors for the statistics outputs' (never used) gradients
         ctx.n_out = 3
@@ -182,12 +180,12 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
 
 def conv3x3_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
     """conv3x3 plus the kernel's GroupNorm statistics epilogue: (y, (st, sc)) for ``group_norm_silu(y, ..., conv_stats=)`` -- the norm then needs no
-    pass of its own over y for its moments, as in the sampling engine (Block: conv -> statistics -> finalize -> apply).  (y, None) where the layer
-    runs on the split-K form, which has no statistics epilogue."""
+    pass of its own over y for its moments, as in the sampling engine (Block: conv -> statistics -> finalize -> apply); the split-K form of the deep
+    layers leaves the same slots from its reduction kernel."""
     if tuple(weight.shape[2:]) != (3, 3) or x.dim() != 4 or x.shape[1] != weight.shape[1]:
         raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)} is not a 3x3 convolution")
     y, st, sc = Conv3x3Function.apply(x, weight, bias, True)
-    return y, ((st, sc) if st.numel() else None)
+    return y, (st, sc)
 
 
 class GroupNormFunction(torch.autograd.Function):
