@@ -10,9 +10,9 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { F_NONE, F_PKFMA, F_PKADD, F_FMA, F_EXP, F_RCP, F_ACCREAD, F_ACCWRITE, F_MOV, F_CNDMASK, F_MAD24, F_DSW_A, F_DSW_V, F_DSR, F_BST, F_KINDS };
+enum { F_NONE, F_PKFMA, F_PKADD, F_FMA, F_EXP, F_RCP, F_ACCREAD, F_ACCWRITE, F_MOV, F_CNDMASK, F_MAD24, F_DSW_A, F_DSW_V, F_DSR, F_BST, F_DSW64, F_DSW32, F_DSW64X2, F_KINDS };
 const char* NAMES[] = {"none", "v_pk_fma_f32", "v_pk_add_f32", "v_fma_f32", "v_exp_f32", "v_rcp_f32", "v_accvgpr_read", "v_accvgpr_write", "v_mov_b32",
-                       "v_cndmask_b32", "v_mad_u32_u24", "ds_write_b128<-a", "ds_write_b128<-v", "ds_read_b128", "buffer_store_x4"};
+                       "v_cndmask_b32", "v_mad_u32_u24", "ds_write_b128<-a", "ds_write_b128<-v", "ds_read_b128", "buffer_store_x4", "ds_write_b64", "ds_write_b32", "ds_write2_b64"};
 
 struct Regs { double v[8]; float s[8]; f32x4 d[4]; f32x4 av[2]; unsigned lp, goff; int rs[4]; };
 
@@ -34,6 +34,9 @@ __device__ __forceinline__ void filler(int n, Regs& r) {
     if (KIND == F_DSW_A) asm volatile("ds_write_b128 %0, %1" :: "v"(r.lp), "a"(r.av[0]) : "memory");
     if (KIND == F_DSW_V) asm volatile("ds_write_b128 %0, %1" :: "v"(r.lp), "v"(r.d[n & 3]) : "memory");
     if (KIND == F_DSR) asm volatile("ds_read_b128 %0, %1" : "=v"(r.d[n & 3]) : "v"(r.lp));
+    if (KIND == F_DSW64) asm volatile("ds_write_b64 %0, %1" :: "v"(r.lp), "v"(r.v[n & 3]) : "memory");              // 8 bytes per lane (the lanes' 16-byte slots: half of each)
+    if (KIND == F_DSW32) asm volatile("ds_write_b32 %0, %1" :: "v"(r.lp), "v"(r.s[n & 3]) : "memory");
+    if (KIND == F_DSW64X2) asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" :: "v"(r.lp), "v"(r.v[n & 3]), "v"(r.v[(n + 1) & 3]) : "memory");   // the same 16 bytes as b128, as two qwords
     if (KIND == F_BST) {
         i32x4 q = {r.rs[0], r.rs[1], r.rs[2], r.rs[3]};
         asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(r.d[n & 3]), "v"(r.goff), "s"(q) : "memory");
@@ -183,5 +186,6 @@ int main() {
     rows<F_PKFMA>(dout, g); rows<F_PKADD>(dout, g); rows<F_FMA>(dout, g); rows<F_EXP>(dout, g); rows<F_RCP>(dout, g);
     rows<F_ACCREAD>(dout, g); rows<F_ACCWRITE>(dout, g); rows<F_MOV>(dout, g); rows<F_CNDMASK>(dout, g); rows<F_MAD24>(dout, g);
     rows<F_DSW_A>(dout, g); rows<F_DSW_V>(dout, g); rows<F_DSR>(dout, g); rows<F_BST>(dout, g);
+    rows<F_DSW64>(dout, g); rows<F_DSW32>(dout, g); rows<F_DSW64X2>(dout, g);
     return 0;
 }
