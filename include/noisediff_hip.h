@@ -134,6 +134,12 @@ int nd_pack_conv3x3_wino_weight_dgrad(const float* oihw_fwd, float* packed, int 
  * 1 GiB / 2^24 pixels (rejected otherwise: the caller picks nd_conv3x3_wino2_nhwc_f32).  `weight` from
  * nd_pack_conv3x3_wino4_weight (U = G g G^T in blocks [cin/8][coutP/16][18 position pairs][64 lanes][4]). */
 int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream);
+/* The same kernel on 16 x 16-pixel regions with TWO co-resident workgroups per CU (two waves per SIMD: one workgroup's LDS round trips,
+ * barriers, store queue and transforms run under the other's MFMAs; r4).  Same packed weights, statistics slots and descriptor, and the
+ * same bits as nd_conv3x3_wino4_nhwc_f32 (identical arithmetic in identical order).  Plain and GroupNorm-affine + SiLU sources only
+ * (Block.proj of ResnetBlock, Diffusion_arch.py:128-170; the resampling convs :75,533,547); also the F(4x4) path of images narrower
+ * than 32 pixels (BASELINE config 2's 16 x 16 stage). */
+int nd_conv3x3_wino4_16_nhwc_f32(const nd_conv3x3* d, void* stream);
 /* its statistics epilogue writes ONE slot per 16 x 16-pixel tile (the F(2x2) kernels: two) */
 int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);

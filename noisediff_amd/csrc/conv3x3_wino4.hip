@@ -50,15 +50,32 @@ constexpr int KC4 = 16;                              // channels per K chunk
 constexpr int NPOS = 36;                             // positions (xi, nu) == patch entries (a, b)
 constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk image: 36 entries x 1 KB = 36 KB
 
-// LDS map (bytes): [raw halo image 46080][V image of tile group 0 / 1: 2 x 36864][per-thread tables: source pixel u32 x 10, (row, column) u32 x 10,
-// raw-image address of a staged item u16 x 10, raw-image address of the transform lane's patch columns u16 x 12][bias of every cout].  The raw
+// LDS map (bytes): [raw halo image][V image of every tile group: NTG x 36864][per-thread tables: source pixel u32 x RAW_IT, (NTG == 2: (row, column) u32 x RAW_IT,)
+// raw-image address of a staged item u16 x RAW_IT, raw-image address of the transform lane's patch columns u16 x 12][NTG == 2: bias of every cout].  The raw
 // image sits at address 0 so that its addresses fit 16 bits.
-constexpr int RAW_FLOATS = 18 * 40 * 16;                                  // 18 halo rows x 40 records of 64 bytes
-constexpr int TAB_BYTES = (10 + 10) * 256 * 4 + (10 + 12) * 256 * 2;
-constexpr int BIAS_OFF_BYTES = RAW_FLOATS * 4 + 2 * VD_FLOATS * 4 + TAB_BYTES;
-constexpr int MAX_COUT = 2048;                                           // the whole bias vector (padded to cout tiles) lives in LDS
-constexpr int LDS_BYTES = BIAS_OFF_BYTES + MAX_COUT * 4;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
+//
+// NTG = tile groups (16 x 16-pixel tiles of 16 F(4x4) tiles) per workgroup:
+//   NTG == 2 (r2/r3): a 16 x 32-pixel region, ONE workgroup per CU, 72 accumulators per wave, every weight fragment serves two MFMAs, 156 KB of LDS.
+//   NTG == 1 (r4):    a 16 x 16-pixel region, TWO co-resident workgroups per CU (two waves per SIMD, 256 registers each: 36 accumulators = 128 AGPRs + 16 VGPRs),
+//                     78 KB of LDS each.  Nothing overlaps a wave's own LDS round trips, barriers, store queue and transform with its MFMAs any more -- the
+//                     OTHER workgroup's MFMAs do (the fp32 MFMA shares the VALU lanes, so only waits can be hidden, never VALU work); the price is that
+//                     a weight fragment serves one MFMA quad instead of two (32 B/clk per CU from the L2 instead of 16).  It is also the F(4x4) path of
+//                     images narrower than 32 pixels.  Same arithmetic in the same order: the two forms agree bit for bit.
+constexpr int MAX_COUT = 2048;                                           // NTG == 2: the whole bias vector (padded to cout tiles) lives in LDS
+template <int NTG>
+struct W4Geo {
+    static constexpr int REG_W = 16 * NTG, HALO_W = REG_W + 2;            // region width, halo columns (18 halo rows)
+    static constexpr int RAW_ROWP = NTG == 2 ? 40 : 24;                   // records of 64 bytes per halo row (row stride = 0 mod 256 bytes: the bank pattern of the swizzle)
+    static constexpr int RAW_ITEMS = 18 * HALO_W * 4, RAW_IT = (RAW_ITEMS + 255) / 256;      // (pixel, channel quad) items per chunk: 10 / 6 per thread
+    static constexpr int RAW_FLOATS = 18 * RAW_ROWP * 16;
+    static constexpr bool RTAB = NTG == 2;                                // the (row, column) table of the items (NTG == 1 recomputes it per border tile: LDS)
+    static constexpr int TAB_BYTES = (RAW_IT + (RTAB ? RAW_IT : 0)) * 256 * 4 + (RAW_IT + 12) * 256 * 2;
+    static constexpr int BIAS_OFF_BYTES = RAW_FLOATS * 4 + NTG * VD_FLOATS * 4 + TAB_BYTES;
+    static constexpr int LDS_BYTES = BIAS_OFF_BYTES + (NTG == 2 ? MAX_COUT * 4 : 0);
+    static constexpr int WG_PER_CU = NTG == 2 ? 1 : 2;
+    static constexpr int ACC_AGPR = NTG == 2 ? 64 : 32;                   // accumulators [0, ACC_AGPR) in the AGPR half (256 / 128 registers), the rest in VGPRs
+    static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS map");
+};
 
 #ifndef W4_UR
 #define W4_UR 18             // weight fragments in flight per wave in the K loop (x 4 registers); a stage consumes 18
@@ -93,6 +110,24 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
 #ifndef W4_XF_SPLIT
 #define W4_XF_SPLIT 1        // the "every wave has read its V operands" barrier between the input transform's two passes (0: behind both)
 #endif
+#ifndef W4_UR1
+#define W4_UR1 9             // NTG == 1 (two workgroups per CU, 128 VGPRs per wave): weight fragments in flight per wave; a stage consumes 18
+#endif
+#ifndef W4_UR1_AFF
+#define W4_UR1_AFF 6         // ... of its GroupNorm-affine + SiLU variant
+#endif
+#ifndef W4_UR1_EPI
+#define W4_UR1_EPI 0         // ... across its epilogue (none: with any, the output transform spills -- and a scratch reload drains the stores issued before it)
+#endif
+#ifndef W4_UR1_XF
+#define W4_UR1_XF 6          // ... across the input transform between two chunks (its 18 + 6 packed values need the registers)
+#endif
+#ifndef W4_PAIR_SKEW
+#define W4_PAIR_SKEW 2       // NTG == 1: s_sleep(32) units (2048 cycles) by which the second workgroup of a CU starts later
+#endif
+#ifndef W4_PRIO
+#define W4_PRIO 0            // NTG == 1: s_setprio level of a wave inside its transform / epilogue (VALU phases; the other workgroup's waves sit in MFMA stages at level 0)
+#endif
 #ifndef W4_ABLATE
 #define W4_ABLATE 0          // diagnostic builds only: 1 no staging, 2 no weight loads, 4 no transform, 8 no epilogue stores,
                              // 16 halo loaded but not written to LDS, 32 written but not loaded, 64 every halo load from the same pixels
@@ -120,7 +155,6 @@ struct Wino4Args {
 #define W4_MFMA_AZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, 0" : "=&a"(acc) : "v"(uv), "v"(vv))
 #define W4_MFMA_VZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, 0" : "=&v"(acc) : "v"(uv), "v"(vv))
 #define W4_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
-constexpr int ACC_AGPR = 64;                         // accumulators [0, 64) in a[0:255], [64, 72) in VGPRs
 
 // one row of B^T applied to six packed values (the same code serves the column pass)
 __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
@@ -136,6 +170,23 @@ __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
     t[5] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(cm5, d[3], d[5]));
 }
 
+// rows 3 HALF .. 3 HALF + 2 of B^T d (six packed instructions each way: the split costs nothing)
+template <int HALF>
+__device__ __forceinline__ void w4_bt_half(const f32x2 (&d)[6], f32x2 (&t)[3]) {
+    const f32x2 c4 = {4.0f, 4.0f}, cm4 = {-4.0f, -4.0f}, cm5 = {-5.0f, -5.0f}, c2 = {2.0f, 2.0f}, cm2 = {-2.0f, -2.0f};
+    if (HALF == 0) {
+        const f32x2 p = __builtin_elementwise_fma(cm4, d[2], d[4]), q = __builtin_elementwise_fma(cm4, d[1], d[3]);
+        t[0] = __builtin_elementwise_fma(c4, d[0], __builtin_elementwise_fma(cm5, d[2], d[4]));
+        t[1] = p + q;
+        t[2] = p - q;
+    } else {
+        const f32x2 r = d[4] - d[2], s = d[3] - d[1];
+        t[0] = __builtin_elementwise_fma(c2, s, r);
+        t[1] = __builtin_elementwise_fma(cm2, s, r);
+        t[2] = __builtin_elementwise_fma(c4, d[1], __builtin_elementwise_fma(cm5, d[3], d[5]));
+    }
+}
+
 // STREAM: the output tensor is far larger than the L2s (host: >= ND_W4_STREAM_MB, default 48 MB): its stores carry the non-temporal
 // system-scope policy bits, so the L2s stream them out instead of allocating lines for them.  With the default policy a 64 -> 64 layer at
 // 256 x 256 spends 2.3 k cycles more in the K chunk that follows an epilogue (its halo reads queue behind the output's write-back) and
@@ -145,18 +196,23 @@ __device__ __forceinline__ void w4_bt(const f32x2 (&d)[6], f32x2 (&t)[6]) {
 // 32 x 32 with 4 samples: 64 items for 256 CUs, each walking 32 K chunks -- are cut along cin: item (split, sample, region, cout tile) walks
 // `chunks_per_split` chunks starting at chunk split * chunks_per_split and writes its partial sums to out[split] (the host passes a workspace
 // and no bias); w4_splitk_reduce_kernel adds the partials in split order and the bias.  The split count is fixed by the shape alone.
-template <int MODE, bool STREAM, bool SPLIT = false>
-__global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
+template <int MODE, bool STREAM, bool SPLIT = false, int NTG = 2>
+__global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const Wino4Args a) {
+    using Geo = W4Geo<NTG>;
+    constexpr int RAW_FLOATS = Geo::RAW_FLOATS, BIAS_OFF_BYTES = Geo::BIAS_OFF_BYTES, ACC_AGPR = Geo::ACC_AGPR, REG_W = Geo::REG_W, HALO_W = Geo::HALO_W;
     constexpr bool MAP = MODE == ND_PRO_AFFINE_MAP_SILU;                  // + per-pixel scale / shift maps (ResnetBlock2)
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAP;               // GroupNorm-affine + SiLU applied while the halo is written to LDS
     constexpr bool LEAKY = MODE == ND_PRO_LEAKY || MODE == ND_PRO_LEAKY_SECOND;      // LSID: LeakyReLU(0.2) of the producer, applied by the consumer
-    constexpr int UR = MAP ? W4_UR_MAP : AFF ? W4_UR_AFF : W4_UR, UR_EPI = W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
+    constexpr int UR = NTG == 1 ? (AFF ? W4_UR1_AFF : W4_UR1) : MAP ? W4_UR_MAP : AFF ? W4_UR_AFF : W4_UR, UR_EPI = NTG == 1 ? W4_UR1_EPI : W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
+    static_assert(NTG == 2 || !MAP, "the map prologue (20 more staging registers per halo item in flight) stays on the one-workgroup form");
     extern __shared__ __attribute__((aligned(16))) float lds_[];        // the LDS map above (dynamic shared memory starts at LDS address 0)
-    float* const Vd = lds_ + RAW_FLOATS;                                // [tg 2][VD_FLOATS]: the V images
+    float* const Vd = lds_ + RAW_FLOATS;                                // [tg NTG][VD_FLOATS]: the V images
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tg = wave >> 1, ch2 = wave & 1;                            // tile group; cout half (and transform half) of this wave
+    // transform roles: NTG == 2: wave = (tile group, channel half): a lane owns a whole 6 x 6 patch of a channel pair; NTG == 1: wave = (row half, channel half):
+    // a lane produces rows xi = 3 rh .. 3 rh + 2 of V for its (tile, channel pair) -- 256 work items either way
+    const int tg = NTG == 2 ? wave >> 1 : 0, rh = wave >> 1, ch2 = wave & 1;
     const int tile = lane & 15, kq = lane >> 4;
 
     const int wgid = nd_xcd_remap(blockIdx.x, gridDim.x);
@@ -178,6 +234,12 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     // Only where a workgroup walks four tiles or more (the full-resolution layers: -3 %); with one or two tiles each the wait itself shows (+1.5 %).
     if (a.total_wg >= 4 * (int)gridDim.x)
         for (int k = (int)(blockIdx.x >> 3) & 15; k > 0; --k) __builtin_amdgcn_s_sleep(W4_STAGGER);
+#endif
+#if W4_PAIR_SKEW
+    // NTG == 1: the two workgroups of a CU are dispatched together; the second one starts about half a K chunk later, so that its transform / epilogue phases
+    // (no MFMAs) fall under the other's stage loops from the first chunk on
+    if (NTG == 1 && 2 * blockIdx.x >= gridDim.x)
+        for (int k = 0; k < W4_PAIR_SKEW; ++k) __builtin_amdgcn_s_sleep(32);
 #endif
     const nd_src& s = a.d.src;
     const int H = a.d.H, W = a.d.W, Cin = a.d.cin, Cout = a.d.cout;
@@ -203,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     //      The raw image in LDS: record (row r, column c) of 64 bytes at index r * 40 + cperm(c), cperm swapping column bits
     //      0-1 with bits 2-3, and the channel pair P of a pixel in 8-byte slot P ^ swz(r, c): the transform's reads -- tiles 4 pixels
     //      apart in x and y -- then fall on different banks.
-    constexpr int RAW_ROWP = 40, RAW_ITEMS = 18 * 34 * 4, RAW_IT = (RAW_ITEMS + 255) / 256;      // 10
+    constexpr int RAW_ROWP = Geo::RAW_ROWP, RAW_IT = Geo::RAW_IT;         // 40 records per row, 10 items per thread (NTG == 1: 24, 6)
     // Source addressing: byte address = resource base + soffset (SGPR: the region's base pixel and the chunk's channel base) +
     // voffset (VGPR: item pixel relative to the region x pixel stride + channel quad).  The resources start one row + one pixel in
     // front of the tensors, so that soffset is never negative, and end with the tensors.  Halo entries outside the image carry
@@ -220,29 +282,33 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     const __amdgpu_buffer_rsrc_t rsrc1 = s.p1 ? src_rsrc(s.p1, s.ld1) : rsrc0;
     const __amdgpu_buffer_rsrc_t rsrcm = MAP ? src_rsrc(s.map, 2 * Ctot) : rsrc0;
     const int map_shift = s.map_blocked ? 64 : Ctot * 4;                 // bytes from a channel's scale to its shift (blocked layout: [chunk][scale 16 | shift 16])
-    float* const vd_tg = Vd + tg * VD_FLOATS;                            // this tile group's V image
+    float* const vd_tg = Vd + tg * VD_FLOATS;                            // the V image this wave's transform lanes write
     char* const rawbuf = reinterpret_cast<char*>(lds_);                  // [18][40] records of 64 bytes
-    lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + 2 * VD_FLOATS) + tid;    // [10][256] source pixel of this thread's items
+    lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + NTG * VD_FLOATS) + tid;  // [RAW_IT][256] source pixel of this thread's items
     auto cperm = [](int c) { return ((c >> 2) & 3) | ((c & 3) << 2) | (c & 48); };
     auto swz = [](int r, int c) { return (2 * ((r >> 2) & 3)) ^ (4 * ((c >> 3) & 1)); };       // slot swizzle of a pixel's 8 channel pairs (even: quads stay 16 contiguous bytes)
     const int sq = tid & 3;                                              // channel quad of this thread's items
     // per-thread constants live in LDS tables (thread-private columns), not in registers: [10] LDS address of staged item k,
     // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
     // patch crosses a multiple-of-4 row): entry (a, b) is at ttab[(a >> 2) * 6 + b] + a * RAW_ROWP * 64
-    lds_u32_ptr const rtab = ptab + RAW_IT * 256;                       // [10] item k: pixel relative to the region | halo row << 16 | column << 24 (stage_tile, once per tile)
-    lds_u16_ptr const dtab = (lds_u16_ptr)(rtab - tid + RAW_IT * 256) + tid;    // [10] LDS address of staged item k (16 bits: the raw image starts at 0)
+    lds_u32_ptr const rtab = ptab + RAW_IT * 256;                       // [RAW_IT] item k: pixel relative to the region | halo row << 16 | column << 24 (stage_tile, once per tile; NTG == 2 only)
+    lds_u16_ptr const dtab = (lds_u16_ptr)(ptab - tid + (Geo::RTAB ? 2 : 1) * RAW_IT * 256) + tid;    // [RAW_IT] LDS address of staged item k (16 bits: the raw image starts at 0)
     lds_u16_ptr const ttab = dtab + RAW_IT * 256;
     float* const bias_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_) + BIAS_OFF_BYTES);
-#pragma unroll
-    for (int k = 0; k < RAW_IT; ++k) {
-        const int pix = (tid >> 2) + 64 * k, r = pix / 34, c = pix - 34 * r;
-        // (the per-item values are tables, not registers: kept in registers they get spilled, and a scratch reload in the K loop
-        //  drains the weight ring; any per-item VALU arithmetic in the stage loops costs an MFMA <-> VALU switch)
-        dtab[k * 256] = (unsigned short)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS (items beyond pixel 611 are never written)
+    auto item_rc = [&](int k, int tid_) {                                // item k of this thread: pixel relative to the region | halo row << 16 | column << 24
+        const int pix = (tid_ >> 2) + 64 * k, r = pix / HALO_W, c = pix - HALO_W * r;
         // pixel of halo entry (r, c) relative to the region's base pixel (one source row above, one pixel left of the halo origin):
         // nearest-x2 upsample addressing halves the coordinates -- (16 ty - 1 + r) >> 1 = 8 ty - 1 + ((r + 1) >> 1)
         const int dy = up ? (r + 1) >> 1 : r, dx = up ? (c + 1) >> 1 : c;
-        rtab[k * 256] = (unsigned)(dy * sW + dx) | ((unsigned)r << 16) | ((unsigned)c << 24);
+        return (unsigned)(dy * sW + dx) | ((unsigned)r << 16) | ((unsigned)c << 24);
+    };
+#pragma unroll
+    for (int k = 0; k < RAW_IT; ++k) {
+        const int pix = (tid >> 2) + 64 * k, r = pix / HALO_W, c = pix - HALO_W * r;
+        // (the per-item values are tables, not registers: kept in registers they get spilled, and a scratch reload in the K loop
+        //  drains the weight ring; any per-item VALU arithmetic in the stage loops costs an MFMA <-> VALU switch)
+        dtab[k * 256] = (unsigned short)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS (items beyond pixel 611 are never written)
+        if (Geo::RTAB) rtab[k * 256] = item_rc(k, tid);
     }
     // the transform's own lane mapping (any lane may produce any V element): 16 consecutive lanes = 8 tiles x the two channel
     // pairs of a quad, so that the compiler's paired LDS accesses (ds_read2 / ds_write2: 16-lane groups, 32 banks) are conflict-free
@@ -252,13 +318,18 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int bx = 0; bx < 6; ++bx) {
-            const int r0 = 4 * (t_tile >> 2) + 4 * h, c = 16 * tg + 4 * (t_tile & 3) + bx;
+            const int r0 = 4 * (t_tile >> 2) + 4 * h, c = 16 * tg + 4 * (t_tile & 3) + bx;         // (NTG == 1: tg = 0)
             ttab[(h * 6 + bx) * 256] = (unsigned short)((4 * (t_tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + t_kq) ^ swz(r0, c)) * 8));
         }
     const unsigned t_lds = (unsigned)(ch2 * 1024 + (t_kq >> 1) * 512 + t_tile * 32 + (t_kq & 1) * 16);  // V image address of the transform lane
     // the bias of every cout (zero beyond cout / without a bias) -> LDS, once per workgroup: the epilogues read it with an LDS load.  (A global
     // load there shares the in-order vmcnt counter with the output stores: waiting for it drained every store issued before it.)
-    for (int i = tid; i < a.n_tiles * 64; i += 256) bias_lds[i] = (a.d.bias && i < Cout) ? a.d.bias[i] : 0.0f;
+    // NTG == 1 has no LDS left for it: the lane's bias (cout = cg * 16 + (l & 15)) is loaded into a register at the start of every tile, long before the
+    // epilogue (a resource of zero records without a bias: the load returns 0, as it does for a padded cout)
+    if (NTG == 2)
+        for (int i = tid; i < a.n_tiles * 64; i += 256) bias_lds[i] = (a.d.bias && i < Cout) ? a.d.bias[i] : 0.0f;
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d.bias ? a.d.bias : a.d.weight), 0, a.d.bias ? Cout * 4 : 0, 0x00020000);
+    float bias_r = 0.0f;
 
     const unsigned OOB = 0x7FFFFFF0u;                                    // byte offset beyond any tensor: the load returns zeros (padding)
     int sb_ = 0;
@@ -267,17 +338,19 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     f32x4 tA4 = {1, 1, 1, 1}, tD4 = {0, 0, 0, 0};                        // AFF: loaded with a chunk's halo, applied when it is written to LDS
     auto stage_tile = [&](int b_, int ty_, int rx_) {
         sb_ = b_;
-        spx_ = (unsigned)((b_ * sH + ((ty_ * 16) >> up)) * sW + ((rx_ * 32) >> up));
+        spx_ = (unsigned)((b_ * sH + ((ty_ * 16) >> up)) * sW + ((rx_ * REG_W) >> up));
         // halo rows / columns inside the image (scalars); a region away from the border keeps the table of the one before it
         const int r_lo = ty_ == 0 ? 1 : 0, r_n = min(17, H - ty_ * 16) - r_lo;
-        const int c_lo = rx_ == 0 ? 1 : 0, c_n = min(33, W - rx_ * 32) - c_lo;
-        const bool interior = r_lo == 0 && r_n == 17 && c_lo == 0 && c_n == 33;
+        const int c_lo = rx_ == 0 ? 1 : 0, c_n = min(HALO_W - 1, W - rx_ * REG_W) - c_lo;
+        const bool interior = r_lo == 0 && r_n == 17 && c_lo == 0 && c_n == HALO_W - 1;
         if (!(interior && tab_clean)) {
+            int tid_ = tid;                                              // NTG == 1 recomputes the items' (row, column) here: kept visible, hipcc computes the 18 values once,
+            if (!Geo::RTAB) asm volatile("" : "+v"(tid_));               // spills them and reloads them from scratch -- a vmcnt(0) drain of the weight ring per border tile
 #pragma unroll
             for (int k = 0; k < RAW_IT; ++k) {
-                const unsigned rc = rtab[k * 256];
+                const unsigned rc = Geo::RTAB ? rtab[k * 256] : item_rc(k, tid_);
                 const unsigned r = (rc >> 16) & 255u, c = rc >> 24;
-                const bool ok = r - (unsigned)r_lo <= (unsigned)r_n && c - (unsigned)c_lo <= (unsigned)c_n;   // (items beyond pixel 611 have r >= 18)
+                const bool ok = r - (unsigned)r_lo <= (unsigned)r_n && c - (unsigned)c_lo <= (unsigned)c_n;   // (items beyond the halo's last pixel have r >= 18)
                 ptab[k * 256] = ok ? (rc & 0xFFFFu) : PX_MARK;            // outside the image: beyond the resource, the load returns the zero padding
             }
         }
@@ -324,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #endif
     };
     auto stage_commit_one = [&](int k, unsigned daddr, unsigned pxk) {   // daddr = dtab[k * 256], pxk = ptab[k * 256] (AFF only): read ahead by the caller
-        if (k == RAW_IT - 1 && (tid >> 2) + 64 * k >= 18 * 34) return;   // the last round covers 36 pixels only
+        if (k == RAW_IT - 1 && (tid >> 2) + 64 * k >= 18 * HALO_W) return;   // the last round covers 36 (NTG == 1: 4) pixels only
         f32x4 v = raw[k];
         if (AFF) {
             // GroupNorm-affine + SiLU on the raw halo (each pixel once: 40 values per thread and chunk); silu(x) = x / (1 + 2^(-x log2 e)).
@@ -406,15 +479,48 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
 #endif
     };
 
+    // NTG == 1: the same transform with a lane producing HALF the rows of V for its (tile, channel pair) -- waves 0, 1: xi = 0..2, waves 2, 3: xi = 3..5 --
+    // so that all 256 threads take part with 18 + 6 live packed values instead of 36 (128 VGPRs per wave).  Column by column: six raw reads, three rows
+    // of B^T d; then the three rows times B and their nine 16-byte writes.  It runs between two barriers of its own (the raw image is complete and the V
+    // image is free / the V image is complete); the other workgroup of the CU has the matrix pipe meanwhile.
+    auto xf_half = [&](float* buf) {
+#if !(W4_ABLATE & 4)
+        unsigned t_addr[12];
+        xf_addr(t_addr);
+        f32x2 T[3][6];
+        auto pass1 = [&](auto half_c) {
+#pragma unroll
+            for (int bx = 0; bx < 6; ++bx) {
+                f32x2 col[6], t[3];
+#pragma unroll
+                for (int ay = 0; ay < 6; ++ay) col[ay] = *reinterpret_cast<const f32x2*>(rawbuf + t_addr[(ay >> 2) * 6 + bx] + ay * (RAW_ROWP * 64));
+                w4_bt_half<decltype(half_c)::value>(col, t);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) T[i][bx] = t[i];
+            }
+        };
+        if (rh == 0) pass1(std::integral_constant<int, 0>{}); else pass1(std::integral_constant<int, 1>{});
+        char* base = reinterpret_cast<char*>(buf) + t_lds + rh * (9 * 2048);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                                    // V[3 rh + i] = T[i] B
+            f32x2 v[6];
+            w4_bt(T[i], v);
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+                *reinterpret_cast<f32x4*>(base + (i * 3 + h) * 2048) = f32x4{v[2 * h].x, v[2 * h].y, v[2 * h + 1].x, v[2 * h + 1].y};
+        }
+#endif
+    };
+
     // ---- MFMA side
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.d.weight), 0, (int)((long)a.n_c8 * a.n_cg * 18 * 256 * 4), 0x00020000);
     const unsigned wvoff = (unsigned)(lane * 16);
     auto wblock = [&](int c8_, int cg_) { return __builtin_amdgcn_readfirstlane(((c8_ * a.n_cg + cg_) * 18) * 1024); };
 
-    f32x4 acc[2 * NPOS];                                                 // [position][cout group j]: 2 * pos + j
+    f32x4 acc[NTG * NPOS];                                               // [position][tile group j]: NTG * pos + j
     f32x4 U[UR];                                                         // ring: fragment pp of a stage (positions 2pp, 2pp+1) lives in U[(OFF + pp) % UR]
-    f32x4 Vr[W4_VR][2];                                                  // ring: V of position pair pp, one per tile group, in Vr[pp % W4_VR]
+    f32x4 Vr[W4_VR][NTG];                                                // ring: V of position pair pp, one per tile group, in Vr[pp % W4_VR]
     static_assert(36 % UR == 0, "the ring must close over a chunk's two stages of 18 fragments");
     auto load_u = [&](int slot, int q, int wb) {                         // q in [0, 18): position pair
 #if !(W4_ABLATE & 2)
@@ -423,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     };
     auto read_v = [&](const char* v0base, const char* v1base, int pp) {
         Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x4*>(v0base + pp * 2048);
-        Vr[pp % W4_VR][1] = *reinterpret_cast<const f32x4*>(v1base + pp * 2048);
+        if (NTG == 2) Vr[pp % W4_VR][NTG - 1] = *reinterpret_cast<const f32x4*>(v1base + pp * 2048);
     };
     auto mfma = [&](auto first_c, int idx, float av, float bv) {
         constexpr bool FIRST = decltype(first_c)::value;
@@ -451,19 +557,26 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             if (pp + W4_VR - 1 < 18) read_v(v0base, v1base, pp + W4_VR - 1);
             pre(pp);                                                     // LDS table reads of mid(pp): their latency hides under the MFMAs
             const f32x4 u = U[(OFF + pp) % UR];
-            const f32x4 va = Vr[pp % W4_VR][0], vb = Vr[pp % W4_VR][1];     // {pos 2pp: ch even, odd; pos 2pp+1: ch even, odd}
+            const f32x4 va = Vr[pp % W4_VR][0], vb = Vr[pp % W4_VR][NTG - 1];     // {pos 2pp: ch even, odd; pos 2pp+1: ch even, odd}
             __builtin_amdgcn_sched_barrier(0);
             // even channels of the pair first (the first touch of every accumulator in a tile's first stage), then the odd ones:
-            // an accumulator is used again four MFMAs later (dependent latency 40 cycles, issue 32).  Each weight fragment serves
-            // both tile groups: it is loaded once per workgroup.
-            mfma(first_c, 4 * pp + 0, u.x, va.x);
-            mfma(first_c, 4 * pp + 1, u.x, vb.x);
-            mfma(first_c, 4 * pp + 2, u.z, va.z);
-            mfma(first_c, 4 * pp + 3, u.z, vb.z);
-            mfma(std::false_type{}, 4 * pp + 0, u.y, va.y);
-            mfma(std::false_type{}, 4 * pp + 1, u.y, vb.y);
-            mfma(std::false_type{}, 4 * pp + 2, u.w, va.w);
-            mfma(std::false_type{}, 4 * pp + 3, u.w, vb.w);
+            // an accumulator is used again four (NTG == 1: two) MFMAs later (dependent latency 40 cycles, issue 32).  NTG == 2: each weight
+            // fragment serves both tile groups: it is loaded once per workgroup.
+            if (NTG == 2) {
+                mfma(first_c, 4 * pp + 0, u.x, va.x);
+                mfma(first_c, 4 * pp + 1, u.x, vb.x);
+                mfma(first_c, 4 * pp + 2, u.z, va.z);
+                mfma(first_c, 4 * pp + 3, u.z, vb.z);
+                mfma(std::false_type{}, 4 * pp + 0, u.y, va.y);
+                mfma(std::false_type{}, 4 * pp + 1, u.y, vb.y);
+                mfma(std::false_type{}, 4 * pp + 2, u.w, va.w);
+                mfma(std::false_type{}, 4 * pp + 3, u.w, vb.w);
+            } else {
+                mfma(first_c, 2 * pp + 0, u.x, va.x);
+                mfma(first_c, 2 * pp + 1, u.z, va.z);
+                mfma(std::false_type{}, 2 * pp + 0, u.y, va.y);
+                mfma(std::false_type{}, 2 * pp + 1, u.w, va.w);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = (hi(pp) > DIN ? hi(pp) : DIN); q < hi(pp + 1); ++q) {     // the slot just consumed takes the fragment UR ahead
@@ -512,14 +625,14 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
     for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, dtab[k * 256], AFF ? ptab[k * 256] : 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    {
+    if constexpr (NTG == 2) {
         f32x2 T[6][6];
         unsigned t_addr[12];
         xf_addr(t_addr);
 #pragma unroll
         for (int ay = 0; ay < 6; ++ay) xf_read(T, t_addr, ay);
         xf_finish(T, vd_tg, [] {});
-    }
+    } else xf_half(vd_tg);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -555,6 +668,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             using IOFF1 = std::integral_constant<int, 18 % UR>;
             using IUR = std::integral_constant<int, UR>;
             using IEPI = std::integral_constant<int, UR_EPI>;
+            using IXF = std::integral_constant<int, NTG == 1 ? (W4_UR1_XF < UR ? W4_UR1_XF : UR) : UR>;      // fragments in flight across the transform between two chunks
             constexpr bool FIRST = decltype(first_c)::value;              // first chunk of a tile: the ring comes out of an epilogue
             // the next item's halo: requested over the first position pairs of stage 0, written to the raw image over stage 1
             // (unconditional: behind the very last item this is a harmless re-stage of the tile's first chunk -- a conditional load /
@@ -578,7 +692,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                     }
                 } else if (pp < RAW_IT) tab1 = dtab[pp * 256];
             };
-            f32x2 T[6][6];                                                // the next item's patch of this transform lane: read under the tail of stage 1
+            f32x2 T[NTG == 2 ? 6 : 1][6];                                 // NTG == 2: the next item's patch of this transform lane: read under the tail of stage 1
             unsigned t_addr[12];
             auto commit = [&](int pp) {
                 if (AFF || LEAKY) {     // the activation is VALU work: one clump (every MFMA <-> VALU switch costs ~18 cycles)
@@ -587,16 +701,21 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                         for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, tabd[(AFF || LEAKY) ? k : 0], PRE_P ? tabp[PRE_P ? k : 0] : MAP ? ptab[k * 256] : 0u);
                     }
                 } else if (pp < RAW_IT) stage_commit_one(pp, tab1, 0u);
-                if (pp == W4_XF_AT) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this thread's share of the raw image is written ...
-                    __builtin_amdgcn_s_barrier();                        // ... and so is every other wave's
-                    xf_addr(t_addr);
+                if constexpr (NTG == 2) {
+                    if (pp == W4_XF_AT) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this thread's share of the raw image is written ...
+                        __builtin_amdgcn_s_barrier();                        // ... and so is every other wave's
+                        xf_addr(t_addr);
+                    }
+                    if (pp > W4_XF_AT && pp <= W4_XF_AT + 6) xf_read(T, t_addr, pp - W4_XF_AT - 1);
                 }
-                if (pp > W4_XF_AT && pp <= W4_XF_AT + 6) xf_read(T, t_addr, pp - W4_XF_AT - 1);
             };
             W4_T0();
-            stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IUR>{}, IUR{}, v0cur, v1cur, w0, w1, issue_pre, issue);
-            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IUR>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit_pre, commit);
+            if (NTG == 1 && FIRST)                                        // this tile's bias (lane = cout): in flight over the whole first stage
+                bias_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(cg * 16 + (lane & 15)) * 4u, 0, 0));
+            stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IXF>{}, IUR{}, v0cur, v1cur, w0, w1, issue_pre, issue);
+            if (NTG == 1 && FIRST) asm volatile("" : "+v"(bias_r));      // waited for HERE (every older load has been consumed), not behind the ring in the epilogue
+            stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IXF>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit_pre, commit);
 #ifdef W4_STAMP
             if (FIRST) W4_ACC(stamp_first);
             if (last) W4_ACC(stamp_last);
@@ -604,13 +723,23 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
             if (!FIRST && !last && ch == 2) W4_ACC(stamp_third);
 #endif
             W4_T0();
-            xf_finish(T, vd_tg, [&] {
-                W4_ACC(stamp_xf);
-                W4_T0();
-                __builtin_amdgcn_s_barrier();                            // every wave has read its last V operands of this chunk
+            if constexpr (NTG == 2) {
+                xf_finish(T, vd_tg, [&] {
+                    W4_ACC(stamp_xf);
+                    W4_T0();
+                    __builtin_amdgcn_s_barrier();                        // every wave has read its last V operands of this chunk
+                    W4_ACC(stamp_wait);
+                    W4_T0();
+                });
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this thread's share of the raw image is written ...
+                __builtin_amdgcn_s_barrier();                            // ... so is every other wave's, and every wave has read its last V operands of this chunk
                 W4_ACC(stamp_wait);
                 W4_T0();
-            });
+                if (W4_PRIO) __builtin_amdgcn_s_setprio(W4_PRIO);
+                xf_half(vd_tg);
+                if (W4_PRIO) __builtin_amdgcn_s_setprio(0);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                // the next item's V images are complete
             W4_ACC(stamp_xf);
@@ -631,13 +760,14 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
         //      at 16 B/clk -- 8 k cycles per 128 KB region tile (tools/microbench/store_patterns.hip).
         W4_T0();
         W4_MFMA_DRAIN();
+        if (NTG == 1 && W4_PRIO) __builtin_amdgcn_s_setprio(W4_PRIO);
 
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d.out, 0, (int)((unsigned)(SPLIT ? a.splits : 1) * a.d.B * H * W * a.d.ldo * 4u), 0x00020000);
         int Wt = __builtin_amdgcn_readfirstlane(W), ldot = __builtin_amdgcn_readfirstlane(a.d.ldo);
         asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the store offsets from being hoisted into (spilled) SGPRs
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {                                    // the two 16x16-pixel tiles (tile groups) of the region
-            const int tx = 2 * rx + j;
+        for (int j = 0; j < NTG; ++j) {                                  // the 16x16-pixel tiles (tile groups) of the region
+            const int tx = NTG * rx + j;
             if (tx < a.tiles_x) {
                 int l15 = lane;
                 asm volatile("" : "+v"(l15));                              // (lane-derived values are recomputed per tile: hoisted to the kernel's start they get spilled)
@@ -662,6 +792,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                     int step4 = ldot * 16, back3 = ldot * -12, rowadv = (Wt - 7) * ldot * 4;   // pixel (i, 4 r + jj): r -> r + 1, (jj, r + 1) -> (jj + 1, r), next row
                     asm volatile("" : "+s"(step4), "+s"(back3), "+s"(rowadv));
                     const f32x2 c2 = {2.0f, 2.0f}, c4 = {4.0f, 4.0f}, c8 = {8.0f, 8.0f};
+                    const int rowlim = FULL ? 4 : H - py0, collim = FULL ? 16 : W - px0;     // !FULL: rows / columns of the lane's tile row inside the image
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {                        // tiles (2 h, 2 h + 1) of the lane's tile row = registers 2 h, 2 h + 1 of every accumulator
                         int soff = h * 32 * ldot;                        // byte offset of pixel (0, 8 h): one running scalar, see below
@@ -669,10 +800,10 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                         f32x2 Z[4][6];
 #pragma unroll
                         for (int nu = 0; nu < 6; ++nu) {                 // Z = A^T M, one column of positions at a time: short live ranges
-                            auto M = [&](int xi) { return read_acc2(2 * (xi * 6 + nu) + j, h); };
+                            auto M = [&](int xi) { return read_acc2(NTG * (xi * 6 + nu) + j, h); };
                             f32x2 m1 = M(1);
                             const f32x2 m2 = M(2);
-                            if (nu == 1) m1 += *bias_p;                   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
+                            if (nu == 1) m1 += NTG == 2 ? *bias_p : bias_r;   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
                             const f32x2 p = m1 + m2, q = m1 - m2;
                             const f32x2 m3 = M(3), m4 = M(4);
                             const f32x2 r = m3 + m4, u = m3 - m4;
@@ -698,9 +829,13 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                                     pivot = __shfl(v.x, l15);
                                 f32x2 in2 = {1.0f, 1.0f};                // !FULL: which of the two pixels are inside the image
                                 if (!FULL) {
-                                    const bool row_in = py0 + i < H;
-                                    in2.x = (row_in && px0 + 8 * h + jj < W) ? 1.0f : 0.0f;
-                                    in2.y = (row_in && px0 + 8 * h + 4 + jj < W) ? 1.0f : 0.0f;
+                                    // (the row limit is made opaque at every use: left visible, hipcc computes the 64 (row, column) lane masks of a tile up front,
+                                    //  128 SGPRs that push the kernel's long-lived scalars into VGPR lanes -- v_readlane in every K chunk)
+                                    int rl = rowlim;
+                                    asm volatile("" : "+v"(rl));
+                                    const bool row_in = i < rl;
+                                    in2.x = (row_in && 8 * h + jj < collim) ? 1.0f : 0.0f;
+                                    in2.y = (row_in && 8 * h + 4 + jj < collim) ? 1.0f : 0.0f;
                                 }
                                 if (STATS) {
                                     f32x2 dv = v - f32x2{pivot, pivot};
@@ -754,6 +889,7 @@ __global__ __launch_bounds__(256, 1) void wino4_kernel(const Wino4Args a) {
                 }
             }
         }
+        if (NTG == 1 && W4_PRIO) __builtin_amdgcn_s_setprio(0);
         W4_ACC(stamp_epi);
 #ifdef W4_STAMP_DRAIN          // diagnostic: how long do the epilogue's stores (and the weight fragments in flight) take to complete
         W4_T0();
@@ -829,12 +965,13 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-template <int MODE, bool STREAM>
+template <int MODE, bool STREAM, int NTG = 2>
 int launch4s(const Wino4Args& a, hipStream_t st) {
     static nd_device_once configured;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, STREAM>), LDS_BYTES, "nd_conv3x3_wino4")) return e;
-    const long resident = nd_device_cus();                // one workgroup per CU (registers, LDS)
-    hipLaunchKernelGGL((wino4_kernel<MODE, STREAM>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    constexpr int LDS_BYTES = W4Geo<NTG>::LDS_BYTES;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, STREAM, false, NTG>), LDS_BYTES, "nd_conv3x3_wino4")) return e;
+    const long resident = (long)nd_device_cus() * W4Geo<NTG>::WG_PER_CU;      // one (NTG == 1: two) workgroup(s) per CU (registers, LDS)
+    hipLaunchKernelGGL((wino4_kernel<MODE, STREAM, false, NTG>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
     return 0;
 }
 
@@ -911,19 +1048,20 @@ __global__ __launch_bounds__(256) void w4_splitk_reduce_stats_kernel(const float
 template <int MODE>
 int launch4_split(const Wino4Args& a, hipStream_t st) {
     static nd_device_once configured;
+    constexpr int LDS_BYTES = W4Geo<2>::LDS_BYTES;
     if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, false, true>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
     const long resident = nd_device_cus();
     hipLaunchKernelGGL((wino4_kernel<MODE, false, true>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
     return 0;
 }
 
-template <int MODE>
+template <int MODE, int NTG = 2>
 int launch4(const Wino4Args& a, hipStream_t st) {
     static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;     // A/B knob (tools/ only)
     static const int stream_kinds = getenv("ND_W4_STREAM_KINDS") ? atoi(getenv("ND_W4_STREAM_KINDS")) : 7;           // A/B knob (tools/ only)
     const int kind = (MODE == ND_PRO_AFFINE_SILU || MODE == ND_PRO_AFFINE_MAP_SILU) ? 2 : a.d.stats ? 1 : 4;   // block2 / block1 / resampling convs
     const long out_bytes = (long)a.d.B * a.d.H * a.d.W * a.d.ldo * 4;
-    return (out_bytes >= stream_min && (stream_kinds & kind)) ? launch4s<MODE, true>(a, st) : launch4s<MODE, false>(a, st);
+    return (out_bytes >= stream_min && (stream_kinds & kind)) ? launch4s<MODE, true, NTG>(a, st) : launch4s<MODE, false, NTG>(a, st);
 }
 
 }  // namespace
@@ -954,7 +1092,7 @@ extern "C" int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* 
 extern "C" int nd_conv3x3_wino4_stat_slots(int H, int W) { return nd_cdiv(W, 16) * nd_cdiv(H, 16); }
 
 // descriptor checks shared by the entry points; fills the launch arguments
-static int w4_prepare(const nd_conv3x3* d, Wino4Args& a) {
+static int w4_prepare(const nd_conv3x3* d, Wino4Args& a, int ntg = 2) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_conv3x3_wino4: null descriptor");
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3_wino4: null tensor pointer");
@@ -1000,7 +1138,7 @@ static int w4_prepare(const nd_conv3x3* d, Wino4Args& a) {
     a.d = *d;
     a.tiles_x = nd_cdiv(d->W, 16);
     a.tiles_y = nd_cdiv(d->H, 16);
-    a.regions_x = nd_cdiv(d->W, 32);
+    a.regions_x = nd_cdiv(d->W, 16 * ntg);
     a.n_tiles = nd_cdiv(d->cout, 64);
     a.n_cg = nd_round_up(d->cout, 64) / 16;
     a.n_c8 = nd_round_up(nd_cdiv(d->cin, 8), 2);
@@ -1028,6 +1166,19 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     }
     if (rc) return rc;
     return nd_launch_status("nd_conv3x3_wino4_nhwc_f32");
+}
+
+// The same operator on 16 x 16-pixel regions with two co-resident workgroups per CU (wino4_kernel<..., NTG = 1>): same packed weights, same statistics
+// slots, same descriptor checks, the same bits as nd_conv3x3_wino4_nhwc_f32.  Plain and GroupNorm-affine + SiLU sources (the map / LeakyReLU prologues stay
+// on the 16 x 32 form).  It is the F(4x4) path of images narrower than 32 pixels.
+extern "C" int nd_conv3x3_wino4_16_nhwc_f32(const nd_conv3x3* d, void* stream) {
+    Wino4Args a;
+    if (int e = w4_prepare(d, a, 1)) return e;
+    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
+               "nd_conv3x3_wino4_16: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4<ND_PRO_AFFINE_SILU, 1>(a, st) : launch4<ND_PRO_NONE, 1>(a, st)) return rc;
+    return nd_launch_status("nd_conv3x3_wino4_16_nhwc_f32");
 }
 
 // ---- split-K (training at small batch, and any plain layer without a statistics epilogue whose items fill a fraction of the chip)

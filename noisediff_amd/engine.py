@@ -49,6 +49,10 @@ WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never t
 # a sample's bits would depend on the batch it is sharded into, which the default path rules out (see _wino4_takes).  16 patches per GPU never split.
 SPLIT_K = os.environ.get("ND_SPLIT_K", "0") != "0"
 EIGHT_TILES_RULE = os.environ.get("ND_W4_EIGHT_TILES", "1") != "0"     # A-B knob (tools/): 0 = F(4x4) also for layers with <= 8 workgroup tiles per sample
+# r4: the F(4x4) kernel on 16 x 16-pixel regions with two co-resident workgroups per CU (nd_conv3x3_wino4_16_nhwc_f32).  "narrow" (default): where the
+# 16 x 32 form has too few regions per sample or the image is narrower than 32 pixels (those layers ran on F(2x2) before); "all": wherever it takes the
+# layer; "0": never.  Either way a function of the sample's geometry alone, and the same bits as the 16 x 32 form.
+WINO4_16 = os.environ.get("ND_WINO4_16", "narrow")
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -454,7 +458,8 @@ class Plan:
         wino2 = (wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
                  and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
                  and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
-        wino4 = wino and self._wino4_takes(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W)
+        w4kind = self._wino4_kind(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W) if wino else ""
+        wino4 = bool(w4kind)
         st = sc = None
         slots = 0
         if stats:     # per-(slot, channel) {sum, M2} partials for nd_groupnorm_finalize_f32: F(4x4) one slot per 16 x 16 tile, F(2x2) two
@@ -467,11 +472,11 @@ class Plan:
             raise L.HipError(f"{name}: the scale / shift map was produced in the blocked layout but the layer does not run on conv3x3_wino4")
         # ONE packing of the weight is read (and marked for the weight broadcast): F(4x4), F(2x2) or the direct form
         d.weight = e.p(name + (".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
-        entry = ("nd_conv3x3_wino4_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
+        entry = (f"nd_conv3x3_{w4kind}_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
                  "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32")
         meta = {"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
-                "tiling": 9004 if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
-        splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and wino4 and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
+                "tiling": (9016 if w4kind == "wino4_16" else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
+        splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and w4kind == "wino4" and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
         if splits > 1 and splits * self.B * H * W * cout * 4 < (1 << 31):
             ws = self._alloc(splits * self.B * H * W * cout)
             meta["splits"] = splits
@@ -482,10 +487,28 @@ class Plan:
         self._keep.append(d)
         return out, st, sc, slots
 
-    def _wino4_takes(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int) -> bool:
-        """F(4x4,3x3) (1.78x fewer MFMAs than F(2x2,3x3); 16 x 32-pixel regions, 16-channel K chunks) wherever its kernel takes the
+    def _wino4_kind(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int) -> str:
+        """"wino4" (16 x 32-pixel regions, one workgroup per CU), "wino4_16" (16 x 16-pixel regions, two per CU) or "" (another kernel).
+        F(4x4,3x3) (1.78x fewer MFMAs than F(2x2,3x3); 16-channel K chunks) wherever a form of its kernel takes the
         layer: plain / GroupNorm-affine (+ per-pixel map) + SiLU inputs, concat on a chunk boundary, images that fill its regions,
         sources below 1 GiB and 2^24 pixels (the host checks of nd_conv3x3_wino4_nhwc_f32)."""
+        up = 1 if upsample else 0
+        src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
+        src_bytes = src_px * 4 * max(ld0, ld1)
+        common = (WINOGRAD and WINO4 and H >= 16 and W >= 16 and cout <= 2048 and (name + ".weight.wino4") in self.e.slots
+                  and W <= 2048 and (c1 == 0 or (c0 % 16 == 0 and not up)) and src_bytes < (1 << 30) - (1 << 16) and src_px < (1 << 24)
+                  and (not up or (H % 2 == 0 and W % 2 == 0)))
+        if not common:
+            return ""
+        # the 16 x 16-region form: plain and affine + SiLU sources; regions of any image are at least half used from W = 16 on (W % 16 == 0 or W >= 48)
+        takes16 = WINO4_16 != "0" and mode in (L.PRO_NONE, L.PRO_AFFINE_SILU) and (W % 16 == 0 or W >= 48)
+        few = ((H + 15) // 16) * ((W + 31) // 32) * ((cout + 63) // 64) <= 8       # <= 8 items of the 16 x 32 form per SAMPLE
+        if takes16 and (WINO4_16 == "all" or W < 32 or (few and EIGHT_TILES_RULE and not SPLIT_K)):
+            return "wino4_16"
+        return "wino4" if self._wino4_takes(name, mode, upsample, c0, c1, ld0, ld1, cin, cout, H, W) else ""
+
+    def _wino4_takes(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int) -> bool:
+        """The 16 x 32-region form."""
         up = 1 if upsample else 0
         # Layers with at most eight F(4x4) workgroup tiles (16 x 32 pixels x 64 couts) per SAMPLE -- 256 -> 256 at 32 x 32 -- fill half of an
         # MI355X at the usual 16 patches per GPU; F(2x2)'s 16 x 16-pixel tiles fill it (84 vs 114 us per layer).  The rule looks at the

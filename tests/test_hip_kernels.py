@@ -629,7 +629,7 @@ def test_conv3x3_winograd_matches_direct_semantics(ctx, case, entry):
     assert rel_err(hu.nchw(out), ref) < 1e-5
 
 
-def _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats=True):
+def _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats=True, entry="nd_conv3x3_wino4_nhwc_f32"):
     import hiputil as hu
     out = hu.full((B, H, W, cout))
     d = L.Conv3x3()
@@ -640,7 +640,7 @@ def _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats=True):
     if stats:
         st, sc = hu.full((B, slots, cout, 2)), hu.full((slots,))
         d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
-    L.call("nd_conv3x3_wino4_nhwc_f32", C.byref(d), ctx.stream)
+    L.call(entry, C.byref(d), ctx.stream)
     ctx.sync()
     return out, st, sc, slots
 
@@ -826,6 +826,66 @@ def test_conv3x3_wino4_headline_shapes(ctx, case):
         act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
         out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
         assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
+
+
+# BASELINE config 2 (d=64, 128x128): the H/8 stage is 16 x 16 pixels -- narrower than the 16 x 32 regions of the one-workgroup form -- and the H/4 stage
+# has eight of those regions per sample (SURVEY Appendix A, H/8 and H/4 columns; Diffusion_arch.py:533,547).  (B, H, W, cin, cout, concat c0, upsample)
+CFG2_CASES = {
+    "c2_h8_512_512": (16, 16, 16, 512, 512, 0, 0),
+    "c2_h8_768cat_512": (16, 16, 16, 768, 512, 512, 0),
+    "c2_h8_256_512": (16, 16, 16, 256, 512, 0, 0),
+    "c2_h4_384cat_256": (16, 32, 32, 384, 256, 256, 0),
+    "c2_h4_up_512_256": (2, 32, 32, 512, 256, 0, 1),
+}
+W16_CASES = {**{k: v + (0, 0) for k, v in WINO_CASES.items()}, **{k: HEADLINE_CASES[k] for k in ("h8_768cat_512", "h4_384cat_256", "h1_up_128_64", "h1_64_64")},
+             **CFG2_CASES, "ragged_17x33": (2, 17, 33, 48, 80, 0, 0), "odd_rows_50x18": (1, 50, 18, 32, 64, 16, 0)}
+
+
+@pytest.mark.parametrize("case", sorted(W16_CASES))
+def test_conv3x3_wino4_16_pixel_regions_equal_the_one_workgroup_form(ctx, case):
+    """nd_conv3x3_wino4_16_nhwc_f32 (16 x 16-pixel regions, two co-resident workgroups per CU) against nn.Conv2d AND against
+    nd_conv3x3_wino4_nhwc_f32 bit for bit wherever that kernel takes the shape -- output and GroupNorm partials, plain / concat / nearest-x2 /
+    affine + SiLU sources, ragged images, images narrower than 32 pixels, partial K chunks and cout tiles; bitwise repeat."""
+    import hiputil as hu
+    B, H, W, cin, cout, c0, up = W16_CASES[case]
+    cin = max(cin, 24)
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    bound = 1.0 / np.sqrt(9 * cin)
+    x = U(case + ".x", (B, cin, hs, ws), -1.5, 1.5)
+    w = U(case + ".w", (cout, cin, 3, 3), -bound, bound)
+    b = U(case + ".b", (cout,), -bound, bound)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, padding=1)
+    wd, bd = hu.dev(w), hu.dev(b)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    run16 = lambda s, stats=True: _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats, entry="nd_conv3x3_wino4_16_nhwc_f32")
+    run32 = lambda s, stats=True: _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats)
+    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
+    out, st, sc, slots = run16(s)
+    assert rel_err(hu.nchw(out), ref) < 5e-5
+    _check_gn(ctx, case, ref, st, sc, slots, B, cout, 5e-5)
+    out2, st2, *_ = run16(s)
+    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
+    o32, s32, c32, _ = run32(s)                                          # same arithmetic in the same order: identical bits
+    assert torch.equal(out.cpu(), o32.cpu()) and torch.equal(st.cpu(), s32.cpu()) and torch.equal(sc.cpu(), c32.cpu())
+    out_ns, *_ = run16(s, stats=False)
+    assert torch.equal(out.cpu(), out_ns.cpu())
+    if not up:
+        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
+        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+        mad = hu.dev(torch.stack((M, A, D), 1))
+        sa = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:]), L.PRO_AFFINE_SILU, mad=mad) if c0 else hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=mad)
+        out, st, *_ = run16(sa)
+        assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
+        o32, s32, *_ = run32(sa)
+        assert torch.equal(out.cpu(), o32.cpu()) and torch.equal(st.cpu(), s32.cpu())
+    for mode in (L.PRO_LEAKY, L.PRO_AFFINE_MAP_SILU):                    # these prologues stay on the one-workgroup form
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out = hu.src(hu.nhwc(x), None, mode), wp.data_ptr(), bd.data_ptr(), out.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, hs, ws, cin, cout, cout
+        assert ctx.lib.nd_conv3x3_wino4_16_nhwc_f32(C.byref(d), ctx.stream) != 0
 
 
 @pytest.mark.parametrize("dim,B", [(64, 16), (16, 2), (128, 8), (48, 3)])
