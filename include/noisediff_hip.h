@@ -140,6 +140,9 @@ int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream);
  * (Block.proj of ResnetBlock, Diffusion_arch.py:128-170; the resampling convs :75,533,547); also the F(4x4) path of images narrower
  * than 32 pixels (BASELINE config 2's 16 x 16 stage). */
 int nd_conv3x3_wino4_16_nhwc_f32(const nd_conv3x3* d, void* stream);
+/* ... and on 16 x 32-pixel regions with eight waves per workgroup (two per SIMD: waves 0-3 tile group 0, waves 4-7 tile group 1, in phase by
+ * construction; weight fragments shared through the L1).  Same restrictions and bits as nd_conv3x3_wino4_16_nhwc_f32. */
+int nd_conv3x3_wino4_8w_nhwc_f32(const nd_conv3x3* d, void* stream);
 /* its statistics epilogue writes ONE slot per 16 x 16-pixel tile (the F(2x2) kernels: two) */
 int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);

@@ -62,18 +62,22 @@ constexpr int VD_FLOATS = NPOS * 256;                // one tile group's chunk i
 //                     a weight fragment serves one MFMA quad instead of two (32 B/clk per CU from the L2 instead of 16).  It is also the F(4x4) path of
 //                     images narrower than 32 pixels.  Same arithmetic in the same order: the two forms agree bit for bit.
 constexpr int MAX_COUT = 2048;                                           // NTG == 2: the whole bias vector (padded to cout tiles) lives in LDS
-template <int NTG>
+template <int NTG, int NW = 4>
 struct W4Geo {
+    static constexpr int NT = 64 * NW;                                    // threads: NW waves (4: one per SIMD and workgroup; 8: two per SIMD in ONE workgroup)
+    static constexpr int TGW = NTG * 4 / NW;                              // tile groups a wave multiplies: 2 (72 accumulators, 512 registers) or 1 (36, 256 registers)
     static constexpr int REG_W = 16 * NTG, HALO_W = REG_W + 2;            // region width, halo columns (18 halo rows)
     static constexpr int RAW_ROWP = NTG == 2 ? 40 : 24;                   // records of 64 bytes per halo row (row stride = 0 mod 256 bytes: the bank pattern of the swizzle)
-    static constexpr int RAW_ITEMS = 18 * HALO_W * 4, RAW_IT = (RAW_ITEMS + 255) / 256;      // (pixel, channel quad) items per chunk: 10 / 6 per thread
+    static constexpr int RAW_ITEMS = 18 * HALO_W * 4, RAW_IT = (RAW_ITEMS + NT - 1) / NT;      // (pixel, channel quad) items per chunk: 10 / 6 / 5 per thread
     static constexpr int RAW_FLOATS = 18 * RAW_ROWP * 16;
-    static constexpr bool RTAB = NTG == 2;                                // the (row, column) table of the items (NTG == 1 recomputes it per border tile: LDS)
-    static constexpr int TAB_BYTES = (RAW_IT + (RTAB ? RAW_IT : 0)) * 256 * 4 + (RAW_IT + 12) * 256 * 2;
+    static constexpr bool RTAB = TGW == 2;                                // the (row, column) table of the items (the 256-register forms recompute it per border tile: LDS)
+    static constexpr bool BIAS_LDS = TGW == 2;                            // the whole bias vector in LDS (the 256-register forms: a register per tile)
+    static constexpr int TAB_BYTES = (RAW_IT + (RTAB ? RAW_IT : 0)) * NT * 4 + (RAW_IT + 12) * NT * 2;
     static constexpr int BIAS_OFF_BYTES = RAW_FLOATS * 4 + NTG * VD_FLOATS * 4 + TAB_BYTES;
-    static constexpr int LDS_BYTES = BIAS_OFF_BYTES + (NTG == 2 ? MAX_COUT * 4 : 0);
+    static constexpr int LDS_BYTES = BIAS_OFF_BYTES + (BIAS_LDS ? MAX_COUT * 4 : 0);
     static constexpr int WG_PER_CU = NTG == 2 ? 1 : 2;
-    static constexpr int ACC_AGPR = NTG == 2 ? 64 : 32;                   // accumulators [0, ACC_AGPR) in the AGPR half (256 / 128 registers), the rest in VGPRs
+    static constexpr int ACC_AGPR = TGW == 2 ? 64 : 32;                   // accumulators [0, ACC_AGPR) in the AGPR half (256 / 128 registers), the rest in VGPRs
+    static_assert(NW == 4 || (NW == 8 && NTG == 2), "four waves, or eight on the 16 x 32 region");
     static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS map");
 };
 
@@ -196,15 +200,16 @@ __device__ __forceinline__ void w4_bt_half(const f32x2 (&d)[6], f32x2 (&t)[3]) {
 // 32 x 32 with 4 samples: 64 items for 256 CUs, each walking 32 K chunks -- are cut along cin: item (split, sample, region, cout tile) walks
 // `chunks_per_split` chunks starting at chunk split * chunks_per_split and writes its partial sums to out[split] (the host passes a workspace
 // and no bias); w4_splitk_reduce_kernel adds the partials in split order and the bias.  The split count is fixed by the shape alone.
-template <int MODE, bool STREAM, bool SPLIT = false, int NTG = 2>
-__global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const Wino4Args a) {
-    using Geo = W4Geo<NTG>;
+template <int MODE, bool STREAM, bool SPLIT = false, int NTG = 2, int NW = 4>
+__global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_kernel(const Wino4Args a) {
+    using Geo = W4Geo<NTG, NW>;
+    constexpr int NT = Geo::NT, TGW = Geo::TGW;
     constexpr int RAW_FLOATS = Geo::RAW_FLOATS, BIAS_OFF_BYTES = Geo::BIAS_OFF_BYTES, ACC_AGPR = Geo::ACC_AGPR, REG_W = Geo::REG_W, HALO_W = Geo::HALO_W;
     constexpr bool MAP = MODE == ND_PRO_AFFINE_MAP_SILU;                  // + per-pixel scale / shift maps (ResnetBlock2)
     constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAP;               // GroupNorm-affine + SiLU applied while the halo is written to LDS
     constexpr bool LEAKY = MODE == ND_PRO_LEAKY || MODE == ND_PRO_LEAKY_SECOND;      // LSID: LeakyReLU(0.2) of the producer, applied by the consumer
-    constexpr int UR = NTG == 1 ? (AFF ? W4_UR1_AFF : W4_UR1) : MAP ? W4_UR_MAP : AFF ? W4_UR_AFF : W4_UR, UR_EPI = NTG == 1 ? W4_UR1_EPI : W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
-    static_assert(NTG == 2 || !MAP, "the map prologue (20 more staging registers per halo item in flight) stays on the one-workgroup form");
+    constexpr int UR = TGW == 1 ? (AFF ? W4_UR1_AFF : W4_UR1) : MAP ? W4_UR_MAP : AFF ? W4_UR_AFF : W4_UR, UR_EPI = TGW == 1 ? W4_UR1_EPI : W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
+    static_assert(TGW == 2 || !MAP, "the map prologue (20 more staging registers per halo item in flight) stays on the 512-register form");
     extern __shared__ __attribute__((aligned(16))) float lds_[];        // the LDS map above (dynamic shared memory starts at LDS address 0)
     float* const Vd = lds_ + RAW_FLOATS;                                // [tg NTG][VD_FLOATS]: the V images
 
@@ -212,7 +217,10 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // transform roles: NTG == 2: wave = (tile group, channel half): a lane owns a whole 6 x 6 patch of a channel pair; NTG == 1: wave = (row half, channel half):
     // a lane produces rows xi = 3 rh .. 3 rh + 2 of V for its (tile, channel pair) -- 256 work items either way
-    const int tg = NTG == 2 ? wave >> 1 : 0, rh = wave >> 1, ch2 = wave & 1;
+    // NW == 8: waves 0-3 multiply tile group 0, waves 4-7 tile group 1 (mtg), both on the same weight fragments (the second request hits the L1); the
+    // transform is the half-row form over 512 lanes.
+    const int mtg = NW == 8 ? wave >> 2 : 0;                             // TGW == 1: the tile group this wave multiplies
+    const int tg = TGW == 2 ? wave >> 1 : mtg, rh = (wave >> 1) & 1, ch2 = wave & 1;      // transform role: tile group, row half (half form), channel half
     const int tile = lane & 15, kq = lane >> 4;
 
     const int wgid = nd_xcd_remap(blockIdx.x, gridDim.x);
@@ -291,12 +299,12 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     // per-thread constants live in LDS tables (thread-private columns), not in registers: [10] LDS address of staged item k,
     // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
     // patch crosses a multiple-of-4 row): entry (a, b) is at ttab[(a >> 2) * 6 + b] + a * RAW_ROWP * 64
-    lds_u32_ptr const rtab = ptab + RAW_IT * 256;                       // [RAW_IT] item k: pixel relative to the region | halo row << 16 | column << 24 (stage_tile, once per tile; NTG == 2 only)
-    lds_u16_ptr const dtab = (lds_u16_ptr)(ptab - tid + (Geo::RTAB ? 2 : 1) * RAW_IT * 256) + tid;    // [RAW_IT] LDS address of staged item k (16 bits: the raw image starts at 0)
-    lds_u16_ptr const ttab = dtab + RAW_IT * 256;
+    lds_u32_ptr const rtab = ptab + RAW_IT * NT;                       // [RAW_IT] item k: pixel relative to the region | halo row << 16 | column << 24 (stage_tile, once per tile; NTG == 2 only)
+    lds_u16_ptr const dtab = (lds_u16_ptr)(ptab - tid + (Geo::RTAB ? 2 : 1) * RAW_IT * NT) + tid;    // [RAW_IT] LDS address of staged item k (16 bits: the raw image starts at 0)
+    lds_u16_ptr const ttab = dtab + RAW_IT * NT;
     float* const bias_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_) + BIAS_OFF_BYTES);
     auto item_rc = [&](int k, int tid_) {                                // item k of this thread: pixel relative to the region | halo row << 16 | column << 24
-        const int pix = (tid_ >> 2) + 64 * k, r = pix / HALO_W, c = pix - HALO_W * r;
+        const int pix = (tid_ >> 2) + (NT / 4) * k, r = pix / HALO_W, c = pix - HALO_W * r;
         // pixel of halo entry (r, c) relative to the region's base pixel (one source row above, one pixel left of the halo origin):
         // nearest-x2 upsample addressing halves the coordinates -- (16 ty - 1 + r) >> 1 = 8 ty - 1 + ((r + 1) >> 1)
         const int dy = up ? (r + 1) >> 1 : r, dx = up ? (c + 1) >> 1 : c;
@@ -304,11 +312,11 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     };
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) {
-        const int pix = (tid >> 2) + 64 * k, r = pix / HALO_W, c = pix - HALO_W * r;
+        const int pix = (tid >> 2) + (NT / 4) * k, r = pix / HALO_W, c = pix - HALO_W * r;
         // (the per-item values are tables, not registers: kept in registers they get spilled, and a scratch reload in the K loop
         //  drains the weight ring; any per-item VALU arithmetic in the stage loops costs an MFMA <-> VALU switch)
-        dtab[k * 256] = (unsigned short)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS (items beyond pixel 611 are never written)
-        if (Geo::RTAB) rtab[k * 256] = item_rc(k, tid);
+        dtab[k * NT] = (unsigned short)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS (items beyond pixel 611 are never written)
+        if (Geo::RTAB) rtab[k * NT] = item_rc(k, tid);
     }
     // the transform's own lane mapping (any lane may produce any V element): 16 consecutive lanes = 8 tiles x the two channel
     // pairs of a quad, so that the compiler's paired LDS accesses (ds_read2 / ds_write2: 16-lane groups, 32 banks) are conflict-free
@@ -318,16 +326,16 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int bx = 0; bx < 6; ++bx) {
-            const int r0 = 4 * (t_tile >> 2) + 4 * h, c = 16 * tg + 4 * (t_tile & 3) + bx;         // (NTG == 1: tg = 0)
-            ttab[(h * 6 + bx) * 256] = (unsigned short)((4 * (t_tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + t_kq) ^ swz(r0, c)) * 8));
+            const int r0 = 4 * (t_tile >> 2) + 4 * h, c = 16 * tg + 4 * (t_tile & 3) + bx;
+            ttab[(h * 6 + bx) * NT] = (unsigned short)((4 * (t_tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + t_kq) ^ swz(r0, c)) * 8));
         }
     const unsigned t_lds = (unsigned)(ch2 * 1024 + (t_kq >> 1) * 512 + t_tile * 32 + (t_kq & 1) * 16);  // V image address of the transform lane
     // the bias of every cout (zero beyond cout / without a bias) -> LDS, once per workgroup: the epilogues read it with an LDS load.  (A global
     // load there shares the in-order vmcnt counter with the output stores: waiting for it drained every store issued before it.)
     // NTG == 1 has no LDS left for it: the lane's bias (cout = cg * 16 + (l & 15)) is loaded into a register at the start of every tile, long before the
     // epilogue (a resource of zero records without a bias: the load returns 0, as it does for a padded cout)
-    if (NTG == 2)
-        for (int i = tid; i < a.n_tiles * 64; i += 256) bias_lds[i] = (a.d.bias && i < Cout) ? a.d.bias[i] : 0.0f;
+    if (Geo::BIAS_LDS)
+        for (int i = tid; i < a.n_tiles * 64; i += NT) bias_lds[i] = (a.d.bias && i < Cout) ? a.d.bias[i] : 0.0f;
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d.bias ? a.d.bias : a.d.weight), 0, a.d.bias ? Cout * 4 : 0, 0x00020000);
     float bias_r = 0.0f;
 
@@ -348,10 +356,10 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
             if (!Geo::RTAB) asm volatile("" : "+v"(tid_));               // spills them and reloads them from scratch -- a vmcnt(0) drain of the weight ring per border tile
 #pragma unroll
             for (int k = 0; k < RAW_IT; ++k) {
-                const unsigned rc = Geo::RTAB ? rtab[k * 256] : item_rc(k, tid_);
+                const unsigned rc = Geo::RTAB ? rtab[k * NT] : item_rc(k, tid_);
                 const unsigned r = (rc >> 16) & 255u, c = rc >> 24;
                 const bool ok = r - (unsigned)r_lo <= (unsigned)r_n && c - (unsigned)c_lo <= (unsigned)c_n;   // (items beyond the halo's last pixel have r >= 18)
-                ptab[k * 256] = ok ? (rc & 0xFFFFu) : PX_MARK;            // outside the image: beyond the resource, the load returns the zero padding
+                ptab[k * NT] = ok ? (rc & 0xFFFFu) : PX_MARK;            // outside the image: beyond the resource, the load returns the zero padding
             }
         }
         tab_clean = interior;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
             tD4 = D - M * A;                                             // (v - M) * A + D = v * A + (D - M * A)
         }
     };
-    auto stage_issue_one = [&](int k, unsigned px) {                     // px = ptab[k * 256], read by the caller one step ahead
+    auto stage_issue_one = [&](int k, unsigned px) {                     // px = ptab[k * NT], read by the caller one step ahead
 #if !(W4_ABLATE & 1)
         // ONE VALU instruction per item (no branch, no masking: every per-item instruction in a stage loop costs an MFMA <-> VALU
         // switch): pixel x stride + this lane's channel-quad offset, the latter out of range for a quad beyond cin.  The table entry
@@ -396,8 +404,8 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
         raw[k] = f32x4{(float)k, 1.0f, 0.5f, 0.25f};
 #endif
     };
-    auto stage_commit_one = [&](int k, unsigned daddr, unsigned pxk) {   // daddr = dtab[k * 256], pxk = ptab[k * 256] (AFF only): read ahead by the caller
-        if (k == RAW_IT - 1 && (tid >> 2) + 64 * k >= 18 * HALO_W) return;   // the last round covers 36 (NTG == 1: 4) pixels only
+    auto stage_commit_one = [&](int k, unsigned daddr, unsigned pxk) {   // daddr = dtab[k * NT], pxk = ptab[k * NT] (AFF only): read ahead by the caller
+        if (k == RAW_IT - 1 && (tid >> 2) + (NT / 4) * k >= 18 * HALO_W) return;   // the last round covers 36 (NTG == 1: 4) pixels only
         f32x4 v = raw[k];
         if (AFF) {
             // GroupNorm-affine + SiLU on the raw halo (each pixel once: 40 values per thread and chunk); silu(x) = x / (1 + 2^(-x log2 e)).
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     // (B^T d B in registers, then -- behind the caller's barrier: every wave has read its last V operands -- the V image)
     auto xf_addr = [&](unsigned (&t_addr)[12]) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) t_addr[i] = ttab[i * 256];
+        for (int i = 0; i < 12; ++i) t_addr[i] = ttab[i * NT];
     };
     auto xf_read = [&](f32x2 (&T)[6][6], const unsigned (&t_addr)[12], int ay) {
 #if !(W4_ABLATE & 4)
@@ -518,9 +526,9 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     const unsigned wvoff = (unsigned)(lane * 16);
     auto wblock = [&](int c8_, int cg_) { return __builtin_amdgcn_readfirstlane(((c8_ * a.n_cg + cg_) * 18) * 1024); };
 
-    f32x4 acc[NTG * NPOS];                                               // [position][tile group j]: NTG * pos + j
+    f32x4 acc[TGW * NPOS];                                               // [position][tile group j]: TGW * pos + j
     f32x4 U[UR];                                                         // ring: fragment pp of a stage (positions 2pp, 2pp+1) lives in U[(OFF + pp) % UR]
-    f32x4 Vr[W4_VR][NTG];                                                // ring: V of position pair pp, one per tile group, in Vr[pp % W4_VR]
+    f32x4 Vr[W4_VR][TGW];                                                // ring: V of position pair pp, one per tile group, in Vr[pp % W4_VR]
     static_assert(36 % UR == 0, "the ring must close over a chunk's two stages of 18 fragments");
     auto load_u = [&](int slot, int q, int wb) {                         // q in [0, 18): position pair
 #if !(W4_ABLATE & 2)
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     };
     auto read_v = [&](const char* v0base, const char* v1base, int pp) {
         Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x4*>(v0base + pp * 2048);
-        if (NTG == 2) Vr[pp % W4_VR][NTG - 1] = *reinterpret_cast<const f32x4*>(v1base + pp * 2048);
+        if (TGW == 2) Vr[pp % W4_VR][TGW - 1] = *reinterpret_cast<const f32x4*>(v1base + pp * 2048);
     };
     auto mfma = [&](auto first_c, int idx, float av, float bv) {
         constexpr bool FIRST = decltype(first_c)::value;
@@ -557,12 +565,12 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
             if (pp + W4_VR - 1 < 18) read_v(v0base, v1base, pp + W4_VR - 1);
             pre(pp);                                                     // LDS table reads of mid(pp): their latency hides under the MFMAs
             const f32x4 u = U[(OFF + pp) % UR];
-            const f32x4 va = Vr[pp % W4_VR][0], vb = Vr[pp % W4_VR][NTG - 1];     // {pos 2pp: ch even, odd; pos 2pp+1: ch even, odd}
+            const f32x4 va = Vr[pp % W4_VR][0], vb = Vr[pp % W4_VR][TGW - 1];     // {pos 2pp: ch even, odd; pos 2pp+1: ch even, odd}
             __builtin_amdgcn_sched_barrier(0);
             // even channels of the pair first (the first touch of every accumulator in a tile's first stage), then the odd ones:
             // an accumulator is used again four (NTG == 1: two) MFMAs later (dependent latency 40 cycles, issue 32).  NTG == 2: each weight
             // fragment serves both tile groups: it is loaded once per workgroup.
-            if (NTG == 2) {
+            if (TGW == 2) {
                 mfma(first_c, 4 * pp + 0, u.x, va.x);
                 mfma(first_c, 4 * pp + 1, u.x, vb.x);
                 mfma(first_c, 4 * pp + 2, u.z, va.z);
@@ -615,17 +623,17 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
     stage_tile(b, ty, rx);
     stage_issue_begin(SPLIT ? sp * n_chunks * KC4 : 0);
 #pragma unroll
-    for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k, ptab[k * 256]);
+    for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k, ptab[k * NT]);
     {
-        const int wb = wblock(SPLIT ? 2 * sp * n_chunks : 0, nt * 4 + wave);
+        const int wb = wblock(SPLIT ? 2 * sp * n_chunks : 0, nt * 4 + (wave & 3));
 #pragma unroll
         for (int q = 0; q < UR_EPI; ++q) load_u(q, q, wb);
     }
 #pragma unroll
-    for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, dtab[k * 256], AFF ? ptab[k * 256] : 0u);
+    for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, dtab[k * NT], AFF ? ptab[k * NT] : 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (NTG == 2) {
+    if constexpr (TGW == 2) {
         f32x2 T[6][6];
         unsigned t_addr[12];
         xf_addr(t_addr);
@@ -647,11 +655,11 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
             if (nt1 == a.n_tiles) { nt1 = 0;  if (++rx1 == a.regions_x) { rx1 = 0;  if (++ty1 == a.tiles_y) { ty1 = 0;  ++b1;  if (SPLIT && b1 == a.d.B) { b1 = 0;  ++sp1; } } } }
         }
         const int ch0 = SPLIT ? sp * n_chunks : 0, ch0n = SPLIT ? sp1 * n_chunks : 0;      // first chunk of this item's / the next item's K range
-        const int cg = nt * 4 + wave, cg_next = (more ? nt1 : nt) * 4 + wave;          // this wave's 16 output channels
+        const int cg = nt * 4 + (wave & 3), cg_next = (more ? nt1 : nt) * 4 + (wave & 3);          // this wave's 16 output channels
 
         auto chunk = [&](int ch, auto first_c, auto last_c) {
-            const char* v0cur = reinterpret_cast<const char*>(Vd) + d_lds;                                       // tile group 0 / 1: V images
-            const char* v1cur = reinterpret_cast<const char*>(Vd + VD_FLOATS) + d_lds;
+            const char* v0cur = reinterpret_cast<const char*>(Vd + mtg * VD_FLOATS) + d_lds;                     // tile group 0 / 1 (TGW == 1: the wave's own): V images
+            const char* v1cur = reinterpret_cast<const char*>(Vd + (NTG - 1) * VD_FLOATS) + d_lds;
             constexpr bool last = decltype(last_c)::value;               // last chunk of the tile (n_chunks >= 2: never also the first)
             const int c8 = 2 * (ch0 + ch);
             // weight blocks: this chunk's two stages, then the next item's first stage (after the very last item: a harmless reload)
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
             using IOFF1 = std::integral_constant<int, 18 % UR>;
             using IUR = std::integral_constant<int, UR>;
             using IEPI = std::integral_constant<int, UR_EPI>;
-            using IXF = std::integral_constant<int, NTG == 1 ? (W4_UR1_XF < UR ? W4_UR1_XF : UR) : UR>;      // fragments in flight across the transform between two chunks
+            using IXF = std::integral_constant<int, TGW == 1 ? (W4_UR1_XF < UR ? W4_UR1_XF : UR) : UR>;      // fragments in flight across the transform between two chunks
             constexpr bool FIRST = decltype(first_c)::value;              // first chunk of a tile: the ring comes out of an epilogue
             // the next item's halo: requested over the first position pairs of stage 0, written to the raw image over stage 1
             // (unconditional: behind the very last item this is a harmless re-stage of the tile's first chunk -- a conditional load /
@@ -676,7 +684,7 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
             unsigned tab1 = 0;                                            // the table entry of position pair pp's item, read ahead of its MFMAs
             constexpr bool PRE_P = AFF && !MAP;                           // (the map variant has no registers to spare: it reads ptab inside the clump)
             unsigned tabd[(AFF || LEAKY) ? RAW_IT : 1], tabp[PRE_P ? RAW_IT : 1];   // AFF / LEAKY: the clump's ten items
-            auto issue_pre = [&](int pp) { if (pp < RAW_IT) tab1 = ptab[pp * 256]; };
+            auto issue_pre = [&](int pp) { if (pp < RAW_IT) tab1 = ptab[pp * NT]; };
             auto issue = [&](int pp) {
                 if (pp == 0) stage_issue_begin(last ? ch0n * KC4 : (ch0 + ch + 1) * KC4);
                 if (pp < RAW_IT) stage_issue_one(pp, tab1);
@@ -686,22 +694,22 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
                     if (pp == W4_COMMIT_AT) {
 #pragma unroll
                         for (int k = 0; k < RAW_IT; ++k) {
-                            tabd[k] = dtab[k * 256];
-                            if (PRE_P) tabp[k] = ptab[k * 256];
+                            tabd[k] = dtab[k * NT];
+                            if (PRE_P) tabp[k] = ptab[k * NT];
                         }
                     }
-                } else if (pp < RAW_IT) tab1 = dtab[pp * 256];
+                } else if (pp < RAW_IT) tab1 = dtab[pp * NT];
             };
-            f32x2 T[NTG == 2 ? 6 : 1][6];                                 // NTG == 2: the next item's patch of this transform lane: read under the tail of stage 1
+            f32x2 T[TGW == 2 ? 6 : 1][6];                                 // TGW == 2: the next item's patch of this transform lane: read under the tail of stage 1
             unsigned t_addr[12];
             auto commit = [&](int pp) {
                 if (AFF || LEAKY) {     // the activation is VALU work: one clump (every MFMA <-> VALU switch costs ~18 cycles)
                     if (pp == W4_COMMIT_AT) {
 #pragma unroll
-                        for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, tabd[(AFF || LEAKY) ? k : 0], PRE_P ? tabp[PRE_P ? k : 0] : MAP ? ptab[k * 256] : 0u);
+                        for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, tabd[(AFF || LEAKY) ? k : 0], PRE_P ? tabp[PRE_P ? k : 0] : MAP ? ptab[k * NT] : 0u);
                     }
                 } else if (pp < RAW_IT) stage_commit_one(pp, tab1, 0u);
-                if constexpr (NTG == 2) {
+                if constexpr (TGW == 2) {
                     if (pp == W4_XF_AT) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this thread's share of the raw image is written ...
                         __builtin_amdgcn_s_barrier();                        // ... and so is every other wave's
@@ -711,10 +719,10 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
                 }
             };
             W4_T0();
-            if (NTG == 1 && FIRST)                                        // this tile's bias (lane = cout): in flight over the whole first stage
+            if (TGW == 1 && FIRST)                                        // this tile's bias (lane = cout): in flight over the whole first stage
                 bias_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(cg * 16 + (lane & 15)) * 4u, 0, 0));
             stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IXF>{}, IUR{}, v0cur, v1cur, w0, w1, issue_pre, issue);
-            if (NTG == 1 && FIRST) asm volatile("" : "+v"(bias_r));      // waited for HERE (every older load has been consumed), not behind the ring in the epilogue
+            if (TGW == 1 && FIRST) asm volatile("" : "+v"(bias_r));      // waited for HERE (every older load has been consumed), not behind the ring in the epilogue
             stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IXF>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit_pre, commit);
 #ifdef W4_STAMP
             if (FIRST) W4_ACC(stamp_first);
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
             if (!FIRST && !last && ch == 2) W4_ACC(stamp_third);
 #endif
             W4_T0();
-            if constexpr (NTG == 2) {
+            if constexpr (TGW == 2) {
                 xf_finish(T, vd_tg, [&] {
                     W4_ACC(stamp_xf);
                     W4_T0();
@@ -760,14 +768,14 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
         //      at 16 B/clk -- 8 k cycles per 128 KB region tile (tools/microbench/store_patterns.hip).
         W4_T0();
         W4_MFMA_DRAIN();
-        if (NTG == 1 && W4_PRIO) __builtin_amdgcn_s_setprio(W4_PRIO);
+        if (TGW == 1 && W4_PRIO) __builtin_amdgcn_s_setprio(W4_PRIO);
 
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d.out, 0, (int)((unsigned)(SPLIT ? a.splits : 1) * a.d.B * H * W * a.d.ldo * 4u), 0x00020000);
         int Wt = __builtin_amdgcn_readfirstlane(W), ldot = __builtin_amdgcn_readfirstlane(a.d.ldo);
         asm volatile("" : "+s"(Wt), "+s"(ldot));                         // per tile: keeps the store offsets from being hoisted into (spilled) SGPRs
 #pragma unroll
-        for (int j = 0; j < NTG; ++j) {                                  // the 16x16-pixel tiles (tile groups) of the region
-            const int tx = NTG * rx + j;
+        for (int j = 0; j < TGW; ++j) {                                  // the 16x16-pixel tiles (tile groups) this wave holds
+            const int tx = NTG * rx + (TGW == 2 ? j : mtg);
             if (tx < a.tiles_x) {
                 int l15 = lane;
                 asm volatile("" : "+v"(l15));                              // (lane-derived values are recomputed per tile: hoisted to the kernel's start they get spilled)
@@ -800,10 +808,10 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
                         f32x2 Z[4][6];
 #pragma unroll
                         for (int nu = 0; nu < 6; ++nu) {                 // Z = A^T M, one column of positions at a time: short live ranges
-                            auto M = [&](int xi) { return read_acc2(NTG * (xi * 6 + nu) + j, h); };
+                            auto M = [&](int xi) { return read_acc2(TGW * (xi * 6 + nu) + j, h); };
                             f32x2 m1 = M(1);
                             const f32x2 m2 = M(2);
-                            if (nu == 1) m1 += NTG == 2 ? *bias_p : bias_r;   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
+                            if (nu == 1) m1 += Geo::BIAS_LDS ? *bias_p : bias_r;   // a constant on all 16 outputs of a tile == that constant on position (1, 1): A^T e1 = (1, 1, 1, 1)
                             const f32x2 p = m1 + m2, q = m1 - m2;
                             const f32x2 m3 = M(3), m4 = M(4);
                             const f32x2 r = m3 + m4, u = m3 - m4;
@@ -882,14 +890,14 @@ __global__ __launch_bounds__(256, W4Geo<NTG>::WG_PER_CU) void wino4_kernel(const
                         *reinterpret_cast<f32x2*>(o) = f32x2{S + fc * pivot, fmaxf(Q - S * S / fc, 0.0f)};
                     }
 #ifndef W4_STAMP
-                    if (b == 0 && nt == 0 && wave == 0 && lane == 0) {
+                    if (b == 0 && nt == 0 && (wave & 3) == 0 && lane == 0) {
                         a.d.slot_count[slot] = (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
                     }
 #endif
                 }
             }
         }
-        if (NTG == 1 && W4_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (TGW == 1 && W4_PRIO) __builtin_amdgcn_s_setprio(0);
         W4_ACC(stamp_epi);
 #ifdef W4_STAMP_DRAIN          // diagnostic: how long do the epilogue's stores (and the weight fragments in flight) take to complete
         W4_T0();
@@ -965,13 +973,13 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-template <int MODE, bool STREAM, int NTG = 2>
+template <int MODE, bool STREAM, int NTG = 2, int NW = 4>
 int launch4s(const Wino4Args& a, hipStream_t st) {
     static nd_device_once configured;
-    constexpr int LDS_BYTES = W4Geo<NTG>::LDS_BYTES;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, STREAM, false, NTG>), LDS_BYTES, "nd_conv3x3_wino4")) return e;
-    const long resident = (long)nd_device_cus() * W4Geo<NTG>::WG_PER_CU;      // one (NTG == 1: two) workgroup(s) per CU (registers, LDS)
-    hipLaunchKernelGGL((wino4_kernel<MODE, STREAM, false, NTG>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    constexpr int LDS_BYTES = W4Geo<NTG, NW>::LDS_BYTES;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, STREAM, false, NTG, NW>), LDS_BYTES, "nd_conv3x3_wino4")) return e;
+    const long resident = (long)nd_device_cus() * W4Geo<NTG, NW>::WG_PER_CU;  // one (NTG == 1: two) workgroup(s) per CU (registers, LDS)
+    hipLaunchKernelGGL((wino4_kernel<MODE, STREAM, false, NTG, NW>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(64 * NW), LDS_BYTES, st, a);
     return 0;
 }
 
@@ -1055,13 +1063,13 @@ int launch4_split(const Wino4Args& a, hipStream_t st) {
     return 0;
 }
 
-template <int MODE, int NTG = 2>
+template <int MODE, int NTG = 2, int NW = 4>
 int launch4(const Wino4Args& a, hipStream_t st) {
     static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;     // A/B knob (tools/ only)
     static const int stream_kinds = getenv("ND_W4_STREAM_KINDS") ? atoi(getenv("ND_W4_STREAM_KINDS")) : 7;           // A/B knob (tools/ only)
     const int kind = (MODE == ND_PRO_AFFINE_SILU || MODE == ND_PRO_AFFINE_MAP_SILU) ? 2 : a.d.stats ? 1 : 4;   // block2 / block1 / resampling convs
     const long out_bytes = (long)a.d.B * a.d.H * a.d.W * a.d.ldo * 4;
-    return (out_bytes >= stream_min && (stream_kinds & kind)) ? launch4s<MODE, true, NTG>(a, st) : launch4s<MODE, false, NTG>(a, st);
+    return (out_bytes >= stream_min && (stream_kinds & kind)) ? launch4s<MODE, true, NTG, NW>(a, st) : launch4s<MODE, false, NTG, NW>(a, st);
 }
 
 }  // namespace
@@ -1179,6 +1187,20 @@ extern "C" int nd_conv3x3_wino4_16_nhwc_f32(const nd_conv3x3* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4<ND_PRO_AFFINE_SILU, 1>(a, st) : launch4<ND_PRO_NONE, 1>(a, st)) return rc;
     return nd_launch_status("nd_conv3x3_wino4_16_nhwc_f32");
+}
+
+// The 16 x 32-pixel region with EIGHT waves (two per SIMD in one workgroup: waves 0-3 multiply tile group 0, waves 4-7 tile group 1; r4): the two wave sets
+// run in phase by construction -- the MFMA stages of one cover the LDS / memory waits of the other, the VALU phases (transform, epilogue) of both coincide
+// instead of slipping between the other's MFMAs one instruction at a time -- and every weight fragment is fetched from the L2 once per workgroup (the second
+// wave set's request hits the L1).  Same weights, slots, descriptor and bits.  Plain and GroupNorm-affine + SiLU sources.
+extern "C" int nd_conv3x3_wino4_8w_nhwc_f32(const nd_conv3x3* d, void* stream) {
+    Wino4Args a;
+    if (int e = w4_prepare(d, a, 2)) return e;
+    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
+               "nd_conv3x3_wino4_8w: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4<ND_PRO_AFFINE_SILU, 2, 8>(a, st) : launch4<ND_PRO_NONE, 2, 8>(a, st)) return rc;
+    return nd_launch_status("nd_conv3x3_wino4_8w_nhwc_f32");
 }
 
 // ---- split-K (training at small batch, and any plain layer without a statistics epilogue whose items fill a fraction of the chip)

@@ -841,9 +841,11 @@ W16_CASES = {**{k: v + (0, 0) for k, v in WINO_CASES.items()}, **{k: HEADLINE_CA
              **CFG2_CASES, "ragged_17x33": (2, 17, 33, 48, 80, 0, 0), "odd_rows_50x18": (1, 50, 18, 32, 64, 16, 0)}
 
 
+@pytest.mark.parametrize("entry", ["nd_conv3x3_wino4_16_nhwc_f32", "nd_conv3x3_wino4_8w_nhwc_f32"])
 @pytest.mark.parametrize("case", sorted(W16_CASES))
-def test_conv3x3_wino4_16_pixel_regions_equal_the_one_workgroup_form(ctx, case):
-    """nd_conv3x3_wino4_16_nhwc_f32 (16 x 16-pixel regions, two co-resident workgroups per CU) against nn.Conv2d AND against
+def test_conv3x3_wino4_two_waves_per_simd_forms_equal_the_one_workgroup_form(ctx, case, entry):
+    """nd_conv3x3_wino4_16_nhwc_f32 (16 x 16-pixel regions, two co-resident workgroups per CU) and nd_conv3x3_wino4_8w_nhwc_f32 (16 x 32-pixel regions,
+    eight waves per workgroup) against nn.Conv2d AND against
     nd_conv3x3_wino4_nhwc_f32 bit for bit wherever that kernel takes the shape -- output and GroupNorm partials, plain / concat / nearest-x2 /
     affine + SiLU sources, ragged images, images narrower than 32 pixels, partial K chunks and cout tiles; bitwise repeat."""
     import hiputil as hu
@@ -860,7 +862,7 @@ def test_conv3x3_wino4_16_pixel_regions_equal_the_one_workgroup_form(ctx, case):
     wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
     L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
     ctx.sync()
-    run16 = lambda s, stats=True: _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats, entry="nd_conv3x3_wino4_16_nhwc_f32")
+    run16 = lambda s, stats=True: _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats, entry=entry)
     run32 = lambda s, stats=True: _run_wino4(ctx, s, wp, bd, B, H, W, cin, cout, stats)
     s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
     out, st, sc, slots = run16(s)
@@ -885,7 +887,7 @@ def test_conv3x3_wino4_16_pixel_regions_equal_the_one_workgroup_form(ctx, case):
         d = L.Conv3x3()
         d.src, d.weight, d.bias, d.out = hu.src(hu.nhwc(x), None, mode), wp.data_ptr(), bd.data_ptr(), out.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, hs, ws, cin, cout, cout
-        assert ctx.lib.nd_conv3x3_wino4_16_nhwc_f32(C.byref(d), ctx.stream) != 0
+        assert getattr(ctx.lib, entry)(C.byref(d), ctx.stream) != 0
 
 
 @pytest.mark.parametrize("dim,B", [(64, 16), (16, 2), (128, 8), (48, 3)])
