@@ -107,7 +107,8 @@ def executed_gflop_per_step(plan, L):
 def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
-    CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32", "nd_conv3x3_wino4_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32")
+    CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32", "nd_conv3x3_wino4_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32",
+            "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_splitk_nhwc_f32")
     STREAM = "nd_affine_silu_add_f32"           # the HBM-bound family: GroupNorm-apply + SiLU + residual adds, one pass
     convs = [op for op in plan.step_ops if op[2] in CONV or (op[2] == STREAM and op[3])]
     n_ev = 2 * len(convs)
@@ -146,7 +147,7 @@ def instrumented_pass(loop, plan, L, n_steps):
                 continue
             # conv3x3_wino4 has two instances per prologue mode: outputs of 48 MB and more are stored with the streaming policy bits
             stream = m["tiling"] in (9004, 9016) and 4 * m["B"] * m["H"] * m["W"] * m["cout"] >= int(os.environ.get("ND_W4_STREAM_MB", "48")) << 20
-            d = per.setdefault((m["tiling"], m["mode"], stream), {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
+            d = per.setdefault((m["tiling"], m["mode"], stream, m.get("splits", 1) > 1), {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
             d["ms"] += ms.value
             d["flop"] += conv_flops(m)
             d["bytes"] += conv_bytes(m)
@@ -312,7 +313,7 @@ def roofline(a, loop, plan, L, per_step):
     tot_ms = sum(d["ms"] for d in per.values())
     tot_flop = sum(d["flop"] for d in per.values())
     tot_exec = sum(d["flop"] / WINO_FACTOR.get(k[0], 1.0) for k, d in per.items())
-    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, false, {1 if k[0] == 9016 else 2}>" if k[0] in (9004, 9016) else
+    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, {'true' if len(k) > 3 and k[3] else 'false'}, {1 if k[0] == 9016 else 2}, 4>{' + reduce' if len(k) > 3 and k[3] else ''}" if k[0] in (9004, 9016) else
                        f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
                        f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
     tid, d = max(per.items(), key=lambda kv: kv[1]["ms"])

@@ -159,6 +159,12 @@ int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* packed, int
 int nd_conv3x3_wino4_splitk_plan(int B, int H, int W, int cin, int cout);
 int64_t nd_conv3x3_wino4_splitk_workspace_floats(int B, int H, int W, int cout, int splits);
 int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream);
+/* Split-K on the 16 x 16-region form, for SAMPLING (r4): layers with few (region, cout tile) items per sample -- the 16 x 16 and 32 x 32 stages of
+ * BASELINE config 2 (Diffusion_arch.py:533,547 at H/8) -- are cut along cin.  _plan looks at the SAMPLE's geometry only (no batch argument), so a
+ * sample's bits never depend on the batch it is sharded into: 2, 4 or 8 ranges so that a sample has about 32 items, at least four chunks per range.
+ * Workspace: nd_conv3x3_wino4_splitk_workspace_floats. */
+int nd_conv3x3_wino4_16_splitk_plan(int H, int W, int cin, int cout);
+int nd_conv3x3_wino4_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream);
 
 /* ------------------------------------------------------------------ conv 3x3, training */
 

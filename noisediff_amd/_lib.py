@@ -89,6 +89,8 @@ SIGNATURES = {
     "nd_conv3x3_wino4_splitk_plan": (i32, [i32, i32, i32, i32, i32]),
     "nd_conv3x3_wino4_splitk_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
     "nd_conv3x3_wino4_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
+    "nd_conv3x3_wino4_16_splitk_plan": (i32, [i32, i32, i32, i32]),
+    "nd_conv3x3_wino4_16_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
     "nd_conv3x3_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
     "nd_conv3x3_wgrad_nhwc_f32": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_groupnorm_train_workspace_floats": (i64, [i32, i32, i32]),
@@ -157,7 +159,7 @@ SIGNATURES = {
 
 _UNCHECKED = {"nd_version", "nd_last_error", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
               "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats", "nd_conv3x3_wino_stat_slots", "nd_conv3x3_wino4_stat_slots",
-              "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_token_sum_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
+              "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_16_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_token_sum_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
               "nd_groupnorm_train_workspace_floats", "nd_linear_wgrad_workspace_floats",
               "nd_layernorm_train_workspace_floats", "nd_groupnorm_silu_train_workspace_floats"}
 

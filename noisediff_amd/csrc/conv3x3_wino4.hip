@@ -1053,13 +1053,13 @@ __global__ __launch_bounds__(256) void w4_splitk_reduce_stats_kernel(const float
     if (b == 0 && cgrp == 0 && threadIdx.x == 0) slot_count[slot] = (float)npx;
 }
 
-template <int MODE>
+template <int MODE, int NTG = 2>
 int launch4_split(const Wino4Args& a, hipStream_t st) {
     static nd_device_once configured;
-    constexpr int LDS_BYTES = W4Geo<2>::LDS_BYTES;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, false, true>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
-    const long resident = nd_device_cus();
-    hipLaunchKernelGGL((wino4_kernel<MODE, false, true>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    constexpr int LDS_BYTES = W4Geo<NTG>::LDS_BYTES;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, false, true, NTG>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
+    const long resident = (long)nd_device_cus() * W4Geo<NTG>::WG_PER_CU;
+    hipLaunchKernelGGL((wino4_kernel<MODE, false, true, NTG>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
     return 0;
 }
 
@@ -1228,18 +1228,18 @@ extern "C" int64_t nd_conv3x3_wino4_splitk_workspace_floats(int B, int H, int W,
     return (int64_t)splits * B * H * W * cout;
 }
 
-extern "C" int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {
+static int w4_splitk(const nd_conv3x3* d, float* workspace, int splits, void* stream, int ntg, const char* who) {
     Wino4Args a;
-    if (int e = w4_prepare(d, a)) return e;
-    ND_REQUIRE(workspace && nd_aligned16(workspace), ND_E_BADARG, "nd_conv3x3_wino4_splitk: the workspace must be a 16-byte aligned pointer");
+    if (int e = w4_prepare(d, a, ntg)) return e;
+    ND_REQUIRE(workspace && nd_aligned16(workspace), ND_E_BADARG, "%s: the workspace must be a 16-byte aligned pointer", who);
     ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
-               "nd_conv3x3_wino4_splitk: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)");
+               "%s: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)", who);
     const int n_chunks = nd_cdiv(d->cin, KC4);
     ND_REQUIRE((splits == 2 || splits == 4 || splits == 8) && d->cin % KC4 == 0 && n_chunks % splits == 0 && n_chunks / splits >= 2, ND_E_SHAPE,
-               "nd_conv3x3_wino4_splitk: splits=%d must be 2, 4 or 8 and divide cin=%d into ranges of at least two whole 16-channel chunks", splits, d->cin);
+               "%s: splits=%d must be 2, 4 or 8 and divide cin=%d into ranges of at least two whole 16-channel chunks", who, splits, d->cin);
     const long npix = (long)d->B * d->H * d->W;
-    ND_REQUIRE((long)splits * npix * d->cout * 4 < (1L << 31), ND_E_SHAPE, "nd_conv3x3_wino4_splitk: partial sums of 2 GiB or more");
-    ND_REQUIRE(d->cout % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4_splitk: cout must be a multiple of 4");
+    ND_REQUIRE((long)splits * npix * d->cout * 4 < (1L << 31), ND_E_SHAPE, "%s: partial sums of 2 GiB or more", who);
+    ND_REQUIRE(d->cout % 4 == 0, ND_E_SHAPE, "%s: cout must be a multiple of 4", who);
     const float* bias = d->bias;
     float* out = d->out;
     const int ldo = d->ldo;
@@ -1249,16 +1249,39 @@ extern "C" int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* work
     a.chunks_per_split = n_chunks / splits;
     a.total_wg *= splits;
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4_split<ND_PRO_AFFINE_SILU>(a, st) : launch4_split<ND_PRO_NONE>(a, st)) return rc;
-    if (int e = nd_launch_status("nd_conv3x3_wino4_splitk_nhwc_f32")) return e;
+    const bool aff = d->src.mode == ND_PRO_AFFINE_SILU;
+    if (int rc = ntg == 1 ? (aff ? launch4_split<ND_PRO_AFFINE_SILU, 1>(a, st) : launch4_split<ND_PRO_NONE, 1>(a, st))
+                          : (aff ? launch4_split<ND_PRO_AFFINE_SILU>(a, st) : launch4_split<ND_PRO_NONE>(a, st))) return rc;
+    if (int e = nd_launch_status(who)) return e;
     if (d->stats) {
         const int n_cgrp = nd_cdiv(d->cout, 64);
         hipLaunchKernelGGL(w4_splitk_reduce_stats_kernel, dim3((unsigned)(d->B * a.tiles_x * a.tiles_y * n_cgrp)), dim3(256), 0, st, workspace, bias, out,
                            d->stats, d->slot_count, splits, d->B, d->H, d->W, d->cout, ldo, a.tiles_x, a.tiles_y, n_cgrp);
-        return nd_launch_status("nd_conv3x3_wino4_splitk_nhwc_f32 (reduce + statistics)");
+        return nd_launch_status(who);
     }
     const long total = npix * (d->cout / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, bias, out, splits, npix, d->cout, ldo);
-    return nd_launch_status("nd_conv3x3_wino4_splitk_nhwc_f32 (reduce)");
+    return nd_launch_status(who);
+}
+
+extern "C" int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {
+    return w4_splitk(d, workspace, splits, stream, 2, "nd_conv3x3_wino4_splitk_nhwc_f32");
+}
+
+// Split-K on the 16 x 16-region form for SAMPLING: layers with few items per sample (BASELINE config 2's 16 x 16 and 32 x 32 stages: 512 -> 512 at 16 x 16 is 8
+// items per sample, 128 for 512 workgroup slots at 16 patches per GPU, each walking 32 K chunks).  The split count is a function of the SAMPLE's geometry alone
+// (never of the batch), so a sample's bits do not depend on the batch it is sharded into: 2, 4 or 8 ranges of cin so that a sample has about 32 items, at
+// least four 16-channel chunks per range.
+extern "C" int nd_conv3x3_wino4_16_splitk_plan(int H, int W, int cin, int cout) {
+    if (H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || cin % KC4) return 1;
+    const long items = (long)nd_cdiv(W, 16) * nd_cdiv(H, 16) * nd_cdiv(cout, 64);
+    const int n_chunks = cin / KC4;
+    int splits = 1;
+    while (splits < 8 && items * splits < 32 && n_chunks % (splits * 2) == 0 && n_chunks / (splits * 2) >= 4) splits *= 2;
+    return splits;
+}
+
+extern "C" int nd_conv3x3_wino4_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {
+    return w4_splitk(d, workspace, splits, stream, 1, "nd_conv3x3_wino4_16_splitk_nhwc_f32");
 }

@@ -53,6 +53,7 @@ EIGHT_TILES_RULE = os.environ.get("ND_W4_EIGHT_TILES", "1") != "0"     # A-B kno
 # 16 x 32 form has too few regions per sample or the image is narrower than 32 pixels (those layers ran on F(2x2) before); "all": wherever it takes the
 # layer; "0": never.  Either way a function of the sample's geometry alone, and the same bits as the 16 x 32 form.
 WINO4_16 = os.environ.get("ND_WINO4_16", "narrow")
+WINO4_16_SPLIT = os.environ.get("ND_WINO4_16_SPLIT", "1") != "0"      # A-B knob: 0 = no K ranges on the 16 x 16-region form
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -477,10 +478,12 @@ class Plan:
         meta = {"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
                 "tiling": (9016 if w4kind == "wino4_16" else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
         splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and w4kind == "wino4" and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
+        if w4kind == "wino4_16" and WINO4_16_SPLIT:      # few items per sample: K ranges by the SAMPLE's geometry (the batch never enters: a sample's bits stay batch-invariant)
+            splits = int(e.lib.nd_conv3x3_wino4_16_splitk_plan(H, W, cin, cout))
         if splits > 1 and splits * self.B * H * W * cout * 4 < (1 << 31):
             ws = self._alloc(splits * self.B * H * W * cout)
             meta["splits"] = splits
-            self._add("nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), splits, e.stream, meta=meta)
+            self._add("nd_conv3x3_wino4_16_splitk_nhwc_f32" if w4kind == "wino4_16" else "nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), splits, e.stream, meta=meta)
             self._release(ws)
         else:
             self._add(entry, C.byref(d), e.stream, meta=meta)

@@ -890,6 +890,56 @@ def test_conv3x3_wino4_two_waves_per_simd_forms_equal_the_one_workgroup_form(ctx
         assert getattr(ctx.lib, entry)(C.byref(d), ctx.stream) != 0
 
 
+@pytest.mark.parametrize("case", sorted(CFG2_CASES))
+def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case):
+    """nd_conv3x3_wino4_16_splitk_nhwc_f32 with the split count of nd_conv3x3_wino4_16_splitk_plan (the sample's geometry only) on BASELINE config 2's
+    narrow stages: output against nn.Conv2d and against the unsplit kernel, the GroupNorm partials the reduction leaves, the affine + SiLU prologue,
+    bitwise repeat, and the same bits for a sample whatever batch it sits in."""
+    import hiputil as hu
+    B, H, W, cin, cout, c0, up = CFG2_CASES[case]
+    B = min(B, 4)
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    bound = 1.0 / np.sqrt(9 * cin)
+    x = U(case + ".x", (B, cin, hs, ws), -1.5, 1.5)
+    w = U(case + ".w", (cout, cin, 3, 3), -bound, bound)
+    b = U(case + ".b", (cout,), -bound, bound)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, padding=1)
+    wd, bd = hu.dev(w), hu.dev(b)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    splits = ctx.lib.nd_conv3x3_wino4_16_splitk_plan(H, W, cin, cout)
+    assert splits in (2, 4)
+    slots = ctx.lib.nd_conv3x3_wino4_stat_slots(H, W)
+
+    def run(s, nb=B):
+        out, st, sc = hu.full((nb, H, W, cout)), hu.full((nb, slots, cout, 2)), hu.full((slots,))
+        ws_ = hu.full((ctx.lib.nd_conv3x3_wino4_splitk_workspace_floats(nb, H, W, cout, splits),))
+        d = L.Conv3x3()
+        d.src, d.weight, d.bias, d.out, d.stats, d.slot_count = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st.data_ptr(), sc.data_ptr()
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = nb, H, W, cin, cout, cout
+        L.call("nd_conv3x3_wino4_16_splitk_nhwc_f32", C.byref(d), ws_.data_ptr(), splits, ctx.stream)
+        ctx.sync()
+        return out, st, sc
+
+    mk = lambda xx, **kw: (hu.src(hu.nhwc(xx[:, :c0]), hu.nhwc(xx[:, c0:]), **kw) if c0 else hu.src(hu.nhwc(xx), upsample=up, **kw))
+    out, st, sc = run(mk(x))
+    assert rel_err(hu.nchw(out), ref) < 5e-5
+    _check_gn(ctx, case, ref, st, sc, slots, B, cout, 5e-5)
+    out2, st2, _ = run(mk(x))
+    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
+    o1, s1, _ = run(mk(x[1:2].contiguous()), nb=1)                       # sample 1 alone: the same bits as inside the batch
+    assert torch.equal(out[1:2].cpu(), o1.cpu()) and torch.equal(st[1:2].cpu(), s1.cpu())
+    plain, *_ = _run_wino4(ctx, mk(x), wp, bd, B, H, W, cin, cout, entry="nd_conv3x3_wino4_16_nhwc_f32")
+    assert rel_err(hu.nchw(out), hu.nchw(plain)) < 5e-5                  # another summation order over cin, nothing else (measured 2.3e-5 at 24 chunks)
+    if not up:
+        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
+        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+        out, *_ = run(mk(x, mode=L.PRO_AFFINE_SILU, mad=hu.dev(torch.stack((M, A, D), 1))))
+        assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
+
+
 @pytest.mark.parametrize("dim,B", [(64, 16), (16, 2), (128, 8), (48, 3)])
 def test_cond_step_single_launch_matches_torch(ctx, dim, B):
     """nd_cond_step_f32 == SinusoidalPosEmb -> Linear -> GELU -> Linear -> SiLU -> stacked ResnetBlock.mlp Linears

@@ -278,3 +278,14 @@ def test_split_k_plan_is_a_function_of_the_shape():
     assert plan(1, 32, 32, 1536, 64) == 8 and plan(1, 32, 32, 64, 64) == 1 and plan(1, 32, 32, 72, 64) == 1
     assert plan(4, 256, 256, 64, 64) == 1 and plan(0, 1, 1, 1, 1) == 1
     assert lib.nd_conv3x3_wino4_splitk_workspace_floats(2, 8, 8, 16, 4) == 2 * 8 * 8 * 16 * 4
+
+
+def test_sampling_split_k_plan_looks_at_the_sample_geometry_only():
+    """nd_conv3x3_wino4_16_splitk_plan (host code, no GPU) has no batch argument: BASELINE config 2's 16 x 16 and 32 x 32 stages are cut into K ranges
+    (about 32 items per sample, at least four 16-channel chunks per range), the layers of the 256 x 256 workload that reach the 16 x 16-region form
+    (256 -> 256 at 32 x 32) into two, everything with enough items per sample or too few chunks is left alone."""
+    plan = L.load().nd_conv3x3_wino4_16_splitk_plan
+    assert plan(16, 16, 512, 512) == 4 and plan(16, 16, 768, 512) == 4 and plan(16, 16, 256, 512) == 4 and plan(16, 16, 256, 256) == 4
+    assert plan(32, 32, 256, 256) == 2 and plan(32, 32, 384, 256) == 2 and plan(32, 32, 512, 256) == 2
+    assert plan(32, 32, 512, 512) == 1 and plan(256, 256, 64, 64) == 1 and plan(16, 16, 64, 64) == 1 and plan(16, 16, 72, 64) == 1
+    assert plan(16, 16, 2048, 64) == 8 and plan(0, 16, 64, 64) == 1
