@@ -445,12 +445,21 @@ int nd_graph_begin(void* stream);                 /* hipStreamBeginCapture (thre
 int nd_graph_end(void* stream, void** graph_exec);
 int nd_graph_launch(void* graph_exec, void* stream);
 int nd_graph_destroy(void* graph_exec);
+/* nd_graph_begin / _end / _launch make the STREAM's device current for the call (and restore the caller's): one host thread may drive the
+ * step graphs of several GPUs round-robin -- GaussianDiffusion.sample under nn.DataParallel(device_ids=[...]), models/modules.py:73-83.
+ * nd_stream_device: the device ordinal a stream was created on (-1: unknown). */
+int nd_stream_device(void* stream);
 /* timing on the library's own stream: HIP events are only meaningful on the stream they are
  * recorded on (torch.cuda.Event sees torch's current stream only). */
 int nd_event_create(void** ev);
 int nd_event_record(void* ev, void* stream);
 int nd_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises `stop` */
 int nd_event_destroy(void* ev);
+/* cross-stream dependencies (the fork / join edges of the two-branch step graph: the shot-noise branch of NoiseDiffNet.forward,
+ * Diffusion_arch.py:598-604, is independent of the U-Net until the final add :644): an event without timing, and "stream waits for event".
+ * Recorded / waited on capturing streams they become edges of the captured graph. */
+int nd_event_create_untimed(void** ev);
+int nd_stream_wait_event(void* stream, void* ev);
 
 #ifdef __cplusplus
 }

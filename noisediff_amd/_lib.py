@@ -155,9 +155,12 @@ SIGNATURES = {
     "nd_event_record": (i32, [vp, vp]),
     "nd_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
     "nd_event_destroy": (i32, [vp]),
+    "nd_event_create_untimed": (i32, [C.POINTER(vp)]),
+    "nd_stream_wait_event": (i32, [vp, vp]),
+    "nd_stream_device": (i32, [vp]),
 }
 
-_UNCHECKED = {"nd_version", "nd_last_error", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
+_UNCHECKED = {"nd_version", "nd_last_error", "nd_stream_device", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
               "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats", "nd_conv3x3_wino_stat_slots", "nd_conv3x3_wino4_stat_slots",
               "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_16_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_token_sum_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
               "nd_groupnorm_train_workspace_floats", "nd_linear_wgrad_workspace_floats",

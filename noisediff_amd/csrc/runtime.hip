@@ -61,12 +61,34 @@ extern "C" int nd_stream_create(void** stream) {
 extern "C" int nd_stream_destroy(void* stream) { ND_HIP(hipStreamDestroy((hipStream_t)stream)); return 0; }
 extern "C" int nd_stream_sync(void* stream) { ND_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 
+// Graph and event calls act on a stream that may belong to another device than the thread's current one (one host thread driving the shards of several
+// GPUs: GaussianDiffusion.sample under nn.DataParallel(device_ids=[...]), models/modules.py:73-83): they make the stream's device current for the call.
+struct nd_stream_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit nd_stream_device_guard(void* stream) {
+        int dev = -1;
+        if (stream && hipStreamGetDevice((hipStream_t)stream, &dev) == hipSuccess && hipGetDevice(&prev) == hipSuccess && dev >= 0 && dev != prev)
+            switched = hipSetDevice(dev) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    ~nd_stream_device_guard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+extern "C" int nd_stream_device(void* stream) {
+    int dev = -1;
+    if (!stream || hipStreamGetDevice((hipStream_t)stream, &dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return dev;
+}
+
 extern "C" int nd_graph_begin(void* stream) {
+    nd_stream_device_guard g(stream);
     ND_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     return 0;
 }
 extern "C" int nd_graph_end(void* stream, void** graph_exec) {
     ND_REQUIRE(graph_exec, ND_E_BADARG, "nd_graph_end: null");
+    nd_stream_device_guard dg(stream);
     hipGraph_t g = nullptr;
     ND_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
     hipGraphExec_t ge = nullptr;
@@ -81,6 +103,7 @@ extern "C" int nd_graph_end(void* stream, void** graph_exec) {
 }
 extern "C" int nd_graph_launch(void* graph_exec, void* stream) {
     ND_REQUIRE(graph_exec, ND_E_STATE, "nd_graph_launch: null graph");
+    nd_stream_device_guard dg(stream);
     ND_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
     return 0;
 }
@@ -97,6 +120,16 @@ extern "C" int nd_event_create(void** ev) {
     return 0;
 }
 extern "C" int nd_event_record(void* ev, void* stream) { ND_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+// `stream` waits for `ev` (recorded on another stream): the fork / join edges of the two-branch step graph
+extern "C" int nd_stream_wait_event(void* stream, void* ev) { ND_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return 0; }
+// an event without timing: a pure dependency (cheaper to record, and the only kind a captured cross-stream edge needs)
+extern "C" int nd_event_create_untimed(void** ev) {
+    ND_REQUIRE(ev, ND_E_BADARG, "nd_event_create_untimed: null");
+    hipEvent_t e;
+    ND_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = (void*)e;
+    return 0;
+}
 extern "C" int nd_event_elapsed_ms(void* start, void* stop, float* ms) {
     ND_REQUIRE(ms, ND_E_BADARG, "nd_event_elapsed_ms: null");
     ND_HIP(hipEventSynchronize((hipEvent_t)stop));

@@ -353,6 +353,8 @@ extern "C" int nd_cond_table_build_f32(const float* freqs, const float* W1, cons
     ND_REQUIRE(nd_aligned16(W1) && nd_aligned16(W2), ND_E_ALIGN, "nd_cond_table_build: time_mlp weights must be 16-byte aligned");
     const int Bc = 16;                                                   // timesteps per workgroup: the head's batch size in the step kernel
     const int64_t lds = nd_cond_step_lds_bytes(Bc, dim);
+    ND_REQUIRE(lds <= 160 * 1024, ND_E_SHAPE, "nd_cond_table_build: dim=%d needs %lld bytes of LDS (no table for this width: use nd_cond_step_f32 or the separate launches)",
+               dim, (long long)lds);
     static nd_device_once configured;
     if (lds > 64 * 1024)
         if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(cond_step_kernel), 160 * 1024, "nd_cond_table_build")) return e;

@@ -355,11 +355,12 @@ class _Loop:
             return
         st = self.plan.e.stream
         self.destroy()
-        L.call("nd_graph_begin", st)
-        try:
-            self._step_eager(noise_ptr, stride)
-        finally:
-            L.call("nd_graph_end", st, C.byref(self.graph))
+        with torch.cuda.device(self.plan.dev):
+            L.call("nd_graph_begin", st)
+            try:
+                self._step_eager(noise_ptr, stride)
+            finally:
+                L.call("nd_graph_end", st, C.byref(self.graph))
         self.graph_key = key
 
     def start(self, x_T, step_noise, seed, first_sample, use_graph=True):
@@ -400,11 +401,14 @@ class _Loop:
     def advance(self, n: int = 1) -> None:
         """Enqueue n diffusion steps on the library stream (no host synchronisation)."""
         st = self.plan.e.stream
-        for _ in range(n):
-            if self.use_graph:
-                L.call("nd_graph_launch", self.graph, st)
-            else:
-                self._step_eager(*self._args)
+        # sample() drives the shards of several devices from one host thread (nn.DataParallel(device_ids=[...])): a graph or a kernel is
+        # launched with ITS device current (ADVICE r3; nd_graph_launch also sets the stream's device itself)
+        with torch.cuda.device(self.plan.dev):
+            for _ in range(n):
+                if self.use_graph:
+                    L.call("nd_graph_launch", self.graph, st)
+                else:
+                    self._step_eager(*self._args)
 
     def run(self, x_T, step_noise, seed, first_sample, return_all=False, use_graph=True):
         p = self.plan

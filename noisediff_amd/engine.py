@@ -187,7 +187,11 @@ class Engine:
         add("time_freqs", self.dim // 2, "derived", (self.dim // 2,))
         # time_mlp's result for every timestep 0 .. TIME_TABLE_ROWS - 1 (st = SiLU(time_mlp(emb(t))), Diffusion_arch.py:100-107,502-507,149): the
         # step kernel looks the head up instead of running two dependent small Linears at the start of every diffusion step
-        add("time_table", TIME_TABLE_ROWS * 4 * self.dim, "derived", (TIME_TABLE_ROWS, 4 * self.dim))
+        # (only where the table's builder runs: its head batch of 16 timesteps needs 16 * dim * 36 bytes of LDS and 4 * dim <= 2048 -- dim <= 280;
+        #  wider nets keep nd_cond_step_f32 / the separate launches, as before r3)
+        self.time_table = TIME_TABLE and 4 * self.dim <= 2048 and self.lib.nd_cond_step_lds_bytes(16, self.dim) <= 160 * 1024
+        if self.time_table:
+            add("time_table", TIME_TABLE_ROWS * 4 * self.dim, "derived", (TIME_TABLE_ROWS, 4 * self.dim))
         self.arena_floats = off
 
     def view(self, name: str) -> torch.Tensor:
@@ -206,6 +210,7 @@ class Engine:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         """Pack a reference-layout state dict (any device) into the arena."""
         st = self.stream
+        self.valid = None                          # every slice is (re)written below: an engine adopted from a partial broadcast may repack (ADVICE r3)
         keep = []
         used = set(self.used)                      # packing addresses every slice; `used` records what the PLANS read
         with torch.cuda.device(self.device):
@@ -253,9 +258,10 @@ class Engine:
             e = math.log(10000) / (half - 1)
             self.view("time_freqs").copy_(torch.exp(torch.arange(half) * -e).to(torch.float32))
             torch.cuda.synchronize(self.device)
-            L.call("nd_cond_table_build_f32", self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"), self.p("time_mlp.3.weight"),
-                   self.p("time_mlp.3.bias"), self.p("time_table"), TIME_TABLE_ROWS, self.dim, st)
-            L.call("nd_stream_sync", st)
+            if self.time_table:
+                L.call("nd_cond_table_build_f32", self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"), self.p("time_mlp.3.weight"),
+                       self.p("time_mlp.3.bias"), self.p("time_table"), TIME_TABLE_ROWS, self.dim, st)
+                L.call("nd_stream_sync", st)
         self.loaded, self.valid, self.used = True, None, used
 
     def broadcast_state_dict(self, sd: Optional[Dict[str, torch.Tensor]], src: int = 0, group=None) -> int:
@@ -692,12 +698,12 @@ class Plan:
 
     def _record_time(self) -> None:
         e, d = self.e, self.e.dim
-        if COND_STEP and e.lib.nd_cond_step_lds_bytes(self.B, d) <= 160 * 1024:
+        if COND_STEP and 4 * d <= 2048 and e.lib.nd_cond_step_lds_bytes(self.B, d) <= 160 * 1024:
             # one launch: time embedding, time_mlp, SiLU and every ResnetBlock.mlp projection (tproj)
             args = (self.time.data_ptr(), e.p("time_freqs"), e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"),
                     e.p("time_mlp.3.weight"), e.p("time_mlp.3.bias"), e.p("tproj.weight"), e.p("tproj.bias"), self.tproj.data_ptr(),
                     e.tproj_rows, self.B, d, e.tproj_rows)
-            if TIME_TABLE:
+            if e.time_table:
                 self._add("nd_cond_step_table_f32", *args, e.p("time_table"), TIME_TABLE_ROWS, e.stream)
             else:
                 self._add("nd_cond_step_f32", *args, e.stream)

@@ -51,12 +51,18 @@ def broadcast_weights(net, device: torch.device, src: int = 0, group=None, shape
 
 def sample_sharded(sample_fn: Callable[..., torch.Tensor], total_batch: int,
                    make_condition: Callable[[int, int], Dict[str, torch.Tensor]], *, seed: int,
-                   set_offset: Optional[Callable[[int], None]] = None, gather: bool = False, group=None, **kw):
+                   set_offset: Optional[Callable[[int], None]] = None, gather: bool = False, group=None,
+                   device: Optional[torch.device] = None, **kw):
     """Run ``sample_fn(batch_size=hi-lo, condition=make_condition(lo, hi), seed=seed, **kw)`` on this
     rank's rows.  ``set_offset(lo)`` tells the sampler the global index of its first sample so that the
     device noise stream of row i is the same whatever the number of ranks.  With ``gather`` every rank
-    returns the full (total_batch, ...) result (one all-gather at the very end), else its own rows."""
+    returns the full (total_batch, ...) result (one all-gather at the very end), else its own rows.
+    ``device``: where a rank WITHOUT rows (world > total_batch) builds its part of the all-gather -- the collective's backend decides
+    what it accepts (RCCL: device tensors only), so the placeholder must live where the other ranks' results live; default: this
+    rank's current CUDA device under the nccl backend, else the CPU."""
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    if total_batch <= 0:
+        raise ValueError(f"sample_sharded: total_batch={total_batch}: nothing to sample")
     lo, hi = shard_bounds(total_batch, rank, world)
     if set_offset is not None:
         set_offset(lo)
@@ -69,8 +75,13 @@ def sample_sharded(sample_fn: Callable[..., torch.Tensor], total_batch: int,
     shapes = [None] * world
     dist.all_gather_object(shapes, tail, group=group)
     tail = next(s for s in shapes if s is not None)
-    ref = out if out is not None else torch.zeros((0,) + tail)
-    pad = torch.zeros((n_max,) + tail, dtype=ref.dtype, device=ref.device)
+    if out is not None:
+        pad_dev = out.device
+    elif device is not None:
+        pad_dev = torch.device(device)
+    else:       # a rank without rows: the all-gather of an RCCL group takes device tensors only (r3 built this placeholder on the CPU)
+        pad_dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    pad = torch.zeros((n_max,) + tail, dtype=out.dtype if out is not None else torch.float32, device=pad_dev)
     if out is not None:
         pad[: hi - lo] = out
     parts = [torch.empty_like(pad) for _ in range(world)]

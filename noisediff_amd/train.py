@@ -626,14 +626,27 @@ def accelerate(model: nn.Module, norms: bool = True, linears: bool = True) -> in
 _RETARGETED: Dict[tuple, type] = {}
 
 
+def _rebuild_retargeted(base: type, fn_name: str, state):
+    """pickle support (torch.save(model), mp.spawn arguments): the dynamic subclass is not importable by name, so an accelerated
+    module is pickled as (its base class, the name of the HIP forward) and re-targeted when it is loaded."""
+    m = base.__new__(base)
+    m.__dict__.update(state)
+    _retarget(m, globals()[fn_name])
+    return m
+
+
+def _reduce_retargeted(self):
+    return _rebuild_retargeted, (type(self)._nd_accelerated_base, type(self).forward.__name__, self.__dict__.copy())
+
+
 def _retarget(m: nn.Module, fn) -> None:
     """m.__class__ <- the cached subclass of type(m) whose forward is ``fn`` (same name / module / qualname, so structural
     checks by class name and ``isinstance`` keep working)."""
-    base = type(m)
+    base = getattr(type(m), "_nd_accelerated_base", type(m))
     cls = _RETARGETED.get((base, fn))
     if cls is None:
         cls = type(base.__name__, (base,), {"forward": fn, "__module__": base.__module__, "__qualname__": base.__qualname__,
-                                             "__doc__": base.__doc__, "_nd_accelerated_base": base})
+                                             "__doc__": base.__doc__, "_nd_accelerated_base": base, "__reduce__": _reduce_retargeted})
         _RETARGETED[(base, fn)] = cls
     m.__dict__.pop("forward", None)          # an instance attribute (older accelerate(), user patches) would shadow the class
     m.__class__ = cls

@@ -337,6 +337,45 @@ def test_data_parallel_device_ids_shard_the_batch_in_sample():
     assert rel_err(traj.numpy(), ref.numpy()) < SAMPLE_TOL
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the pool's boxes have one; tools/first_node_check.sh runs this on a node)")
+def test_data_parallel_over_two_physical_devices_equals_one_device():
+    """The same comparison with device_ids=[0, 1]: the second shard's engine is a device-to-device copy of the first's arena, its step graph is
+    captured and launched on cuda:1's stream from the one host thread (device guard in _Loop.advance / nd_graph_launch), and the gather copies
+    its rows back to cuda:0.  Equal to the one-device run bit for bit."""
+    dim, H, T, B = 16, 32, 6, 5
+    net = make_net(dim)
+    one = GaussianDiffusion(torch.nn.DataParallel(net, device_ids=[0]), image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    two = GaussianDiffusion(torch.nn.DataParallel(net, device_ids=[0, 1]), image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    assert [d.index for d in two._sampling_devices()] == [0, 1]
+    cond = synth.make_condition(B, H, seed=1)
+    a = one.sample(batch_size=B, condition=to_dev(cond), seed=11)
+    b = two.sample(batch_size=B, condition=to_dev(cond), seed=11)
+    assert b.device == a.device and torch.equal(a, b)
+    assert torch.cuda.current_device() == DEV.index                          # the guards restore the caller's device
+
+
+def test_graph_calls_make_the_streams_device_current():
+    """nd_stream_device reports the device a library stream lives on; nd_graph_begin / _end / _launch run with that device current whatever
+    the thread's current device is (one GPU here: the call sequence and the restored current device)."""
+    import ctypes as C
+    from noisediff_amd import _lib as L
+    lib = L.load()
+    st, g = C.c_void_p(), C.c_void_p()
+    with torch.cuda.device(DEV):
+        L.call("nd_stream_create", C.byref(st))
+    assert lib.nd_stream_device(st) == DEV.index and lib.nd_stream_device(None) == -1
+    x = torch.zeros(64, device=DEV)
+    torch.cuda.synchronize()
+    L.call("nd_graph_begin", st)
+    L.call("nd_philox_normal_f32", x.data_ptr(), C.c_uint64(3), 0, -1, 1, 16, 4, st)
+    L.call("nd_graph_end", st, C.byref(g))
+    L.call("nd_graph_launch", g, st)
+    L.call("nd_stream_sync", st)
+    assert float(x.abs().sum()) > 0 and torch.cuda.current_device() == DEV.index
+    L.call("nd_graph_destroy", g)
+    L.call("nd_stream_destroy", st)
+
+
 def test_data_parallel_forward_replicas_use_the_owners_engines():
     """nn.DataParallel.forward with several device_ids replicates the module (replicas have no parameters of their own) and calls the
     replicas from threads: they must find the owning module's packed weights.  Same result as the bare module."""

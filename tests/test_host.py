@@ -206,6 +206,49 @@ def test_two_rank_sharded_sampling_equals_single_rank_gloo():
     assert float(np.abs(got - ref.numpy()).max()) < 1e-5
 
 
+def _gloo_empty_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from noisediff_amd.shard import sample_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 2                                                            # world 3 > total 2: rank 2 has no rows
+    calls = []
+
+    def sample_fn(batch_size, condition, seed):
+        calls.append(batch_size)
+        return condition["rows"].float().view(-1, 1, 1, 1).expand(batch_size, 4, 2, 2).contiguous() + seed
+
+    out = sample_sharded(sample_fn, total, lambda lo, hi: {"rows": torch.arange(lo, hi)}, seed=5, gather=True, device=torch.device("cpu"))
+    own = sample_sharded(sample_fn, total, lambda lo, hi: {"rows": torch.arange(lo, hi)}, seed=5, gather=False)
+    q.put((rank, out.numpy(), None if own is None else tuple(own.shape), list(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_without_rows_takes_part_in_the_gather_gloo():
+    """world_size 3, two patches: the rank without rows never calls the sampler, builds its placeholder on the device
+    it is told (the collective's backend decides: RCCL takes device tensors only) and still returns the whole batch; without gather it
+    returns None.  total_batch = 0 is refused."""
+    import torch.multiprocessing as mp
+    from noisediff_amd.shard import sample_sharded
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_empty_rank_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(3)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.broadcast_to(np.array([5.0, 6.0], dtype=np.float32).reshape(2, 1, 1, 1), (2, 4, 2, 2))
+    for rank, out, own, calls in got:
+        assert out.shape == (2, 4, 2, 2) and np.array_equal(out, want)
+        assert (own, calls) == ((None, []) if rank == 2 else ((1, 4, 2, 2), [1, 1]))
+    with pytest.raises(ValueError, match="nothing to sample"):
+        sample_sharded(lambda **kw: None, 0, lambda lo, hi: {}, seed=0)
+
+
 def test_generated_npy_contract(tmp_path):
     """file names, CHW fp32 payload, patch grid and the synth -> denoise composition."""
     from noisediff_amd import io
@@ -262,8 +305,16 @@ def test_accelerate_retargets_the_class_so_replicas_and_copies_resolve_forward_t
         for other in (m._replicate_for_data_parallel(), copy.deepcopy(m)):
             assert other is not m and other.forward.__self__ is other and other.forward.__func__ is m.forward.__func__
     assert list(net.state_dict().keys()) == keys
-    clone = pickle.loads(pickle.dumps(nn.Conv2d(8, 8, 3, padding=1)))          # plain modules still pickle; accelerated ones: state dicts travel
+    clone = pickle.loads(pickle.dumps(nn.Conv2d(8, 8, 3, padding=1)))          # plain modules still pickle ...
     assert isinstance(clone, nn.Conv2d)
+    back = pickle.loads(pickle.dumps(net))                                      # ... and so do accelerated ones (torch.save(model), mp.spawn arguments)
+    assert [type(m) for m in back] == [type(m) for m in net] and back[0].forward.__func__ is train._hip_conv_forward
+    assert all(torch.equal(a, b) for a, b in zip(back.state_dict().values(), net.state_dict().values()))
+    import io as _io
+    buf = _io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    assert torch.load(buf, weights_only=False)[1].forward.__func__ is train._hip_norm_forward
     with pytest.raises(Exception, match="HIP library only|no CPU path"):
         conv(torch.zeros(1, 8, 16, 16))                                          # still no CPU fallback
 
