@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--sampling-timesteps", type=int, default=None, help="DDIM steps (default: DDPM over all timesteps)")
     ap.add_argument("--mid-attn", action="store_true", help="Attention between the mid blocks (BASELINE config 4 extension)")
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4"], default=None,
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "ref48"], default=None,
                     help="BASELINE.json presets: cfg2 d64/128x128/B16 DDPM; cfg3 (default workload) d64/256x256/B16 per GPU DDPM; "
                          "cfg4 d128 + mid attention/256x256/B8 per GPU/250-step DDIM")
     ap.add_argument("--full", action="store_true", help="time whole 1000-step sample() calls instead of K steps")
@@ -303,7 +303,8 @@ def launch_ranks(a):
 # F(4x4,3x3) 36 per 16 x 9 = 1/4; the direct kernel 1.  tiling ids: 9001 wino, 9002 wino2, 9004 wino4 (16 x 32-pixel regions), 9016 wino4 on 16 x 16-pixel
 # regions (two workgroups per CU), else direct <TW,MB,NB>
 WINO_FACTOR = {9001: 2.25, 9002: 2.25, 9004: 4.0, 9016: 4.0}
-UNIT_GFLOP = {(64, 128): 68.78, (64, 256): 275.12, (128, 256): 1077.65}     # algorithmic GFLOP per patch.step (dim, size)
+UNIT_GFLOP = {(64, 128): 68.78, (64, 256): 275.12, (128, 256): 1077.65,      # algorithmic GFLOP per patch.step (dim, size)
+              (48, 512): 627.61}     # the reference's shipped workload (script.sh:10), counted the same way (tools/count_reference_flops.py: conv3x3 527.27)
 
 
 def roofline(a, loop, plan, L, per_step):
@@ -383,6 +384,8 @@ def main():
         a.dim, a.size, a.batch = 64, 128, 16
     elif a.config == "cfg4":
         a.dim, a.size, a.batch, a.sampling_timesteps, a.mid_attn = 128, 256, 8, 250, True
+    elif a.config == "ref48":        # the reference's own command line (script.sh:10): --dim 48 --crop_size 512 --batch_size 4, 1000-step DDPM
+        a.dim, a.size, a.batch = 48, 512, 4
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a))            # nothing above this line initialises the GPU
     rank = int(os.environ.get("RANK", 0))

@@ -495,6 +495,44 @@ def test_sampler_config4_ddim8_at_256_matches_oracle():
     assert worst < SAMPLE_TOL, worst
 
 
+def test_reference_shipped_workload_d48_at_512_forward_and_ddpm8_match_oracle():
+    """The reference's own command line (script.sh:10: --dim 48 --crop_size 512 --batch_size 4, DDPM, sigmoid2, pred_v) at its size, one
+    patch: a forward at t = 640 and a complete 8-step DDPM chain (every x_t) against the oracle.  cout = 48 / 96 pad to the
+    F(4x4) kernel's 64-cout tile; d = 48 gives the stages 48 / 96 / 192 / 384 channels at 512 / 256 / 128 / 64 pixels."""
+    _oracle_threads()
+    dim, B, H = 48, 1, 512
+    net = make_net(dim)
+    sd = state_dict(dim)
+    cond = synth.make_condition(B, H, seed=3)
+    x = synth.make_noise(4, "net.x", B, 4, H)
+    t = torch.tensor([640])
+    with torch.inference_mode():
+        y = net(x.to(DEV), t.to(DEV), to_dev(cond)).cpu()
+        ref = O.noisediff_forward(sd, x, t, cond)
+    assert float(ref.abs().max()) > 0.1
+    assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
+    T = 8                                                                # a complete 8-step DDPM chain (x_T -> x_0, the reference's draws injected), every x_t
+    gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(T - 1)])
+    traj = gd.sample(batch_size=B, condition=to_dev(cond), return_all_timesteps=True, noise={"x_T": x_T, "steps": steps}).cpu()
+    ref = O.sample(sd, cond, image_size=H, batch_size=B, timesteps=T, x_T=x_T, noise=lambda i, s_: steps[i], return_all=True)
+    assert traj.shape == ref.shape == (B, T + 1, 4, H, H)
+    worst = max(rel_err(traj[:, k].numpy(), ref[:, k].numpy()) for k in range(T + 1))
+    assert worst < SAMPLE_TOL / 10, worst
+
+
+def test_reference_shipped_workload_kernel_selection():
+    """What `bench.py --config ref48` launches: every 3x3 conv of the d = 48 net at 512 x 512 runs on the F(4x4) kernel (cout 48 / 96 padded to
+    its 64-cout tile, reported in DESIGN as the padding loss), the stage resolutions are 512 / 256 / 128 / 64, and no layer falls to F(2x2)."""
+    net = make_net(48)
+    plan = net.hip_engine(DEV).plan(1, 512, 512)
+    convs = [(name, m) for _, _, name, m in plan.step_ops if m and "tiling" in m]
+    assert len(convs) == 49
+    assert all(name.startswith("nd_conv3x3_wino4") for name, _ in convs), sorted({name for name, _ in convs})
+    assert {(m["H"], m["cout"]) for _, m in convs} >= {(512, 48), (256, 96), (128, 192), (64, 384)}
+
+
 def test_config5_at_512_lsid_and_compose_psnr_match_oracle():
     """BASELINE config 5 at its stated size: LSID.forward on a 512x512x4 frame against the oracle (every conv on conv3x3_wino4 with the
     LeakyReLU prologues -- at 64x64 the narrow layers fall to the F(2x2) kernel), then noise -> clip / compose -> denoise -> PSNR on both sides."""
