@@ -123,9 +123,10 @@ def instrumented_pass(loop, plan, L, n_steps):
         i = 0
         for fn, args, name, meta in plan.step_ops:
             if name in CONV or (name == STREAM and meta):
-                L.call("nd_event_record", evs[2 * i], st)
+                sx = meta.get("_stream", st)                     # the two-branch step: the shot-noise branch's launches sit on the engine's second stream
+                L.call("nd_event_record", evs[2 * i], sx)
                 L.check(fn(*args), name)
-                L.call("nd_event_record", evs[2 * i + 1], st)
+                L.call("nd_event_record", evs[2 * i + 1], sx)
                 i += 1
             else:
                 L.check(fn(*args), name)
@@ -360,7 +361,7 @@ def roofline(a, loop, plan, L, per_step):
             "algorithmic_frac_of_fp32_peak": a.batch * unit / per_step / 1e3 / PEAK_FP32_MFMA_TFLOPS,
             "executed_gflop_per_step": exec_gf, "executed_tflops": exec_gf / per_step / 1e3,
             "executed_frac": exec_gf / per_step / 1e3 / PEAK_FP32_MFMA_TFLOPS,
-            "launches_per_step": len(plan.step_ops) + 3,
+            "launches_per_step": sum(1 for op in plan.step_ops if not op[2].startswith(("nd_event_", "nd_stream_"))) + 3,
             "note": "SURVEY 8d module-hook FLOPs of the reference forward (includes the layers the build eliminates algebraically)"},
         "by_kernel": {kname(k): {"algorithmic_tflops": v["flop"] / (v["ms"] * 1e-3) / 1e12,
                                  "executed_frac": v["flop"] / WINO_FACTOR.get(k[0], 1.0) / (v["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,

@@ -54,6 +54,16 @@ EIGHT_TILES_RULE = os.environ.get("ND_W4_EIGHT_TILES", "1") != "0"     # A-B kno
 # layer; "0": never.  Either way a function of the sample's geometry alone, and the same bits as the 16 x 32 form.
 WINO4_16 = os.environ.get("ND_WINO4_16", "narrow")
 WINO4_16_SPLIT = os.environ.get("ND_WINO4_16_SPLIT", "1") != "0"      # A-B knob: 0 = no K ranges on the 16 x 16-region form
+# r4: the step as a TWO-BRANCH graph.  The shot-noise branch of NoiseDiffNet.forward (Diffusion_arch.py:598-604: shot_mlp1 -> shot_attn -> shot_mlp2 -> shot_time ->
+# shot_mlp3) is independent of the U-Net until the final add (:644).  Its launches go to a second stream, forked from the trunk at the start of down stage
+# TWO_BRANCH - 1 (1: right behind the time embedding ... 4: at the H/8 stage) and joined in front of final_conv; captured, the two streams become two branches of
+# the step graph, and the branch's full-resolution work fills the kernel tails, the GroupNorm finalizes and the half-empty launches of the trunk's deep stages.
+# Same kernels on the same data: the bits do not change.  "0": one linear chain (r1-r3).
+# MEASURED (profiles/r4a_two_branch_ab.txt, cfg3 and cfg2, one box, alternating): 17.79 ms per step as one chain, 17.82-17.86 with the branch forked at any of
+# the four points; cfg2 5.77 vs 5.83.  The trunk's kernels are persistent one-workgroup-per-CU grids: a second grid only gets CUs as the first one's
+# workgroups retire, which the next trunk kernel would have taken at the same moment -- there is no idle capacity behind a step's 159 launches to fill
+# (tools/step_gaps.py: busy 17.60 of 17.61 ms).  So the default stays one chain; the branch form is kept, tested for identical bits, behind the knob.
+TWO_BRANCH = int(os.environ.get("ND_TWO_BRANCH", "0"))
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -128,6 +138,10 @@ class Engine:
             s = C.c_void_p()
             L.call("nd_stream_create", C.byref(s))
         self.stream = s
+        with torch.cuda.device(device):
+            s2 = C.c_void_p()
+            L.call("nd_stream_create", C.byref(s2))
+        self.stream2 = s2                          # the side branch of the step graph (TWO_BRANCH); ordered against `stream` by events only
         self.plans: Dict[Tuple[int, int, int], "Plan"] = {}
         self.loaded = False
         self.used: set = set()                     # arena slices the recorded plans read (Engine.p): what a broadcast has to carry
@@ -135,12 +149,14 @@ class Engine:
 
     def __del__(self):                      # the engine owns its HIP stream (plans and loops only borrow it)
         s, self.stream = getattr(self, "stream", None), None
-        if s:
-            try:
-                L.call("nd_stream_sync", s)
-                L.call("nd_stream_destroy", s)
-            except Exception:               # interpreter shutdown: the library or the device may already be gone
-                pass
+        s2, self.stream2 = getattr(self, "stream2", None), None
+        for q in (s2, s):
+            if q:
+                try:
+                    L.call("nd_stream_sync", q)
+                    L.call("nd_stream_destroy", q)
+                except Exception:           # interpreter shutdown: the library or the device may already be gone
+                    pass
 
     # ------------------------------------------------------------------ arena layout
     def _layout(self) -> None:
@@ -718,7 +734,11 @@ class Plan:
         e, B, H, W, d = self.e, self.B, self.H, self.W, self.e.dim
         G, tr = RESNET_GROUPS, self.e.traits
         shot_noise = None
+        two = TWO_BRANCH > 0 and tr.shot_branch and not self.debug
+        trunk_ops, main_free = self._ops, self._free
         if tr.shot_branch:
+            if two:      # the branch records into its own list and allocates from its own pool: the trunk must not recycle a buffer the branch may still be using
+                self._ops, self._free = [], {}
             # ---- shot-noise branch, full resolution (:598-604)
             r_shot = self.mlp("shot_mlp1", self._src(self.clean, self.x), 2 * e.inp_dim, d, d, H, W)
             s = self.attn_block("shot_attn", r_shot, H, W)
@@ -728,6 +748,9 @@ class Plan:
             for nm, tt in (("shot_mlp1", r_shot), ("shot_attn", s), ("shot_mlp2", s2), ("shot_time", s3)):
                 self._tap(nm, tt)
             self._release(r_shot, s, s2, s3)
+        shot_ops, fork_at = self._ops, {}
+        self._ops, self._free = trunk_ops, main_free
+        fork_at[1] = len(self._ops)                # right behind the time embedding
         # ---- trunk
         x0 = self._alloc(B, H, W, d)
         self._add("nd_conv7x7_c4_f32", self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
@@ -746,6 +769,7 @@ class Plan:
         h, w = H, W
         for i, (cin, cout) in enumerate(stage_dims(d)):
             p = f"downs.{i}"
+            fork_at[i + 1] = fork_at.get(i + 1, len(self._ops))        # fork point i + 1: the start of down stage i
             x1 = self.resnet(p + ".0", x, None, cin, h, w, G)
             self._release(x)
             x2 = self.resnet(p + ".1", x1, None, cin, h, w, G)
@@ -794,11 +818,36 @@ class Plan:
         self._release(x)
         xf = self._tap("final_res_block", self.resnet("final_res_block", xp, x0, d, H, W, G))
         self._release(xp, x0)
+        if two:
+            self._splice_branch(shot_ops, fork_at[min(max(TWO_BRANCH, 1), 4)])
         # NoiseDiffNet: shot + read (:644); the ablation nets return final_conv(x) alone
         self.pw("final_conv", self._src(xf), d, e.inp_dim, H * W, W, res0=shot_noise, out=self.model_out)
         self._release(xf)
-        if shot_noise is not None:
+        if shot_noise is not None and not two:     # (two branches: the branch's buffers stay out of the trunk's pool for the plan's life)
             self._release(shot_noise)
+
+    def _splice_branch(self, branch_ops: List[Op], at: int) -> None:
+        """Put `branch_ops` on the engine's second stream: fork from the main stream in front of recorded op `at`, join at the current end of the list.
+        Eagerly the events order the two streams; under hipStreamBeginCapture the same calls make the branch a second branch of the graph."""
+        e = self.e
+        main, side = e.stream, e.stream2
+        fork, join = C.c_void_p(), C.c_void_p()
+        with torch.cuda.device(self.dev):
+            L.call("nd_event_create_untimed", C.byref(fork))
+            L.call("nd_event_create_untimed", C.byref(join))
+        self._events = getattr(self, "_events", []) + [fork, join]
+        lib = e.lib
+        moved = []
+        for fn, args, name, meta in branch_ops:        # the recorded launches carry the main stream: the same launches on the side stream
+            args2 = tuple(side if a is main else a for a in args)
+            assert any(a is side for a in args2), name
+            self._keep.append(args2)
+            moved.append((fn, args2, name, None if meta is None else dict(meta, _stream=side)))
+        head = [(lib.nd_event_record, (fork, main), "nd_event_record", None), (lib.nd_stream_wait_event, (side, fork), "nd_stream_wait_event", None)]
+        tail = [(lib.nd_event_record, (join, side), "nd_event_record", None)]
+        self._ops[at:at] = head + moved + tail
+        self._ops.append((lib.nd_stream_wait_event, (main, join), "nd_stream_wait_event", None))
+        self.branch_ops = len(moved)
 
     def _mid_attention(self, x: torch.Tensor, h: int, w: int, prefix: str = "mid_attn") -> torch.Tensor:
         """x = Attention(x) + x (Diffusion_arch.py:237-266): between the mid blocks (BASELINE config 4) or as a stage's full attention."""

@@ -201,6 +201,41 @@ def test_graph_replay_equals_eager_launches():
     assert torch.equal(ref, eager)
 
 
+def test_two_branch_step_graph_equals_the_linear_chain_bit_for_bit():
+    """The step graph with the shot-noise branch (Diffusion_arch.py:598-604) on a second stream -- forked at every supported point, joined in front of
+    final_conv -- against the one-chain step: identical bits, replayed as a graph and launched eagerly (the events order the two streams either way);
+    the branch's launches all sit on the side stream and allocate from their own pool."""
+    from noisediff_amd import engine as E
+    dim, B, H = 16, 3, 32
+    cond = to_dev(synth.make_condition(B, H, seed=1))
+    saved = E.TWO_BRANCH
+    outs = {}
+    try:
+        for mode in (0, 1, 2, 3, 4):
+            E.TWO_BRANCH = mode
+            net = make_net(dim)
+            gd = GaussianDiffusion(net, image_size=H, timesteps=20, beta_schedule="sigmoid2").to(DEV)
+            outs[mode] = gd.sample(batch_size=B, condition=cond, seed=11).cpu()
+            loop = next(iter(gd._loop_cache.values()))
+            plan = loop.plan
+            eager = loop.run(x_T=None, step_noise=None, seed=11, first_sample=0, use_graph=False).cpu()
+            assert torch.equal(outs[mode], eager)
+            names = [name for _, _, name, _ in plan.step_ops]
+            if mode == 0:
+                assert "nd_stream_wait_event" not in names
+                continue
+            e = plan.e
+            assert names.count("nd_stream_wait_event") == 2 and names.count("nd_event_record") == 2 and plan.branch_ops >= 8
+            lo, hi = names.index("nd_stream_wait_event"), len(names) - 1 - names[::-1].index("nd_event_record")
+            side = [args for _, args, name, _ in plan.step_ops[lo + 1:hi]]
+            assert len(side) == plan.branch_ops and all(any(a is e.stream2 for a in args) and not any(a is e.stream for a in args) for args in side)
+            assert names[-2] == "nd_stream_wait_event" and names[-1] == "nd_pointwise_gemm_nhwc_f32"          # join, then final_conv (+ shot_noise)
+    finally:
+        E.TWO_BRANCH = saved
+    for mode in (1, 2, 3, 4):
+        assert torch.equal(outs[0], outs[mode]), mode
+
+
 def test_full_size_properties_config2():
     """BASELINE config 2 shape (d=64, 128x128x4, batch 16), a few DDPM steps: size-independent properties --
     per-sample independence (batch of 16 == the same samples run as batch of 4) and finiteness."""
