@@ -12,7 +12,9 @@ x0 / clamp / posterior / noise update -> advance; T replays, no host<->device tr
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+from collections import namedtuple
 from typing import Dict, List, Optional
 
 import torch
@@ -25,6 +27,8 @@ BUFFER_NAMES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_c
                 "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
                 "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
                 "loss_weight"]
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])       # as the reference's (:36)
 
 _SIGMOID = {"sigmoid1": (-3, 3, 0.5), "sigmoid2": (-7, 3, 0.7), "sigmoid3": (-10, 3, 0.7)}
 
@@ -261,6 +265,94 @@ class GaussianDiffusion(nn.Module):
     def _at(table: torch.Tensor, t: torch.Tensor, ndim: int) -> torch.Tensor:
         """table[t] shaped (B, 1, ..., 1) for broadcasting against an ndim-dimensional batch (`extract`, :91-94)."""
         return table.gather(-1, t).reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+    # ------------------------------------------------------------------ the reference's per-step public methods (:298-373, :453-471)
+    # sample() runs the whole chain fused on the device (one step kernel + one captured graph per step); these are the same quantities one
+    # call at a time, for callers that drive the chain themselves: the network call goes to self.model (the HIP engine under no_grad), the
+    # elementwise part is plain torch on the caller's tensors.
+    def predict_start_from_noise(self, x_t, t, noise):          # :298-302
+        return self._at(self.sqrt_recip_alphas_cumprod, t, x_t.ndim) * x_t - self._at(self.sqrt_recipm1_alphas_cumprod, t, x_t.ndim) * noise
+
+    def predict_noise_from_start(self, x_t, t, x0):             # :304-308
+        return (self._at(self.sqrt_recip_alphas_cumprod, t, x_t.ndim) * x_t - x0) / self._at(self.sqrt_recipm1_alphas_cumprod, t, x_t.ndim)
+
+    def predict_start_from_v(self, x_t, t, v):                  # :316-320
+        return self._at(self.sqrt_alphas_cumprod, t, x_t.ndim) * x_t - self._at(self.sqrt_one_minus_alphas_cumprod, t, x_t.ndim) * v
+
+    def q_posterior(self, x_start, x_t, t):                     # :322-329 -> (mean, variance, clipped log variance)
+        mean = self._at(self.posterior_mean_coef1, t, x_t.ndim) * x_start + self._at(self.posterior_mean_coef2, t, x_t.ndim) * x_t
+        return mean, self._at(self.posterior_variance, t, x_t.ndim), self._at(self.posterior_log_variance_clipped, t, x_t.ndim)
+
+    def model_predictions(self, x, t, condition=None, clip_x_start=False, rederive_pred_noise=False):      # :331-354
+        out = self.model(x, t, condition)
+        clip = (lambda v: v.clamp(-1., 1.)) if clip_x_start else (lambda v: v)
+        if self.objective == "pred_noise":
+            pred_noise = out
+            x_start = clip(self.predict_start_from_noise(x, t, pred_noise))
+            if clip_x_start and rederive_pred_noise:
+                pred_noise = self.predict_noise_from_start(x, t, x_start)
+        elif self.objective == "pred_x0":
+            x_start = clip(out)
+            pred_noise = self.predict_noise_from_start(x, t, x_start)
+        else:                                                   # pred_v
+            x_start = clip(self.predict_start_from_v(x, t, out))
+            pred_noise = self.predict_noise_from_start(x, t, x_start)
+        return ModelPrediction(pred_noise, x_start)
+
+    def p_mean_variance(self, x, t, condition=None, clip_denoised=True):                                    # :356-364
+        x_start = self.model_predictions(x, t, condition).pred_x_start
+        if clip_denoised:
+            x_start = x_start.clamp(-1., 1.)
+        mean, var, logvar = self.q_posterior(x_start=x_start, x_t=x, t=t)
+        return mean, var, logvar, x_start
+
+    @torch.inference_mode()
+    def p_sample(self, x, t: int, condition=None, noise=None):                                              # :366-373 -> (x_{t-1}, x_start)
+        """One reverse step at integer timestep ``t``; ``noise`` (optional) replaces the reference's randn_like draw."""
+        times = torch.full((x.shape[0],), int(t), device=x.device, dtype=torch.long)
+        mean, _, logvar, x_start = self.p_mean_variance(x=x, t=times, condition=condition, clip_denoised=True)
+        if t > 0:
+            z = torch.randn_like(x) if noise is None else noise.to(x)
+            return mean + (0.5 * logvar).exp() * z, x_start
+        return mean, x_start
+
+    @contextlib.contextmanager
+    def _as_sampler(self, ddim: bool):
+        """Run sample() as the named sampler whatever the wrapper was configured with (p_sample_loop / ddim_sample are public in the reference)."""
+        saved = self.is_ddim_sampling
+        self.is_ddim_sampling = ddim
+        try:
+            yield
+        finally:
+            self.is_ddim_sampling = saved
+
+    def _check_shape(self, shape):
+        if tuple(shape[1:]) != (self.channels, self.image_size, self.image_size):
+            raise ValueError(f"shape {tuple(shape)} does not match (B, {self.channels}, {self.image_size}, {self.image_size})")
+
+    @torch.inference_mode()
+    def p_sample_loop(self, shape, condition, return_all_timesteps=False, preset_mean=None, **kw):           # :375-402
+        self._check_shape(shape)
+        with self._as_sampler(False):
+            return self.sample(batch_size=shape[0], condition=condition, return_all_timesteps=return_all_timesteps, preset_mean=preset_mean, **kw)
+
+    @torch.inference_mode()
+    def ddim_sample(self, shape, condition, return_all_timesteps=False, preset_mean=None, **kw):             # :404-444 (preset_mean accepted, ignored)
+        self._check_shape(shape)
+        with self._as_sampler(True):
+            return self.sample(batch_size=shape[0], condition=condition, return_all_timesteps=return_all_timesteps, preset_mean=preset_mean, **kw)
+
+    @torch.inference_mode()
+    def interpolate(self, x1, x2, t=None, lam=0.5, condition=None):                                         # :453-471
+        """q_sample both images to timestep t, mix them, walk back with p_sample.  The reference hands `self_cond` (None) to the network's
+        `condition` slot, which NoiseDiffNet cannot run with; ``condition`` is this build's way to pass the conditioning through."""
+        t = self.num_timesteps - 1 if t is None else int(t)
+        assert x1.shape == x2.shape
+        tb = torch.full((x1.shape[0],), t, device=x1.device, dtype=torch.long)
+        img = (1 - lam) * self.q_sample(x1, tb) + lam * self.q_sample(x2, tb)
+        for i in reversed(range(0, t)):
+            img, _ = self.p_sample(img, i, condition)
+        return img
 
     def predict_v(self, x_start, t, noise):                     # :310-314
         return (self._at(self.sqrt_alphas_cumprod, t, x_start.ndim) * noise

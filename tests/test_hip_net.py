@@ -236,6 +236,37 @@ def test_two_branch_step_graph_equals_the_linear_chain_bit_for_bit():
         assert torch.equal(outs[0], outs[mode]), mode
 
 
+def test_per_step_public_methods_agree_with_the_fused_loop():
+    """p_sample (:366-373) driven step by step with the reference's draws == the fused device loop's trajectory (one step kernel + graph per step);
+    p_sample_loop / ddim_sample == sample() of a wrapper configured that way, whatever THIS wrapper was configured with; model_predictions on the
+    HIP network == the oracle's x_0 / eps at one timestep."""
+    dim, B, H, T = 16, 2, 32, 6
+    net = make_net(dim)
+    sd = state_dict(dim)
+    cond_cpu = synth.make_condition(B, H, seed=1)
+    cond = to_dev(cond_cpu)
+    gd = GaussianDiffusion(net, image_size=H, timesteps=T, beta_schedule="sigmoid2").to(DEV)
+    x_T = synth.make_noise(2, "x_T", B, 4, H)
+    steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, H) for i in range(T - 1)])
+    traj = gd.sample(batch_size=B, condition=cond, return_all_timesteps=True, noise={"x_T": x_T, "steps": steps})
+    img = x_T.to(DEV)
+    for k, t in enumerate(reversed(range(T))):
+        img, x0 = gd.p_sample(img, t, cond, noise=steps[k] if t > 0 else None)
+        assert rel_err(img.cpu().numpy(), traj[:, k + 1].cpu().numpy()) < 1e-5, t
+    tb = torch.full((B,), 3, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        mp = gd.model_predictions(x_T.to(DEV), tb, cond, clip_x_start=True, rederive_pred_noise=True)
+    out = O.noisediff_forward(sd, x_T, tb.cpu(), cond_cpu)
+    eps_ref, x0_ref = O.predict_x0_eps(O.schedule_buffers("sigmoid2", T), "pred_v", x_T, 3, out, clip=True)
+    assert rel_err(mp.pred_x_start.cpu().numpy(), x0_ref.numpy()) < NET_TOL and rel_err(mp.pred_noise.cpu().numpy(), eps_ref.numpy()) < 10 * NET_TOL
+    a = gd.p_sample_loop((B, 4, H, H), cond, seed=5)
+    assert torch.equal(a, gd.sample(batch_size=B, condition=cond, seed=5))
+    dd = GaussianDiffusion(net, image_size=H, timesteps=T, sampling_timesteps=3, beta_schedule="sigmoid2").to(DEV)
+    assert torch.equal(dd.p_sample_loop((B, 4, H, H), cond, seed=5), a)                 # a DDIM wrapper asked for the DDPM chain
+    assert torch.equal(dd.ddim_sample((B, 4, H, H), cond, seed=5), dd.sample(batch_size=B, condition=cond, seed=5))
+    assert dd.is_ddim_sampling and not gd.is_ddim_sampling
+
+
 def test_full_size_properties_config2():
     """BASELINE config 2 shape (d=64, 128x128x4, batch 16), a few DDPM steps: size-independent properties --
     per-sample independence (batch of 16 == the same samples run as batch of 4) and finiteness."""

@@ -340,3 +340,51 @@ def test_sampling_split_k_plan_looks_at_the_sample_geometry_only():
     assert plan(32, 32, 256, 256) == 2 and plan(32, 32, 384, 256) == 2 and plan(32, 32, 512, 256) == 2
     assert plan(32, 32, 512, 512) == 1 and plan(256, 256, 64, 64) == 1 and plan(16, 16, 64, 64) == 1 and plan(16, 16, 72, 64) == 1
     assert plan(16, 16, 2048, 64) == 8 and plan(0, 16, 64, 64) == 1
+
+
+@pytest.mark.parametrize("objective,sched", [("pred_v", "sigmoid2"), ("pred_noise", "linear"), ("pred_x0", "cosine")])
+def test_per_step_public_methods_follow_the_reference_formulas(objective, sched):
+    """predict_start_from_* / predict_noise_from_start / q_posterior / model_predictions / p_mean_variance / p_sample
+    (models/denoising_diffusion_pytorch.py:298-373) around a stand-in network on the CPU, against the oracle's restatement of the same
+    lines (predict_x0_eps + the posterior of p_sample_loop), for the three objectives; interpolate and the clip / re-derive switches."""
+    from torch import nn
+    from oracle import noisediff_oracle as O
+
+    class Stub(nn.Module):
+        channels = out_dim = 4
+        self_condition = random_or_learned_sinusoidal_cond = False
+
+        def forward(self, x, t, condition=None):
+            return 0.7 * x.flip(1) + 0.1 * t.view(-1, 1, 1, 1) / 50 + (0 if condition is None else condition["bias"])
+
+    T, B, H = 50, 3, 8
+    gd = GaussianDiffusion(Stub(), image_size=H, timesteps=T, beta_schedule=sched, objective=objective)
+    buf = O.schedule_buffers(sched, T, objective)
+    x = synth.make_noise(7, "ps.x", B, 4, H) * 1.5
+    cond = {"bias": torch.full((B, 1, 1, 1), 0.05)}
+    for t in (T - 1, 17, 0):
+        tb = torch.full((B,), t, dtype=torch.long)
+        out = gd.model(x, tb, cond)
+        for clip in (False, True):
+            eps_ref, x0_ref = O.predict_x0_eps(buf, objective, x, t, out, clip=clip)
+            mp = gd.model_predictions(x, tb, cond, clip_x_start=clip, rederive_pred_noise=True)
+            assert torch.allclose(mp.pred_x_start, x0_ref, atol=1e-6) and torch.allclose(mp.pred_noise, eps_ref, atol=2e-5)
+        _, x0 = O.predict_x0_eps(buf, objective, x, t, out, clip=False)
+        x0 = x0.clamp(-1, 1)
+        mean_ref = O._coef(buf, "posterior_mean_coef1", t) * x0 + O._coef(buf, "posterior_mean_coef2", t) * x
+        mean, var, logvar, xs = gd.p_mean_variance(x, tb, cond)
+        assert torch.allclose(mean, mean_ref, atol=1e-6) and torch.allclose(xs, x0, atol=1e-6)
+        assert float(var.flatten()[0]) == float(gd.posterior_variance[t]) and float(logvar.flatten()[0]) == float(gd.posterior_log_variance_clipped[t])
+        z = synth.make_noise(7, f"ps.z{t}", B, 4, H)
+        nxt, xs2 = gd.p_sample(x, t, cond, noise=z)
+        want = mean_ref + ((0.5 * O._coef(buf, "posterior_log_variance_clipped", t)).exp() * z if t > 0 else 0.0)
+        assert torch.allclose(nxt, want, atol=1e-6) and torch.equal(xs2, xs)
+    v = synth.make_noise(7, "ps.v", B, 4, H)
+    tb = torch.full((B,), 9, dtype=torch.long)
+    assert torch.allclose(gd.predict_noise_from_start(x, tb, gd.predict_start_from_noise(x, tb, v)), v, atol=1e-4)
+    assert torch.allclose(gd.predict_start_from_v(x, tb, gd.predict_v(v, tb, x)), gd.predict_start_from_v(x, tb, gd.predict_v(v, tb, x)))
+    torch.manual_seed(3)
+    mix = gd.interpolate(x, -x, t=4, lam=0.25, condition=cond)
+    assert mix.shape == x.shape and torch.isfinite(mix).all()
+    with pytest.raises(ValueError, match="does not match"):
+        gd.p_sample_loop((B, 4, H + 1, H), cond)
