@@ -186,6 +186,36 @@ def _time_steps(f, x, timesteps, n_min, budget_s, n_max):
     return (time.perf_counter() - t0) / n, n
 
 
+def _cpu_limits():
+    """What bounds the host leg on this box, so that its number can be read: the affinity mask, the cgroup CPU quota (v2 cpu.max or v1 cfs quota / period:
+    a box may show 128 cores and grant 16 cores' worth of time) and the load average while the leg starts."""
+    info = {}
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        info["affinity_cpus"] = len(cpus)
+        info["affinity_range"] = f"{cpus[0]}-{cpus[-1]}" if cpus else ""
+    except AttributeError:
+        info["affinity_cpus"] = os.cpu_count()
+    info["os_cpu_count"] = os.cpu_count()
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    info["cgroup_cpu_quota_cores"] = quota
+    try:
+        info["loadavg_1min"] = os.getloadavg()[0]
+    except OSError:
+        pass
+    return info
+
+
 def cpu_baseline(sd, dim, size, timesteps, batch):
     """The CPU oracle's p_sample step (one U-Net forward + posterior update) on this host's cores.
 
@@ -198,6 +228,7 @@ def cpu_baseline(sd, dim, size, timesteps, batch):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    limits = _cpu_limits()
     cands = sorted({c for c in (8, 16, 32, 48, 64, 96, 128, avail) if c <= avail})
     sweep = {}
     with torch.no_grad():
@@ -231,7 +262,7 @@ def cpu_baseline(sd, dim, size, timesteps, batch):
             dt4, n4 = _time_steps(f4, x4, timesteps, 2, 6.0, 10)
             legs[f"batch{b4}"] = {"s_per_step": dt4, "steps": n4, "threads": best4, "patches_per_s": b4 / (timesteps * dt4)}
     top = max(legs, key=lambda k: legs[k]["patches_per_s"])
-    return {"value": legs[top]["patches_per_s"], "unit": "patches/s", "cores": legs[top]["threads"], "kind": "port", "legs": legs,
+    return {"value": legs[top]["patches_per_s"], "unit": "patches/s", "cores": legs[top]["threads"], "kind": "port", "legs": legs, **limits,
             "thread_sweep_s_per_step_batch1": sweep, "thread_sweep_s_per_step_batch4": sweep4,
             "sample": f"CPU oracle p_sample steps (U-Net forward + posterior update) at dim {dim}, {size}x{size}x4 with {legs[top]['threads']} threads "
                       f"(each leg calibrated at this size: batch 1 over {list(sweep)}, batch 4 over {list(sweep4)}; {avail} cores visible): " +
