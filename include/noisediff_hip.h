@@ -143,6 +143,13 @@ int nd_conv3x3_wino4_16_nhwc_f32(const nd_conv3x3* d, void* stream);
 /* ... and on 16 x 32-pixel regions with eight waves per workgroup (two per SIMD: waves 0-3 tile group 0, waves 4-7 tile group 1, in phase by
  * construction; weight fragments shared through the L1).  Same restrictions and bits as nd_conv3x3_wino4_16_nhwc_f32. */
 int nd_conv3x3_wino4_8w_nhwc_f32(const nd_conv3x3* d, void* stream);
+/* The same operator with the position products on the f16 matrix instruction and every operand split into two f16 terms (V = V1 + V2, U 2^11 = U1 + U2; three
+ * products V1 U1 + V1 U2 + V2 U1 accumulated in fp32; conv3x3_wino4h.hip, r4, opt-in: ND_CONV_F16X3=1 in the engine).  As accurate as nd_conv3x3_wino4_nhwc_f32
+ * against an fp64 convolution (8e-6 ... 1.2e-5 of max|y|: the error of both is the fp32 Winograd transforms'), not bit-identical to it.  Same descriptor,
+ * prologues, statistics epilogue and restrictions as nd_conv3x3_wino4_nhwc_f32; `weight` from nd_pack_conv3x3_wino4h_weight (as many floats as
+ * nd_pack_conv3x3_wino4_weight_floats).  The fp32 MFMA shares the VALU's lanes on gfx950; this one does not. */
+int nd_conv3x3_wino4h_nhwc_f32(const nd_conv3x3* d, void* stream);
+int nd_pack_conv3x3_wino4h_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 /* its statistics epilogue writes ONE slot per 16 x 16-pixel tile (the F(2x2) kernels: two) */
 int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);

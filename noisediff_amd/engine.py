@@ -64,6 +64,10 @@ WINO4_16_SPLIT = os.environ.get("ND_WINO4_16_SPLIT", "1") != "0"      # A-B knob
 # workgroups retire, which the next trunk kernel would have taken at the same moment -- there is no idle capacity behind a step's 159 launches to fill
 # (tools/step_gaps.py: busy 17.60 of 17.61 ms).  So the default stays one chain; the branch form is kept, tested for identical bits, behind the knob.
 TWO_BRANCH = int(os.environ.get("ND_TWO_BRANCH", "0"))
+# r4 (opt-in): the F(4x4) position products on the f16 matrix instruction with both operands split into two f16 terms and three products accumulated in fp32
+# (nd_conv3x3_wino4h_nhwc_f32, conv3x3_wino4h.hip) for the layers of the 16 x 32-region form.  As accurate as the fp32 kernel against an fp64 convolution
+# (tests/test_hip_kernels.py::test_conv3x3_wino4h_*), not bit-identical to it; the fp32 MFMA shares the VALU's lanes on gfx950, the f16 one does not.
+CONV_F16X3 = os.environ.get("ND_CONV_F16X3", "0") != "0"
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -177,6 +181,8 @@ class Engine:
                 add(p.name + ".wino", self.lib.nd_pack_conv3x3_wino_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
                 if WINO4 and _wino4_layer(p.shape[1], p.shape[0]):
                     add(p.name + ".wino4", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
+                    if CONV_F16X3:
+                        add(p.name + ".wino4h", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind in ("pw", "pw_unshuffle"):
                 n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
                 if p.name in _MAP_PRODUCERS and p.shape[0] % 32 == 0:
@@ -248,6 +254,8 @@ class Engine:
                     L.call("nd_pack_conv3x3_wino_weight", t.data_ptr(), self.p(p.name + ".wino"), p.shape[1], p.shape[0], st)
                     if p.name + ".wino4" in self.slots:
                         L.call("nd_pack_conv3x3_wino4_weight", t.data_ptr(), self.p(p.name + ".wino4"), p.shape[1], p.shape[0], st)
+                    if p.name + ".wino4h" in self.slots:
+                        L.call("nd_pack_conv3x3_wino4h_weight", t.data_ptr(), self.p(p.name + ".wino4h"), p.shape[1], p.shape[0], st)
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
                     if p.name + ".blk16" in self.slots:
@@ -494,12 +502,14 @@ class Plan:
         if src.map_blocked and not wino4:
             raise L.HipError(f"{name}: the scale / shift map was produced in the blocked layout but the layer does not run on conv3x3_wino4")
         # ONE packing of the weight is read (and marked for the weight broadcast): F(4x4), F(2x2) or the direct form
-        d.weight = e.p(name + (".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
-        entry = (f"nd_conv3x3_{w4kind}_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
+        lowlat_split = SPLIT_K and w4kind == "wino4" and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU) and int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) > 1
+        f16x3 = w4kind == "wino4" and (name + ".weight.wino4h") in e.slots and not lowlat_split      # (the opt-in low-latency split keeps the fp32 kernel)
+        d.weight = e.p(name + (".weight.wino4h" if f16x3 else ".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
+        entry = ("nd_conv3x3_wino4h_nhwc_f32" if f16x3 else f"nd_conv3x3_{w4kind}_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
                  "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32")
         meta = {"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
-                "tiling": (9016 if w4kind == "wino4_16" else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
-        splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and w4kind == "wino4" and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
+                "tiling": (9016 if w4kind == "wino4_16" else 9104 if f16x3 else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
+        splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and w4kind == "wino4" and not f16x3 and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
         if w4kind == "wino4_16" and WINO4_16_SPLIT:      # few items per sample: K ranges by the SAMPLE's geometry (the batch never enters: a sample's bits stay batch-invariant)
             splits = int(e.lib.nd_conv3x3_wino4_16_splitk_plan(H, W, cin, cout))
         if splits > 1 and splits * self.B * H * W * cout * 4 < (1 << 31):

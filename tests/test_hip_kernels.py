@@ -890,6 +890,59 @@ def test_conv3x3_wino4_two_waves_per_simd_forms_equal_the_one_workgroup_form(ctx
         assert getattr(ctx.lib, entry)(C.byref(d), ctx.stream) != 0
 
 
+W4H_CASES = {**{k: v + (0, 0) for k, v in WINO_CASES.items()}, **HEADLINE_CASES}
+
+
+@pytest.mark.parametrize("case", sorted(W4H_CASES))
+def test_conv3x3_wino4h_f16_split_products_match_conv2d_at_the_fp32_kernels_tolerance(ctx, case):
+    """nd_conv3x3_wino4h_nhwc_f32 -- F(4x4) with the position products as a three-product split on the f16 matrix instruction (V = V1 + V2, U 2^11 = U1 + U2,
+    fp32 accumulation) -- against nn.Conv2d at the SAME 5e-5 as the fp32 F(4x4) kernel, with a float64 convolution as the yardstick for both kernels' errors
+    (the split's must not exceed 1.5x the fp32 kernel's + 2e-6); GroupNorm partials, concat / nearest-x2 / affine + SiLU / LeakyReLU sources, bitwise repeat,
+    large activations (x 200: the first f16 term near its range)."""
+    import hiputil as hu
+    B, H, W, cin, cout, c0, up = W4H_CASES[case]
+    cin = max(cin, 24)
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    bound = 1.0 / np.sqrt(9 * cin)
+    x = U(case + ".x", (B, cin, hs, ws), -1.5, 1.5)
+    w = U(case + ".w", (cout, cin, 3, 3), -bound, bound)
+    b = U(case + ".b", (cout,), -bound, bound)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref64 = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    ref = ref64.float()
+    wd, bd = hu.dev(w), hu.dev(b)
+    n = ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout)
+    wph, wp4 = hu.full((n,)), hu.full((n,))
+    L.call("nd_pack_conv3x3_wino4h_weight", wd.data_ptr(), wph.data_ptr(), cin, cout, ctx.stream)
+    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp4.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    runh = lambda s, stats=True: _run_wino4(ctx, s, wph, bd, B, H, W, cin, cout, stats, entry="nd_conv3x3_wino4h_nhwc_f32")
+    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
+    out, st, sc, slots = runh(s)
+    assert rel_err(hu.nchw(out), ref) < 5e-5
+    _check_gn(ctx, case, ref, st, sc, slots, B, cout, 5e-5)
+    out2, st2, *_ = runh(s)
+    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
+    o32, *_ = _run_wino4(ctx, s, wp4, bd, B, H, W, cin, cout)
+    scale = max(1.0, float(ref64.abs().max()))
+    e16 = float((hu.nchw(out).double() - ref64).abs().max()) / scale
+    e32 = float((hu.nchw(o32).double() - ref64).abs().max()) / scale
+    assert e16 < 1.5 * e32 + 2e-6, (e16, e32)
+    if not up:
+        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
+        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+        mad = hu.dev(torch.stack((M, A, D), 1))
+        sa = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:]), L.PRO_AFFINE_SILU, mad=mad) if c0 else hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=mad)
+        out, *_ = runh(sa, stats=False)
+        assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
+        if not c0:
+            out, *_ = runh(hu.src(hu.nhwc(x), None, L.PRO_LEAKY), stats=False)
+            assert rel_err(hu.nchw(out), F.conv2d(F.leaky_relu(x, 0.2), w, b, padding=1)) < 5e-5
+            xb = x * 200.0                                               # |V| up to ~3e4: the first f16 term near the top of its range
+            out, *_ = runh(hu.src(hu.nhwc(xb)), stats=False)
+            assert rel_err(hu.nchw(out), F.conv2d(xb.double(), w.double(), b.double(), padding=1).float()) < 5e-5
+
+
 @pytest.mark.parametrize("case", sorted(CFG2_CASES))
 def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case):
     """nd_conv3x3_wino4_16_splitk_nhwc_f32 with the split count of nd_conv3x3_wino4_16_splitk_plan (the sample's geometry only) on BASELINE config 2's
