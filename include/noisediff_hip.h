@@ -149,6 +149,7 @@ int nd_conv3x3_wino4_8w_nhwc_f32(const nd_conv3x3* d, void* stream);
  * prologues, statistics epilogue and restrictions as nd_conv3x3_wino4_nhwc_f32; `weight` from nd_pack_conv3x3_wino4h_weight (as many floats as
  * nd_pack_conv3x3_wino4_weight_floats).  The fp32 MFMA shares the VALU's lanes on gfx950; this one does not. */
 int nd_conv3x3_wino4h_nhwc_f32(const nd_conv3x3* d, void* stream);
+int nd_conv3x3_wino4h_16_nhwc_f32(const nd_conv3x3* d, void* stream);   /* ... on 16 x 16-pixel regions, two workgroups per CU (plain / affine + SiLU sources) */
 int nd_pack_conv3x3_wino4h_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 /* its statistics epilogue writes ONE slot per 16 x 16-pixel tile (the F(2x2) kernels: two) */
 int nd_conv3x3_wino4_stat_slots(int H, int W);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "nd_conv3x3_wino4_16_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_conv3x3_wino4_8w_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_conv3x3_wino4h_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
+    "nd_conv3x3_wino4h_16_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_pack_conv3x3_wino4h_weight": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_conv3x3_wino4_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_wino4_weight": (i32, [vp, vp, i32, i32, vp]),

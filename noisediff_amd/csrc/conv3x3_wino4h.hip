@@ -431,10 +431,12 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4h
     // f16: a transformed value pair (channels 2P, 2P + 1 of one position) -> its two f16 terms.  v_cvt_pkrtz rounds toward zero, so the first term never overflows to inf
     // (it saturates at 65504 and the remainder carries the rest: exact up to |V| = 1.3e5), and the remainder v - V1 is exact in fp32
     auto split_store = [&](char* dst, f32x2 v) {
-        const auto h1 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
-        const auto h2 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h1[0], v.y - (float)h1[1]);
-        *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, h1);
-        *reinterpret_cast<unsigned*>(dst + 8) = __builtin_bit_cast(unsigned, h2);
+        const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+        float r0, r1;      // v - float(V1), exact: one mixed-precision fma each (hipcc turns fma(x, -1, y) back into a convert and a subtraction)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w1), "v"(v.x));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w1), "v"(v.y));
+        *reinterpret_cast<unsigned*>(dst) = w1;
+        *reinterpret_cast<unsigned*>(dst + 8) = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     };
     auto xf_finish = [&](f32x2 (&T)[6][6], float* buf, auto&& before_write) {
 #if !(W4_ABLATE & 4)
@@ -497,14 +499,13 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4h
             }
         };
         if (rh == 0) pass1(std::integral_constant<int, 0>{}); else pass1(std::integral_constant<int, 1>{});
-        char* base = reinterpret_cast<char*>(buf) + t_lds + rh * (9 * 2048);
+        char* base = reinterpret_cast<char*>(buf) + t_lds + rh * (18 * 1024);      // f16: rows xi = 3 rh .. 3 rh + 2 = positions 18 rh .. 18 rh + 17
 #pragma unroll
         for (int i = 0; i < 3; ++i) {                                    // V[3 rh + i] = T[i] B
             f32x2 v[6];
             w4_bt(T[i], v);
 #pragma unroll
-            for (int h = 0; h < 3; ++h)
-                *reinterpret_cast<f32x4*>(base + (i * 3 + h) * 2048) = f32x4{v[2 * h].x, v[2 * h].y, v[2 * h + 1].x, v[2 * h + 1].y};
+            for (int nu = 0; nu < 6; ++nu) split_store(base + (i * 6 + nu) * 1024, v[nu]);
         }
 #endif
     };
@@ -560,16 +561,21 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4h
             // even channels of the pair first (the first touch of every accumulator in a tile's first stage), then the odd ones:
             // an accumulator is used again four (NTG == 1: two) MFMAs later (dependent latency 40 cycles, issue 32).  NTG == 2: each weight
             // fragment serves both tile groups: it is loaded once per workgroup.
-            {   // f16: position POS0 + pp, both tile groups: V1 U1 (the first touch of the accumulators in a tile's first chunk), V1 U2, V2 U1
-                static_assert(TGW == 2, "the f16 kernel is built on the 16 x 32-region form");
+            {   // f16: position POS0 + pp, the wave's tile group(s): V1 U1 (the first touch of the accumulators in a tile's first chunk), V1 U2, V2 U1
                 const f32x2 u1 = {u.x, u.y}, u2 = {u.z, u.w}, a1 = {va.x, va.y}, a2 = {va.z, va.w}, b1 = {vb.x, vb.y}, b2 = {vb.z, vb.w};
                 const int P = POS0 + pp;
-                mfma(first_c, 2 * P + 0, u1, a1);
-                mfma(first_c, 2 * P + 1, u1, b1);
-                mfma(std::false_type{}, 2 * P + 0, u2, a1);
-                mfma(std::false_type{}, 2 * P + 1, u2, b1);
-                mfma(std::false_type{}, 2 * P + 0, u1, a2);
-                mfma(std::false_type{}, 2 * P + 1, u1, b2);
+                if (TGW == 2) {
+                    mfma(first_c, 2 * P + 0, u1, a1);
+                    mfma(first_c, 2 * P + 1, u1, b1);
+                    mfma(std::false_type{}, 2 * P + 0, u2, a1);
+                    mfma(std::false_type{}, 2 * P + 1, u2, b1);
+                    mfma(std::false_type{}, 2 * P + 0, u1, a2);
+                    mfma(std::false_type{}, 2 * P + 1, u1, b2);
+                } else {       // (an accumulator three times in a row: tools/microbench/f16_mfma_dep.hip -- 17.2 ticks per MFMA at any reuse distance)
+                    mfma(first_c, P, u1, a1);
+                    mfma(std::false_type{}, P, u2, a1);
+                    mfma(std::false_type{}, P, u1, a2);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -706,7 +712,7 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4h
             };
             W4_T0();
             if (TGW == 1 && FIRST)                                        // this tile's bias (lane = cout): in flight over the whole first stage
-                bias_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(cg * 16 + (lane & 15)) * 4u, 0, 0));
+                bias_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(cg * 16 + (lane & 15)) * 4u, 0, 0)) * W4H_WSCALE;
             stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IXF>{}, IUR{}, std::integral_constant<int, 0>{}, v0cur, v1cur, w0, w1, issue_pre, issue);
             if (TGW == 1 && FIRST) asm volatile("" : "+v"(bias_r));      // waited for HERE (every older load has been consumed), not behind the ring in the epilogue
             // (f16: positions 18-35 are touched for the first time here in a tile's first chunk)
@@ -961,21 +967,21 @@ __global__ void pack_wino4h_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
-template <int MODE, bool STREAM>
+template <int MODE, bool STREAM, int NTG = 2, int NW = 4>
 int launch4hs(const Wino4Args& a, hipStream_t st) {
     static nd_device_once configured;
-    constexpr int LDS_BYTES = W4Geo<2, 4>::LDS_BYTES;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4h_kernel<MODE, STREAM, false, 2, 4>), LDS_BYTES, "nd_conv3x3_wino4h")) return e;
-    const long resident = nd_device_cus();
-    hipLaunchKernelGGL((wino4h_kernel<MODE, STREAM, false, 2, 4>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    constexpr int LDS_BYTES = W4Geo<NTG, NW>::LDS_BYTES;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4h_kernel<MODE, STREAM, false, NTG, NW>), LDS_BYTES, "nd_conv3x3_wino4h")) return e;
+    const long resident = (long)nd_device_cus() * W4Geo<NTG, NW>::WG_PER_CU;
+    hipLaunchKernelGGL((wino4h_kernel<MODE, STREAM, false, NTG, NW>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(64 * NW), LDS_BYTES, st, a);
     return 0;
 }
 
-template <int MODE>
+template <int MODE, int NTG = 2, int NW = 4>
 int launch4h(const Wino4Args& a, hipStream_t st) {
     static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;
     const long out_bytes = (long)a.d.B * a.d.H * a.d.W * a.d.ldo * 4;
-    return out_bytes >= stream_min ? launch4hs<MODE, true>(a, st) : launch4hs<MODE, false>(a, st);
+    return out_bytes >= stream_min ? launch4hs<MODE, true, NTG, NW>(a, st) : launch4hs<MODE, false, NTG, NW>(a, st);
 }
 
 }  // namespace
@@ -992,8 +998,7 @@ extern "C" int nd_pack_conv3x3_wino4h_weight(const float* oihw, float* packed, i
 }
 
 // descriptor checks shared by the entry points; fills the launch arguments
-static int w4h_prepare(const nd_conv3x3* d, Wino4Args& a) {
-    const int ntg = 2;
+static int w4h_prepare(const nd_conv3x3* d, Wino4Args& a, int ntg = 2) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_conv3x3_wino4h: null descriptor");
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_conv3x3_wino4h: null tensor pointer");
@@ -1067,4 +1072,16 @@ extern "C" int nd_conv3x3_wino4h_nhwc_f32(const nd_conv3x3* d, void* stream) {
     }
     if (rc) return rc;
     return nd_launch_status("nd_conv3x3_wino4h_nhwc_f32");
+}
+
+// ... on 16 x 16-pixel regions with two co-resident workgroups per CU (the fp32 experiment of conv3x3_wino4.hip, where it bought nothing: there every instruction of
+// one workgroup is VALU work that stops the other's MFMAs; with the f16 instruction one workgroup's transform / epilogue can run beside the other's MFMAs).
+extern "C" int nd_conv3x3_wino4h_16_nhwc_f32(const nd_conv3x3* d, void* stream) {
+    Wino4Args a;
+    if (int e = w4h_prepare(d, a, 1)) return e;
+    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
+               "nd_conv3x3_wino4h_16: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4h<ND_PRO_AFFINE_SILU, 1, 4>(a, st) : launch4h<ND_PRO_NONE, 1, 4>(a, st)) return rc;
+    return nd_launch_status("nd_conv3x3_wino4h_16_nhwc_f32");
 }

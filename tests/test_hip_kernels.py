@@ -923,6 +923,8 @@ def test_conv3x3_wino4h_f16_split_products_match_conv2d_at_the_fp32_kernels_tole
     _check_gn(ctx, case, ref, st, sc, slots, B, cout, 5e-5)
     out2, st2, *_ = runh(s)
     assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
+    o16r, s16r, *_ = _run_wino4(ctx, s, wph, bd, B, H, W, cin, cout, entry="nd_conv3x3_wino4h_16_nhwc_f32")      # its 16 x 16-region form: the same bits
+    assert torch.equal(out.cpu(), o16r.cpu()) and torch.equal(st.cpu(), s16r.cpu())
     o32, *_ = _run_wino4(ctx, s, wp4, bd, B, H, W, cin, cout)
     scale = max(1.0, float(ref64.abs().max()))
     e16 = float((hu.nchw(out).double() - ref64).abs().max()) / scale

@@ -17,7 +17,7 @@ ROUNDS = int(os.environ.get("ROUNDS", "5"))
 ENTRIES = [e for e in os.environ.get("ENTRIES", "wino2,wino4,wino4_16,wino4_8w").split(",")]
 NAMES = {"wino2": ("nd_conv3x3_wino2_nhwc_f32", "nd_pack_conv3x3_wino_weight"), "wino4": ("nd_conv3x3_wino4_nhwc_f32", "nd_pack_conv3x3_wino4_weight"),
          "wino4_16": ("nd_conv3x3_wino4_16_nhwc_f32", "nd_pack_conv3x3_wino4_weight"), "wino4_8w": ("nd_conv3x3_wino4_8w_nhwc_f32", "nd_pack_conv3x3_wino4_weight"),
-         "wino4h": ("nd_conv3x3_wino4h_nhwc_f32", "nd_pack_conv3x3_wino4h_weight")}       # f16 split: its own packing of the same size
+         "wino4h": ("nd_conv3x3_wino4h_nhwc_f32", "nd_pack_conv3x3_wino4h_weight"), "wino4h_16": ("nd_conv3x3_wino4h_16_nhwc_f32", "nd_pack_conv3x3_wino4h_weight")}       # f16 split: its own packing of the same size
 
 SHAPES = [  # (B, H, W, cin, cout, mode)
     (16, 256, 256, 64, 64, 0), (16, 256, 256, 64, 64, 1), (16, 256, 256, 128, 64, 0), (16, 128, 128, 128, 128, 0), (16, 128, 128, 128, 128, 1),
@@ -70,6 +70,8 @@ for sh in SHAPES:
         frac = 18.0 * cin * cout * H * W * B / (us * 1e-6) / (4.0 if kind != "wino2" else 2.25) / 157.3e12
         cells.append(f"{kind} {us:8.1f} us ({frac:.3f})")
     same = ""
+    if "wino4h" in outs and "wino4h_16" in outs:
+        same += " | wino4h_16 bits " + ("EQUAL" if torch.equal(outs["wino4h"][0], outs["wino4h_16"][0]) and torch.equal(outs["wino4h"][1], outs["wino4h_16"][1]) else "DIFFER")
     if "wino4" in outs and "wino4h" in outs:
         same += f" | wino4h vs wino4 max diff {float((outs['wino4'][0] - outs['wino4h'][0]).abs().max()):.2e}"
     if "wino4" in outs:
