@@ -31,5 +31,16 @@ python bench.py --config ref48 --steps 10 > gpurun_out/${T}_bench_ref48.jsonl 2>
 python bench.py --gpus 2 --one-device --backend gloo --no-cpu --steps 10 > gpurun_out/${T}_bench_2rank_selflaunch_one_device.jsonl 2>/dev/null
 python bench.py --full --steps 1 --warmup 0 --no-cpu --no-roofline > gpurun_out/${T}_bench_full.jsonl 2>/dev/null
 python tools/lsid_bench.py > gpurun_out/${T}_lsid.log 2>&1
+# the opt-in f16-split product form of the 3x3 convolutions (ND_CONV_F16X3=1): the same lines, its kernel stats, and the GPU suite on it
+for c in "" "--config cfg2" "--config cfg4" "--config ref48"; do
+  n=$(echo "${c:-default}" | sed 's/--config //')
+  ND_CONV_F16X3=1 python bench.py $c --no-cpu --no-alt --steps 20 > gpurun_out/${T}_bench_${n}_f16x3.jsonl 2>/dev/null
+done
+ND_CONV_F16X3=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}h -- python3 bench.py --steps 5 --warmup 1 --soak-s 0 --no-cpu --no-alt --no-roofline > gpurun_out/prof_${T}h.log 2>&1
+cp $(ls gpurun_out/prof_${T}h/*/*kernel_stats.csv | head -1) gpurun_out/${T}_rocprofv3_kernel_stats_bench_steps5_f16x3.csv
+rm -rf gpurun_out/prof_${T}h
+ND_CONV_F16X3=1 python -m pytest tests -m gpu -q > gpurun_out/${T}_pytest_f16x3.log 2>&1 || tail -20 gpurun_out/${T}_pytest_f16x3.log
+tail -1 gpurun_out/${T}_pytest_f16x3.log
+for f in default_f16x3 cfg2_f16x3 cfg4_f16x3 ref48_f16x3; do [ -f gpurun_out/${T}_bench_$f.jsonl ] && { echo "== $f"; python tools/bench_line.py < gpurun_out/${T}_bench_$f.jsonl; }; done
 for f in default cfg2 cfg4 ref48 full; do [ -f gpurun_out/${T}_bench_$f.jsonl ] && { echo "== $f"; python tools/bench_line.py < gpurun_out/${T}_bench_$f.jsonl; }; done
 fi
