@@ -13,8 +13,9 @@ forward against the reference's golden activations and loss / gradients against 
 """
 from __future__ import annotations
 
+import logging
 import math
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -25,6 +26,8 @@ from .spec import noisediff_param_spec
 
 P = Dict[str, torch.Tensor]
 GROUPS, POS_GROUPS, HEADS = 8, 2, 4
+_log = logging.getLogger(__name__)
+FALLBACKS: Dict[Tuple[str, str], str] = {}      # (layer, operator) -> why it runs on PyTorch although the network is .hip() (filled on first use, logged once each)
 
 
 class _Ops:
@@ -52,6 +55,13 @@ class _Ops:
         for n, part in zip(names, ss_all.split([self.p[n + ".mlp.1.weight"].shape[0] for n in names], dim=1)):
             self.ss[n] = part
 
+    def _left_library(self, name: str, op: str, why: str) -> None:
+        """A layer of a .hip() network that runs on PyTorch's own kernel instead of the HIP library: said once per (layer, operator), on the
+        `noisediff_amd.trainable` logger (the fallbacks by shape were silent), and counted in `FALLBACKS`."""
+        if self.hip and (name, op) not in FALLBACKS:
+            FALLBACKS[(name, op)] = why
+            _log.warning("%s: %s stays on PyTorch (%s)", name, op, why)
+
     def conv(self, name: str, x: torch.Tensor, padding: int = 0) -> torch.Tensor:
         w, b = self.p[name + ".weight"], self.p.get(name + ".bias")
         if self.hip and x.is_cuda and w.shape[2:] == (3, 3) and padding == 1 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
@@ -60,6 +70,8 @@ class _Ops:
         if self.hip and x.is_cuda and w.shape[2:] == (1, 1) and padding == 0 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
             from . import train
             return train.conv1x1(x, w, b)
+        if x.is_cuda:
+            self._left_library(name, f"conv{w.shape[2]}x{w.shape[3]}", f"{w.shape[1]} -> {w.shape[0]} channels: the library's differentiable convolutions are 3x3 (channels % 8) and 1x1 (channels % 4)")
         return F.conv2d(x, w, b, padding=padding)
 
     def linear(self, name: str, x: torch.Tensor) -> torch.Tensor:
@@ -67,6 +79,8 @@ class _Ops:
         if self.hip and x.is_cuda and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
             from . import train
             return train.linear(x, w, b)
+        if x.is_cuda:
+            self._left_library(name, "linear", f"{w.shape[1]} -> {w.shape[0]}: channel counts must be multiples of 4")
         return F.linear(x, w, b)
 
     def group_norm(self, name: str, x: torch.Tensor, groups: int) -> torch.Tensor:
@@ -75,6 +89,7 @@ class _Ops:
             from . import train
             if train._group_norm_ok(x.shape[1], groups):                     # wider nets (dim > 128: C > 1024) stay on PyTorch's norm
                 return train.group_norm(x, groups, w, b, 1e-5)
+            self._left_library(name, "group_norm", f"C = {x.shape[1]}, {groups} groups: outside the library's norm (C <= 1024, C % 4 == 0)")
         return F.group_norm(x, groups, w, b, eps=1e-5)
 
     def layer_norm(self, name: str, x: torch.Tensor) -> torch.Tensor:
@@ -83,6 +98,7 @@ class _Ops:
             from . import train
             if train._layer_norm_ok(x.shape[-1]):
                 return train.layer_norm(x, w, b, 1e-5)
+            self._left_library(name, "layer_norm", f"C = {x.shape[-1]}: the library's LayerNorm takes C = 64, 128 or a multiple of 256")
         return F.layer_norm(x, x.shape[-1:], w, b, eps=1e-5)
 
     # ---- composite layers ------------------------------------------------------------------------------------------

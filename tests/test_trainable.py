@@ -119,6 +119,12 @@ def test_hip_convs_and_norms_keep_loss_and_gradients_and_weights_load_into_the_s
         assert sq == pytest.approx(float(golden("training", "train.grad_sq_norm")), rel=1e-3)
     for k in out[0][1]:
         assert rel_err(out[1][1][k].numpy(), out[0][1][k].numpy()) < 5e-4, k
+    # what a .hip() network leaves on PyTorch is said, not silent: at this toy width (d = 16) the 7x7 stem (MIOpen), the 2-channel pos_enc 1x1
+    # conv and the LayerNorms (C = 16 ... 128 below the library's 64 / 128 / 256 k) -- and no 3x3 conv, GroupNorm or Linear
+    from noisediff_amd import trainable
+    left = set(trainable.FALLBACKS)
+    assert ("init_conv", "conv7x7") in left and ("pos_enc.weights", "conv1x1") in left
+    assert {op for _, op in left} <= {"conv7x7", "conv1x1", "layer_norm"} and all(n == "pos_enc.weights" for n, op in left if op == "conv1x1"), left
     # a step of Adam on the accelerated net, then its weights sample on the HIP network
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     opt.step()
