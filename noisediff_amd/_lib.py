@@ -86,6 +86,10 @@ SIGNATURES = {
     "nd_conv3x3_wino4h_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_conv3x3_wino4h_16_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_pack_conv3x3_wino4h_weight": (i32, [vp, vp, i32, i32, vp]),
+    "nd_conv3x3_f16x3_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
+    "nd_conv3x3_f16x3_takes": (i32, [C.POINTER(Conv3x3)]),
+    "nd_pack_conv3x3_f16x3_weight_floats": (i64, [i32, i32]),
+    "nd_pack_conv3x3_f16x3_weight": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_conv3x3_wino4_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_wino4_weight": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_conv3x3_wino4_weight_dgrad": (i32, [vp, vp, i32, i32, vp]),
@@ -116,9 +120,15 @@ SIGNATURES = {
     "nd_pointwise_chain_supported": (i32, [i32, i32, i32, i32]),
     "nd_pack_chain_weight_floats": (i64, [i32, i32, i32]),
     "nd_pack_chain_weight": (i32, [vp, vp, i32, i32, i32, vp]),
+    "nd_pointwise_chain_f16x3_nhwc_f32": (i32, [C.POINTER(Chain), vp]),
+    "nd_pointwise_chain_f16x3_supported": (i32, [i32, i32, i32, i32]),
+    "nd_pack_chain_weight_h": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_floats": (i64, [i32, i32]),
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
+    "nd_pointwise_gemm_f16x3_nhwc_f32": (i32, [C.POINTER(Pointwise), vp]),
+    "nd_pointwise_gemm_f16x3_takes": (i32, [C.POINTER(Pointwise)]),
+    "nd_pack_pointwise_weight_h": (i32, [vp, vp, i32, i32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
     "nd_groupnorm_finalize_train_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),
@@ -163,7 +173,7 @@ SIGNATURES = {
     "nd_stream_device": (i32, [vp]),
 }
 
-_UNCHECKED = {"nd_version", "nd_last_error", "nd_stream_device", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
+_UNCHECKED = {"nd_version", "nd_last_error", "nd_stream_device", "nd_pointwise_gemm_f16x3_takes", "nd_pointwise_chain_f16x3_supported", "nd_conv3x3_f16x3_takes", "nd_pack_conv3x3_f16x3_weight_floats", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
               "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats", "nd_conv3x3_wino_stat_slots", "nd_conv3x3_wino4_stat_slots",
               "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_16_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_token_sum_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
               "nd_groupnorm_train_workspace_floats", "nd_linear_wgrad_workspace_floats",

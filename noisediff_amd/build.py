@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnoisediff_hip.so")
-SOURCES = ["runtime", "conv3x3", "conv3x3_wino", "conv3x3_wino2", "conv3x3_wino4", "conv3x3_wino4h", "conv3x3_wgrad", "linear_wgrad", "pointwise", "pwchain", "norm", "norm_train", "small", "sampler",
+SOURCES = ["runtime", "conv3x3", "conv3x3_wino", "conv3x3_wino2", "conv3x3_wino4", "conv3x3_wino4h", "conv3x3_f16x3", "conv3x3_wgrad", "linear_wgrad", "pointwise", "pwchain", "norm", "norm_train", "small", "sampler",
            "attention", "linattn"]
 ARCH = "gfx950"
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc 7.2 parks
@@ -31,6 +31,7 @@ SPECIAL = {
     # one wave per SIMD: 144 accumulator registers in the AGPR half, the rest of the pipeline state in the VGPR half
     "conv3x3_wino4": ("conv3x3_wino4", BASE_FLAGS),
     "conv3x3_wino4h": ("conv3x3_wino4h", BASE_FLAGS),
+    "conv3x3_f16x3": ("conv3x3_f16x3", BASE_FLAGS),
 }
 
 

@@ -68,6 +68,14 @@ TWO_BRANCH = int(os.environ.get("ND_TWO_BRANCH", "0"))
 # (nd_conv3x3_wino4h_nhwc_f32, conv3x3_wino4h.hip) for the layers of the 16 x 32-region form.  As accurate as the fp32 kernel against an fp64 convolution
 # (tests/test_hip_kernels.py::test_conv3x3_wino4h_*), not bit-identical to it; the fp32 MFMA shares the VALU's lanes on gfx950, the f16 one does not.
 CONV_F16X3 = os.environ.get("ND_CONV_F16X3", "0") != "0"
+# ... the layers of up to DIRECT_F16X3_MAX_CIN input channels as a DIRECT convolution in the same product form (nd_conv3x3_f16x3_nhwc_f32, conv3x3_f16x3.hip:
+# no Winograd transforms, the double-rate f16 instruction): at 64 / 128 channels the F(4x4) kernel spends most of a tile outside the matrix instructions.
+# ND_CONV_DIRECT_F16X3=<max cin> (0: off)
+DIRECT_F16X3_MAX_CIN = int(os.environ.get("ND_CONV_DIRECT_F16X3", "0")) if CONV_F16X3 else 0
+# ... and the wide 1x1 layers with it (nd_pointwise_gemm_f16x3_nhwc_f32, the 128-pixel-tile kernel of pointwise.hip); ND_PW_F16X3=0 keeps those on fp32 MFMAs (A/B knob)
+PW_F16X3 = CONV_F16X3 and os.environ.get("ND_PW_F16X3", "1") != "0"
+# ... and the fused Mlp / AttnBlock chains of the 48- and 64-channel stages (nd_pointwise_chain_f16x3_nhwc_f32, pwchain.hip); ND_CHAIN_F16X3=0: A/B knob
+CHAIN_F16X3 = CONV_F16X3 and os.environ.get("ND_CHAIN_F16X3", "1") != "0"
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -183,6 +191,8 @@ class Engine:
                     add(p.name + ".wino4", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
                     if CONV_F16X3:
                         add(p.name + ".wino4h", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
+                    if DIRECT_F16X3_MAX_CIN and p.shape[1] <= DIRECT_F16X3_MAX_CIN and p.shape[1] % 16 == 0 and p.shape[0] % 64 == 0:
+                        add(p.name + ".f16x3", self.lib.nd_pack_conv3x3_f16x3_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind in ("pw", "pw_unshuffle"):
                 n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
                 if p.name in _MAP_PRODUCERS and p.shape[0] % 32 == 0:
@@ -190,9 +200,13 @@ class Engine:
                     # the 16-channel-blocked layout the F(4x4,3x3) kernel reads one 128-byte line at a time (nd_src.map_blocked)
                     add(p.name + ".blk16", n, "derived", p.shape)
                     add(p.name[:-len("weight")] + "bias.blk16", p.shape[0], "derived", (p.shape[0],))
+                if kind == "pw" and PW_F16X3 and p.shape[1] % 64 == 0 and p.shape[1] >= 128 and p.shape[0] % 128 == 0:
+                    add(p.name + ".h", n, "derived", p.shape)        # the wide layers' f16-split packing (nd_pointwise_gemm_f16x3_nhwc_f32)
                 if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
                     first = int(p.name.endswith(_CHAIN_FIRST))
                     add(p.name + ".chain", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
+                    if CHAIN_F16X3:
+                        add(p.name + ".chain.h", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
             elif kind == "conv7":
                 n = 196 * p.shape[0]
             else:
@@ -256,8 +270,12 @@ class Engine:
                         L.call("nd_pack_conv3x3_wino4_weight", t.data_ptr(), self.p(p.name + ".wino4"), p.shape[1], p.shape[0], st)
                     if p.name + ".wino4h" in self.slots:
                         L.call("nd_pack_conv3x3_wino4h_weight", t.data_ptr(), self.p(p.name + ".wino4h"), p.shape[1], p.shape[0], st)
+                    if p.name + ".f16x3" in self.slots:
+                        L.call("nd_pack_conv3x3_f16x3_weight", t.data_ptr(), self.p(p.name + ".f16x3"), p.shape[1], p.shape[0], st)
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
+                    if p.name + ".h" in self.slots:
+                        L.call("nd_pack_pointwise_weight_h", t.data_ptr(), self.p(p.name + ".h"), p.shape[1], p.shape[0], st)
                     if p.name + ".blk16" in self.slots:
                         perm = _blocked_map_rows(p.shape[0] // 2).to(self.device)
                         tp = t[perm].contiguous()
@@ -267,6 +285,9 @@ class Engine:
                         self.view(bname + ".blk16").copy_(sd[bname].detach().to(device=self.device, dtype=torch.float32)[perm])
                     if p.name + ".chain" in self.slots:
                         L.call("nd_pack_chain_weight", t.data_ptr(), self.p(p.name + ".chain"), p.shape[1], p.shape[0],
+                               int(p.name.endswith(_CHAIN_FIRST)), st)
+                    if p.name + ".chain.h" in self.slots:
+                        L.call("nd_pack_chain_weight_h", t.data_ptr(), self.p(p.name + ".chain.h"), p.shape[1], p.shape[0],
                                int(p.name.endswith(_CHAIN_FIRST)), st)
                 elif kind == "pw_unshuffle":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], p.shape[1] // 4, st)
@@ -504,11 +525,16 @@ class Plan:
         # ONE packing of the weight is read (and marked for the weight broadcast): F(4x4), F(2x2) or the direct form
         lowlat_split = SPLIT_K and w4kind == "wino4" and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU) and int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) > 1
         f16x3 = w4kind == "wino4" and (name + ".weight.wino4h") in e.slots and not lowlat_split      # (the opt-in low-latency split keeps the fp32 kernel)
-        d.weight = e.p(name + (".weight.wino4h" if f16x3 else ".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
-        entry = ("nd_conv3x3_wino4h_nhwc_f32" if f16x3 else f"nd_conv3x3_{w4kind}_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
+        # ... or the direct f16-split convolution (same statistics slots as the F(4x4) kernels, so it only stands in for them)
+        direct = wino4 and not lowlat_split and (name + ".weight.f16x3") in e.slots and bool(e.lib.nd_conv3x3_f16x3_takes(C.byref(d)))
+        f16x3 = f16x3 and not direct
+        d.weight = e.p(name + (".weight.f16x3" if direct else ".weight.wino4h" if f16x3 else ".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
+        if direct:
+            w4kind = "direct_f16x3"
+        entry = ("nd_conv3x3_f16x3_nhwc_f32" if direct else "nd_conv3x3_wino4h_nhwc_f32" if f16x3 else f"nd_conv3x3_{w4kind}_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
                  "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32")
         meta = {"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
-                "tiling": (9016 if w4kind == "wino4_16" else 9104 if f16x3 else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
+                "tiling": (9116 if direct else 9016 if w4kind == "wino4_16" else 9104 if f16x3 else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
         splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and w4kind == "wino4" and not f16x3 and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
         if w4kind == "wino4_16" and WINO4_16_SPLIT:      # few items per sample: K ranges by the SAMPLE's geometry (the batch never enters: a sample's bits stay batch-invariant)
             splits = int(e.lib.nd_conv3x3_wino4_16_splitk_plan(H, W, cin, cout))
@@ -579,8 +605,10 @@ class Plan:
             d.vec = vec.data_ptr()
         if gn_t is not None:
             d.gn_t, d.ldt, d.gn_mad = gn_t.data_ptr(), gn_t.shape[-1], gn_mad.data_ptr()
-        self._add("nd_pointwise_gemm_nhwc_f32", C.byref(d), e.stream,
-                  meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout})
+        entry = "nd_pointwise_gemm_nhwc_f32"
+        if not variant and (name + ".weight.h") in e.slots and e.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d)):      # opt-in (CONV_F16X3): the wide layers' products as f16 splits
+            d.weight, entry = e.p(name + ".weight.h"), "nd_pointwise_gemm_f16x3_nhwc_f32"
+        self._add(entry, C.byref(d), e.stream, meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout})
         self._keep.append(d)
         return out
 
@@ -640,10 +668,12 @@ class Plan:
         out = self._alloc(self.B, HW, stages[-1][2])
         d = L.Chain()
         d.src, d.out, d.n_stages, d.B, d.HW, d.ldo = src, out.data_ptr(), len(stages), self.B, HW, stages[-1][2]
+        widths = [stages[0][1]] + [st_[2] for st_ in stages] + [0] * (3 - len(stages))
+        hf = (all((layer + ".weight.chain.h") in e.slots for layer, *_ in stages) and bool(e.lib.nd_pointwise_chain_f16x3_supported(*widths)))    # opt-in (CONV_F16X3)
         for i, (layer, cin, cout, act, res) in enumerate(stages):
-            d.st[i].weight, d.st[i].bias = e.p(layer + ".weight.chain"), e.p(layer + ".bias")
+            d.st[i].weight, d.st[i].bias = e.p(layer + (".weight.chain.h" if hf else ".weight.chain")), e.p(layer + ".bias")
             d.st[i].cin, d.st[i].cout, d.st[i].act, d.st[i].res = cin, cout, act, res
-        self._add("nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
+        self._add("nd_pointwise_chain_f16x3_nhwc_f32" if hf else "nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
                   meta={"layer": name, "B": self.B, "HW": HW, "cin": stages[0][1], "cout": stages[-1][2],
                         "flop_per_px": 2.0 * sum(c_in * c_out for _, c_in, c_out, _, _ in stages)})
         self._keep.append(d)

@@ -63,12 +63,16 @@ def pack_conv3(ctx, w):
     return out
 
 
-def pack_pw(ctx, w, unshuffle_c=0):
+def pack_pw(ctx, w, unshuffle_c=0, f16x3=False):
+    """f16x3: the two-f16-term packing of nd_pointwise_gemm_f16x3_nhwc_f32 (same size)."""
     w = w.reshape(w.shape[0], -1)
     cout, cin = w.shape
     n = ctx.lib.nd_pack_pointwise_weight_floats(cin, cout)
     wd, out = dev(w), torch.empty(n, device=DEV)
-    L.call("nd_pack_pointwise_weight", wd.data_ptr(), out.data_ptr(), cin, cout, unshuffle_c, ctx.stream)
+    if f16x3:
+        L.call("nd_pack_pointwise_weight_h", wd.data_ptr(), out.data_ptr(), cin, cout, ctx.stream)
+    else:
+        L.call("nd_pack_pointwise_weight", wd.data_ptr(), out.data_ptr(), cin, cout, unshuffle_c, ctx.stream)
     ctx.sync()
     return out
 
@@ -90,7 +94,7 @@ def conv3x3(ctx, s, wp, bias, B, H, W, cin, cout, stats=False):
     return out, st, sc, slots
 
 
-def pointwise(ctx, s, wp, bias, B, HW, W, cin, cout, act=0, res0=None, res1=None, vec=None, gn_t=None, gn_mad=None):
+def pointwise(ctx, s, wp, bias, B, HW, W, cin, cout, act=0, res0=None, res1=None, vec=None, gn_t=None, gn_mad=None, entry="nd_pointwise_gemm_nhwc_f32"):
     out = full((B, HW, cout))
     d = L.Pointwise()
     d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr()
@@ -103,7 +107,7 @@ def pointwise(ctx, s, wp, bias, B, HW, W, cin, cout, act=0, res0=None, res1=None
         d.vec = vec.data_ptr()
     if gn_t is not None:
         d.gn_t, d.ldt, d.gn_mad = gn_t.data_ptr(), gn_t.shape[-1], gn_mad.data_ptr()
-    L.call("nd_pointwise_gemm_nhwc_f32", C.byref(d), ctx.stream)
+    L.call(entry, C.byref(d), ctx.stream)
     ctx.sync()
     return out
 

@@ -221,11 +221,18 @@ CHAIN_CASES = {  # (B, HW, [widths]): Mlp chains (two stages) and AttnBlock tail
 }
 
 
-@pytest.mark.parametrize("case", sorted(CHAIN_CASES))
-def test_pointwise_chain_matches_layer_by_layer(ctx, case):
-    """nd_pointwise_chain_nhwc_f32 == the same Linear layers applied one by one (Mlp :340-356, AttnBlock tail :405-443)."""
+def _chain_forms(case):
+    w = CHAIN_CASES[case][2]
+    return ["fp32", "f16x3"] if tuple(w) in ((64, 64, 64), (64, 128, 64, 64), (8, 64, 64), (48, 48, 48), (48, 96, 48, 48), (64, 64, 4)) else ["fp32"]
+
+
+@pytest.mark.parametrize("case,form", [(c, f) for c in sorted(CHAIN_CASES) for f in _chain_forms(c)])
+def test_pointwise_chain_matches_layer_by_layer(ctx, case, form):
+    """nd_pointwise_chain_nhwc_f32 == the same Linear layers applied one by one (Mlp :340-356, AttnBlock tail :405-443).
+    form f16x3: nd_pointwise_chain_f16x3_nhwc_f32 (every product three f16 MFMAs of two-term operands) on the widths it instantiates, same tolerance."""
     import hiputil as hu
     B, HW, widths = CHAIN_CASES[case]
+    pack, entry = ("nd_pack_chain_weight_h", "nd_pointwise_chain_f16x3_nhwc_f32") if form == "f16x3" else ("nd_pack_chain_weight", "nd_pointwise_chain_nhwc_f32")
     n = len(widths) - 1
     x = U(case + ".x", (B, HW, widths[0]), -1.5, 1.5)
     ws = [U(f"{case}.w{i}", (widths[i + 1], widths[i]), -0.3, 0.3) for i in range(n)]
@@ -235,7 +242,7 @@ def test_pointwise_chain_matches_layer_by_layer(ctx, case):
     for i in range(n):
         wd = hu.dev(ws[i])
         wp = hu.full((ctx.lib.nd_pack_chain_weight_floats(widths[i], widths[i + 1], int(i == 0)),))
-        L.call("nd_pack_chain_weight", wd.data_ptr(), wp.data_ptr(), widths[i], widths[i + 1], int(i == 0), ctx.stream)
+        L.call(pack, wd.data_ptr(), wp.data_ptr(), widths[i], widths[i + 1], int(i == 0), ctx.stream)
         bd = hu.dev(bs[i])
         keep += [wd, wp, bd]
         d.st[i].weight, d.st[i].bias, d.st[i].cin, d.st[i].cout = wp.data_ptr(), bd.data_ptr(), widths[i], widths[i + 1]
@@ -257,12 +264,12 @@ def test_pointwise_chain_matches_layer_by_layer(ctx, case):
         x1 = x + vec[:, None]
         h = F.gelu(F.linear(F.layer_norm(x1, (Cc,), g, be, eps=1e-5), ws[0], bs[0]))
         ref = F.linear(F.linear(h, ws[1], bs[1]) + x1, ws[2], bs[2]) + x
-    L.call("nd_pointwise_chain_nhwc_f32", C.byref(d), ctx.stream)
+    L.call(entry, C.byref(d), ctx.stream)
     ctx.sync()
     assert rel_err(out.cpu(), ref) < TOL
     # widths this build does not instantiate are refused, not approximated
     d.st[0].cout = d.st[1].cin = 160
-    assert ctx.lib.nd_pointwise_chain_nhwc_f32(C.byref(d), ctx.stream) != 0
+    assert getattr(ctx.lib, entry)(C.byref(d), ctx.stream) != 0
     assert b"not instantiated" in ctx.lib.nd_last_error()
 
 
@@ -352,40 +359,48 @@ def test_pointwise_pipelined_chunks_concat_and_prologues(ctx, cin):
     assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
 
 
-def test_pointwise_large_tile_kernel(ctx):
+PW_FORMS = {"fp32": "nd_pointwise_gemm_nhwc_f32", "f16x3": "nd_pointwise_gemm_f16x3_nhwc_f32"}
+
+
+@pytest.mark.parametrize("form", sorted(PW_FORMS))
+def test_pointwise_large_tile_kernel(ctx, form):
     """The one-wave-per-SIMD form of the 1x1 GEMM (pointwise_big_kernel: cin % 64 == 0, cout % 128 == 0 and at least one 128-pixel
-    tile per CU): 3 chunks of 64 channels, a ragged last pixel tile, concat on a chunk boundary, every prologue, all epilogue operands."""
+    tile per CU): 3 chunks of 64 channels, a ragged last pixel tile, concat on a chunk boundary, every prologue, all epilogue operands.
+    form f16x3: the opt-in entry that runs every product as three f16 MFMAs of two-term operands -- the same cases at the same tolerance."""
     import hiputil as hu
+    import functools
     B, HW, W, cin, cout = 2, 8200, 100, 192, 256              # 2 x 65 x 2 = 260 workgroups
+    pwf = functools.partial(hu.pointwise, entry=PW_FORMS[form])
     x = U("big.x", (B, HW, cin), -1.5, 1.5)
     w, b = U("big.w", (cout, cin), -0.2, 0.2), U("big.b", (cout,))
-    wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
+    wp, xd, bd = hu.pack_pw(ctx, w, f16x3=form == "f16x3"), hu.dev(x), hu.dev(b)
     lin = F.linear(x, w, b)
-    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
+    assert rel_err(pwf(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
     xa, xb = hu.dev(x[..., :128].contiguous()), hu.dev(x[..., 128:].contiguous())
-    assert rel_err(hu.pointwise(ctx, hu.src(xa, xb), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
-    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_SILU), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(F.silu(x), w, b)) < TOL
-    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_LEAKY), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(F.leaky_relu(x, 0.2), w, b)) < TOL
+    assert rel_err(pwf(ctx, hu.src(xa, xb), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
+    assert rel_err(pwf(ctx, hu.src(xd, None, L.PRO_SILU), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(F.silu(x), w, b)) < TOL
+    assert rel_err(pwf(ctx, hu.src(xd, None, L.PRO_LEAKY), wp, bd, B, HW, W, cin, cout).cpu(), F.linear(F.leaky_relu(x, 0.2), w, b)) < TOL
     mad = U("big.mad", (B, 3, cin), 0.5, 1.5)
     ref = F.linear(F.silu((x - mad[:, None, 0]) * mad[:, None, 1] + mad[:, None, 2]), w, b)
-    assert rel_err(hu.pointwise(ctx, hu.src(xd, None, L.PRO_AFFINE_SILU, mad=hu.dev(mad)), wp, bd, B, HW, W, cin, cout).cpu(), ref) < TOL
+    assert rel_err(pwf(ctx, hu.src(xd, None, L.PRO_AFFINE_SILU, mad=hu.dev(mad)), wp, bd, B, HW, W, cin, cout).cpu(), ref) < TOL
     vec, g, be = U("big.v", (B, cin)), U("big.g", (cin,), 0.5, 1.5), U("big.be", (cin,))
     rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
     L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
     ctx.sync()
     s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
     ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
-    assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
+    assert rel_err(pwf(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
     # epilogue operands: two residuals, a per-sample vector, the fused ResnetBlock tail silu(GroupNorm-affine(t))
     r0, r1, ov, t = U("big.r0", (B, HW, cout)), U("big.r1", (B, HW, cout)), U("big.ov", (B, cout)), U("big.t", (B, HW, cout), -1.5, 1.5)
     tm = U("big.tm", (B, 3, cout), 0.5, 1.5)
     ref = lin + r0 + r1 + ov[:, None] + F.silu((t - tm[:, None, 0]) * tm[:, None, 1] + tm[:, None, 2])
-    out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), res1=hu.dev(r1), vec=hu.dev(ov), gn_t=hu.dev(t), gn_mad=hu.dev(tm))
+    out = pwf(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), res1=hu.dev(r1), vec=hu.dev(ov), gn_t=hu.dev(t), gn_mad=hu.dev(tm))
     assert rel_err(out.cpu(), ref) < TOL
 
 
 @pytest.mark.parametrize("cin,cout", [(1024, 2048), (2048, 1024), (1024, 1024)])
-def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout):
+@pytest.mark.parametrize("form", sorted(PW_FORMS))
+def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout, form):
     """pointwise_big_kernel at BASELINE config 4's widths (d=128: FeedForward 1024 -> 2048 -> 1024 and proj_out 1024 -> 1024 on the
     32 x 32 = 1024 tokens of the H/8 stage; 16 / 32 K chunks of 64): LayerNorm prologue + GELU, plain, residual + per-sample vector."""
     import hiputil as hu
@@ -393,9 +408,9 @@ def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout):
     bound = 1.0 / np.sqrt(cin)
     x = U(f"c4pw.x.{cin}", (B, HW, cin), -1.5, 1.5)
     w, b = U(f"c4pw.w.{cin}.{cout}", (cout, cin), -bound, bound), U(f"c4pw.b.{cout}", (cout,), -bound, bound)
-    wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
+    wp, xd, bd = hu.pack_pw(ctx, w, f16x3=form == "f16x3"), hu.dev(x), hu.dev(b)
     lin = F.linear(x, w, b)
-    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
+    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, entry=PW_FORMS[form]).cpu(), lin) < TOL
     if cin <= 1024:                                           # LayerNorm feeds ff.net.0.0 only (its rows are at most 8 d = 1024 wide)
         vec, g, be = U(f"c4pw.v.{cin}", (B, cin)), U(f"c4pw.g.{cin}", (cin,), 0.5, 1.5), U(f"c4pw.be.{cin}", (cin,))
         rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
@@ -403,10 +418,29 @@ def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout):
         ctx.sync()
         s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
         ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
-        assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
+        assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU, entry=PW_FORMS[form]).cpu(), ref) < TOL
     r0, ov = U(f"c4pw.r0.{cout}", (B, HW, cout)), U(f"c4pw.ov.{cout}", (B, cout))
-    out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), vec=hu.dev(ov))
+    out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), vec=hu.dev(ov), entry=PW_FORMS[form])
     assert rel_err(out.cpu(), lin + r0 + ov[:, None]) < TOL
+
+
+def test_pointwise_f16x3_entry_refuses_layers_of_the_other_kernels(ctx):
+    """nd_pointwise_gemm_f16x3_nhwc_f32 is the 128-pixel-tile kernel only: a narrow layer (cin = 64) or a cout that is not whole 128-wide tiles is an error
+    (ND_E_SHAPE), and nd_pointwise_gemm_f16x3_takes says so beforehand -- never a silent change of kernel or product form.  The batch does not enter:
+    a layer with two tiles is taken like one with thousands (a sample's bits must not depend on the batch it sits in)."""
+    import hiputil as hu
+    for (B, HW, cin, cout, takes) in [(2, 8200, 192, 256, 1), (2, 8200, 64, 128, 0), (1, 256, 128, 128, 1), (2, 8200, 192, 192, 0)]:
+        x, w = hu.dev(U(f"pwh.x.{cin}", (B, HW, cin))), U(f"pwh.w.{cin}.{cout}", (cout, cin), -0.2, 0.2)
+        wp, out = hu.pack_pw(ctx, w, f16x3=True), hu.full((B, HW, cout))
+        d = L.Pointwise()
+        d.src, d.weight, d.out = hu.src(x), wp.data_ptr(), out.data_ptr()
+        d.B, d.HW, d.W, d.cin, d.cout, d.ldo = B, HW, 1, cin, cout, cout
+        assert ctx.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d)) == takes
+        rc = ctx.lib.nd_pointwise_gemm_f16x3_nhwc_f32(C.byref(d), ctx.stream)
+        ctx.sync()
+        assert (rc == 0) == bool(takes)
+        if not takes:
+            assert b"f16x3" in ctx.lib.nd_last_error()
 
 
 def test_affine_silu_add_and_rmsnorm(ctx):
@@ -943,6 +977,97 @@ def test_conv3x3_wino4h_f16_split_products_match_conv2d_at_the_fp32_kernels_tole
             xb = x * 200.0                                               # |V| up to ~3e4: the first f16 term near the top of its range
             out, *_ = runh(hu.src(hu.nhwc(xb)), stats=False)
             assert rel_err(hu.nchw(out), F.conv2d(xb.double(), w.double(), b.double(), padding=1).float()) < 5e-5
+
+
+D16_CASES = {  # (B, H, W, cin, cout, c0 of a concat, nearest-x2 source)
+    "h1_64_64": (2, 64, 96, 64, 64, 0, 0),                  # 2 x 4 x 3 = 24 items on 256 CUs: every workgroup has one tile
+    "h1_64_64_many": (3, 256, 256, 64, 64, 0, 0),           # 384 items: workgroups with two tiles (the pipeline across tiles)
+    "h1_128cat_64": (2, 64, 64, 128, 64, 64, 0),
+    "h2_128_128": (2, 32, 64, 128, 128, 0, 0),              # two cout tiles per region
+    "h2_up_256_128": (1, 32, 64, 256, 128, 0, 1),
+    "one_chunk": (1, 16, 32, 16, 64, 0, 0),
+    "h4_48cat_192": (1, 16, 32, 48, 192, 32, 0),
+}
+
+
+@pytest.mark.parametrize("case", sorted(D16_CASES))
+def test_conv3x3_f16x3_direct_split_products_match_conv2d(ctx, case):
+    """nd_conv3x3_f16x3_nhwc_f32 -- the direct convolution on the double-rate f16 matrix instruction, every product a three-product split of two-term
+    operands with fp32 accumulation -- against nn.Conv2d at the 2e-5 of the direct fp32 kernel (no Winograd transform amplifies anything), with a float64
+    convolution as the yardstick (its error must not exceed 1.5x the fp32 F(4x4) kernel's + 2e-6); GroupNorm partials in the F(4x4) kernels' slots,
+    concat / nearest-x2 / affine + SiLU sources, bitwise repeat, statistics on and off, large activations (x 200), a padded output row."""
+    import hiputil as hu
+    B, H, W, cin, cout, c0, up = D16_CASES[case]
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    bound = 1.0 / np.sqrt(9 * cin)
+    x = U(case + ".dx", (B, cin, hs, ws), -1.5, 1.5)
+    w = U(case + ".dw", (cout, cin, 3, 3), -bound, bound)
+    b = U(case + ".db", (cout,), -bound, bound)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref64 = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    ref = ref64.float()
+    wd, bd = hu.dev(w), hu.dev(b)
+    wph = hu.full((ctx.lib.nd_pack_conv3x3_f16x3_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_f16x3_weight", wd.data_ptr(), wph.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    runh = lambda s, stats=True: _run_wino4(ctx, s, wph, bd, B, H, W, cin, cout, stats, entry="nd_conv3x3_f16x3_nhwc_f32")
+    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
+    out, st, sc, slots = runh(s)
+    assert rel_err(hu.nchw(out), ref) < TOL
+    _check_gn(ctx, case, ref, st, sc, slots, B, cout, TOL)
+    assert torch.equal(sc.cpu(), torch.full((slots,), 256.0))
+    out2, st2, *_ = runh(s)
+    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
+    out_ns, *_ = runh(s, stats=False)
+    assert torch.equal(out.cpu(), out_ns.cpu())
+    if cin > 16:                                                          # the fp32 F(4x4) kernel as the error yardstick (it needs two K chunks)
+        wp4 = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
+        L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp4.data_ptr(), cin, cout, ctx.stream)
+        ctx.sync()
+        o32, *_ = _run_wino4(ctx, s, wp4, bd, B, H, W, cin, cout)
+        scale = max(1.0, float(ref64.abs().max()))
+        e16 = float((hu.nchw(out).double() - ref64).abs().max()) / scale
+        e32 = float((hu.nchw(o32).double() - ref64).abs().max()) / scale
+        assert e16 < 1.5 * e32 + 2e-6, (e16, e32)
+    if not up:
+        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
+        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
+        mad = hu.dev(torch.stack((M, A, D), 1))
+        sa = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:]), L.PRO_AFFINE_SILU, mad=mad) if c0 else hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=mad)
+        refa = F.conv2d(act, w, b, padding=1)
+        out, st, sc, slots = runh(sa)
+        assert rel_err(hu.nchw(out), refa) < TOL
+        _check_gn(ctx, case + ".a", refa, st, sc, slots, B, cout, TOL)
+        if not c0:
+            xb = x * 200.0                                               # the first f16 term near the top of its range
+            out, *_ = runh(hu.src(hu.nhwc(xb)), stats=False)
+            assert rel_err(hu.nchw(out), F.conv2d(xb.double(), w.double(), b.double(), padding=1).float()) < TOL
+            # a padded output row (ldo > cout): the padding keeps its bits
+            outp = torch.full((B, H, W, cout + 8), 7.0, device=hu.DEV)
+            d = L.Conv3x3()
+            d.src, d.weight, d.bias, d.out = hu.src(hu.nhwc(x)), wph.data_ptr(), bd.data_ptr(), outp.data_ptr()
+            d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout + 8
+            torch.cuda.synchronize()
+            L.call("nd_conv3x3_f16x3_nhwc_f32", C.byref(d), ctx.stream)
+            ctx.sync()
+            assert rel_err(hu.nchw(outp[..., :cout].contiguous()), ref) < TOL and bool((outp[..., cout:] == 7.0).all())
+
+
+def test_conv3x3_f16x3_refuses_what_it_does_not_cover(ctx):
+    """nd_conv3x3_f16x3_takes / the entry's ND_E_SHAPE: ragged regions (H % 16, W % 32), cin % 16, cout % 64, the map / LeakyReLU prologues."""
+    import hiputil as hu
+    x = hu.full((1, 32, 64, 64))
+    wph, out = hu.full((ctx.lib.nd_pack_conv3x3_f16x3_weight_floats(64, 64),)), hu.full((1, 32, 64, 64))
+    for (H, W, cin, cout, mode, takes) in [(32, 64, 64, 64, L.PRO_NONE, 1), (24, 64, 64, 64, L.PRO_NONE, 0), (32, 48, 64, 64, L.PRO_NONE, 0),
+                                           (32, 64, 24, 64, L.PRO_NONE, 0), (32, 64, 64, 32, L.PRO_NONE, 0), (32, 64, 64, 64, L.PRO_LEAKY, 0)]:
+        d = L.Conv3x3()
+        d.src, d.weight, d.out = hu.src(x, None, mode), wph.data_ptr(), out.data_ptr()
+        d.src.c0 = cin
+        d.B, d.H, d.W, d.cin, d.cout, d.ldo = 1, H, W, cin, cout, 64
+        assert ctx.lib.nd_conv3x3_f16x3_takes(C.byref(d)) == takes
+        rc = ctx.lib.nd_conv3x3_f16x3_nhwc_f32(C.byref(d), ctx.stream)
+        ctx.sync()
+        assert (rc == 0) == bool(takes)
 
 
 @pytest.mark.parametrize("case", sorted(CFG2_CASES))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""One-line summary of bench.py JSON lines read from stdin (ms/step, patches/s, conv3x3 family, per-kernel executed fractions) -- for A/B scripts."""
-import json, sys
-for l in sys.stdin:
+"""One-line summary of bench.py JSON lines read from the files named on the command line, or from stdin (ms/step, patches/s, conv3x3 family, per-kernel executed fractions) -- for A/B scripts."""
+import fileinput, json
+for l in fileinput.input():
     if not l.startswith("{"):
         continue
     j = json.loads(l)

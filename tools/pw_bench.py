@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """nd_pointwise_gemm_nhwc_f32 on the bench workload's wide 1x1 layers: correctness against torch and us / TF per layer.
-ND_PW_BIG=0 (pipelined 64-pixel tiles) / 1 (large tiles, one wave per SIMD) / 2 (large tiles, 128 couts only): run once per value."""
+ND_PW_BIG=0 (pipelined 64-pixel tiles) / 1 (large tiles, one wave per SIMD) / 2 (large tiles, 128 couts only): run once per value.
+Both product forms of the large-tile kernel per layer: fp32 MFMAs (nd_pointwise_gemm_nhwc_f32) and the f16 three-product split
+(nd_pointwise_gemm_f16x3_nhwc_f32, where it takes the layer); errors are against an fp64 product, relative to the output's largest magnitude."""
 import os, sys, ctypes as C
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import torch, torch.nn.functional as F
 torch.zeros(1, device="cuda")
 from noisediff_amd import _lib as L
+if os.environ.get("ND_LIB"):
+    L.load(os.environ["ND_LIB"])
 import hiputil as hu
 ctx = hu.Ctx()
 B = 16
@@ -15,35 +19,45 @@ LAYERS = [(1024, 768, 512, 512, 0, 0), (1024, 512, 1024, 0, 1, 0), (1024, 1024, 
           (4096, 384, 256, 256, 0, 0), (4096, 256, 512, 0, 1, 0), (4096, 512, 256, 0, 0, 1), (4096, 256, 256, 0, 0, 1),
           (16384, 192, 128, 128, 0, 0), (16384, 128, 256, 0, 1, 0), (16384, 256, 128, 0, 0, 1), (16384, 128, 128, 0, 0, 1),
           (65536, 128, 128, 0, 0, 0)]
-tot = 0.0
+tot = {"fp32": 0.0, "f16x3": 0.0}
 for (HW, cin, cout, c0, ln, res) in LAYERS:
     g = torch.Generator().manual_seed(HW + cin)
     x = torch.randn(B, HW, cin, generator=g); w = torch.randn(cout, cin, generator=g) / cin ** 0.5; b = torch.randn(cout, generator=g)
     xd, wp, bd = hu.dev(x), hu.pack_pw(ctx, w), hu.dev(b)
+    wh = torch.empty_like(wp); wdev = hu.dev(w)
+    L.call("nd_pack_pointwise_weight_h", wdev.data_ptr(), wh.data_ptr(), cin, cout, ctx.stream); ctx.sync()
+    x64, w64, b64 = xd.double(), wdev.double(), bd.double()          # fp64 reference on the device, from the operands the kernel reads
     r = torch.randn(B, HW, cout, generator=g) if res else None
     rd = hu.dev(r) if res else None
     keep = []
     if c0:
-        xa, xb = hu.dev(x[..., :c0].contiguous()), hu.dev(x[..., c0:].contiguous()); s = hu.src(xa, xb); ref = F.linear(x, w, b)
+        xa, xb = hu.dev(x[..., :c0].contiguous()), hu.dev(x[..., c0:].contiguous()); s = hu.src(xa, xb); ref = F.linear(x64, w64, b64)
     elif ln:
         vec, gm, be = torch.randn(B, cin, generator=g), torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
         rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
         L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream); ctx.sync()
         s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(gm), beta=hu.dev(be), rowstats=rs)
-        ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), gm, be, eps=1e-5), w, b))
+        ref = F.gelu(F.linear(F.layer_norm(x64 + vd.double()[:, None], (cin,), hu.dev(gm).double(), hu.dev(be).double(), eps=1e-5), w64, b64))
     else:
-        s = hu.src(xd); ref = F.linear(x, w, b) + (r if res else 0)
+        s = hu.src(xd); ref = F.linear(x64, w64, b64) + (rd.double() if res else 0)
     out = hu.full((B, HW, cout))
     d = L.Pointwise(); d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
     d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = B, HW, int(HW ** 0.5), cin, cout, cout, (L.ACT_GELU if ln else 0)
     if res: d.res0, d.ldr0 = rd.data_ptr(), cout
-    L.call("nd_pointwise_gemm_nhwc_f32", C.byref(d), ctx.stream); ctx.sync()
-    err = float((out.cpu() - ref).abs().max() / ref.abs().max())
-    e0, e1 = C.c_void_p(), C.c_void_p(); L.call("nd_event_create", C.byref(e0)); L.call("nd_event_create", C.byref(e1))
-    reps = 10
-    L.call("nd_event_record", e0, ctx.stream)
-    for _ in range(reps): L.call("nd_pointwise_gemm_nhwc_f32", C.byref(d), ctx.stream)
-    L.call("nd_event_record", e1, ctx.stream); ms = C.c_float(); L.call("nd_event_elapsed_ms", e0, e1, C.byref(ms))
-    us = ms.value / reps * 1e3; tot += us
-    print(f"{cin:5d} -> {cout:5d} @{HW:6d}px {'cat ' if c0 else 'LN+GELU ' if ln else 'res ' if res else ''}: {us:8.1f} us {2.0 * B * HW * cin * cout / us / 1e6:6.1f} TF  rel err {err:.1e}", flush=True)
-print(f"total {tot:.1f} us (ND_PW_BIG={os.environ.get('ND_PW_BIG', '1')})")
+    cells = []
+    for form, entry, wt in (("fp32", "nd_pointwise_gemm_nhwc_f32", wp), ("f16x3", "nd_pointwise_gemm_f16x3_nhwc_f32", wh)):
+        d.weight = wt.data_ptr()
+        if form == "f16x3" and not ctx.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d)):
+            cells.append("f16x3: not taken"); continue
+        out.zero_(); torch.cuda.synchronize()        # (zero_ runs on torch's stream, the kernel on ctx.stream)
+        L.call(entry, C.byref(d), ctx.stream); ctx.sync()
+        err = float((out.double() - ref).abs().max() / ref.abs().max())
+        e0, e1 = C.c_void_p(), C.c_void_p(); L.call("nd_event_create", C.byref(e0)); L.call("nd_event_create", C.byref(e1))
+        reps = 10
+        L.call("nd_event_record", e0, ctx.stream)
+        for _ in range(reps): L.call(entry, C.byref(d), ctx.stream)
+        L.call("nd_event_record", e1, ctx.stream); ms = C.c_float(); L.call("nd_event_elapsed_ms", e0, e1, C.byref(ms))
+        us = ms.value / reps * 1e3; tot[form] += us
+        cells.append(f"{form} {us:8.1f} us {2.0 * B * HW * cin * cout / us / 1e6:6.1f} TF rel err {err:.1e}")
+    print(f"{cin:5d} -> {cout:5d} @{HW:6d}px {'cat ' if c0 else 'LN+GELU ' if ln else 'res ' if res else ''}: " + " | ".join(cells), flush=True)
+print("total us:", {k: round(v, 1) for k, v in tot.items()}, f"(ND_PW_BIG={os.environ.get('ND_PW_BIG', '1')})")
