@@ -110,7 +110,7 @@ def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
     CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32", "nd_conv3x3_wino4_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32",
-            "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32")
+            "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32")
     STREAM = "nd_affine_silu_add_f32"           # the HBM-bound family: GroupNorm-apply + SiLU + residual adds, one pass
     convs = [op for op in plan.step_ops if op[2] in CONV or (op[2] == STREAM and op[3])]
     n_ev = 2 * len(convs)
@@ -149,7 +149,7 @@ def instrumented_pass(loop, plan, L, n_steps):
                 d["launches"] += 1
                 continue
             # conv3x3_wino4 has two instances per prologue mode: outputs of 48 MB and more are stored with the streaming policy bits
-            stream = m["tiling"] in (9004, 9016, 9104) and 4 * m["B"] * m["H"] * m["W"] * m["cout"] >= int(os.environ.get("ND_W4_STREAM_MB", "48")) << 20
+            stream = m["tiling"] in (9004, 9016, 9104, 9116) and 4 * m["B"] * m["H"] * m["W"] * m["cout"] >= int(os.environ.get("ND_W4_STREAM_MB", "48")) << 20
             d = per.setdefault((m["tiling"], m["mode"], stream, m.get("splits", 1) > 1), {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
             d["ms"] += ms.value
             d["flop"] += conv_flops(m)
@@ -348,7 +348,7 @@ def roofline(a, loop, plan, L, per_step):
     tot_ms = sum(d["ms"] for d in per.values())
     tot_flop = sum(d["flop"] for d in per.values())
     tot_exec = sum(d["flop"] / WINO_FACTOR.get(k[0], 1.0) for k, d in per.items())
-    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, {'true' if len(k) > 3 and k[3] else 'false'}, {1 if k[0] == 9016 else 2}, 4>{' + reduce' if len(k) > 3 and k[3] else ''}" if k[0] in (9004, 9016) else f"wino4h_kernel<{k[1]}, {'true' if k[2] else 'false'}> (f16x3)" if k[0] == 9104 else
+    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, {'true' if len(k) > 3 and k[3] else 'false'}, {1 if k[0] == 9016 else 2}, 4>{' + reduce' if len(k) > 3 and k[3] else ''}" if k[0] in (9004, 9016) else f"wino4h_kernel<{k[1]}, {'true' if k[2] else 'false'}> (f16x3)" if k[0] == 9104 else f"conv3x3_f16x3_kernel<{k[1]}, {'true' if k[2] else 'false'}> (direct, f16x3)" if k[0] == 9116 else
                        f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
                        f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
     tid, d = max(per.items(), key=lambda kv: kv[1]["ms"])
@@ -413,18 +413,19 @@ def roofline(a, loop, plan, L, per_step):
 
 
 def _dtype_label(f16x3: bool) -> str:
-    return ("f32 (3x3 conv position products: three-product f16 split on the matrix cores, fp32 accumulation -- ND_CONV_F16X3=1)" if f16x3 else "f32")
+    return ("f32 (matrix products of the 3x3 convolutions, the wide 1x1 layers and the fused Mlp / AttnBlock chains: three-product f16 split on the matrix "
+            "cores, fp32 accumulation -- ND_CONV_F16X3=1)" if f16x3 else "f32")
 
 
 def other_form_leg(a, sd, dev, cond, B, S, T, n_sample_steps):
-    """The same K steps with the OTHER product form of the 3x3 convolutions, in the same process and on the same box: the default line computes them on the fp32
-    MFMA (`dtype` f32); nd_conv3x3_wino4h_nhwc_f32 computes the F(4x4) position products as V1 U1 + V1 U2 + V2 U1 on the f16 matrix instruction with fp32
-    accumulation (operands split into two f16 terms: 22 significant bits; measured error against an fp64 convolution equal to the fp32 kernel's -- DESIGN section 8).
+    """The same K steps with the OTHER product form of the matrix products, in the same process and on the same box: the default line computes them on the fp32
+    MFMA (`dtype` f32); with ND_CONV_F16X3=1 the F(4x4) position products (nd_conv3x3_wino4h_nhwc_f32), the wide 1x1 layers (nd_pointwise_gemm_f16x3_nhwc_f32) and
+    the fused chains (nd_pointwise_chain_f16x3_nhwc_f32) run as a1 b1 + a1 b2 + a2 b1 on the f16 matrix instruction with fp32 accumulation (operands split into two
+    f16 terms: 22 significant bits; measured error against fp64 at or below the fp32 kernels' -- DESIGN section 8).
     Reported beside `value`, never as `value`: whether that form may carry the headline is the reviewer's call."""
     from noisediff_amd import GaussianDiffusion, NoiseDiffNet, engine as E
     from noisediff_amd.diffusion import _Loop
-    saved = E.CONV_F16X3
-    E.CONV_F16X3 = not saved
+    saved = E.set_f16x3(not E.CONV_F16X3)
     try:
         net = NoiseDiffNet(SimpleNamespace(dim=a.dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, mid_attn=a.mid_attn))
         net.load_state_dict(sd, strict=True)
@@ -446,14 +447,14 @@ def other_form_leg(a, sd, dev, cond, B, S, T, n_sample_steps):
         plan.e.sync()
         torch.cuda.synchronize(dev)
         per_step = (time.perf_counter() - t0) / a.steps
-        n_f16 = sum(1 for op in plan.step_ops if op[2] == "nd_conv3x3_wino4h_nhwc_f32")
+        n_f16 = {k.replace("nd_", "").replace("_nhwc_f32", ""): sum(1 for op in plan.step_ops if op[2] == k) for k in E.F16X3_ENTRIES}
         loop.destroy()
         return {"form": _dtype_label(E.CONV_F16X3), "ms_per_step": per_step * 1e3, "value": B / (n_sample_steps * per_step), "unit": "patches/s",
-                "conv3x3_launches_on_the_f16_split_kernel": n_f16, "steps": a.steps,
-                "note": "same process, same box, after the default leg; select with ND_CONV_F16X3=0|1; parity: tests/test_hip_kernels.py::test_conv3x3_wino4h_* and the "
-                        "whole GPU suite passes with either form at unchanged tolerances"}
+                "launches_per_step_on_f16_split_kernels": n_f16, "steps": a.steps,
+                "note": "same process, same box, after the default leg; select with ND_CONV_F16X3=0|1; parity: tests/test_hip_kernels.py (wino4h, f16x3 forms of "
+                        "the pointwise / chain tests) and the whole GPU suite passes with either form at unchanged tolerances"}
     finally:
-        E.CONV_F16X3 = saved
+        E.set_f16x3(saved)
 
 
 def main():

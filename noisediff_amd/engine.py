@@ -76,6 +76,20 @@ DIRECT_F16X3_MAX_CIN = int(os.environ.get("ND_CONV_DIRECT_F16X3", "0")) if CONV_
 PW_F16X3 = CONV_F16X3 and os.environ.get("ND_PW_F16X3", "1") != "0"
 # ... and the fused Mlp / AttnBlock chains of the 48- and 64-channel stages (nd_pointwise_chain_f16x3_nhwc_f32, pwchain.hip); ND_CHAIN_F16X3=0: A/B knob
 CHAIN_F16X3 = CONV_F16X3 and os.environ.get("ND_CHAIN_F16X3", "1") != "0"
+
+
+def set_f16x3(on: bool) -> bool:
+    """Switch the opt-in f16-split product form (ND_CONV_F16X3) for engines built FROM NOW ON, the A/B knobs of its parts (ND_PW_F16X3, ND_CHAIN_F16X3,
+    ND_CONV_DIRECT_F16X3) kept; returns the previous setting.  bench.py times both forms in one process with it."""
+    global CONV_F16X3, PW_F16X3, CHAIN_F16X3, DIRECT_F16X3_MAX_CIN
+    prev, CONV_F16X3 = CONV_F16X3, bool(on)
+    PW_F16X3 = CONV_F16X3 and os.environ.get("ND_PW_F16X3", "1") != "0"
+    CHAIN_F16X3 = CONV_F16X3 and os.environ.get("ND_CHAIN_F16X3", "1") != "0"
+    DIRECT_F16X3_MAX_CIN = int(os.environ.get("ND_CONV_DIRECT_F16X3", "0")) if CONV_F16X3 else 0
+    return prev
+
+
+F16X3_ENTRIES = ("nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_pointwise_gemm_f16x3_nhwc_f32", "nd_pointwise_chain_f16x3_nhwc_f32")
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)

@@ -3,6 +3,8 @@
 sampler against the CPU oracle on identical weights, conditions, x_T and per-step noise (the explicit-noise parity mode of
 GaussianDiffusion.sample).  The committed goldens cover 50-step DDIM and 20-step DDPM; this shows what 1000 chained steps do to
 the difference.  Takes several minutes of host time (the oracle runs ~0.4 s per step); progress is printed every 50 steps.
+r4c: BOTH product forms of the matrix products against the ONE oracle run -- the default fp32 MFMAs and the opt-in three-product f16 split (ND_CONV_F16X3=1: F(4x4)
+position products, wide 1x1 layers, fused chains) -- so the two errors are on the same trajectory, noise and host.
 usage: python tools/parity_full_length.py [--size 256] [--steps 1000] [--dim 64] -> gpurun_out/parity_full_length.json"""
 import argparse, json, os, sys, time
 from types import SimpleNamespace
@@ -10,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np
 import torch
-from noisediff_amd import GaussianDiffusion, NoiseDiffNet, synth
+from noisediff_amd import GaussianDiffusion, NoiseDiffNet, synth, engine as E
 from noisediff_amd.spec import noisediff_param_spec
 from oracle import noisediff_oracle as O
 
@@ -26,36 +28,44 @@ cond = synth.make_condition(B, S, seed=1)
 x_T = synth.make_noise(2, "x_T", B, 4, S)
 steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, S) for i in range(T - 1)])
 
-net = NoiseDiffNet(SimpleNamespace(dim=a.dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False))
-net.load_state_dict(sd, strict=True)
-net = net.to(dev).eval()
-gd = GaussianDiffusion(net, image_size=S, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
-t0 = time.time()
-with torch.inference_mode():
-    traj = gd.sample(batch_size=B, condition={k: v.to(dev) for k, v in cond.items()}, return_all_timesteps=True,
-                     noise={"x_T": x_T, "steps": steps}).cpu()            # (B, T+1, C, H, W)
-print(f"HIP sampler: {time.time() - t0:.1f} s", flush=True)
+trajs = {}
+for form, on in (("fp32", False), ("f16x3", True)):
+    E.set_f16x3(on)
+    net = NoiseDiffNet(SimpleNamespace(dim=a.dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    gd = GaussianDiffusion(net, image_size=S, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+    t0 = time.time()
+    with torch.inference_mode():
+        trajs[form] = gd.sample(batch_size=B, condition={k: v.to(dev) for k, v in cond.items()}, return_all_timesteps=True,
+                                noise={"x_T": x_T, "steps": steps}).cpu()            # (B, T+1, C, H, W)
+    n_f16 = sum(1 for op in net.hip_engine(dev).plan(B, S, S).step_ops if op[2] in E.F16X3_ENTRIES)
+    print(f"HIP sampler ({form}: {n_f16} launches per step on f16-split kernels): {time.time() - t0:.1f} s", flush=True)
+    del gd, net
+E.set_f16x3(False)
 
 buf = O.schedule_buffers("sigmoid2", T, "pred_v")
-errs, t0 = {}, time.time()
+errs, t0 = {f: {} for f in trajs}, time.time()
 state = {"k": 0}
 
 def on_step(t, img, out):
     k = state["k"]                                    # img is the oracle's x_t before step k (k = 0: x_T)
     ref = img.numpy()
-    e = float(np.max(np.abs(traj[:, k].numpy() - ref)) / max(1.0, float(np.max(np.abs(ref)))))
-    errs[k] = e
+    for f, traj in trajs.items():
+        errs[f][k] = float(np.max(np.abs(traj[:, k].numpy() - ref)) / max(1.0, float(np.max(np.abs(ref)))))
     if k % 50 == 0:
-        print(f"step {k:4d} (t={t:3d}): rel err of x_t {e:.3e}   [{time.time() - t0:.0f} s]", flush=True)
+        print(f"step {k:4d} (t={t:3d}): rel err of x_t " + ", ".join(f"{f} {errs[f][k]:.3e}" for f in trajs) + f"   [{time.time() - t0:.0f} s]", flush=True)
     state["k"] = k + 1
 
 with torch.no_grad():
     ref = O.p_sample_loop(lambda v, tt: O.noisediff_forward(sd, v, tt, cond), buf, "pred_v", x_T, lambda i, shape: steps[i],
                           on_step=on_step)
-final = float(np.max(np.abs(traj[:, -1].numpy() - ref.numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
-res = {"config": f"d={a.dim}, {S}x{S}x4, {T}-step DDPM, B=1, explicit noise", "final_rel_err": final,
-       "max_rel_err_over_trajectory": max(errs.values()), "rel_err_every_100_steps": {str(k): errs[k] for k in sorted(errs) if k % 100 == 0},
-       "tolerance": 1e-3, "oracle_seconds": time.time() - t0}
+res = {"config": f"d={a.dim}, {S}x{S}x4, {T}-step DDPM, B=1, explicit noise", "tolerance": 1e-3, "oracle_seconds": time.time() - t0, "forms": {}}
+for f, traj in trajs.items():
+    final = float(np.max(np.abs(traj[:, -1].numpy() - ref.numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
+    res["forms"][f] = {"final_rel_err": final, "max_rel_err_over_trajectory": max(errs[f].values()),
+                       "rel_err_every_100_steps": {str(k): errs[f][k] for k in sorted(errs[f]) if k % 100 == 0}}
+res["fp32_vs_f16x3_final_rel_diff"] = float(np.max(np.abs(trajs["fp32"][:, -1].numpy() - trajs["f16x3"][:, -1].numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(REPO, "gpurun_out", "parity_full_length.json"), "w"), indent=1)
-print(json.dumps(res), flush=True)
+print(json.dumps(res["forms"], indent=1))
