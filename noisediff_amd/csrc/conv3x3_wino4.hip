@@ -499,7 +499,8 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w1), "v"(v.x));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w1), "v"(v.y));
         *reinterpret_cast<unsigned*>(dst) = w1;
-        *reinterpret_cast<unsigned*>(dst + 8) = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));          // the exact remainders, rounded to nearest (v_cvt_pk_f16_f32; nd_split4_f16: a truncated second term biases every operand one way)
+        *reinterpret_cast<unsigned*>(dst + 8) = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, h2v));
 #endif
     };
     auto xf_finish = [&](f32x2 (&T)[6][6], float* buf, auto&& before_write) {

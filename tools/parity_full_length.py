@@ -19,6 +19,8 @@ from oracle import noisediff_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=256); ap.add_argument("--steps", type=int, default=1000)
 ap.add_argument("--dim", type=int, default=64); ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--oracle-dtype", choices=["f32", "f64"], default="f32",
+                help="f64: the oracle's arithmetic in float64 (torch default dtype) -- the yardstick that shares no rounding with either product form; about twice the host time")
 a = ap.parse_args()
 torch.set_num_threads(a.threads)
 dev = torch.device("cuda", 0)
@@ -44,28 +46,33 @@ for form, on in (("fp32", False), ("f16x3", True)):
     del gd, net
 E.set_f16x3(False)
 
+odt = torch.float64 if a.oracle_dtype == "f64" else torch.float32
+torch.set_default_dtype(odt)
+conv = lambda d: {k: (v.to(odt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
 buf = O.schedule_buffers("sigmoid2", T, "pred_v")
+buf = conv(buf) if isinstance(buf, dict) else buf
+sd_o, cond_o = conv(sd), conv(cond)
 errs, t0 = {f: {} for f in trajs}, time.time()
 state = {"k": 0}
 
 def on_step(t, img, out):
     k = state["k"]                                    # img is the oracle's x_t before step k (k = 0: x_T)
-    ref = img.numpy()
+    ref = img.double().numpy()
     for f, traj in trajs.items():
-        errs[f][k] = float(np.max(np.abs(traj[:, k].numpy() - ref)) / max(1.0, float(np.max(np.abs(ref)))))
+        errs[f][k] = float(np.max(np.abs(traj[:, k].double().numpy() - ref)) / max(1.0, float(np.max(np.abs(ref)))))
     if k % 50 == 0:
         print(f"step {k:4d} (t={t:3d}): rel err of x_t " + ", ".join(f"{f} {errs[f][k]:.3e}" for f in trajs) + f"   [{time.time() - t0:.0f} s]", flush=True)
     state["k"] = k + 1
 
 with torch.no_grad():
-    ref = O.p_sample_loop(lambda v, tt: O.noisediff_forward(sd, v, tt, cond), buf, "pred_v", x_T, lambda i, shape: steps[i],
-                          on_step=on_step)
-res = {"config": f"d={a.dim}, {S}x{S}x4, {T}-step DDPM, B=1, explicit noise", "tolerance": 1e-3, "oracle_seconds": time.time() - t0, "forms": {}}
+    ref = O.p_sample_loop(lambda v, tt: O.noisediff_forward(sd_o, v, tt, cond_o), buf, "pred_v", x_T.to(odt), lambda i, shape: steps[i].to(odt),
+                          on_step=on_step).double()
+res = {"config": f"d={a.dim}, {S}x{S}x4, {T}-step DDPM, B=1, explicit noise", "oracle_arithmetic": a.oracle_dtype, "tolerance": 1e-3, "oracle_seconds": time.time() - t0, "forms": {}}
 for f, traj in trajs.items():
-    final = float(np.max(np.abs(traj[:, -1].numpy() - ref.numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
+    final = float(np.max(np.abs(traj[:, -1].double().numpy() - ref.numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
     res["forms"][f] = {"final_rel_err": final, "max_rel_err_over_trajectory": max(errs[f].values()),
                        "rel_err_every_100_steps": {str(k): errs[f][k] for k in sorted(errs[f]) if k % 100 == 0}}
 res["fp32_vs_f16x3_final_rel_diff"] = float(np.max(np.abs(trajs["fp32"][:, -1].numpy() - trajs["f16x3"][:, -1].numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(REPO, "gpurun_out", "parity_full_length.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(REPO, "gpurun_out", f"parity_full_length{'_f64_oracle' if a.oracle_dtype == 'f64' else ''}.json"), "w"), indent=1)
 print(json.dumps(res["forms"], indent=1))
