@@ -36,6 +36,7 @@ for c in "" "--config cfg2" "--config cfg4" "--config ref48"; do
   n=$(echo "${c:-default}" | sed 's/--config //')
   ND_CONV_F16X3=1 python bench.py $c --no-cpu --no-alt --steps 20 > gpurun_out/${T}_bench_${n}_f16x3.jsonl 2>/dev/null
 done
+ND_CONV_F16X3=1 python bench.py --full --steps 1 --warmup 0 --no-cpu --no-alt --no-roofline > gpurun_out/${T}_bench_full_f16x3.jsonl 2>/dev/null
 ND_CONV_F16X3=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}h -- python3 bench.py --steps 5 --warmup 1 --soak-s 0 --no-cpu --no-alt --no-roofline > gpurun_out/prof_${T}h.log 2>&1
 cp $(ls gpurun_out/prof_${T}h/*/*kernel_stats.csv | head -1) gpurun_out/${T}_rocprofv3_kernel_stats_bench_steps5_f16x3.csv
 rm -rf gpurun_out/prof_${T}h
