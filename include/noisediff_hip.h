@@ -300,7 +300,9 @@ int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cou
  * a layer it does not accept is an error (ND_E_SHAPE), never a silent change of kernel. */
 int nd_pointwise_gemm_f16x3_nhwc_f32(const nd_pointwise* d, void* stream);
 int nd_pointwise_gemm_f16x3_takes(const nd_pointwise* d);
-int nd_pack_pointwise_weight_h(const float* w, float* packed, int cin, int cout, void* stream);
+/* `layernorm_source`: 1 for a layer that is read through the ND_PRO_LAYERNORM prologue (FeedForward's first Linear) -- those run the K = 8 form of the kernel and its
+ * packing, every other prologue the K = 16 form (v_mfma_f32_32x32x16_f16); a weight packed for one and used with the other computes garbage, so the caller keeps them apart. */
+int nd_pack_pointwise_weight_h(const float* w, float* packed, int cin, int cout, int layernorm_source, void* stream);
 
 /* ------------------------------------------------------------------ chained pointwise layers
  * Two or three per-pixel Linear layers in one kernel, the intermediate activations never leaving registers:

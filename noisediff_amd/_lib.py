@@ -128,7 +128,7 @@ SIGNATURES = {
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
     "nd_pointwise_gemm_f16x3_nhwc_f32": (i32, [C.POINTER(Pointwise), vp]),
     "nd_pointwise_gemm_f16x3_takes": (i32, [C.POINTER(Pointwise)]),
-    "nd_pack_pointwise_weight_h": (i32, [vp, vp, i32, i32, vp]),
+    "nd_pack_pointwise_weight_h": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
     "nd_groupnorm_finalize_train_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),

@@ -348,6 +348,13 @@ constexpr int BKC = 64, BLDA = BKC + 4;
 // and their size: {first terms ch0..3 | second terms ch0..3}.  The split of the activations happens in stage_write (v_cvt_pkrtz + v_fma_mix_f32: the
 // remainder is exact; nd_split4_f16); the weights are split by nd_pack_pointwise_weight_h; the epilogue multiplies by 2^-11.
 #define PWB_MFMA_H(acc, av, bv) asm volatile("v_mfma_f32_32x32x8_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+// ... and on the double-rate instruction (r4c, PWH_K16): v_mfma_f32_32x32x16_f16 contracts 16 channels in the same 32 cycles (tools/microbench/f16_mfma_32x32.hip); a lane then
+// holds 8 consecutive channels of an operand term, so a 16-channel group of the A tile is 64 bytes per pixel {A1 ch0..7 | A1 ch8..15 | A2 ch0..7 | A2 ch8..15} (written as two 8-byte
+// pieces per staged quad) and the packed weight is [cin/16][term][channel half][coutP] x 16 bytes.
+#define PWB_MFMA_H16(acc, av, bv) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
+#ifndef PWH_K16
+#define PWH_K16 1
+#endif
 #ifndef PWH_RS
 #define PWH_RS 4             // weight-fragment ring of the f16 form: slots (a power of two); PWH_RS - 1 groups of 8 channels in flight
 #endif
@@ -356,7 +363,11 @@ constexpr int BKC = 64, BLDA = BKC + 4;
 #endif
 template <int NB, int MODE, bool HF = false>
 __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
-    constexpr int RS = HF ? PWH_RS : 4, RD = RS - 1;          // weight ring: slots, groups ahead     // (218 registers at NB = 2: two workgroups still share a CU)
+    constexpr int RS = HF ? PWH_RS : 4, RD = RS - 1;          // weight ring: slots, groups ahead
+    // f16 form on the double-rate instruction: groups of 16 channels, both terms as separate operands.  Not under the LayerNorm prologue: with the row statistics and the
+    // gamma / beta / vector constants live it needs 288 registers (one workgroup per CU: measured slower than the K = 8 form), so those layers keep the K = 8 form and packing
+    constexpr bool K16 = HF && PWH_K16 && MODE != ND_PRO_LAYERNORM;
+    constexpr int NT = K16 ? 2 : 1;     // (218 registers at NB = 2: two workgroups still share a CU)
     constexpr int MB = 2, BM = 2 * MB * 32;                   // 128 pixels
     constexpr int SIT = BM / 16;                              // staging passes: 128 rows x 16 channel quads / 256 threads
     constexpr int ABUF = BM * BLDA;
@@ -406,17 +417,22 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
         }
     }
 
-    f32x4 bq[RS][NB], av[2][MB], raw[SIT];
+    f32x4 bq[RS][NB][NT], av[2][MB][NT], raw[SIT];
     f32x4 pA, pB, pC;                                          // per-chunk channel constants of the prologue
     auto load_b = [&](int slot, int cb, int g) {               // weight fragments of channels cb + 8g .. + 7
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            bq[slot & (RS - 1)][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                wrsrc, wvoff, __builtin_amdgcn_readfirstlane((((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 16), 0));
+#pragma unroll
+            for (int term = 0; term < NT; ++term)             // (K16: g counts 16-channel groups, a fragment per term)
+                bq[slot & (RS - 1)][nb][term] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, wvoff, __builtin_amdgcn_readfirstlane(K16 ? ((((cb >> 4) + g) * 2 + term) * 2 * a.coutP + nb * 32) * 16
+                                                                        : (((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 16), 0));
     };
     auto load_a = [&](int slot, const float* src, int g) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) av[slot & 1][mb] = nd_ld4(&src[a_off[mb] + g * 8]);
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int term = 0; term < NT; ++term) av[slot & 1][mb][term] = nd_ld4(&src[a_off[mb] + (K16 ? g * 16 + term * 8 : g * 8)]);
     };
     auto stage_load = [&](int cb) {
         const bool sec = cb >= s.c0;                          // wave-uniform: a 64-channel chunk never straddles the sources (host check)
@@ -451,6 +467,11 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
             const f32x4 zero = {0, 0, 0, 0};
             v = (p0 + r < HW) ? v : zero;
             if (HF) v = nd_split4_f16(v);
+            if (K16) {                                        // quad -> (group of 16, channel half, low / high four): 8 bytes of first terms, 8 of second terms
+                float* p = &dst[r * BLDA + (quad >> 2) * 16 + ((quad >> 1) & 1) * 4 + (quad & 1) * 2];
+                *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
+                *reinterpret_cast<f32x2*>(p + 8) = f32x2{v.z, v.w};
+            } else
             nd_st4(&dst[r * BLDA + quad * 4], v);
         }
     };
@@ -472,6 +493,24 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
         float* nxt = Ab + ((c + 1) & 1) * ABUF;
         const int cb = c * BKC, cbn = (c + 1 < n_chunks ? c + 1 : c) * BKC;      // behind the last chunk: a harmless re-stage of it
         load_a(0, cur, 0);
+        if (K16) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                      // groups of 16 channels: 12 MFMAs of 32 cycles each
+                if (g + RD < 4) load_b(g + RD, cb, g + RD); else load_b(g + RD, cbn, g + RD - 4);
+                if (g + 1 < 4) load_a(g + 1, cur, g + 1);
+                if (g == 0) stage_load(cbn);
+                if (g == 2) stage_write(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int term = 0; term < 3; ++term)             // A1 W1, A1 W2, A2 W1
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            PWB_MFMA_H16(acc[mb][nb], av[g & 1][mb][term == 2 ? NT - 1 : 0], bq[g & (RS - 1)][nb][term == 1 ? NT - 1 : 0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             // (no branch between a load and the MFMAs it overlaps, see above; sched_barriers pin load / MFMA order)
@@ -487,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            const f32x4 av4 = av[g & 1][mb], bv4 = bq[g & (RS - 1)][nb];
+                            const f32x4 av4 = av[g & 1][mb][0], bv4 = bq[g & (RS - 1)][nb][0];
                             const f32x2 a1 = {av4.x, av4.y}, a2 = {av4.z, av4.w}, b1 = {bv4.x, bv4.y}, b2 = {bv4.z, bv4.w};
                             if (term == 0) PWB_MFMA_H(acc[mb][nb], a1, b1);
                             else if (term == 1) PWB_MFMA_H(acc[mb][nb], a1, b2);
@@ -499,9 +538,10 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) PWB_MFMA(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
+                        for (int nb = 0; nb < NB; ++nb) PWB_MFMA(acc[mb][nb], av[g & 1][mb][0][k], bq[g & 3][nb][0][k]);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         __syncthreads();                                       // the other buffer is complete, this one has been consumed
     }
@@ -713,12 +753,31 @@ __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __rest
     }
 }
 
-// (cout, cin) -> [cinP/4][coutP] slots of 16 bytes: 2^11 w of the slot's four channels as two f16 terms {W1 ch0..3 | W2 ch0..3} (pointwise_big_kernel<.., HF>)
-__global__ void pack_pointwise_h_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int cinP, int coutP) {
+// (cout, cin) -> 2^11 w as two f16 terms in the operand order of pointwise_big_kernel<.., HF>.  k16 (the double-rate instruction: every prologue but LayerNorm):
+// [cinP/16][term 2][channel half 2][coutP] slots of 16 bytes = 8 consecutive channels of one term; else (K = 8: the layers read through a LayerNorm prologue)
+// [cinP/4][coutP] slots {W1 ch0..3 | W2 ch0..3}
+__global__ void pack_pointwise_h_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int cinP, int coutP, int k16) {
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
     const size_t total = (size_t)(cinP / 4) * coutP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int n = i % coutP, q = i / coutP;
+        const int n = i % coutP;
+        if (k16) {
+        size_t r = i / coutP;
+        const int h = r & 1, term = (r >> 1) & 1, G = (int)(r >> 2);
+        _Float16 t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = G * 16 + h * 8 + e;
+            const float u = (n < cout && k < cin) ? w[(size_t)n * cin + k] * 2048.0f : 0.0f;
+            const _Float16 h1 = (_Float16)fminf(fmaxf(u, -65504.0f), 65504.0f);           // (a weight beyond 32 saturates the first term; the remainder carries on)
+            t[e] = term ? (_Float16)fminf(fmaxf(u - (float)h1, -65504.0f), 65504.0f) : h1;
+        }
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, h2v{t[2 * e], t[2 * e + 1]});
+        nd_st4(out + i * 4, v);
+        } else {
+        const int q = i / coutP;
         _Float16 h1[4], h2[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -731,6 +790,7 @@ __global__ void pack_pointwise_h_kernel(const float* __restrict__ w, float* __re
         v.x = __builtin_bit_cast(float, h2v{h1[0], h1[1]});  v.y = __builtin_bit_cast(float, h2v{h1[2], h1[3]});
         v.z = __builtin_bit_cast(float, h2v{h2[0], h2[1]});  v.w = __builtin_bit_cast(float, h2v{h2[2], h2[3]});
         nd_st4(out + i * 4, v);
+        }
     }
 }
 
@@ -918,12 +978,12 @@ extern "C" int nd_pointwise_gemm_f16x3_nhwc_f32(const nd_pointwise* d, void* str
 // (a sample's bits must not depend on the batch it is sharded into); no pointer is dereferenced.
 extern "C" int nd_pointwise_gemm_f16x3_takes(const nd_pointwise* d) { return d && pw_big_tiles(d, true) > 0 ? 1 : 0; }
 
-extern "C" int nd_pack_pointwise_weight_h(const float* w, float* packed, int cin, int cout, void* stream) {
+extern "C" int nd_pack_pointwise_weight_h(const float* w, float* packed, int cin, int cout, int layernorm_source, void* stream) {
     ND_REQUIRE(w && packed, ND_E_BADARG, "nd_pack_pointwise_weight_h: null pointer");
     ND_REQUIRE(cin > 0 && cout > 0, ND_E_BADARG, "nd_pack_pointwise_weight_h: non-positive size");
     const int cinP = nd_round_up(cin, 8), coutP = nd_round_up(cout, 64);
     const size_t total = (size_t)(cinP / 4) * coutP;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_pointwise_h_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, cinP, coutP);
+    hipLaunchKernelGGL(pack_pointwise_h_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, cinP, coutP, (PWH_K16 && !layernorm_source) ? 1 : 0);
     return nd_launch_status("nd_pack_pointwise_weight_h");
 }

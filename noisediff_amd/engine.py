@@ -289,7 +289,8 @@ class Engine:
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
                     if p.name + ".h" in self.slots:
-                        L.call("nd_pack_pointwise_weight_h", t.data_ptr(), self.p(p.name + ".h"), p.shape[1], p.shape[0], st)
+                        # (the layers read through a LayerNorm prologue -- FeedForward's first Linear -- have their own operand order: pw() checks the pairing)
+                        L.call("nd_pack_pointwise_weight_h", t.data_ptr(), self.p(p.name + ".h"), p.shape[1], p.shape[0], int(p.name.endswith(_CHAIN_FIRST[0])), st)
                     if p.name + ".blk16" in self.slots:
                         perm = _blocked_map_rows(p.shape[0] // 2).to(self.device)
                         tp = t[perm].contiguous()
@@ -620,7 +621,8 @@ class Plan:
         if gn_t is not None:
             d.gn_t, d.ldt, d.gn_mad = gn_t.data_ptr(), gn_t.shape[-1], gn_mad.data_ptr()
         entry = "nd_pointwise_gemm_nhwc_f32"
-        if not variant and (name + ".weight.h") in e.slots and e.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d)):      # opt-in (CONV_F16X3): the wide layers' products as f16 splits
+        if (not variant and (name + ".weight.h") in e.slots and e.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d))
+                and (src.mode == L.PRO_LAYERNORM) == (name + ".weight").endswith(_CHAIN_FIRST[0])):      # opt-in (CONV_F16X3): the wide layers' products as f16 splits; the packing matches the prologue
             d.weight, entry = e.p(name + ".weight.h"), "nd_pointwise_gemm_f16x3_nhwc_f32"
         self._add(entry, C.byref(d), e.stream, meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout})
         self._keep.append(d)

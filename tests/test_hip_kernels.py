@@ -389,7 +389,8 @@ def test_pointwise_large_tile_kernel(ctx, form):
     ctx.sync()
     s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
     ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
-    assert rel_err(pwf(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
+    wpl = hu.pack_pw(ctx, w, f16x3=form == "f16x3", layernorm_source=True)      # (f16x3: a layer behind the LayerNorm prologue has its own operand order)
+    assert rel_err(pwf(ctx, s, wpl, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
     # epilogue operands: two residuals, a per-sample vector, the fused ResnetBlock tail silu(GroupNorm-affine(t))
     r0, r1, ov, t = U("big.r0", (B, HW, cout)), U("big.r1", (B, HW, cout)), U("big.ov", (B, cout)), U("big.t", (B, HW, cout), -1.5, 1.5)
     tm = U("big.tm", (B, 3, cout), 0.5, 1.5)
@@ -418,7 +419,8 @@ def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout, form):
         ctx.sync()
         s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
         ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
-        assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU, entry=PW_FORMS[form]).cpu(), ref) < TOL
+        wpl = hu.pack_pw(ctx, w, f16x3=form == "f16x3", layernorm_source=True)
+        assert rel_err(hu.pointwise(ctx, s, wpl, bd, B, HW, W, cin, cout, act=L.ACT_GELU, entry=PW_FORMS[form]).cpu(), ref) < TOL
     r0, ov = U(f"c4pw.r0.{cout}", (B, HW, cout)), U(f"c4pw.ov.{cout}", (B, cout))
     out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), vec=hu.dev(ov), entry=PW_FORMS[form])
     assert rel_err(out.cpu(), lin + r0 + ov[:, None]) < TOL

@@ -25,7 +25,7 @@ for (HW, cin, cout, c0, ln, res) in LAYERS:
     x = torch.randn(B, HW, cin, generator=g); w = torch.randn(cout, cin, generator=g) / cin ** 0.5; b = torch.randn(cout, generator=g)
     xd, wp, bd = hu.dev(x), hu.pack_pw(ctx, w), hu.dev(b)
     wh = torch.empty_like(wp); wdev = hu.dev(w)
-    L.call("nd_pack_pointwise_weight_h", wdev.data_ptr(), wh.data_ptr(), cin, cout, ctx.stream); ctx.sync()
+    L.call("nd_pack_pointwise_weight_h", wdev.data_ptr(), wh.data_ptr(), cin, cout, int(bool(ln)), ctx.stream); ctx.sync()
     x64, w64, b64 = xd.double(), wdev.double(), bd.double()          # fp64 reference on the device, from the operands the kernel reads
     r = torch.randn(B, HW, cout, generator=g) if res else None
     rd = hu.dev(r) if res else None
