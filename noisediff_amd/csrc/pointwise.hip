@@ -365,7 +365,9 @@ template <int NB, int MODE, bool HF = false>
 __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
     constexpr int RS = HF ? PWH_RS : 4, RD = RS - 1;          // weight ring: slots, groups ahead
     // f16 form on the double-rate instruction: groups of 16 channels, both terms as separate operands.  Not under the LayerNorm prologue: with the row statistics and the
-    // gamma / beta / vector constants live it needs 288 registers (one workgroup per CU: measured slower than the K = 8 form), so those layers keep the K = 8 form and packing
+    // gamma / beta / vector constants live it needs 288 registers (one workgroup per CU: measured slower than the K = 8 form; with a two-slot weight ring it fits 256 and is
+    // 10-20 % faster, but produced sporadic wrong pixel rows at B = 16 that the K = 8 form and the four-slot ring never show -- not understood, not kept), so those layers
+    // keep the K = 8 form and packing
     constexpr bool K16 = HF && PWH_K16 && MODE != ND_PRO_LAYERNORM;
     constexpr int NT = K16 ? 2 : 1;     // (218 registers at NB = 2: two workgroups still share a CU)
     constexpr int MB = 2, BM = 2 * MB * 32;                   // 128 pixels
