@@ -731,6 +731,61 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     pw_epilogue<MB, NB>(a, acc, As, b, p0, n0);
 }
 
+// ---- narrow outputs (cout <= 8: final_conv, Diffusion_arch.py:554 -- 64 -> 4 at full resolution): on the MFMA tiles 60 of 64 output columns are padding and the layer
+// runs at the padded product's rate (123 us at 256 x 256 x 16, 2.3 TB/s); here it is a streaming dot product on the VALU.  Four lanes share a pixel: lane part p reads
+// the channel quads p, p + 4, ... (the four lanes of a pixel read 64 contiguous bytes per step), keeps CO partial sums (fmaf chains), the four parts are added with two
+// DPP steps and lane 0 of the quad applies bias / activation / residuals and stores.  Weights [cin/4][CO][4] in LDS (<= 32 KB), read as broadcasts.
+template <int CO>
+__global__ __launch_bounds__(256) void pointwise_narrow_kernel(const PwArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[256 * 8 * 4];
+    const int tid = threadIdx.x, part = tid & 3;
+    const nd_src& s = a.d.src;
+    const int nq = a.d.cin >> 2, cout = a.d.cout;
+    for (int i = tid; i < nq * CO; i += 256) {
+        const int kq = i / CO, n = i - kq * CO;
+        const f32x4 zero = {0, 0, 0, 0};
+        nd_st4(wl + i * 4, n < cout ? nd_ld4(a.d.weight + ((size_t)kq * a.coutP + n) * 4) : zero);
+    }
+    __syncthreads();
+    const long P = (long)a.d.B * a.d.HW;
+    for (long base = (long)blockIdx.x * 64; base < P; base += (long)gridDim.x * 64) {
+        const long pix = base + (tid >> 2), pc = pix < P ? pix : P - 1;      // (clamped: every lane takes part in the DPP steps)
+        float acc[CO];
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[n] = 0.0f;
+        const float* r0 = s.p0 + pc * s.ld0;
+        const float* r1 = s.p1 ? s.p1 + pc * s.ld1 - s.c0 : r0;
+#pragma unroll 4
+        for (int kq = part; kq < nq; kq += 4) {
+            const int c = kq * 4;
+            const f32x4 x = nd_ld4((c < s.c0 ? r0 : r1) + c);
+#pragma unroll
+            for (int n = 0; n < CO; ++n) {
+                const f32x4 w = nd_ld4(wl + (kq * CO + n) * 4);
+                acc[n] = fmaf(x.w, w.w, fmaf(x.z, w.z, fmaf(x.y, w.y, fmaf(x.x, w.x, acc[n]))));
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < CO; ++n) {                        // parts 0 + 1, 2 + 3, then the two pairs (quad_perm [1 0 3 2], [2 3 0 1])
+            acc[n] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[n]), 0xB1, 0xF, 0xF, true));
+            acc[n] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[n]), 0x4E, 0xF, 0xF, true));
+        }
+        if (part == 0 && pix < P) {
+#pragma unroll
+            for (int q = 0; q < CO / 4; ++q) {
+                if (q * 4 >= cout) break;
+                f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                if (a.d.bias) v += nd_ld4(a.d.bias + 4 * q);
+                if (a.d.act == ND_ACT_GELU) v = nd_gelu4(v);
+                else if (a.d.act == ND_ACT_SILU) v = nd_silu4(v);
+                if (a.d.res0) v += nd_ld4(a.d.res0 + pix * a.d.ldr0 + 4 * q);
+                if (a.d.res1) v += nd_ld4(a.d.res1 + pix * a.d.ldr1 + 4 * q);
+                nd_st4(a.d.out + pix * a.d.ldo + 4 * q, v);
+            }
+        }
+    }
+}
+
 // (cout, cin) -> [cinP/4][coutP][4], optional K permutation for pixel-unshuffled inputs
 // transposed: `w` is (cin, cout) row-major -- the forward weight of the Linear whose DATA gradient dx = dy @ W this packing serves
 __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __restrict__ out,
@@ -946,6 +1001,16 @@ int pw_run(const nd_pointwise* d, void* stream, bool hf) {
     ND_REQUIRE(wg < (1L << 31), ND_E_SHAPE, "nd_pointwise: grid too large");
     a.total_wg = (int)wg;
     hipStream_t st = (hipStream_t)stream;
+    // narrow outputs: a streaming dot product instead of an MFMA tile that is 15/16 padding (geometry only; A/B knob ND_PW_NARROW=0, tools/ only)
+    static const bool use_narrow = !(getenv("ND_PW_NARROW") && atoi(getenv("ND_PW_NARROW")) == 0);
+    if (!hf && use_narrow && d->cout <= 8 && d->cout % 4 == 0 && d->cin <= 1024 && s.mode == ND_PRO_NONE && !s.unshuffle && d->shuffle_c == 0 && !d->gn_t && !d->vec &&
+        (s.c1 == 0 || nd_aligned16(s.p1))) {
+        const long blocks = ((long)d->B * d->HW + 63) / 64;
+        const int grid = (int)(blocks < 8L * nd_device_cus() ? blocks : 8L * nd_device_cus());
+        if (d->cout <= 4) hipLaunchKernelGGL((pointwise_narrow_kernel<4>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pointwise_narrow_kernel<8>), dim3(grid), dim3(256), 0, st, a);
+        return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
+    }
     const bool pipe = pw_pipe_takes(d);
     const long tiles = pw_big_tiles(d, hf);
     ND_REQUIRE(!hf || tiles > 0, ND_E_SHAPE, "nd_pointwise_gemm_f16x3: the layer is not one of the 128-pixel-tile kernel's (ask nd_pointwise_gemm_f16x3_takes first)");

@@ -208,6 +208,31 @@ def test_pointwise_plain_and_epilogues(ctx, case):
     assert rel_err(out.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("cin,cout,c0", [(64, 4, 0), (64, 8, 0), (128, 4, 64), (24, 4, 0), (256, 8, 128)])
+def test_pointwise_narrow_outputs_streaming_kernel(ctx, cin, cout, c0):
+    """cout <= 8 (final_conv, Diffusion_arch.py:554: 64 -> 4): nd_pointwise_gemm_nhwc_f32 runs a streaming dot product (four lanes per pixel) instead of an MFMA tile
+    that is 15/16 padding.  Plain + bias, a virtual concat, activation + two residuals, no bias, a pixel count that is not a multiple of 64, bitwise repeat; with a
+    per-sample vector the layer goes back to the MFMA kernels (same result)."""
+    import hiputil as hu
+    B, HW, W = 3, 37 * 5, 5                                   # 555 pixels: the last block of 64 is ragged
+    x = U(f"nar.x.{cin}", (B, HW, cin), -1.5, 1.5)
+    w, b = U(f"nar.w.{cin}.{cout}", (cout, cin), -0.3, 0.3), U(f"nar.b.{cout}", (cout,))
+    r0, r1, vec = U(f"nar.r0.{cout}", (B, HW, cout)), U(f"nar.r1.{cout}", (B, HW, cout)), U(f"nar.v.{cout}", (B, cout))
+    wp, bd = hu.pack_pw(ctx, w), hu.dev(b)
+    s = hu.src(hu.dev(x[..., :c0].contiguous()), hu.dev(x[..., c0:].contiguous())) if c0 else hu.src(hu.dev(x))
+    lin = F.linear(x, w, b)
+    out = hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout)
+    assert rel_err(out.cpu(), lin) < TOL
+    out2 = hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout)
+    assert torch.equal(out.cpu(), out2.cpu())
+    out = hu.pointwise(ctx, s, wp, None, B, HW, W, cin, cout, act=L.ACT_SILU, res0=hu.dev(r0), res1=hu.dev(r1))
+    assert rel_err(out.cpu(), F.silu(F.linear(x, w)) + r0 + r1) < TOL
+    out = hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU, res0=hu.dev(r0))
+    assert rel_err(out.cpu(), F.gelu(lin) + r0) < TOL
+    out = hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, vec=hu.dev(vec))          # (a per-sample vector: the MFMA kernels)
+    assert rel_err(out.cpu(), lin + vec[:, None]) < TOL
+
+
 CHAIN_CASES = {  # (B, HW, [widths]): Mlp chains (two stages) and AttnBlock tails (three stages, LayerNorm + residuals)
     "mlp1_d64": (2, 64, [8, 64, 64]),
     "mlp2_d64": (2, 96, [64, 64, 64]),
