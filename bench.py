@@ -110,7 +110,7 @@ def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
     CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32", "nd_conv3x3_wino4_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32",
-            "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32")
+            "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_conv3x3_wino4h_16_splitk_nhwc_f32")
     STREAM = "nd_affine_silu_add_f32"           # the HBM-bound family: GroupNorm-apply + SiLU + residual adds, one pass
     convs = [op for op in plan.step_ops if op[2] in CONV or (op[2] == STREAM and op[3])]
     n_ev = 2 * len(convs)
@@ -336,7 +336,7 @@ def launch_ranks(a):
 # MFMA multiplies actually issued per algorithmic multiply: Winograd F(2x2,3x3) does 16 per 2x2 outputs x 9 taps = 1/2.25,
 # F(4x4,3x3) 36 per 16 x 9 = 1/4; the direct kernel 1.  tiling ids: 9001 wino, 9002 wino2, 9004 wino4 (16 x 32-pixel regions), 9016 wino4 on 16 x 16-pixel
 # regions (two workgroups per CU), else direct <TW,MB,NB>
-WINO_FACTOR = {9001: 2.25, 9002: 2.25, 9004: 4.0, 9016: 4.0, 9104: 4.0}     # (9104: the f16 three-product split of F(4x4): `executed` is then priced as if on the fp32 pipe)
+WINO_FACTOR = {9001: 2.25, 9002: 2.25, 9004: 4.0, 9016: 4.0, 9104: 4.0, 9117: 4.0}     # (9104: the f16 three-product split of F(4x4): `executed` is then priced as if on the fp32 pipe)
 UNIT_GFLOP = {(64, 128): 68.78, (64, 256): 275.12, (128, 256): 1077.65,      # algorithmic GFLOP per patch.step (dim, size)
               (48, 512): 627.61}     # the reference's shipped workload (script.sh:10), counted the same way (tools/count_reference_flops.py: conv3x3 527.27)
 
@@ -348,7 +348,7 @@ def roofline(a, loop, plan, L, per_step):
     tot_ms = sum(d["ms"] for d in per.values())
     tot_flop = sum(d["flop"] for d in per.values())
     tot_exec = sum(d["flop"] / WINO_FACTOR.get(k[0], 1.0) for k, d in per.items())
-    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, {'true' if len(k) > 3 and k[3] else 'false'}, {1 if k[0] == 9016 else 2}, 4>{' + reduce' if len(k) > 3 and k[3] else ''}" if k[0] in (9004, 9016) else f"wino4h_kernel<{k[1]}, {'true' if k[2] else 'false'}> (f16x3)" if k[0] == 9104 else f"conv3x3_f16x3_kernel<{k[1]}, {'true' if k[2] else 'false'}> (direct, f16x3)" if k[0] == 9116 else
+    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, {'true' if len(k) > 3 and k[3] else 'false'}, {1 if k[0] == 9016 else 2}, 4>{' + reduce' if len(k) > 3 and k[3] else ''}" if k[0] in (9004, 9016) else f"wino4h_kernel<{k[1]}, {'true' if k[2] else 'false'}> (f16x3)" if k[0] == 9104 else f"conv3x3_f16x3_kernel<{k[1]}, {'true' if k[2] else 'false'}> (direct, f16x3)" if k[0] == 9116 else f"wino4h_kernel<{k[1]}, false, true, 1, 4> + reduce (f16x3)" if k[0] == 9117 else
                        f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
                        f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
     tid, d = max(per.items(), key=lambda kv: kv[1]["ms"])

@@ -151,6 +151,8 @@ int nd_conv3x3_wino4_8w_nhwc_f32(const nd_conv3x3* d, void* stream);
 int nd_conv3x3_wino4h_nhwc_f32(const nd_conv3x3* d, void* stream);
 int nd_conv3x3_wino4h_16_nhwc_f32(const nd_conv3x3* d, void* stream);   /* ... on 16 x 16-pixel regions, two workgroups per CU (plain / affine + SiLU sources) */
 int nd_pack_conv3x3_wino4h_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
+/* ... and with the geometry-only split of K of nd_conv3x3_wino4_16_splitk_nhwc_f32 (same plan, workspace and reduction; the partial tensors come from the f16 kernel) */
+int nd_conv3x3_wino4h_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream);
 /* The same opt-in product form as a DIRECT convolution on the double-rate f16 matrix instruction (conv3x3_f16x3.hip, r4): no Winograd transform, so
  * it wins where the transforms dominate (the 64- and 128-channel layers of the full-resolution stages: Block.proj, Diffusion_arch.py:131,136).
  * Covers whole 16 x 32-pixel regions (H % 16 == 0, W % 32 == 0), cin % 16 == 0, cout % 64 == 0, plain and GroupNorm-affine + SiLU sources, virtual

@@ -98,6 +98,7 @@ SIGNATURES = {
     "nd_conv3x3_wino4_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
     "nd_conv3x3_wino4_16_splitk_plan": (i32, [i32, i32, i32, i32]),
     "nd_conv3x3_wino4_16_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
+    "nd_conv3x3_wino4h_16_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
     "nd_conv3x3_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
     "nd_conv3x3_wgrad_nhwc_f32": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_groupnorm_train_workspace_floats": (i64, [i32, i32, i32]),

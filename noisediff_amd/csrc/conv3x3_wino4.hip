@@ -1063,6 +1063,87 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
 #endif
 }
 
+// ---- split-K: the reduction kernels and the launcher of the SPLIT instances (both product forms: under W4_F16X3 wino4_kernel is wino4h_kernel)
+// out[n][c] = sum over the splits (in split order) of part[s][n][c] + bias[c]; n = pixel (B * H * W), float4 per thread
+__global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                               int splits, long npix, int cout, int ldo) {
+    const int cq = cout >> 2;
+    const long total = npix * cq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / cq;
+        const int c = (int)(i - n * cq) * 4;
+        f32x4 acc = nd_ld4(part + n * cout + c);
+        for (int s = 1; s < splits; ++s) acc += nd_ld4(part + ((long)s * npix + n) * cout + c);
+        if (bias) acc += nd_ld4(bias + c);
+        nd_st4(out + n * ldo + c, acc);
+    }
+}
+
+// The same reduction for layers with a statistics epilogue (Block.proj: the GroupNorm that follows pools them): one workgroup per (sample, 16 x 16-pixel
+// tile) -- the tile is one statistics slot of nd_conv3x3_wino4_stat_slots -- adds the partial tensors' tile (+ bias), stores it, and leaves the slot's
+// per-channel {sum, M2 about the tile's mean} in `stats` exactly as wino4_kernel's own epilogue does (pivot = the tile's first pixel; M2 = Q - S^2 / n).
+// Thread = (channel quad, pixel row group); the row groups meet through LDS in a fixed order.
+__global__ __launch_bounds__(256) void w4_splitk_reduce_stats_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                                     float* __restrict__ stats, float* __restrict__ slot_count, int splits, int B, int H, int W,
+                                                                     int cout, int ldo, int tiles_x, int tiles_y, int n_cgrp) {
+    __shared__ __attribute__((aligned(16))) float red[2][256][4];
+    int bid = blockIdx.x;
+    const int cgrp = bid % n_cgrp;  bid /= n_cgrp;                 // 64 couts (16 channel quads) per workgroup: small images still give the chip work
+    const int slot = bid % (tiles_x * tiles_y), b = bid / (tiles_x * tiles_y);
+    const int ty = slot / tiles_x, tx = slot % tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16, th = min(16, H - y0), tw = min(16, W - x0), npx = th * tw;
+    const long npix = (long)B * H * W;
+    const int q = cgrp * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;      // channel quad, pixel row group (16 of them)
+    const bool act = 4 * q < cout;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, pv = {0, 0, 0, 0};
+    if (act) {
+        const f32x4 bq = bias ? nd_ld4(bias + 4 * q) : f32x4{0, 0, 0, 0};
+        {   // pivot: the tile's first pixel, summed the same way
+            const long n0 = ((long)b * H + y0) * W + x0;
+            pv = nd_ld4(part + n0 * cout + 4 * q);
+            for (int sp = 1; sp < splits; ++sp) pv += nd_ld4(part + ((long)sp * npix + n0) * cout + 4 * q);
+            pv += bq;
+        }
+        for (int p = rg; p < npx; p += 16) {
+            const int py = p / tw, px = p - py * tw;
+            const long n = ((long)b * H + y0 + py) * W + x0 + px;
+            f32x4 v = nd_ld4(part + n * cout + 4 * q);
+            for (int sp = 1; sp < splits; ++sp) v += nd_ld4(part + ((long)sp * npix + n) * cout + 4 * q);
+            v += bq;
+            nd_st4(out + n * ldo + 4 * q, v);
+            const f32x4 dv = v - pv;
+            s1 += dv;  s2 += dv * dv;
+        }
+    }
+    *reinterpret_cast<f32x4*>(red[0][threadIdx.x]) = s1;
+    *reinterpret_cast<f32x4*>(red[1][threadIdx.x]) = s2;
+    __syncthreads();
+    if (act && rg == 0) {
+        for (int r = 1; r < 16; ++r) {
+            s1 += *reinterpret_cast<const f32x4*>(red[0][r * 16 + (threadIdx.x & 15)]);
+            s2 += *reinterpret_cast<const f32x4*>(red[1][r * 16 + (threadIdx.x & 15)]);
+        }
+        const float fn = (float)npx;
+        float* o = stats + (((size_t)b * tiles_x * tiles_y + slot) * cout + 4 * q) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = s1[i] + fn * pv[i];
+            o[2 * i + 1] = fmaxf(s2[i] - s1[i] * s1[i] / fn, 0.0f);
+        }
+    }
+    if (b == 0 && cgrp == 0 && threadIdx.x == 0) slot_count[slot] = (float)npx;
+}
+
+template <int MODE, int NTG = 2>
+int launch4_split(const Wino4Args& a, hipStream_t st) {
+    static nd_device_once configured;
+    constexpr int LDS_BYTES = W4Geo<NTG>::LDS_BYTES;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, false, true, NTG>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
+    const long resident = (long)nd_device_cus() * W4Geo<NTG>::WG_PER_CU;
+    hipLaunchKernelGGL((wino4_kernel<MODE, false, true, NTG>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
+    return 0;
+}
+
 #if W4_F16X3
 // OIHW (cout, cin, 3, 3) -> U = G g G^T * 2^11 as two f16 terms, in blocks [cin/16][position half 2][cout/16][18 positions][64 lanes][16 bytes]:
 // lane (cout = l & 15, kg = l >> 4) holds for position p = 18 half + q the four channels 4 kg .. 4 kg + 3 of its chunk: {U1 ch0 ch1 | U1 ch2 ch3 | U2 ch0 ch1 | U2 ch2 ch3}
@@ -1200,86 +1281,6 @@ int launch4s(const Wino4Args& a, hipStream_t st) {
     return 0;
 }
 
-// out[n][c] = sum over the splits (in split order) of part[s][n][c] + bias[c]; n = pixel (B * H * W), float4 per thread
-__global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
-                                                               int splits, long npix, int cout, int ldo) {
-    const int cq = cout >> 2;
-    const long total = npix * cq;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long n = i / cq;
-        const int c = (int)(i - n * cq) * 4;
-        f32x4 acc = nd_ld4(part + n * cout + c);
-        for (int s = 1; s < splits; ++s) acc += nd_ld4(part + ((long)s * npix + n) * cout + c);
-        if (bias) acc += nd_ld4(bias + c);
-        nd_st4(out + n * ldo + c, acc);
-    }
-}
-
-// The same reduction for layers with a statistics epilogue (Block.proj: the GroupNorm that follows pools them): one workgroup per (sample, 16 x 16-pixel
-// tile) -- the tile is one statistics slot of nd_conv3x3_wino4_stat_slots -- adds the partial tensors' tile (+ bias), stores it, and leaves the slot's
-// per-channel {sum, M2 about the tile's mean} in `stats` exactly as wino4_kernel's own epilogue does (pivot = the tile's first pixel; M2 = Q - S^2 / n).
-// Thread = (channel quad, pixel row group); the row groups meet through LDS in a fixed order.
-__global__ __launch_bounds__(256) void w4_splitk_reduce_stats_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
-                                                                     float* __restrict__ stats, float* __restrict__ slot_count, int splits, int B, int H, int W,
-                                                                     int cout, int ldo, int tiles_x, int tiles_y, int n_cgrp) {
-    __shared__ __attribute__((aligned(16))) float red[2][256][4];
-    int bid = blockIdx.x;
-    const int cgrp = bid % n_cgrp;  bid /= n_cgrp;                 // 64 couts (16 channel quads) per workgroup: small images still give the chip work
-    const int slot = bid % (tiles_x * tiles_y), b = bid / (tiles_x * tiles_y);
-    const int ty = slot / tiles_x, tx = slot % tiles_x;
-    const int y0 = ty * 16, x0 = tx * 16, th = min(16, H - y0), tw = min(16, W - x0), npx = th * tw;
-    const long npix = (long)B * H * W;
-    const int q = cgrp * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;      // channel quad, pixel row group (16 of them)
-    const bool act = 4 * q < cout;
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, pv = {0, 0, 0, 0};
-    if (act) {
-        const f32x4 bq = bias ? nd_ld4(bias + 4 * q) : f32x4{0, 0, 0, 0};
-        {   // pivot: the tile's first pixel, summed the same way
-            const long n0 = ((long)b * H + y0) * W + x0;
-            pv = nd_ld4(part + n0 * cout + 4 * q);
-            for (int sp = 1; sp < splits; ++sp) pv += nd_ld4(part + ((long)sp * npix + n0) * cout + 4 * q);
-            pv += bq;
-        }
-        for (int p = rg; p < npx; p += 16) {
-            const int py = p / tw, px = p - py * tw;
-            const long n = ((long)b * H + y0 + py) * W + x0 + px;
-            f32x4 v = nd_ld4(part + n * cout + 4 * q);
-            for (int sp = 1; sp < splits; ++sp) v += nd_ld4(part + ((long)sp * npix + n) * cout + 4 * q);
-            v += bq;
-            nd_st4(out + n * ldo + 4 * q, v);
-            const f32x4 dv = v - pv;
-            s1 += dv;  s2 += dv * dv;
-        }
-    }
-    *reinterpret_cast<f32x4*>(red[0][threadIdx.x]) = s1;
-    *reinterpret_cast<f32x4*>(red[1][threadIdx.x]) = s2;
-    __syncthreads();
-    if (act && rg == 0) {
-        for (int r = 1; r < 16; ++r) {
-            s1 += *reinterpret_cast<const f32x4*>(red[0][r * 16 + (threadIdx.x & 15)]);
-            s2 += *reinterpret_cast<const f32x4*>(red[1][r * 16 + (threadIdx.x & 15)]);
-        }
-        const float fn = (float)npx;
-        float* o = stats + (((size_t)b * tiles_x * tiles_y + slot) * cout + 4 * q) * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[2 * i] = s1[i] + fn * pv[i];
-            o[2 * i + 1] = fmaxf(s2[i] - s1[i] * s1[i] / fn, 0.0f);
-        }
-    }
-    if (b == 0 && cgrp == 0 && threadIdx.x == 0) slot_count[slot] = (float)npx;
-}
-
-template <int MODE, int NTG = 2>
-int launch4_split(const Wino4Args& a, hipStream_t st) {
-    static nd_device_once configured;
-    constexpr int LDS_BYTES = W4Geo<NTG>::LDS_BYTES;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, false, true, NTG>), LDS_BYTES, "nd_conv3x3_wino4_splitk")) return e;
-    const long resident = (long)nd_device_cus() * W4Geo<NTG>::WG_PER_CU;
-    hipLaunchKernelGGL((wino4_kernel<MODE, false, true, NTG>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(256), LDS_BYTES, st, a);
-    return 0;
-}
-
 template <int MODE, int NTG = 2, int NW = 4>
 int launch4(const Wino4Args& a, hipStream_t st) {
     static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;     // A/B knob (tools/ only)
@@ -1377,6 +1378,44 @@ static int w4_prepare(const nd_conv3x3* d, Wino4Args& a, int ntg = 2) {
     return 0;
 }
 
+// split-K launch shared by the entry points of both product forms: SPLIT instances into `workspace`, then the reduction (+ bias, + statistics)
+static int w4_splitk(const nd_conv3x3* d, float* workspace, int splits, void* stream, int ntg, const char* who) {
+    Wino4Args a;
+    if (int e = w4_prepare(d, a, ntg)) return e;
+    ND_REQUIRE(workspace && nd_aligned16(workspace), ND_E_BADARG, "%s: the workspace must be a 16-byte aligned pointer", who);
+    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
+               "%s: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)", who);
+    const int n_chunks = nd_cdiv(d->cin, KC4);
+    ND_REQUIRE((splits == 2 || splits == 4 || splits == 8) && d->cin % KC4 == 0 && n_chunks % splits == 0 && n_chunks / splits >= 2, ND_E_SHAPE,
+               "%s: splits=%d must be 2, 4 or 8 and divide cin=%d into ranges of at least two whole 16-channel chunks", who, splits, d->cin);
+    const long npix = (long)d->B * d->H * d->W;
+    ND_REQUIRE((long)splits * npix * d->cout * 4 < (1L << 31), ND_E_SHAPE, "%s: partial sums of 2 GiB or more", who);
+    ND_REQUIRE(d->cout % 4 == 0, ND_E_SHAPE, "%s: cout must be a multiple of 4", who);
+    const float* bias = d->bias;
+    float* out = d->out;
+    const int ldo = d->ldo;
+    a.d.out = workspace;  a.d.ldo = d->cout;  a.d.bias = nullptr;       // partial sums [split][B][H][W][cout]; the bias joins in the reduction
+    a.d.stats = nullptr;  a.d.slot_count = nullptr;                      // ... and so do the statistics (of the SUMMED output)
+    a.splits = splits;
+    a.chunks_per_split = n_chunks / splits;
+    a.total_wg *= splits;
+    hipStream_t st = (hipStream_t)stream;
+    const bool aff = d->src.mode == ND_PRO_AFFINE_SILU;
+    if (int rc = ntg == 1 ? (aff ? launch4_split<ND_PRO_AFFINE_SILU, 1>(a, st) : launch4_split<ND_PRO_NONE, 1>(a, st))
+                          : (aff ? launch4_split<ND_PRO_AFFINE_SILU>(a, st) : launch4_split<ND_PRO_NONE>(a, st))) return rc;
+    if (int e = nd_launch_status(who)) return e;
+    if (d->stats) {
+        const int n_cgrp = nd_cdiv(d->cout, 64);
+        hipLaunchKernelGGL(w4_splitk_reduce_stats_kernel, dim3((unsigned)(d->B * a.tiles_x * a.tiles_y * n_cgrp)), dim3(256), 0, st, workspace, bias, out,
+                           d->stats, d->slot_count, splits, d->B, d->H, d->W, d->cout, ldo, a.tiles_x, a.tiles_y, n_cgrp);
+        return nd_launch_status(who);
+    }
+    const long total = npix * (d->cout / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, bias, out, splits, npix, d->cout, ldo);
+    return nd_launch_status(who);
+}
+
 #if W4_F16X3
 extern "C" int nd_conv3x3_wino4h_nhwc_f32(const nd_conv3x3* d, void* stream) {
     Wino4Args a;
@@ -1405,6 +1444,12 @@ extern "C" int nd_conv3x3_wino4h_16_nhwc_f32(const nd_conv3x3* d, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4h<ND_PRO_AFFINE_SILU, 1, 4>(a, st) : launch4h<ND_PRO_NONE, 1, 4>(a, st)) return rc;
     return nd_launch_status("nd_conv3x3_wino4h_16_nhwc_f32");
+}
+
+// ... and its geometry-only split of K for the narrow layers (nd_conv3x3_wino4_16_splitk_plan; BASELINE config 2's 16 x 16 / 32 x 32 stages): the SPLIT instances of the f16 kernel
+// write the partial tensors, the fp32 reduction adds them in range order (+ bias, + statistics) exactly as for nd_conv3x3_wino4_16_splitk_nhwc_f32
+extern "C" int nd_conv3x3_wino4h_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {
+    return w4_splitk(d, workspace, splits, stream, 1, "nd_conv3x3_wino4h_16_splitk_nhwc_f32");
 }
 #else
 extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
@@ -1474,43 +1519,6 @@ extern "C" int nd_conv3x3_wino4_splitk_plan(int B, int H, int W, int cin, int co
 extern "C" int64_t nd_conv3x3_wino4_splitk_workspace_floats(int B, int H, int W, int cout, int splits) {
     if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || splits <= 0) return -1;
     return (int64_t)splits * B * H * W * cout;
-}
-
-static int w4_splitk(const nd_conv3x3* d, float* workspace, int splits, void* stream, int ntg, const char* who) {
-    Wino4Args a;
-    if (int e = w4_prepare(d, a, ntg)) return e;
-    ND_REQUIRE(workspace && nd_aligned16(workspace), ND_E_BADARG, "%s: the workspace must be a 16-byte aligned pointer", who);
-    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
-               "%s: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)", who);
-    const int n_chunks = nd_cdiv(d->cin, KC4);
-    ND_REQUIRE((splits == 2 || splits == 4 || splits == 8) && d->cin % KC4 == 0 && n_chunks % splits == 0 && n_chunks / splits >= 2, ND_E_SHAPE,
-               "%s: splits=%d must be 2, 4 or 8 and divide cin=%d into ranges of at least two whole 16-channel chunks", who, splits, d->cin);
-    const long npix = (long)d->B * d->H * d->W;
-    ND_REQUIRE((long)splits * npix * d->cout * 4 < (1L << 31), ND_E_SHAPE, "%s: partial sums of 2 GiB or more", who);
-    ND_REQUIRE(d->cout % 4 == 0, ND_E_SHAPE, "%s: cout must be a multiple of 4", who);
-    const float* bias = d->bias;
-    float* out = d->out;
-    const int ldo = d->ldo;
-    a.d.out = workspace;  a.d.ldo = d->cout;  a.d.bias = nullptr;       // partial sums [split][B][H][W][cout]; the bias joins in the reduction
-    a.d.stats = nullptr;  a.d.slot_count = nullptr;                      // ... and so do the statistics (of the SUMMED output)
-    a.splits = splits;
-    a.chunks_per_split = n_chunks / splits;
-    a.total_wg *= splits;
-    hipStream_t st = (hipStream_t)stream;
-    const bool aff = d->src.mode == ND_PRO_AFFINE_SILU;
-    if (int rc = ntg == 1 ? (aff ? launch4_split<ND_PRO_AFFINE_SILU, 1>(a, st) : launch4_split<ND_PRO_NONE, 1>(a, st))
-                          : (aff ? launch4_split<ND_PRO_AFFINE_SILU>(a, st) : launch4_split<ND_PRO_NONE>(a, st))) return rc;
-    if (int e = nd_launch_status(who)) return e;
-    if (d->stats) {
-        const int n_cgrp = nd_cdiv(d->cout, 64);
-        hipLaunchKernelGGL(w4_splitk_reduce_stats_kernel, dim3((unsigned)(d->B * a.tiles_x * a.tiles_y * n_cgrp)), dim3(256), 0, st, workspace, bias, out,
-                           d->stats, d->slot_count, splits, d->B, d->H, d->W, d->cout, ldo, a.tiles_x, a.tiles_y, n_cgrp);
-        return nd_launch_status(who);
-    }
-    const long total = npix * (d->cout / 4);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, bias, out, splits, npix, d->cout, ldo);
-    return nd_launch_status(who);
 }
 
 extern "C" int nd_conv3x3_wino4_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {

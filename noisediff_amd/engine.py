@@ -89,7 +89,8 @@ def set_f16x3(on: bool) -> bool:
     return prev
 
 
-F16X3_ENTRIES = ("nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_pointwise_gemm_f16x3_nhwc_f32", "nd_pointwise_chain_f16x3_nhwc_f32")
+F16X3_SPLIT = os.environ.get("ND_F16X3_SPLIT", "1") != "0"       # A/B knob: the narrow layers' geometry-only K split on the f16 kernel too (ND_CONV_F16X3=1)
+F16X3_ENTRIES = ("nd_conv3x3_wino4h_16_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_pointwise_gemm_f16x3_nhwc_f32", "nd_pointwise_chain_f16x3_nhwc_f32")
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -556,7 +557,11 @@ class Plan:
         if splits > 1 and splits * self.B * H * W * cout * 4 < (1 << 31):
             ws = self._alloc(splits * self.B * H * W * cout)
             meta["splits"] = splits
-            self._add("nd_conv3x3_wino4_16_splitk_nhwc_f32" if w4kind == "wino4_16" else "nd_conv3x3_wino4_splitk_nhwc_f32", C.byref(d), ws.data_ptr(), splits, e.stream, meta=meta)
+            entry_s = "nd_conv3x3_wino4_16_splitk_nhwc_f32" if w4kind == "wino4_16" else "nd_conv3x3_wino4_splitk_nhwc_f32"
+            if w4kind == "wino4_16" and WINO4_16_SPLIT and (name + ".weight.wino4h") in e.slots and F16X3_SPLIT:      # opt-in form: the narrow layers' partial tensors from the f16 kernel
+                d.weight, entry_s = e.p(name + ".weight.wino4h"), "nd_conv3x3_wino4h_16_splitk_nhwc_f32"
+                meta["tiling"] = 9117
+            self._add(entry_s, C.byref(d), ws.data_ptr(), splits, e.stream, meta=meta)
             self._release(ws)
         else:
             self._add(entry, C.byref(d), e.stream, meta=meta)

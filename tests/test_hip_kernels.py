@@ -1097,13 +1097,17 @@ def test_conv3x3_f16x3_refuses_what_it_does_not_cover(ctx):
         assert (rc == 0) == bool(takes)
 
 
+@pytest.mark.parametrize("form", ["fp32", "f16x3"])
 @pytest.mark.parametrize("case", sorted(CFG2_CASES))
-def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case):
+def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case, form):
     """nd_conv3x3_wino4_16_splitk_nhwc_f32 with the split count of nd_conv3x3_wino4_16_splitk_plan (the sample's geometry only) on BASELINE config 2's
     narrow stages: output against nn.Conv2d and against the unsplit kernel, the GroupNorm partials the reduction leaves, the affine + SiLU prologue,
-    bitwise repeat, and the same bits for a sample whatever batch it sits in."""
+    bitwise repeat, and the same bits for a sample whatever batch it sits in.  form f16x3: nd_conv3x3_wino4h_16_splitk_nhwc_f32 (the partial tensors from the
+    f16-split kernel, the same plan, workspace and reduction), the same checks at the same tolerances."""
     import hiputil as hu
     B, H, W, cin, cout, c0, up = CFG2_CASES[case]
+    pack, entry, plain_entry = (("nd_pack_conv3x3_wino4h_weight", "nd_conv3x3_wino4h_16_splitk_nhwc_f32", "nd_conv3x3_wino4h_16_nhwc_f32") if form == "f16x3" else
+                                ("nd_pack_conv3x3_wino4_weight", "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32"))
     B = min(B, 4)
     hs, ws = (H // 2, W // 2) if up else (H, W)
     bound = 1.0 / np.sqrt(9 * cin)
@@ -1114,7 +1118,7 @@ def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case):
     ref = F.conv2d(xin, w, b, padding=1)
     wd, bd = hu.dev(w), hu.dev(b)
     wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
-    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    L.call(pack, wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
     ctx.sync()
     splits = ctx.lib.nd_conv3x3_wino4_16_splitk_plan(H, W, cin, cout)
     assert splits in (2, 4)
@@ -1126,7 +1130,7 @@ def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case):
         d = L.Conv3x3()
         d.src, d.weight, d.bias, d.out, d.stats, d.slot_count = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st.data_ptr(), sc.data_ptr()
         d.B, d.H, d.W, d.cin, d.cout, d.ldo = nb, H, W, cin, cout, cout
-        L.call("nd_conv3x3_wino4_16_splitk_nhwc_f32", C.byref(d), ws_.data_ptr(), splits, ctx.stream)
+        L.call(entry, C.byref(d), ws_.data_ptr(), splits, ctx.stream)
         ctx.sync()
         return out, st, sc
 
@@ -1138,7 +1142,7 @@ def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case):
     assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
     o1, s1, _ = run(mk(x[1:2].contiguous()), nb=1)                       # sample 1 alone: the same bits as inside the batch
     assert torch.equal(out[1:2].cpu(), o1.cpu()) and torch.equal(st[1:2].cpu(), s1.cpu())
-    plain, *_ = _run_wino4(ctx, mk(x), wp, bd, B, H, W, cin, cout, entry="nd_conv3x3_wino4_16_nhwc_f32")
+    plain, *_ = _run_wino4(ctx, mk(x), wp, bd, B, H, W, cin, cout, entry=plain_entry)
     assert rel_err(hu.nchw(out), hu.nchw(plain)) < 5e-5                  # another summation order over cin, nothing else (measured 2.3e-5 at 24 chunks)
     if not up:
         M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
