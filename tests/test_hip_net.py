@@ -528,6 +528,39 @@ def test_net_forward_headline_sizes_match_oracle(dim, H, B, mid):
     assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
 
 
+def test_f16_split_product_form_net_and_sampler_match_oracle():
+    """The opt-in product form (engine.set_f16x3 / ND_CONV_F16X3=1) inside the default GPU suite: d=64 at 256x256 with every family on its f16-split kernel --
+    F(4x4) position products (conv3x3_wino4h), the wide 1x1 layers (pointwise_big_kernel<.., HF>), the fused chains (chain_kernel<.., HF>) and the narrow layers'
+    K split -- one forward against the oracle at the net tolerance, a 3-step DDIM against the oracle at the sampler tolerance, and the plan really carries those
+    entries (the whole suite is also run with ND_CONV_F16X3=1: profiles/r4*_pytest_f16x3.log)."""
+    from noisediff_amd import engine as E
+    _oracle_threads()
+    dim, H, B, S = 64, 256, 1, 3
+    prev = E.set_f16x3(True)
+    try:
+        net = make_net(dim)
+        sd = state_dict(dim)
+        cond = synth.make_condition(B, H, seed=5)
+        x = synth.make_noise(6, "f16.x", B, 4, H)
+        t = torch.tensor([412])
+        with torch.inference_mode():
+            y = net(x.to(DEV), t.to(DEV), to_dev(cond)).cpu()
+            ref = O.noisediff_forward(sd, x, t, cond)
+        assert rel_err(y.numpy(), ref.numpy()) < NET_TOL
+        names = [op[2] for op in net.hip_engine(DEV).plan(B, H, H).step_ops]
+        for entry, at_least in (("nd_conv3x3_wino4h_nhwc_f32", 40), ("nd_pointwise_gemm_f16x3_nhwc_f32", 15), ("nd_pointwise_chain_f16x3_nhwc_f32", 6),
+                                ("nd_conv3x3_wino4h_16_splitk_nhwc_f32", 4)):
+            assert names.count(entry) >= at_least, (entry, names.count(entry))
+        gd = GaussianDiffusion(net, image_size=H, timesteps=1000, sampling_timesteps=S, ddim_sampling_eta=0.5, beta_schedule="sigmoid2").to(DEV)
+        x_T = synth.make_noise(7, "f16.x_T", B, 4, H)
+        steps = torch.stack([synth.make_noise(7, f"f16.noise.{i}", B, 4, H) for i in range(S - 1)])
+        out = gd.sample(batch_size=B, condition=to_dev(cond), noise={"x_T": x_T, "steps": steps}).cpu()
+        ref = O.sample(sd, cond, image_size=H, batch_size=B, timesteps=1000, sampling_timesteps=S, eta=0.5, x_T=x_T, noise=lambda i, s_: steps[i])
+        assert rel_err(out.numpy(), ref.numpy()) < SAMPLE_TOL / 10
+    finally:
+        E.set_f16x3(prev)
+
+
 def test_config4_kernel_selection_at_its_size():
     """What `bench.py --config cfg4` launches (d=128 + mid Attention, 256x256): the 1024 / 1536 -> 1024 convs at 32x32 run on conv3x3_wino4,
     the wide token Linears are in the plan and the attention kernel sees N = 1024 -- so the parity cases above / below cover that selection."""
