@@ -91,7 +91,7 @@ def executed_gflop_per_step(plan, L):
     tot = 0.0
     for fn, args, name, meta in plan.step_ops:
         if not meta:
-            if name == "nd_conv7x7_c4_f32":
+            if name in ("nd_conv7x7_c4_f32", "nd_conv7x7_c4_f16x3_f32"):
                 tot += 2.0 * 196 * plan.e.dim * plan.B * plan.H * plan.W
             elif name == "nd_attention_mfma_f32":
                 B_, N, heads, dh = args[4], args[5], args[6], args[7]

@@ -405,6 +405,10 @@ int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, in
  * weight packed [7*7*4][cout] by nd_pack_conv7x7_weight. */
 int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo,
                       int B, int H, int W, int cout, void* stream);
+/* the same layer with every product as three f16 MFMAs of two-term operands, fp32 accumulation (the opt-in product form of nd_conv3x3_wino4h_nhwc_f32 for the stem);
+ * same arguments, the SAME packed weights (the kernel splits them itself) */
+int nd_conv7x7_c4_f16x3_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo,
+                            int B, int H, int W, int cout, void* stream);
 int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout, void* stream);
 /* LearnedSinusoidalPosEmb (:331-337): position NCHW (B,2,H,W) -> NHWC (B,H,W,3*hid):
  * w = conv1x1(position); cat(w, sin(2 pi w), cos(2 pi w)). */

@@ -142,6 +142,7 @@ SIGNATURES = {
     "nd_cond_step_table_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "nd_embedding_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nd_conv7x7_c4_f16x3_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_pack_conv7x7_weight": (i32, [vp, vp, i32, vp]),
     "nd_pos_enc_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_maxpool2x2_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),

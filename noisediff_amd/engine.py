@@ -89,8 +89,13 @@ def set_f16x3(on: bool) -> bool:
     return prev
 
 
+def _stem_entry() -> str:
+    """init_conv / cond_init_conv (7x7, 4 input channels): the f16-split form with ND_CONV_F16X3=1 (ND_STEM_F16X3=0: A/B knob)."""
+    return "nd_conv7x7_c4_f16x3_f32" if (CONV_F16X3 and os.environ.get("ND_STEM_F16X3", "1") != "0") else "nd_conv7x7_c4_f32"
+
+
 F16X3_SPLIT = os.environ.get("ND_F16X3_SPLIT", "1") != "0"       # A/B knob: the narrow layers' geometry-only K split on the f16 kernel too (ND_CONV_F16X3=1)
-F16X3_ENTRIES = ("nd_conv3x3_wino4h_16_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_pointwise_gemm_f16x3_nhwc_f32", "nd_pointwise_chain_f16x3_nhwc_f32")
+F16X3_ENTRIES = ("nd_conv7x7_c4_f16x3_f32", "nd_conv3x3_wino4h_16_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_pointwise_gemm_f16x3_nhwc_f32", "nd_pointwise_chain_f16x3_nhwc_f32")
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -768,7 +773,7 @@ class Plan:
         if tr.cond_branch:
             # clean-image encoding of the UNet_PosEmbV2* nets (others_arch.py:491-492): step-invariant, so it runs here
             ce = self._alloc(B, H, W, e.dim)
-            self._add("nd_conv7x7_c4_f32", self.clean.data_ptr(), e.p("cond_init_conv.weight"), e.p("cond_init_conv.bias"),
+            self._add(_stem_entry(), self.clean.data_ptr(), e.p("cond_init_conv.weight"), e.p("cond_init_conv.bias"),
                       ce.data_ptr(), e.dim, B, H, W, e.dim, st)
             self.clean_emb = self._tap("clean_emb", self.resnet("cond_res_block1", ce, None, e.dim, H, W, RESNET_GROUPS))
             self._release(ce)                  # clean_emb itself is never released: every step reads it
@@ -814,7 +819,7 @@ class Plan:
         fork_at[1] = len(self._ops)                # right behind the time embedding
         # ---- trunk
         x0 = self._alloc(B, H, W, d)
-        self._add("nd_conv7x7_c4_f32", self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
+        self._add(_stem_entry(), self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
                   B, H, W, d, e.stream)
         self._tap("init_conv", x0)
         xin = x0

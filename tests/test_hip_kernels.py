@@ -534,15 +534,17 @@ def test_small_ops(ctx):
     assert torch.equal(a.cpu(), x4.permute(0, 2, 3, 1)) and torch.equal(bb.cpu(), x4)
 
 
+@pytest.mark.parametrize("entry", ["nd_conv7x7_c4_f32", "nd_conv7x7_c4_f16x3_f32"])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 40, 24, 48), (2, 64, 64, 64), (1, 19, 45, 128), (1, 16, 32, 20)])
-def test_conv7x7(ctx, shape):
+def test_conv7x7(ctx, shape, entry):
+    """init_conv (Diffusion_arch.py:478); entry ..._f16x3: the same layer as three f16 products of two-term operands, same packed weights, same tolerance."""
     import hiputil as hu
     B, H, W, cout = shape
     x, w, b = U("c7.x", (B, 4, H, W), -1.5, 1.5), U("c7.w", (cout, 4, 7, 7), -0.1, 0.1), U("c7.b", (cout,))
     wp, out = torch.empty(196 * cout, device=hu.DEV), torch.empty(B, H, W, cout, device=hu.DEV)
     xd, wd, bd = hu.nhwc(x), hu.dev(w), hu.dev(b)
     L.call("nd_pack_conv7x7_weight", wd.data_ptr(), wp.data_ptr(), cout, ctx.stream)
-    L.call("nd_conv7x7_c4_f32", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, B, H, W, cout, ctx.stream)
+    L.call(entry, xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, B, H, W, cout, ctx.stream)
     ctx.sync()
     assert rel_err(hu.nchw(out), F.conv2d(x, w, b, padding=3)) < TOL
 
