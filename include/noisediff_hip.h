@@ -396,6 +396,11 @@ int nd_cond_table_build_f32(const float* freqs, const float* W1, const float* b1
 int nd_cond_step_table_f32(const int64_t* time, const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2,
                            const float* Wp, const float* bp, float* out, int ld_out, int B, int dim, int J, const float* table, int table_rows,
                            void* stream);
+/* ... and with the projection tabulated as well: `ptable` (table_rows x J, row t = the J outputs for timestep t, filled by calling nd_cond_step_table_f32 on the
+ * timesteps 0 .. table_rows-1 with ld_out = J).  When every sample's timestep lies in the table the launch copies B rows (the same bits); otherwise it computes. */
+int nd_cond_step_ptable_f32(const int64_t* time, const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2,
+                            const float* Wp, const float* bp, float* out, int ld_out, int B, int dim, int J, const float* table, int table_rows,
+                            const float* ptable, void* stream);
 /* nn.Embedding lookup (:591): out[b] = table[idx[b]], idx int64. */
 int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, int B, int rows, int dim, void* stream);
 

@@ -140,6 +140,7 @@ SIGNATURES = {
     "nd_cond_step_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_cond_table_build_f32": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "nd_cond_step_table_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "nd_cond_step_ptable_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp]),
     "nd_embedding_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_conv7x7_c4_f16x3_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -264,7 +264,23 @@ __global__ __launch_bounds__(1024) void cond_step_kernel(const int64_t* __restri
                                                          const float* __restrict__ W2, const float* __restrict__ b2,
                                                          const float* __restrict__ Wp, const float* __restrict__ bp,
                                                          float* __restrict__ out, int ld_out, int B, int d, int J,
-                                                         const float* __restrict__ table, int table_rows, float* __restrict__ table_out) {
+                                                         const float* __restrict__ table, int table_rows, float* __restrict__ table_out,
+                                                         const float* __restrict__ ptable = nullptr) {
+    // `ptable` (rows x J): the WHOLE result for timestep = row index (nd_cond_step_ptable_f32; built by nd_cond_proj_table_build_f32 from this kernel's own rows, so a
+    // lookup is the very same bits): when every sample's timestep is inside it, the step's conditioning is a copy of B rows (48 -> a few us at the start of every step);
+    // any timestep outside it sends the whole batch down the computing path.
+    if (ptable && !table_out) {
+        bool all_in = true;
+        for (int b = 0; b < B; ++b) all_in = all_in && time[b] >= 0 && time[b] < table_rows;     // (uniform: every thread reads the same B values)
+        if (all_in) {
+            const int J4 = J >> 2;
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * J4; i += (long)gridDim.x * blockDim.x) {
+                const int b = (int)(i / J4), j = (int)(i - (long)b * J4) * 4;
+                nd_st4(out + (size_t)b * ld_out + j, nd_ld4(ptable + (size_t)time[b] * J + j));
+            }
+            return;
+        }
+    }
     // `table` (rows x 4d): the head's result st for timestep = row index, built once per weight set by this kernel itself (`table_out`
     // mode: workgroup w computes the head for timesteps 16 w .. 16 w + 15 and writes it instead of projecting).  With a table whose rows
     // cover every sample's timestep the head -- two dependent small Linears behind barriers, ~50 us of latency at the start of EVERY diffusion
@@ -415,6 +431,25 @@ extern "C" int nd_cond_step_table_f32(const int64_t* time, const float* freqs, c
     hipLaunchKernelGGL(cond_step_kernel, dim3(rows16 < cus ? rows16 : cus), dim3(1024), (size_t)lds, (hipStream_t)stream, time, freqs, W1, b1, W2, b2, Wp, bp,
                        out, ld_out, B, dim, J, table, table_rows, (float*)nullptr);
     return nd_launch_status("nd_cond_step_table_f32");
+}
+
+// ... with the projection itself tabulated (`ptable`: rows x J, row t = what this entry computes for timestep t; J and ld_out multiples of 4)
+extern "C" int nd_cond_step_ptable_f32(const int64_t* time, const float* freqs, const float* W1, const float* b1, const float* W2, const float* b2,
+                                       const float* Wp, const float* bp, float* out, int ld_out, int B, int dim, int J, const float* table, int table_rows,
+                                       const float* ptable, void* stream) {
+    ND_REQUIRE(time && freqs && W1 && b1 && W2 && b2 && Wp && bp && out && table && ptable, ND_E_BADARG, "nd_cond_step_ptable: null pointer");
+    ND_REQUIRE(B > 0 && dim >= 8 && dim % 8 == 0 && 4 * dim <= 2048 && J > 0 && J % 4 == 0 && ld_out >= J && ld_out % 4 == 0 && table_rows > 0, ND_E_SHAPE,
+               "nd_cond_step_ptable: B=%d dim=%d J=%d ld_out=%d rows=%d (dim a multiple of 8, 4 dim <= 2048, J and ld_out multiples of 4)", B, dim, J, ld_out, table_rows);
+    ND_REQUIRE(nd_aligned16(W1) && nd_aligned16(W2) && nd_aligned16(out) && nd_aligned16(ptable), ND_E_ALIGN, "nd_cond_step_ptable: weights, out and ptable must be 16-byte aligned");
+    const int64_t lds = nd_cond_step_lds_bytes(B, dim);
+    ND_REQUIRE(lds <= 160 * 1024, ND_E_SHAPE, "nd_cond_step_ptable: B * dim = %d needs %lld bytes of LDS", B * dim, (long long)lds);
+    static nd_device_once configured;
+    if (lds > 64 * 1024)
+        if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(cond_step_kernel), 160 * 1024, "nd_cond_step_ptable")) return e;
+    const int rows16 = nd_cdiv(J, 16), cus = nd_device_cus();
+    hipLaunchKernelGGL(cond_step_kernel, dim3(rows16 < cus ? rows16 : cus), dim3(1024), (size_t)lds, (hipStream_t)stream, time, freqs, W1, b1, W2, b2, Wp, bp,
+                       out, ld_out, B, dim, J, table, table_rows, (float*)nullptr, ptable);
+    return nd_launch_status("nd_cond_step_ptable_f32");
 }
 
 extern "C" int nd_sinusoidal_time_emb_f32(const int64_t* time, const float* freqs, float* emb, int B, int half, void* stream) {

@@ -98,6 +98,7 @@ F16X3_SPLIT = os.environ.get("ND_F16X3_SPLIT", "1") != "0"       # A/B knob: the
 F16X3_ENTRIES = ("nd_conv7x7_c4_f16x3_f32", "nd_conv3x3_wino4h_16_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_pointwise_gemm_f16x3_nhwc_f32", "nd_pointwise_chain_f16x3_nhwc_f32")
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
+PROJ_TABLE = os.environ.get("ND_PROJ_TABLE", "1") != "0"   # A-B knob: 0 = only the head is tabulated, the stacked projection is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
 
 
@@ -248,6 +249,9 @@ class Engine:
         self.time_table = TIME_TABLE and 4 * self.dim <= 2048 and self.lib.nd_cond_step_lds_bytes(16, self.dim) <= 160 * 1024
         if self.time_table:
             add("time_table", TIME_TABLE_ROWS * 4 * self.dim, "derived", (TIME_TABLE_ROWS, 4 * self.dim))
+            # ... and the stacked ResnetBlock.mlp projection of every tabulated timestep (41 MB at d = 64): a step's time conditioning is then a copy of B rows
+            if PROJ_TABLE and self.tproj_rows % 4 == 0 and TIME_TABLE_ROWS * self.tproj_rows * 4 <= (192 << 20):
+                add("tproj_table", TIME_TABLE_ROWS * self.tproj_rows, "derived", (TIME_TABLE_ROWS, self.tproj_rows))
         self.arena_floats = off
 
     def view(self, name: str) -> torch.Tensor:
@@ -328,6 +332,16 @@ class Engine:
                 L.call("nd_cond_table_build_f32", self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"), self.p("time_mlp.3.weight"),
                        self.p("time_mlp.3.bias"), self.p("time_table"), TIME_TABLE_ROWS, self.dim, st)
                 L.call("nd_stream_sync", st)
+                if "tproj_table" in self.slots:      # rows of the projection table = what the per-step launch computes for t = 0 .. rows-1 (same kernel code: same bits)
+                    ts = torch.arange(TIME_TABLE_ROWS, dtype=torch.int64, device=self.device)
+                    torch.cuda.synchronize(self.device)
+                    J = self.tproj_rows
+                    for t0 in range(0, TIME_TABLE_ROWS, 16):
+                        nb = min(16, TIME_TABLE_ROWS - t0)
+                        L.call("nd_cond_step_table_f32", ts.data_ptr() + 8 * t0, self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"),
+                               self.p("time_mlp.3.weight"), self.p("time_mlp.3.bias"), self.p("tproj.weight"), self.p("tproj.bias"),
+                               self.p("tproj_table") + 4 * t0 * J, J, nb, self.dim, J, self.p("time_table"), TIME_TABLE_ROWS, st)
+                    L.call("nd_stream_sync", st)
         self.loaded, self.valid, self.used = True, None, used
 
     def broadcast_state_dict(self, sd: Optional[Dict[str, torch.Tensor]], src: int = 0, group=None) -> int:
@@ -785,7 +799,9 @@ class Plan:
             args = (self.time.data_ptr(), e.p("time_freqs"), e.p("time_mlp.1.weight"), e.p("time_mlp.1.bias"),
                     e.p("time_mlp.3.weight"), e.p("time_mlp.3.bias"), e.p("tproj.weight"), e.p("tproj.bias"), self.tproj.data_ptr(),
                     e.tproj_rows, self.B, d, e.tproj_rows)
-            if e.time_table:
+            if e.time_table and "tproj_table" in e.slots and e.tproj_rows % 4 == 0:
+                self._add("nd_cond_step_ptable_f32", *args, e.p("time_table"), TIME_TABLE_ROWS, e.p("tproj_table"), e.stream)
+            elif e.time_table:
                 self._add("nd_cond_step_table_f32", *args, e.p("time_table"), TIME_TABLE_ROWS, e.stream)
             else:
                 self._add("nd_cond_step_f32", *args, e.stream)

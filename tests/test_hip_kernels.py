@@ -1236,3 +1236,21 @@ def test_cond_step_single_launch_matches_torch(ctx, dim, B):
                dWp.data_ptr(), dbp.data_ptr(), b_.data_ptr(), J, B, dim, J, table.data_ptr(), rows, ctx.stream)
         ctx.sync()
         assert torch.equal(a_.cpu(), b_.cpu())
+    # ... and the projection tabulated as well (row t = what the launch computes for timestep t): a copy of B rows with the same bits; a timestep beyond the table: computed
+    if J % 4 == 0:
+        ptable, ts = hu.full((rows, J)), hu.dev(torch.arange(rows, dtype=torch.int64))
+        for t0 in range(0, rows, 16):
+            nb = min(16, rows - t0)
+            L.call("nd_cond_step_table_f32", ts.data_ptr() + 8 * t0, fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+                   dWp.data_ptr(), dbp.data_ptr(), ptable.data_ptr() + 4 * t0 * J, J, nb, dim, J, table.data_ptr(), rows, ctx.stream)
+        ctx.sync()
+        assert not torch.isnan(ptable).any()
+        for tt in (t, torch.where(torch.arange(B) == B - 1, torch.tensor(1234), t)):
+            tdev = hu.dev(tt)
+            a_, b_ = hu.full((B, J)), hu.full((B, J))
+            L.call("nd_cond_step_f32", tdev.data_ptr(), fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+                   dWp.data_ptr(), dbp.data_ptr(), a_.data_ptr(), J, B, dim, J, ctx.stream)
+            L.call("nd_cond_step_ptable_f32", tdev.data_ptr(), fd.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+                   dWp.data_ptr(), dbp.data_ptr(), b_.data_ptr(), J, B, dim, J, table.data_ptr(), rows, ptable.data_ptr(), ctx.stream)
+            ctx.sync()
+            assert torch.equal(a_.cpu(), b_.cpu())
