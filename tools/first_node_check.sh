@@ -22,10 +22,12 @@ for n in 2 4 8; do
   echo "== $n GPUs (weak scaling: 16 patches per GPU)"
   python bench.py --gpus $n --steps 20 --warmup 3 --no-cpu | tee gpurun_out/first_node_n$n.jsonl | python tools/bench_line.py || exit 1
 done
+echo "== the opt-in f16-split product form at the largest device count (ND_CONV_F16X3=1: same sharding, same single weight broadcast)"
+ND_CONV_F16X3=1 python bench.py --gpus $N --steps 20 --warmup 3 --no-cpu --no-alt | tee gpurun_out/first_node_f16x3_n$N.jsonl | python tools/bench_line.py || exit 1
 python - <<'PY'
 import glob, json
 base = None
-for f in sorted(glob.glob("gpurun_out/first_node_n*.jsonl"), key=lambda s: int(s.split("_n")[-1].split(".")[0])):
+for f in sorted(glob.glob("gpurun_out/first_node_n[0-9]*.jsonl"), key=lambda s: int(s.split("_n")[-1].split(".")[0])):
     j = [json.loads(l) for l in open(f) if l.startswith("{")][-1]
     n = j["n_gpus"]
     base = base or j["value"] / n
