@@ -20,7 +20,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=256); ap.add_argument("--steps", type=int, default=1000)
 ap.add_argument("--dim", type=int, default=64); ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--oracle-dtype", choices=["f32", "f64"], default="f32",
-                help="f64: the oracle's arithmetic in float64 (torch default dtype) -- the yardstick that shares no rounding with either product form; about twice the host time")
+                help="f64: the oracle's arithmetic in float64 (torch default dtype) -- the yardstick that shares no rounding with either product form; about nine times the host time")
+ap.add_argument("--first-step", type=int, default=0); ap.add_argument("--last-step", type=int, default=-1,
+                help="oracle steps [first, last) of the chain in this call (a float64 run does not fit one 20-minute GPU-box call): the state after `last` goes to --state-out")
+ap.add_argument("--state-in", default=""); ap.add_argument("--state-out", default="")
 a = ap.parse_args()
 torch.set_num_threads(a.threads)
 dev = torch.device("cuda", 0)
@@ -64,15 +67,39 @@ def on_step(t, img, out):
         print(f"step {k:4d} (t={t:3d}): rel err of x_t " + ", ".join(f"{f} {errs[f][k]:.3e}" for f in trajs) + f"   [{time.time() - t0:.0f} s]", flush=True)
     state["k"] = k + 1
 
-with torch.no_grad():
-    ref = O.p_sample_loop(lambda v, tt: O.noisediff_forward(sd_o, v, tt, cond_o), buf, "pred_v", x_T.to(odt), lambda i, shape: steps[i].to(odt),
-                          on_step=on_step).double()
-res = {"config": f"d={a.dim}, {S}x{S}x4, {T}-step DDPM, B=1, explicit noise", "oracle_arithmetic": a.oracle_dtype, "tolerance": 1e-3, "oracle_seconds": time.time() - t0, "forms": {}}
+k0, k1 = a.first_step, (T if a.last_step < 0 else min(a.last_step, T))
+if a.state_in:
+    stt = torch.load(a.state_in)
+    assert stt["step"] == k0, (stt["step"], k0)
+    img, draw = stt["img"].to(odt), stt["draw"]
+else:
+    assert k0 == 0
+    img, draw = x_T.to(odt), 0
+state["k"] = k0
+with torch.no_grad():                                  # the loop of oracle.p_sample_loop (:414-438), resumable
+    for k in range(k0, k1):
+        t = T - 1 - k
+        tt = torch.full((B,), t, dtype=torch.long)
+        out = O.noisediff_forward(sd_o, img, tt, cond_o)
+        on_step(t, img, out)
+        _, x0 = O.predict_x0_eps(buf, "pred_v", img, t, out, clip=False)
+        x0 = x0.clamp(-1.0, 1.0)
+        mean = O._coef(buf, "posterior_mean_coef1", t) * x0 + O._coef(buf, "posterior_mean_coef2", t) * img
+        if t > 0:
+            img = mean + (0.5 * O._coef(buf, "posterior_log_variance_clipped", t)).exp() * steps[draw].to(odt)
+            draw += 1
+        else:
+            img = mean + (0.5 * O._coef(buf, "posterior_log_variance_clipped", t)).exp() * 0.0
+if a.state_out:
+    torch.save({"step": k1, "img": img.double(), "draw": draw}, a.state_out)
+ref = img.double()
+res = {"config": f"d={a.dim}, {S}x{S}x4, {T}-step DDPM, B=1, explicit noise", "oracle_arithmetic": a.oracle_dtype, "oracle_steps": [k0, k1], "tolerance": 1e-3,
+       "oracle_seconds": time.time() - t0, "forms": {}}
 for f, traj in trajs.items():
-    final = float(np.max(np.abs(traj[:, -1].double().numpy() - ref.numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
+    final = float(np.max(np.abs(traj[:, k1].double().numpy() - ref.numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))      # x after step k1 (k1 = T: x_0)
     res["forms"][f] = {"final_rel_err": final, "max_rel_err_over_trajectory": max(errs[f].values()),
                        "rel_err_every_100_steps": {str(k): errs[f][k] for k in sorted(errs[f]) if k % 100 == 0}}
-res["fp32_vs_f16x3_final_rel_diff"] = float(np.max(np.abs(trajs["fp32"][:, -1].numpy() - trajs["f16x3"][:, -1].numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
+res["fp32_vs_f16x3_final_rel_diff"] = float(np.max(np.abs(trajs["fp32"][:, k1].numpy() - trajs["f16x3"][:, k1].numpy())) / max(1.0, float(np.max(np.abs(ref.numpy())))))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(REPO, "gpurun_out", f"parity_full_length{'_f64_oracle' if a.oracle_dtype == 'f64' else ''}.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(REPO, "gpurun_out", f"parity_full_length{'_f64_oracle' if a.oracle_dtype == 'f64' else ''}{f'_{k0}_{k1}' if (k0, k1) != (0, T) else ''}.json"), "w"), indent=1)
 print(json.dumps(res["forms"], indent=1))
