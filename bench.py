@@ -64,8 +64,7 @@ def parse():
     ap.add_argument("--broadcast", choices=["weights", "plan-slices", "arena"], default="weights",
                     help="what the one collective carries: the raw fp32 weights (every rank packs its arena), the packed slices the plan reads, the whole packed arena")
     ap.add_argument("--soak-s", type=float, default=3.0, help="seconds of untimed step replays before the W warm-up steps")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second leg that times the same K steps with the OTHER conv3x3 product form "
-                                                          "(fp32 MFMA <-> three-product f16 split, ND_CONV_F16X3)")
+    ap.add_argument("--no-alt", action="store_true", help="accepted and ignored (r4 timed a second product form here; there is one form since r5)")
     return ap.parse_args()
 
 
@@ -91,7 +90,7 @@ def executed_gflop_per_step(plan, L):
     tot = 0.0
     for fn, args, name, meta in plan.step_ops:
         if not meta:
-            if name in ("nd_conv7x7_c4_f32", "nd_conv7x7_c4_f16x3_f32"):
+            if name == "nd_conv7x7_c4_f32":
                 tot += 2.0 * 196 * plan.e.dim * plan.B * plan.H * plan.W
             elif name == "nd_attention_mfma_f32":
                 B_, N, heads, dh = args[4], args[5], args[6], args[7]
@@ -110,7 +109,7 @@ def instrumented_pass(loop, plan, L, n_steps):
     """Eager replay of n_steps with a HIP event pair around every conv3x3 launch (library stream)."""
     st = plan.e.stream
     CONV = ("nd_conv3x3_nhwc_f32", "nd_conv3x3_wino_nhwc_f32", "nd_conv3x3_wino2_nhwc_f32", "nd_conv3x3_wino4_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32",
-            "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_conv3x3_wino4h_16_splitk_nhwc_f32")
+            "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_splitk_nhwc_f32")
     STREAM = "nd_affine_silu_add_f32"           # the HBM-bound family: GroupNorm-apply + SiLU + residual adds, one pass
     convs = [op for op in plan.step_ops if op[2] in CONV or (op[2] == STREAM and op[3])]
     n_ev = 2 * len(convs)
@@ -125,10 +124,9 @@ def instrumented_pass(loop, plan, L, n_steps):
         i = 0
         for fn, args, name, meta in plan.step_ops:
             if name in CONV or (name == STREAM and meta):
-                sx = meta.get("_stream", st)                     # the two-branch step: the shot-noise branch's launches sit on the engine's second stream
-                L.call("nd_event_record", evs[2 * i], sx)
+                L.call("nd_event_record", evs[2 * i], st)
                 L.check(fn(*args), name)
-                L.call("nd_event_record", evs[2 * i + 1], sx)
+                L.call("nd_event_record", evs[2 * i + 1], st)
                 i += 1
             else:
                 L.check(fn(*args), name)
@@ -149,7 +147,7 @@ def instrumented_pass(loop, plan, L, n_steps):
                 d["launches"] += 1
                 continue
             # conv3x3_wino4 has two instances per prologue mode: outputs of 48 MB and more are stored with the streaming policy bits
-            stream = m["tiling"] in (9004, 9016, 9104, 9116) and 4 * m["B"] * m["H"] * m["W"] * m["cout"] >= int(os.environ.get("ND_W4_STREAM_MB", "48")) << 20
+            stream = m["tiling"] in (9004, 9016) and 4 * m["B"] * m["H"] * m["W"] * m["cout"] >= int(os.environ.get("ND_W4_STREAM_MB", "48")) << 20
             d = per.setdefault((m["tiling"], m["mode"], stream, m.get("splits", 1) > 1), {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "launches": 0})
             d["ms"] += ms.value
             d["flop"] += conv_flops(m)
@@ -336,7 +334,7 @@ def launch_ranks(a):
 # MFMA multiplies actually issued per algorithmic multiply: Winograd F(2x2,3x3) does 16 per 2x2 outputs x 9 taps = 1/2.25,
 # F(4x4,3x3) 36 per 16 x 9 = 1/4; the direct kernel 1.  tiling ids: 9001 wino, 9002 wino2, 9004 wino4 (16 x 32-pixel regions), 9016 wino4 on 16 x 16-pixel
 # regions (two workgroups per CU), else direct <TW,MB,NB>
-WINO_FACTOR = {9001: 2.25, 9002: 2.25, 9004: 4.0, 9016: 4.0, 9104: 4.0, 9117: 4.0}     # (9104: the f16 three-product split of F(4x4): `executed` is then priced as if on the fp32 pipe)
+WINO_FACTOR = {9001: 2.25, 9002: 2.25, 9004: 4.0, 9016: 4.0}
 UNIT_GFLOP = {(64, 128): 68.78, (64, 256): 275.12, (128, 256): 1077.65,      # algorithmic GFLOP per patch.step (dim, size)
               (48, 512): 627.61}     # the reference's shipped workload (script.sh:10), counted the same way (tools/count_reference_flops.py: conv3x3 527.27)
 
@@ -348,7 +346,7 @@ def roofline(a, loop, plan, L, per_step):
     tot_ms = sum(d["ms"] for d in per.values())
     tot_flop = sum(d["flop"] for d in per.values())
     tot_exec = sum(d["flop"] / WINO_FACTOR.get(k[0], 1.0) for k, d in per.items())
-    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, {'true' if len(k) > 3 and k[3] else 'false'}, {1 if k[0] == 9016 else 2}, 4>{' + reduce' if len(k) > 3 and k[3] else ''}" if k[0] in (9004, 9016) else f"wino4h_kernel<{k[1]}, {'true' if k[2] else 'false'}> (f16x3)" if k[0] == 9104 else f"conv3x3_f16x3_kernel<{k[1]}, {'true' if k[2] else 'false'}> (direct, f16x3)" if k[0] == 9116 else f"wino4h_kernel<{k[1]}, false, true, 1, 4> + reduce (f16x3)" if k[0] == 9117 else
+    kname = lambda k: (f"wino2_kernel<{k[1]}>" if k[0] == 9002 else f"wino4_kernel<{k[1]}, {'true' if k[2] else 'false'}, {'true' if len(k) > 3 and k[3] else 'false'}, {1 if k[0] == 9016 else 2}, 4>{' + reduce' if len(k) > 3 and k[3] else ''}" if k[0] in (9004, 9016) else
                        f"wino_kernel<1, {k[1]}, 32>" if k[0] == 9001 else
                        f"conv3x3_kernel<{k[0] // 100}, {(k[0] // 10) % 10}, {k[0] % 10}, {k[1]}>")   # as rocprofv3 prints it
     tid, d = max(per.items(), key=lambda kv: kv[1]["ms"])
@@ -410,51 +408,6 @@ def roofline(a, loop, plan, L, per_step):
             "frac": gbs / PEAK_HBM_GBS, "launches_per_step": stream["launches"] // n_inst,
             "ms_per_step": stream["ms"] / n_inst}
     return out
-
-
-def _dtype_label(f16x3: bool) -> str:
-    return ("f32 (matrix products of the 3x3 convolutions, the wide 1x1 layers and the fused Mlp / AttnBlock chains: three-product f16 split on the matrix "
-            "cores, fp32 accumulation -- ND_CONV_F16X3=1)" if f16x3 else "f32")
-
-
-def other_form_leg(a, sd, dev, cond, B, S, T, n_sample_steps):
-    """The same K steps with the OTHER product form of the matrix products, in the same process and on the same box: the default line computes them on the fp32
-    MFMA (`dtype` f32); with ND_CONV_F16X3=1 the F(4x4) position products (nd_conv3x3_wino4h_nhwc_f32), the wide 1x1 layers (nd_pointwise_gemm_f16x3_nhwc_f32) and
-    the fused chains (nd_pointwise_chain_f16x3_nhwc_f32) run as a1 b1 + a1 b2 + a2 b1 on the f16 matrix instruction with fp32 accumulation (operands split into two
-    f16 terms: 22 significant bits; measured error against fp64 at or below the fp32 kernels' -- DESIGN section 8).
-    Reported beside `value`, never as `value`: whether that form may carry the headline is the reviewer's call."""
-    from noisediff_amd import GaussianDiffusion, NoiseDiffNet, engine as E
-    from noisediff_amd.diffusion import _Loop
-    saved = E.set_f16x3(not E.CONV_F16X3)
-    try:
-        net = NoiseDiffNet(SimpleNamespace(dim=a.dim, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, mid_attn=a.mid_attn))
-        net.load_state_dict(sd, strict=True)
-        net = net.to(dev).eval()
-        gd = GaussianDiffusion(net, image_size=S, timesteps=T, sampling_timesteps=a.sampling_timesteps, beta_schedule="sigmoid2", objective="pred_v").to(dev)
-        plan = net.hip_engine(dev).plan(B, S, S)
-        plan.set_condition({k: v.to(dev) for k, v in cond.items()})
-        loop = _Loop(gd, plan)
-        loop.start(None, None, seed=1, first_sample=0, use_graph=not a.eager)
-        t_soak = time.perf_counter()
-        while time.perf_counter() - t_soak < min(a.soak_s, 1.5):
-            loop.advance(10)
-            plan.e.sync()
-        loop.advance(a.warmup)
-        plan.e.sync()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        loop.advance(a.steps)
-        plan.e.sync()
-        torch.cuda.synchronize(dev)
-        per_step = (time.perf_counter() - t0) / a.steps
-        n_f16 = {k.replace("nd_", "").replace("_nhwc_f32", ""): sum(1 for op in plan.step_ops if op[2] == k) for k in E.F16X3_ENTRIES}
-        loop.destroy()
-        return {"form": _dtype_label(E.CONV_F16X3), "ms_per_step": per_step * 1e3, "value": B / (n_sample_steps * per_step), "unit": "patches/s",
-                "launches_per_step_on_f16_split_kernels": n_f16, "steps": a.steps,
-                "note": "same process, same box, after the default leg; select with ND_CONV_F16X3=0|1; parity: tests/test_hip_kernels.py (wino4h, f16x3 forms of "
-                        "the pointwise / chain tests) and the whole GPU suite passes with either form at unchanged tolerances"}
-    finally:
-        E.set_f16x3(saved)
 
 
 def main():
@@ -615,7 +568,7 @@ def main():
     out = {
         "metric": f"sampled RAW patches/sec ({S}x{S}x4, {sampler})", "value": value, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _dtype_label(E.CONV_F16X3), "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"NoiseDiffNet dim={a.dim}{' + mid Attention' if a.mid_attn else ''}, {S}x{S}x4 patches, " +
                                sampler + " (sigmoid2, pred_v), "
                                f"{B} patches per GPU; a step = " +
@@ -629,8 +582,6 @@ def main():
         out["multi_gpu"] = bcast
     if rank == 0 and not a.no_roofline:
         out["roofline"] = roofline(a, loop, plan, L, per_step)
-    if rank == 0 and world == 1 and not a.full and not a.no_alt:
-        out["conv3x3_products_other_form"] = other_form_leg(a, sd, dev, cond, B, S, T, n_sample_steps)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items() if not k.startswith("mid_attn.")}, a.dim, S, n_sample_steps, B)
         out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -140,29 +140,6 @@ int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream);
  * (Block.proj of ResnetBlock, Diffusion_arch.py:128-170; the resampling convs :75,533,547); also the F(4x4) path of images narrower
  * than 32 pixels (BASELINE config 2's 16 x 16 stage). */
 int nd_conv3x3_wino4_16_nhwc_f32(const nd_conv3x3* d, void* stream);
-/* ... and on 16 x 32-pixel regions with eight waves per workgroup (two per SIMD: waves 0-3 tile group 0, waves 4-7 tile group 1, in phase by
- * construction; weight fragments shared through the L1).  Same restrictions and bits as nd_conv3x3_wino4_16_nhwc_f32. */
-int nd_conv3x3_wino4_8w_nhwc_f32(const nd_conv3x3* d, void* stream);
-/* The same operator with the position products on the f16 matrix instruction and every operand split into two f16 terms (V = V1 + V2, U 2^11 = U1 + U2; three
- * products V1 U1 + V1 U2 + V2 U1 accumulated in fp32; conv3x3_wino4h.hip, r4, opt-in: ND_CONV_F16X3=1 in the engine).  As accurate as nd_conv3x3_wino4_nhwc_f32
- * against an fp64 convolution (8e-6 ... 1.2e-5 of max|y|: the error of both is the fp32 Winograd transforms'), not bit-identical to it.  Same descriptor,
- * prologues, statistics epilogue and restrictions as nd_conv3x3_wino4_nhwc_f32; `weight` from nd_pack_conv3x3_wino4h_weight (as many floats as
- * nd_pack_conv3x3_wino4_weight_floats).  The fp32 MFMA shares the VALU's lanes on gfx950; this one does not. */
-int nd_conv3x3_wino4h_nhwc_f32(const nd_conv3x3* d, void* stream);
-int nd_conv3x3_wino4h_16_nhwc_f32(const nd_conv3x3* d, void* stream);   /* ... on 16 x 16-pixel regions, two workgroups per CU (plain / affine + SiLU sources) */
-int nd_pack_conv3x3_wino4h_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
-/* ... and with the geometry-only split of K of nd_conv3x3_wino4_16_splitk_nhwc_f32 (same plan, workspace and reduction; the partial tensors come from the f16 kernel) */
-int nd_conv3x3_wino4h_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream);
-/* The same opt-in product form as a DIRECT convolution on the double-rate f16 matrix instruction (conv3x3_f16x3.hip, r4): no Winograd transform, so
- * it wins where the transforms dominate (the 64- and 128-channel layers of the full-resolution stages: Block.proj, Diffusion_arch.py:131,136).
- * Covers whole 16 x 32-pixel regions (H % 16 == 0, W % 32 == 0), cin % 16 == 0, cout % 64 == 0, plain and GroupNorm-affine + SiLU sources, virtual
- * concat on a 16-channel boundary, nearest-x2 upsample addressing (single source), tensors below 2 GiB; nd_conv3x3_f16x3_takes tells (1 / 0), a
- * layer outside that set is an error (ND_E_SHAPE).  Statistics slots: nd_conv3x3_wino4_stat_slots.  `weight` from nd_pack_conv3x3_f16x3_weight
- * (nd_pack_conv3x3_f16x3_weight_floats floats: 9 cin cout, cin padded to 16 and cout to 64). */
-int nd_conv3x3_f16x3_nhwc_f32(const nd_conv3x3* d, void* stream);
-int nd_conv3x3_f16x3_takes(const nd_conv3x3* d);
-int64_t nd_pack_conv3x3_f16x3_weight_floats(int cin, int cout);
-int nd_pack_conv3x3_f16x3_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 /* its statistics epilogue writes ONE slot per 16 x 16-pixel tile (the F(2x2) kernels: two) */
 int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
@@ -294,17 +271,6 @@ int nd_pack_pointwise_weight(const float* w, float* packed, int cin, int cout, i
  * Diffusion_arch.py:156,345-347,410-419), read in place from its forward weight
  * `w_t` ((cin, cout) row-major here = torch's (out_features, in_features) of the forward layer; cin = the forward layer's cout). */
 int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cout, void* stream);
-/* Opt-in product form of the wide layers (the 128-pixel-tile kernel: cin % 64 == 0, cin >= 128, cout % 128 == 0 -- whatever the batch): every
- * fp32 product as three f16 MFMA products of two-term operands, fp32 accumulation -- the form of nd_conv3x3_wino4h_nhwc_f32 for the 1x1 layers
- * (res_conv, FeedForward, Attention projections: Diffusion_arch.py:156,252-253,410-419).  As accurate as the fp32 kernel against an fp64 product at this
- * network's magnitudes (|w| < 32, activations below 6.5e4), not bit-identical to it.  `weight` is nd_pack_pointwise_weight_h's packing (same size as
- * nd_pack_pointwise_weight's); nd_pointwise_gemm_f16x3_takes tells whether the entry accepts a descriptor (1) or not (0), by its geometry alone --
- * a layer it does not accept is an error (ND_E_SHAPE), never a silent change of kernel. */
-int nd_pointwise_gemm_f16x3_nhwc_f32(const nd_pointwise* d, void* stream);
-int nd_pointwise_gemm_f16x3_takes(const nd_pointwise* d);
-/* `layernorm_source`: 1 for a layer that is read through the ND_PRO_LAYERNORM prologue (FeedForward's first Linear) -- those run the K = 8 form of the kernel and its
- * packing, every other prologue the K = 16 form (v_mfma_f32_32x32x16_f16); a weight packed for one and used with the other computes garbage, so the caller keeps them apart. */
-int nd_pack_pointwise_weight_h(const float* w, float* packed, int cin, int cout, int layernorm_source, void* stream);
 
 /* ------------------------------------------------------------------ chained pointwise layers
  * Two or three per-pixel Linear layers in one kernel, the intermediate activations never leaving registers:
@@ -333,13 +299,6 @@ int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream);
 int nd_pointwise_chain_supported(int cin, int n1, int n2, int n3);   /* n3 = 0: two stages */
 int64_t nd_pack_chain_weight_floats(int cin, int cout, int first_stage);
 int nd_pack_chain_weight(const float* w, float* packed, int cin, int cout, int first_stage, void* stream);
-/* Opt-in product form of the chains the fp32 matrix pipe bounds (the d = 64 / 48 network's Mlp and AttnBlock tails): every product as three f16 MFMA
- * products of two-term operands, fp32 accumulation, the chain still register to register (pwchain.hip, HF).  Same descriptor; the stage weights come from
- * nd_pack_chain_weight_h (same size as nd_pack_chain_weight's); nd_pointwise_chain_f16x3_supported lists the instantiated widths, anything else is an
- * error (ND_E_SHAPE).  As accurate as the fp32 chain against an fp64 evaluation, not bit-identical to it. */
-int nd_pointwise_chain_f16x3_nhwc_f32(const nd_chain* d, void* stream);
-int nd_pointwise_chain_f16x3_supported(int cin, int n1, int n2, int n3);
-int nd_pack_chain_weight_h(const float* w, float* packed, int cin, int cout, int first_stage, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm plumbing */
 
@@ -410,10 +369,6 @@ int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, in
  * weight packed [7*7*4][cout] by nd_pack_conv7x7_weight. */
 int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo,
                       int B, int H, int W, int cout, void* stream);
-/* the same layer with every product as three f16 MFMAs of two-term operands, fp32 accumulation (the opt-in product form of nd_conv3x3_wino4h_nhwc_f32 for the stem);
- * same arguments, the SAME packed weights (the kernel splits them itself) */
-int nd_conv7x7_c4_f16x3_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo,
-                            int B, int H, int W, int cout, void* stream);
 int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout, void* stream);
 /* LearnedSinusoidalPosEmb (:331-337): position NCHW (B,2,H,W) -> NHWC (B,H,W,3*hid):
  * w = conv1x1(position); cat(w, sin(2 pi w), cos(2 pi w)). */

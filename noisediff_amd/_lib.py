@@ -82,14 +82,6 @@ SIGNATURES = {
     "nd_pack_conv3x3_wino_weight_dgrad": (i32, [vp, vp, i32, i32, vp]),
     "nd_conv3x3_wino4_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
     "nd_conv3x3_wino4_16_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
-    "nd_conv3x3_wino4_8w_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
-    "nd_conv3x3_wino4h_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
-    "nd_conv3x3_wino4h_16_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
-    "nd_pack_conv3x3_wino4h_weight": (i32, [vp, vp, i32, i32, vp]),
-    "nd_conv3x3_f16x3_nhwc_f32": (i32, [C.POINTER(Conv3x3), vp]),
-    "nd_conv3x3_f16x3_takes": (i32, [C.POINTER(Conv3x3)]),
-    "nd_pack_conv3x3_f16x3_weight_floats": (i64, [i32, i32]),
-    "nd_pack_conv3x3_f16x3_weight": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_conv3x3_wino4_weight_floats": (i64, [i32, i32]),
     "nd_pack_conv3x3_wino4_weight": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_conv3x3_wino4_weight_dgrad": (i32, [vp, vp, i32, i32, vp]),
@@ -98,7 +90,6 @@ SIGNATURES = {
     "nd_conv3x3_wino4_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
     "nd_conv3x3_wino4_16_splitk_plan": (i32, [i32, i32, i32, i32]),
     "nd_conv3x3_wino4_16_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
-    "nd_conv3x3_wino4h_16_splitk_nhwc_f32": (i32, [vp, vp, i32, vp]),
     "nd_conv3x3_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
     "nd_conv3x3_wgrad_nhwc_f32": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_groupnorm_train_workspace_floats": (i64, [i32, i32, i32]),
@@ -121,15 +112,9 @@ SIGNATURES = {
     "nd_pointwise_chain_supported": (i32, [i32, i32, i32, i32]),
     "nd_pack_chain_weight_floats": (i64, [i32, i32, i32]),
     "nd_pack_chain_weight": (i32, [vp, vp, i32, i32, i32, vp]),
-    "nd_pointwise_chain_f16x3_nhwc_f32": (i32, [C.POINTER(Chain), vp]),
-    "nd_pointwise_chain_f16x3_supported": (i32, [i32, i32, i32, i32]),
-    "nd_pack_chain_weight_h": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_floats": (i64, [i32, i32]),
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
-    "nd_pointwise_gemm_f16x3_nhwc_f32": (i32, [C.POINTER(Pointwise), vp]),
-    "nd_pointwise_gemm_f16x3_takes": (i32, [C.POINTER(Pointwise)]),
-    "nd_pack_pointwise_weight_h": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
     "nd_groupnorm_finalize_train_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),
@@ -143,7 +128,6 @@ SIGNATURES = {
     "nd_cond_step_ptable_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp]),
     "nd_embedding_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "nd_conv7x7_c4_f16x3_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_pack_conv7x7_weight": (i32, [vp, vp, i32, vp]),
     "nd_pos_enc_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_maxpool2x2_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
@@ -176,7 +160,7 @@ SIGNATURES = {
     "nd_stream_device": (i32, [vp]),
 }
 
-_UNCHECKED = {"nd_version", "nd_last_error", "nd_stream_device", "nd_pointwise_gemm_f16x3_takes", "nd_pointwise_chain_f16x3_supported", "nd_conv3x3_f16x3_takes", "nd_pack_conv3x3_f16x3_weight_floats", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
+_UNCHECKED = {"nd_version", "nd_last_error", "nd_stream_device", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
               "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats", "nd_conv3x3_wino_stat_slots", "nd_conv3x3_wino4_stat_slots",
               "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_16_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_token_sum_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
               "nd_groupnorm_train_workspace_floats", "nd_linear_wgrad_workspace_floats",

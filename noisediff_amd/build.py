@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnoisediff_hip.so")
-SOURCES = ["runtime", "conv3x3", "conv3x3_wino", "conv3x3_wino2", "conv3x3_wino4", "conv3x3_wino4h", "conv3x3_f16x3", "conv3x3_wgrad", "linear_wgrad", "pointwise", "pwchain", "norm", "norm_train", "small", "sampler",
+SOURCES = ["runtime", "conv3x3", "conv3x3_wino", "conv3x3_wino2", "conv3x3_wino4", "conv3x3_wgrad", "linear_wgrad", "pointwise", "pwchain", "norm", "norm_train", "small", "sampler",
            "attention", "linattn"]
 ARCH = "gfx950"
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc 7.2 parks
@@ -30,8 +30,6 @@ SPECIAL = {
     "conv3x3_wino2": ("conv3x3_wino2", BASE_FLAGS + ["-mllvm", "-pragma-unroll-threshold=1000000"]),
     # one wave per SIMD: 144 accumulator registers in the AGPR half, the rest of the pipeline state in the VGPR half
     "conv3x3_wino4": ("conv3x3_wino4", BASE_FLAGS),
-    "conv3x3_wino4h": ("conv3x3_wino4h", BASE_FLAGS),
-    "conv3x3_f16x3": ("conv3x3_f16x3", BASE_FLAGS),
 }
 
 
@@ -40,6 +38,20 @@ def _hipcc() -> str:
     if not os.path.exists(exe):
         raise RuntimeError("hipcc not found: cannot build libnoisediff_hip.so")
     return exe
+
+
+def _local_includes(src: str, seen=None) -> list:
+    """Files of csrc/ that `src` pulls in with #include "..." (recursively): a source that includes another SOURCE is stale when that one changes."""
+    import re
+    seen = set() if seen is None else seen
+    out = []
+    with open(src) as f:
+        for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), re.M):
+            path = os.path.join(CSRC, name)
+            if os.path.exists(path) and path not in seen:
+                seen.add(path)
+                out += [path] + _local_includes(path, seen)
+    return out
 
 
 def _stale(target: str, deps) -> bool:
@@ -57,7 +69,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for name in SOURCES:
         srcname, flags = SPECIAL.get(name, (name, FLAGS))
         src, obj = os.path.join(CSRC, srcname + ".hip"), os.path.join(OBJ, name + ".o")
-        if force or _stale(obj, [src] + headers):
+        if force or _stale(obj, [src] + headers + _local_includes(src)):
             jobs.append([hipcc, *flags, "-c", src, "-o", obj])
 
     def run(cmd):

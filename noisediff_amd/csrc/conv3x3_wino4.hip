@@ -33,25 +33,6 @@
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 // fp32 rounding of these transforms is ~10x that of F(2x2,3x3) (~1e-5 relative; parity tests at 5e-5).
 //
-// ---- W4_F16X3 (conv3x3_wino4h.hip compiles this file with W4_F16X3 = 1; r4, opt-in: ND_CONV_F16X3=1 in the engine) ----
-// Winograd F(4x4,3x3) 3x3 convolution with the position products on the f16 matrix instruction, operands split into two f16 terms (r4, opt-in).
-// conv3x3_wino4.hip multiplies with v_mfma_f32_16x16x4_f32, and on gfx950 that instruction IS VALU work: its K loop costs MFMA issue + every VALU / LDS-write
-// instruction, serially (two waves per SIMD do not change the total).  The f16 / bf16 matrix instructions run on their own pipe
-// (tools/microbench/bf16_mfma_valu.hip: 18 ticks for 4x the multiplies, non-packed VALU and one ds_read_b128 hide behind each).  Here every operand is split into
-// two f16 terms, V = V1 + V2 and U * 2^11 = U1 + U2 (V1, U1 = the value rounded to f16, V2, U2 = the remainder rounded to f16: 22 significant bits together, the
-// power-of-two weight scale keeps U2 out of the subnormals; v_cvt_pkrtz saturates, so |V| up to 1.3e5 stays exact-ish), and three products are accumulated in fp32:
-// V1 U1 + V1 U2 + V2 U1 (the dropped V2 U2 is 2^-22 of the product).  Measured against an fp64 direct convolution (tools/experiments/bf16_split_accuracy.py and
-// the f16 variant in DESIGN section 8): 8e-6 ... 1.2e-5 of max|y| -- the same as the fp32 F(4x4) path, whose error is the transforms', not the products'.
-// Same bytes everywhere: the V image holds {V1, V2} of 4 channels in the 16 bytes that held 2 positions x 2 channels of fp32, a weight fragment {U1, U2} of 4
-// channels in the 16 bytes that held the fp32 fragment; per 16-channel chunk a wave issues 216 v_mfma_f32_16x16x16_f16 (18 ticks) instead of 288 fp32 MFMAs (34).
-// Structure, staging, transforms, epilogue: conv3x3_wino4.hip's 16 x 32-region form (one workgroup per CU, 72 accumulators per wave); what differs is marked "f16:".
-// Results differ from the fp32 kernel in the last bits (another product rounding), not in accuracy; plain / affine (+ map) + SiLU / LeakyReLU sources.
-#ifndef W4_F16X3
-#define W4_F16X3 0            // 1: conv3x3_wino4h.hip includes this file -- the position products as a three-product f16 split (see the header comment there)
-#endif
-#if W4_F16X3
-#define wino4_kernel wino4h_kernel      // (so that a profile tells the two kernels apart)
-#endif
 #include <stdlib.h>
 #include <type_traits>
 #include "nd_common.h"
@@ -109,7 +90,7 @@ struct W4Geo {
 #endif
 #ifndef W4_UR_MAP
 #define W4_UR_MAP 6          // ... of the map variant (20 more staging registers per in-flight halo item): no spill in any fp32 instance; 9 measures the same
-#endif                       // (W4_F16X3: its map instance spills 7 registers whatever the ring depth -- two launches per step, left as it is)
+#endif
 #ifndef W4_UR_EPI
 #define W4_UR_EPI 6          // ... across a tile's epilogue (its output transform needs the registers): the ring runs down in the
 #endif                       // last stage of a tile and is refilled in one burst at the start of the next tile's first stage
@@ -149,8 +130,6 @@ struct W4Geo {
 #ifndef W4_PAIR_SKEW
 #define W4_PAIR_SKEW 2       // NTG == 1: s_sleep(32) units (2048 cycles) by which the second workgroup of a CU starts later
 #endif
-#if W4_F16X3
-#endif
 #ifndef W4_PRIO
 #define W4_PRIO 0            // NTG == 1: s_setprio level of a wave inside its transform / epilogue (VALU phases; the other workgroup's waves sit in MFMA stages at level 0)
 #endif
@@ -176,19 +155,10 @@ struct Wino4Args {
 #define W4_NOP ""
 #endif
 // (uv = a weight-fragment register: lane (cout l & 15, channel l >> 4) -> the B operand; vv = a V register: lane (tile l & 15, channel l >> 4) -> A)
-#if W4_F16X3
-// f16: one instruction = 16 tiles x 16 couts x 16 channels; uv / vv are 64-bit operands (four f16: the lane's K group)
-#define W4_MFMA_A(acc, uv, vv)  asm volatile(W4_NOP "v_mfma_f32_16x16x16_f16 %0, %2, %1, %0" : "+a"(acc) : "v"(uv), "v"(vv))
-#define W4_MFMA_V(acc, uv, vv)  asm volatile(W4_NOP "v_mfma_f32_16x16x16_f16 %0, %2, %1, %0" : "+v"(acc) : "v"(uv), "v"(vv))
-#define W4_MFMA_AZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x16_f16 %0, %2, %1, 0" : "=&a"(acc) : "v"(uv), "v"(vv))
-#define W4_MFMA_VZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x16_f16 %0, %2, %1, 0" : "=&v"(acc) : "v"(uv), "v"(vv))
-constexpr float W4H_WSCALE = 2048.0f, W4H_WSCALE_INV = 1.0f / 2048.0f;      // the packed weights are U * 2^11 (keeps the second f16 term normal); undone on the outputs
-#else
 #define W4_MFMA_A(acc, uv, vv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+a"(acc) : "v"(uv), "v"(vv))
 #define W4_MFMA_V(acc, uv, vv)  asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+v"(acc) : "v"(uv), "v"(vv))
 #define W4_MFMA_AZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, 0" : "=&a"(acc) : "v"(uv), "v"(vv))
 #define W4_MFMA_VZ(acc, uv, vv) asm volatile(W4_NOP "v_mfma_f32_16x16x4_f32 %0, %2, %1, 0" : "=&v"(acc) : "v"(uv), "v"(vv))
-#endif
 #define W4_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 // one row of B^T applied to six packed values (the same code serves the column pass)
@@ -360,23 +330,13 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
             const int r0 = 4 * (t_tile >> 2) + 4 * h, c = 16 * tg + 4 * (t_tile & 3) + bx;
             ttab[(h * 6 + bx) * NT] = (unsigned short)((4 * (t_tile >> 2) * RAW_ROWP + cperm(c)) * 64 + (((4 * ch2 + t_kq) ^ swz(r0, c)) * 8));
         }
-#if W4_F16X3
-    // f16: V image of a tile group = [position 36][K group 4][tile 16] x 16 bytes {V1 ch 4kg, 4kg+1 | V1 ch 4kg+2, 4kg+3 | V2 ... | V2 ...}: the transform lane of channel pair
-    // P = 4 ch2 + t_kq (channels 2P, 2P+1) writes dword (P & 1) with its V1 pair and dword 2 + (P & 1) with its V2 pair; K group = P >> 1
-    const unsigned t_lds = (unsigned)((2 * ch2 + (t_kq >> 1)) * 256 + t_tile * 16 + (t_kq & 1) * 4);  // V image address of the transform lane
-#else
     const unsigned t_lds = (unsigned)(ch2 * 1024 + (t_kq >> 1) * 512 + t_tile * 32 + (t_kq & 1) * 16);  // V image address of the transform lane
-#endif
     // the bias of every cout (zero beyond cout / without a bias) -> LDS, once per workgroup: the epilogues read it with an LDS load.  (A global
     // load there shares the in-order vmcnt counter with the output stores: waiting for it drained every store issued before it.)
     // NTG == 1 has no LDS left for it: the lane's bias (cout = cg * 16 + (l & 15)) is loaded into a register at the start of every tile, long before the
     // epilogue (a resource of zero records without a bias: the load returns 0, as it does for a padded cout)
     if (Geo::BIAS_LDS)
-#if W4_F16X3
-        for (int i = tid; i < a.n_tiles * 64; i += NT) bias_lds[i] = (a.d.bias && i < Cout) ? a.d.bias[i] * W4H_WSCALE : 0.0f;      // f16: the accumulators hold 2^11 x the sums
-#else
         for (int i = tid; i < a.n_tiles * 64; i += NT) bias_lds[i] = (a.d.bias && i < Cout) ? a.d.bias[i] : 0.0f;
-#endif
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d.bias ? a.d.bias : a.d.weight), 0, a.d.bias ? Cout * 4 : 0, 0x00020000);
     float bias_r = 0.0f;
 
@@ -470,11 +430,7 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     // ---- V image of a tile group (36 KB): [position pair 18][8-channel half g2][kq >> 1][tile 16][kq & 1] x 16 bytes, the 16 bytes
     //      being positions (2pp, 2pp+1) x channels (2kq, 2kq+1) -- what one MFMA lane needs for a position pair, one conflict-free
     //      ds_read_b128 (twice the bytes per LDS cycle of the 8-byte forms).  MFMA lane: + g2 * 1024 + pp * 2048 bytes
-#if W4_F16X3
-    const unsigned d_lds = (unsigned)(kq * 256 + tile * 16);          // f16: MFMA lane (tile, K group kq): + position * 1024
-#else
     const unsigned d_lds = (unsigned)((kq >> 1) * 512 + tile * 32 + (kq & 1) * 16);
-#endif
 
     // input transform of the staged halo (raw image) into this tile group's V image (this wave: half ch2), in three steps so that
     // the raw reads can run under the tail of a stage: xf_addr (the lane's 12 raw addresses), xf_read (patch row `ay`), xf_finish
@@ -488,19 +444,6 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
 #pragma unroll
         for (int bx = 0; bx < 6; ++bx)
             T[ay][bx] = *reinterpret_cast<const f32x2*>(rawbuf + t_addr[(ay >> 2) * 6 + bx] + ay * (RAW_ROWP * 64));
-#endif
-#if W4_F16X3
-    };
-    // f16: a transformed value pair (channels 2P, 2P + 1 of one position) -> its two f16 terms.  v_cvt_pkrtz rounds toward zero, so the first term never overflows to inf
-    // (it saturates at 65504 and the remainder carries the rest: exact up to |V| = 1.3e5), and the remainder v - V1 is exact in fp32
-    auto split_store = [&](char* dst, f32x2 v) {
-        const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
-        float r0, r1;      // v - float(V1), exact: one mixed-precision fma each (hipcc turns fma(x, -1, y) back into a convert and a subtraction)
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w1), "v"(v.x));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w1), "v"(v.y));
-        *reinterpret_cast<unsigned*>(dst) = w1;
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));          // the exact remainders, rounded to nearest (v_cvt_pk_f16_f32; nd_split4_f16: a truncated second term biases every operand one way)
-        *reinterpret_cast<unsigned*>(dst + 8) = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, h2v));
 #endif
     };
     auto xf_finish = [&](f32x2 (&T)[6][6], float* buf, auto&& before_write) {
@@ -524,12 +467,8 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
             w4_bt(T[xi], v);
 #if W4_XF_SPLIT
 #pragma unroll
-#if W4_F16X3
-            for (int nu = 0; nu < 6; ++nu) split_store(base + (xi * 6 + nu) * 1024, v[nu]);     // f16: position (xi, nu) of this lane's channel pair
-#else
             for (int h = 0; h < 3; ++h)                                  // 16 bytes = positions (xi, 2h), (xi, 2h + 1) of this lane's channel pair
                 *reinterpret_cast<f32x4*>(base + (xi * 3 + h) * 2048) = f32x4{v[2 * h].x, v[2 * h].y, v[2 * h + 1].x, v[2 * h + 1].y};
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #else
 #pragma unroll
@@ -541,12 +480,8 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
 #pragma unroll
         for (int xi = 0; xi < 6; ++xi)
 #pragma unroll
-#if W4_F16X3
-            for (int nu = 0; nu < 6; ++nu) split_store(base + (xi * 6 + nu) * 1024, T[xi][nu]);
-#else
             for (int h = 0; h < 3; ++h)
                 *reinterpret_cast<f32x4*>(base + (xi * 3 + h) * 2048) = f32x4{T[xi][2 * h].x, T[xi][2 * h].y, T[xi][2 * h + 1].x, T[xi][2 * h + 1].y};
-#endif
 #endif
 #else
         before_write();
@@ -574,22 +509,14 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
             }
         };
         if (rh == 0) pass1(std::integral_constant<int, 0>{}); else pass1(std::integral_constant<int, 1>{});
-#if W4_F16X3
-        char* base = reinterpret_cast<char*>(buf) + t_lds + rh * (18 * 1024);      // f16: rows xi = 3 rh .. 3 rh + 2 = positions 18 rh .. 18 rh + 17
-#else
         char* base = reinterpret_cast<char*>(buf) + t_lds + rh * (9 * 2048);
-#endif
 #pragma unroll
         for (int i = 0; i < 3; ++i) {                                    // V[3 rh + i] = T[i] B
             f32x2 v[6];
             w4_bt(T[i], v);
 #pragma unroll
-#if W4_F16X3
-            for (int nu = 0; nu < 6; ++nu) split_store(base + (i * 6 + nu) * 1024, v[nu]);
-#else
             for (int h = 0; h < 3; ++h)
                 *reinterpret_cast<f32x4*>(base + (i * 3 + h) * 2048) = f32x4{v[2 * h].x, v[2 * h].y, v[2 * h + 1].x, v[2 * h + 1].y};
-#endif
         }
 #endif
     };
@@ -610,19 +537,10 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
 #endif
     };
     auto read_v = [&](const char* v0base, const char* v1base, int pp) {
-#if W4_F16X3
-        Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x4*>(v0base + pp * 1024);       // f16: one position {V1 | V2} of the lane's K group
-        if (TGW == 2) Vr[pp % W4_VR][TGW - 1] = *reinterpret_cast<const f32x4*>(v1base + pp * 1024);
-#else
         Vr[pp % W4_VR][0] = *reinterpret_cast<const f32x4*>(v0base + pp * 2048);
         if (TGW == 2) Vr[pp % W4_VR][TGW - 1] = *reinterpret_cast<const f32x4*>(v1base + pp * 2048);
-#endif
     };
-#if W4_F16X3
-    auto mfma = [&](auto first_c, int idx, f32x2 av, f32x2 bv) {
-#else
     auto mfma = [&](auto first_c, int idx, float av, float bv) {
-#endif
         constexpr bool FIRST = decltype(first_c)::value;
         if (idx < ACC_AGPR) { if (FIRST) W4_MFMA_AZ(acc[idx], av, bv); else W4_MFMA_A(acc[idx], av, bv); }
         else                { if (FIRST) W4_MFMA_VZ(acc[idx], av, bv); else W4_MFMA_V(acc[idx], av, bv); }
@@ -632,14 +550,8 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     // requested.  `mid(pp)` runs behind position pair pp (halo loads of stage 0, their LDS writes in stage 1).
     // `off_c`: ring slot of the stage's fragment 0 (stage 0 of a chunk: 0, stage 1: 18 % UR; a chunk's 36 fragments close the ring).
     // `din_c` fragments of this stage are in flight on entry, `dout_c` of the next stage on exit (UR in the steady state).
-#if W4_F16X3
-    // f16: a "stage" is 18 of the chunk's 36 POSITIONS (all 16 channels: one MFMA covers K = 16); pos_c = its first position
-    auto stage = [&](auto first_c, auto off_c, auto din_c, auto dout_c, auto pos_c, const char* v0base, const char* v1base, int wb, int nb, auto&& pre, auto&& mid) {
-        constexpr int OFF = decltype(off_c)::value, DIN = decltype(din_c)::value, DOUT = decltype(dout_c)::value, POS0 = decltype(pos_c)::value;
-#else
     auto stage = [&](auto first_c, auto off_c, auto din_c, auto dout_c, const char* v0base, const char* v1base, int wb, int nb, auto&& pre, auto&& mid) {
         constexpr int OFF = decltype(off_c)::value, DIN = decltype(din_c)::value, DOUT = decltype(dout_c)::value;
-#endif
         auto hi = [](int pp) { const int h = pp + UR; return h < 18 + DOUT ? h : 18 + DOUT; };   // fragments requested before position pair pp
 #pragma unroll
         for (int pp = 0; pp < W4_VR - 1; ++pp) read_v(v0base, v1base, pp);
@@ -651,39 +563,6 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pp = 0; pp < 18; ++pp) {
-#if W4_F16X3
-            const f32x4 u = U[(OFF + pp) % UR];
-            const f32x4 va = Vr[pp % W4_VR][0], vb = Vr[pp % W4_VR][TGW - 1];     // {V1 | V2} of the lane's K group, tile group 0 / 1
-            const f32x2 u1 = {u.x, u.y}, u2 = {u.z, u.w}, a1 = {va.x, va.y}, a2 = {va.z, va.w}, b1 = {vb.x, vb.y}, b2 = {vb.z, vb.w};
-            const int P = POS0 + pp;
-            auto refill = [&] {
-#pragma unroll
-                for (int q = (hi(pp) > DIN ? hi(pp) : DIN); q < hi(pp + 1); ++q) {     // the slot just consumed takes the fragment UR ahead
-                    if (q < 18) load_u(OFF + q, q, wb);
-                    else load_u(OFF + q, q - 18, nb);
-                }
-            };
-            // f16: position POS0 + pp, the wave's tile group(s): V1 U1 (the first touch of the accumulators in a tile's first chunk), V1 U2, V2 U1.  (Issuing the position's
-            // loads / LDS accesses BETWEEN its MFMAs instead of behind the last one measures the same and costs three spills: grouped, as in the fp32 form.)
-            if (pp + W4_VR - 1 < 18) read_v(v0base, v1base, pp + W4_VR - 1);
-            pre(pp);
-            __builtin_amdgcn_sched_barrier(0);
-            if (TGW == 2) {
-                mfma(first_c, 2 * P + 0, u1, a1);
-                mfma(first_c, 2 * P + 1, u1, b1);
-                mfma(std::false_type{}, 2 * P + 0, u2, a1);
-                mfma(std::false_type{}, 2 * P + 1, u2, b1);
-                mfma(std::false_type{}, 2 * P + 0, u1, a2);
-                mfma(std::false_type{}, 2 * P + 1, u1, b2);
-            } else {       // (an accumulator three times in a row: tools/microbench/f16_mfma_dep.hip -- 17.2 ticks per MFMA at any reuse distance)
-                mfma(first_c, P, u1, a1);
-                mfma(std::false_type{}, P, u2, a1);
-                mfma(std::false_type{}, P, u1, a2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            refill();
-            mid(pp);
-#else
             if (pp + W4_VR - 1 < 18) read_v(v0base, v1base, pp + W4_VR - 1);
             pre(pp);                                                     // LDS table reads of mid(pp): their latency hides under the MFMAs
             const f32x4 u = U[(OFF + pp) % UR];
@@ -714,7 +593,6 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
                 else load_u(OFF + q, q - 18, nb);
             }
             mid(pp);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -843,20 +721,10 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
             };
             W4_T0();
             if (TGW == 1 && FIRST)                                        // this tile's bias (lane = cout): in flight over the whole first stage
-#if W4_F16X3
-                bias_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(cg * 16 + (lane & 15)) * 4u, 0, 0)) * W4H_WSCALE;
-            stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IXF>{}, IUR{}, std::integral_constant<int, 0>{}, v0cur, v1cur, w0, w1, issue_pre, issue);
-#else
                 bias_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (unsigned)(cg * 16 + (lane & 15)) * 4u, 0, 0));
             stage(first_c, I0{}, std::conditional_t<FIRST, IEPI, IXF>{}, IUR{}, v0cur, v1cur, w0, w1, issue_pre, issue);
-#endif
             if (TGW == 1 && FIRST) asm volatile("" : "+v"(bias_r));      // waited for HERE (every older load has been consumed), not behind the ring in the epilogue
-#if W4_F16X3
-            // (f16: positions 18-35 are touched for the first time here in a tile's first chunk)
-            stage(first_c, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IXF>{}, std::integral_constant<int, 18>{}, v0cur + 18 * 1024, v1cur + 18 * 1024, w1, wn, commit_pre, commit);
-#else
             stage(std::false_type{}, IOFF1{}, IUR{}, std::conditional_t<last, IEPI, IXF>{}, v0cur + 1024, v1cur + 1024, w1, wn, commit_pre, commit);
-#endif
 #ifdef W4_STAMP
             if (FIRST) W4_ACC(stamp_first);
             if (last) W4_ACC(stamp_last);
@@ -965,11 +833,7 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
                             y[3] = __builtin_elementwise_fma(c8, te, tb) + z[5];
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
-#if W4_F16X3
-                                const f32x2 v = y[jj] * W4H_WSCALE_INV;  // pixels (4 kq + i, 4 (2 h + e) + jj) of the tile, e = component (f16: the weight scale undone, exactly)
-#else
                                 const f32x2 v = y[jj];                   // pixels (4 kq + i, 4 (2 h + e) + jj) of the tile, e = component
-#endif
                                 if (STATS && h == 0 && i == 0 && jj == 0)   // one pivot per cout for the whole 16x16 tile: its first pixel (lane l & 15, register 0)
                                     pivot = __shfl(v.x, l15);
                                 f32x2 in2 = {1.0f, 1.0f};                // !FULL: which of the two pixels are inside the image
@@ -1063,7 +927,7 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
 #endif
 }
 
-// ---- split-K: the reduction kernels and the launcher of the SPLIT instances (both product forms: under W4_F16X3 wino4_kernel is wino4h_kernel)
+// ---- split-K: the reduction kernels and the launcher of the SPLIT instances
 // out[n][c] = sum over the splits (in split order) of part[s][n][c] + bias[c]; n = pixel (B * H * W), float4 per thread
 __global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
                                                                int splits, long npix, int cout, int ldo) {
@@ -1144,86 +1008,6 @@ int launch4_split(const Wino4Args& a, hipStream_t st) {
     return 0;
 }
 
-#if W4_F16X3
-// OIHW (cout, cin, 3, 3) -> U = G g G^T * 2^11 as two f16 terms, in blocks [cin/16][position half 2][cout/16][18 positions][64 lanes][16 bytes]:
-// lane (cout = l & 15, kg = l >> 4) holds for position p = 18 half + q the four channels 4 kg .. 4 kg + 3 of its chunk: {U1 ch0 ch1 | U1 ch2 ch3 | U2 ch0 ch1 | U2 ch2 ch3}
-// (U1 = the scaled value rounded to f16, U2 = the remainder rounded to f16).  The same number of bytes as the fp32 packing of conv3x3_wino4.hip.
-__global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int n_c16, int n_cg) {
-    constexpr float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                               {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-    const size_t total = (size_t)n_c16 * n_cg * 64;                      // one thread per (chunk, cout group, lane): its four channels' nine taps, 36 x 16 bytes out
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int l = (int)(i & 63);
-        const size_t blk = i >> 6;
-        const int cg = (int)(blk % n_cg), c16 = (int)(blk / n_cg);
-        const int co = cg * 16 + (l & 15), ch0 = c16 * 16 + 4 * (l >> 4);
-        float g[4][9];
-        bool ok[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ch = ch0 + c;
-            ok[c] = ch < cin && co < cout;
-            const float* gp = w + (ok[c] ? ((size_t)co * cin + ch) * 9 : 0);
-#pragma unroll
-            for (int j = 0; j < 9; ++j) g[c][j] = gp[j];
-        }
-#pragma unroll
-        for (int pos = 0; pos < 36; ++pos) {
-            const int xi = pos / 6, nu = pos % 6, half = pos / 18, q = pos % 18;
-            _Float16 h1[4], h2[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double acc = 0.0;                                        // fp64 accumulation of the 9 products: the packed weights are rounded once
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                    for (int ss = 0; ss < 3; ++ss) acc += (double)G[xi][rr] * (double)g[c][rr * 3 + ss] * (double)G[nu][ss];
-                const float u = ok[c] ? (float)(acc * (double)W4H_WSCALE) : 0.0f;
-                float a = fminf(fmaxf(u, -65504.0f), 65504.0f);           // (a weight beyond 32 would saturate the first term; the remainder carries on)
-                h1[c] = (_Float16)a;
-                h2[c] = (_Float16)fminf(fmaxf(u - (float)h1[c], -65504.0f), 65504.0f);
-            }
-            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-            u32x4_t v;
-            v.x = __builtin_bit_cast(unsigned, h2v{h1[0], h1[1]});  v.y = __builtin_bit_cast(unsigned, h2v{h1[2], h1[3]});
-            v.z = __builtin_bit_cast(unsigned, h2v{h2[0], h2[1]});  v.w = __builtin_bit_cast(unsigned, h2v{h2[2], h2[3]});
-            float* o = out + ((((size_t)c16 * 2 + half) * n_cg + cg) * 18 + q) * 256 + l * 4;
-            *reinterpret_cast<u32x4_t*>(o) = v;
-        }
-    }
-}
-
-template <int MODE, bool STREAM, int NTG = 2, int NW = 4>
-int launch4hs(const Wino4Args& a, hipStream_t st) {
-    static nd_device_once configured;
-    constexpr int LDS_BYTES = W4Geo<NTG, NW>::LDS_BYTES;
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(wino4_kernel<MODE, STREAM, false, NTG, NW>), LDS_BYTES, "nd_conv3x3_wino4h")) return e;
-    const long resident = (long)nd_device_cus() * W4Geo<NTG, NW>::WG_PER_CU;
-    hipLaunchKernelGGL((wino4_kernel<MODE, STREAM, false, NTG, NW>), dim3((unsigned)(a.total_wg < resident ? a.total_wg : resident)), dim3(64 * NW), LDS_BYTES, st, a);
-    return 0;
-}
-
-template <int MODE, int NTG = 2, int NW = 4>
-int launch4h(const Wino4Args& a, hipStream_t st) {
-    static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;
-    const long out_bytes = (long)a.d.B * a.d.H * a.d.W * a.d.ldo * 4;
-    return out_bytes >= stream_min ? launch4hs<MODE, true, NTG, NW>(a, st) : launch4hs<MODE, false, NTG, NW>(a, st);
-}
-
-}  // namespace
-
-// (the packed size equals nd_pack_conv3x3_wino4_weight_floats: 16 bytes per lane, position and 4 channels either way)
-extern "C" int nd_pack_conv3x3_wino4h_weight(const float* oihw, float* packed, int cin, int cout, void* stream) {
-    ND_REQUIRE(oihw && packed, ND_E_BADARG, "nd_pack_conv3x3_wino4h_weight: null pointer");
-    ND_REQUIRE(cin > 0 && cout > 0, ND_E_BADARG, "nd_pack_conv3x3_wino4h_weight: non-positive size");
-    const int n_c16 = nd_cdiv(cin, 16), n_cg = nd_round_up(cout, 64) / 16;
-    const size_t total = (size_t)n_c16 * n_cg * 64;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_wino4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, oihw, packed, cin, cout, n_c16, n_cg);
-    return nd_launch_status("nd_pack_conv3x3_wino4h_weight");
-}
-
-#else
 // OIHW (cout, cin, 3, 3) -> U = G g G^T in blocks [cin/8][cout/16][18 position pairs][64 lanes][4]:
 // lane (cout = l & 15, k = l >> 4) holds {U[2pp][ch 2k], U[2pp][ch 2k+1], U[2pp+1][ch 2k], U[2pp+1][ch 2k+1]} of its block
 // dgrad: `w` is the FORWARD layer's OIHW weight (cin_fwd = cout, cout_fwd = cin) and the packed operator is the data gradient's --
@@ -1317,7 +1101,6 @@ extern "C" int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* 
 
 extern "C" int nd_conv3x3_wino4_stat_slots(int H, int W) { return nd_cdiv(W, 16) * nd_cdiv(H, 16); }
 
-#endif
 // descriptor checks shared by the entry points; fills the launch arguments
 static int w4_prepare(const nd_conv3x3* d, Wino4Args& a, int ntg = 2) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_conv3x3_wino4: null descriptor");
@@ -1416,42 +1199,6 @@ static int w4_splitk(const nd_conv3x3* d, float* workspace, int splits, void* st
     return nd_launch_status(who);
 }
 
-#if W4_F16X3
-extern "C" int nd_conv3x3_wino4h_nhwc_f32(const nd_conv3x3* d, void* stream) {
-    Wino4Args a;
-    if (int e = w4_prepare(d, a)) return e;
-    const nd_src& s = d->src;
-    hipStream_t st = (hipStream_t)stream;
-    int rc;
-    switch (s.mode) {
-        case ND_PRO_AFFINE_SILU: rc = launch4h<ND_PRO_AFFINE_SILU>(a, st); break;
-        case ND_PRO_AFFINE_MAP_SILU: rc = launch4h<ND_PRO_AFFINE_MAP_SILU>(a, st); break;
-        case ND_PRO_LEAKY: rc = launch4h<ND_PRO_LEAKY>(a, st); break;
-        case ND_PRO_LEAKY_SECOND: rc = launch4h<ND_PRO_LEAKY_SECOND>(a, st); break;
-        default: rc = launch4h<ND_PRO_NONE>(a, st); break;
-    }
-    if (rc) return rc;
-    return nd_launch_status("nd_conv3x3_wino4h_nhwc_f32");
-}
-
-// ... on 16 x 16-pixel regions with two co-resident workgroups per CU (the fp32 experiment of conv3x3_wino4.hip, where it bought nothing: there every instruction of
-// one workgroup is VALU work that stops the other's MFMAs; with the f16 instruction one workgroup's transform / epilogue can run beside the other's MFMAs).
-extern "C" int nd_conv3x3_wino4h_16_nhwc_f32(const nd_conv3x3* d, void* stream) {
-    Wino4Args a;
-    if (int e = w4_prepare(d, a, 1)) return e;
-    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
-               "nd_conv3x3_wino4h_16: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)");
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4h<ND_PRO_AFFINE_SILU, 1, 4>(a, st) : launch4h<ND_PRO_NONE, 1, 4>(a, st)) return rc;
-    return nd_launch_status("nd_conv3x3_wino4h_16_nhwc_f32");
-}
-
-// ... and its geometry-only split of K for the narrow layers (nd_conv3x3_wino4_16_splitk_plan; BASELINE config 2's 16 x 16 / 32 x 32 stages): the SPLIT instances of the f16 kernel
-// write the partial tensors, the fp32 reduction adds them in range order (+ bias, + statistics) exactly as for nd_conv3x3_wino4_16_splitk_nhwc_f32
-extern "C" int nd_conv3x3_wino4h_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {
-    return w4_splitk(d, workspace, splits, stream, 1, "nd_conv3x3_wino4h_16_splitk_nhwc_f32");
-}
-#else
 extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     Wino4Args a;
     if (int e = w4_prepare(d, a)) return e;
@@ -1480,20 +1227,6 @@ extern "C" int nd_conv3x3_wino4_16_nhwc_f32(const nd_conv3x3* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4<ND_PRO_AFFINE_SILU, 1>(a, st) : launch4<ND_PRO_NONE, 1>(a, st)) return rc;
     return nd_launch_status("nd_conv3x3_wino4_16_nhwc_f32");
-}
-
-// The 16 x 32-pixel region with EIGHT waves (two per SIMD in one workgroup: waves 0-3 multiply tile group 0, waves 4-7 tile group 1; r4): the two wave sets
-// run in phase by construction -- the MFMA stages of one cover the LDS / memory waits of the other, the VALU phases (transform, epilogue) of both coincide
-// instead of slipping between the other's MFMAs one instruction at a time -- and every weight fragment is fetched from the L2 once per workgroup (the second
-// wave set's request hits the L1).  Same weights, slots, descriptor and bits.  Plain and GroupNorm-affine + SiLU sources.
-extern "C" int nd_conv3x3_wino4_8w_nhwc_f32(const nd_conv3x3* d, void* stream) {
-    Wino4Args a;
-    if (int e = w4_prepare(d, a, 2)) return e;
-    ND_REQUIRE(d->src.mode == ND_PRO_NONE || d->src.mode == ND_PRO_AFFINE_SILU, ND_E_BADARG,
-               "nd_conv3x3_wino4_8w: plain or GroupNorm-affine + SiLU sources (no map / LeakyReLU prologue)");
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = d->src.mode == ND_PRO_AFFINE_SILU ? launch4<ND_PRO_AFFINE_SILU, 2, 8>(a, st) : launch4<ND_PRO_NONE, 2, 8>(a, st)) return rc;
-    return nd_launch_status("nd_conv3x3_wino4_8w_nhwc_f32");
 }
 
 // ---- split-K (training at small batch, and any plain layer without a statistics epilogue whose items fill a fraction of the chip)
@@ -1541,4 +1274,3 @@ extern "C" int nd_conv3x3_wino4_16_splitk_plan(int H, int W, int cin, int cout) 
 extern "C" int nd_conv3x3_wino4_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, int splits, void* stream) {
     return w4_splitk(d, workspace, splits, stream, 1, "nd_conv3x3_wino4_16_splitk_nhwc_f32");
 }
-#endif

@@ -146,29 +146,6 @@ __device__ __forceinline__ float nd_row16_first(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150, 0xF, 0xF, true));
 }
 
-// Four fp32 values -> their two f16 terms {first terms x y | z w | second terms x y | z w} (the f16-split product forms: conv3x3_wino4h.hip,
-// conv3x3_f16x3.hip, pointwise_big_kernel<.., HF>).  v_cvt_pkrtz rounds toward zero, so the first term never overflows to inf (it saturates) and the
-// remainder v - first, computed by v_fma_mix_f32 from the f16 register itself, is exact in fp32; the second term is that remainder rounded to NEAREST
-// (v_cvt_pk_f16_f32, gfx950): a truncated second term would leave every operand short by up to 2^-22 of its value with ONE sign -- errors that add up coherently
-// over the channels of a product and over the steps of a sampling run, where fp32's own rounding is unbiased.
-__device__ __forceinline__ f32x4 nd_split4_f16(f32x4 v) {
-    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
-    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
-    float r0, r1, r2, r3;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h0), "v"(v.x));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h0), "v"(v.y));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h1), "v"(v.z));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h1), "v"(v.w));
-    f32x4 o;
-    o.x = __builtin_bit_cast(float, h0);  o.y = __builtin_bit_cast(float, h1);
-    // (written as a vector conversion, which gfx950 selects as v_cvt_pk_f16_f32: behind an inline-asm producer hipcc does not place the wait states an MFMA
-    //  that reads the register next needs -- the chain kernels feed these straight into v_mfma -- and NaNs appeared)
-    typedef _Float16 nd_h2 __attribute__((ext_vector_type(2)));
-    o.z = __builtin_bit_cast(float, __builtin_convertvector(f32x2{r0, r1}, nd_h2));
-    o.w = __builtin_bit_cast(float, __builtin_convertvector(f32x2{r2, r3}, nd_h2));
-    return o;
-}
-
 // exact-fp32 matrix FMA: D(32x32) += A(32x2) * B(2x32); lane l gives A[l&31][l>>5], B[l>>5][l&31]
 __device__ __forceinline__ f32x16 nd_zero16() {
     f32x16 z;

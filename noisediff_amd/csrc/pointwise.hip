@@ -26,7 +26,7 @@ struct PwArgs {
 };
 
 // Epilogue shared by both kernels: accumulators -> LDS -> (bias, activation, residuals, fused ResnetBlock tail) -> global.
-template <int MB, int NB, int JB = 0, bool HS = false>     // HS: the accumulators hold 2^11 x the sums (f16-split weights, see pointwise_big_kernel)
+template <int MB, int NB, int JB = 0>
 __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][NB], float* As, int b, int p0, int n0, unsigned long long* ph = nullptr) {   // ph: diagnostic phase stamps
     constexpr int BM = 2 * MB * 32, BN = 2 * NB * 32;
     constexpr int LDO = BN + 4;                               // output tile row stride in LDS (floats)
@@ -47,7 +47,7 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x16 (&acc)[MB][N
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                As[((wm * MB + mb) * 32 + nd_acc_row(r, lane)) * LDO + (wn * NB + nb) * 32 + col] = HS ? acc[mb][nb][r] * (1.0f / 2048.0f) : acc[mb][nb][r];
+                As[((wm * MB + mb) * 32 + nd_acc_row(r, lane)) * LDO + (wn * NB + nb) * 32 + col] = acc[mb][nb][r];
     if (ph) ph[2] = __builtin_amdgcn_s_memtime();
     __syncthreads();
     if (ph) ph[3] = __builtin_amdgcn_s_memtime();
@@ -341,35 +341,9 @@ __global__ __launch_bounds__(256, (MB == 1 ? PW_PIPE_OCC : 2)) void pointwise_pi
 #define PWB_MFMA(acc, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
 constexpr int BKC = 64, BLDA = BKC + 4;
 
-// ---- the same kernel with every product as three f16 MFMAs (HF; the opt-in of conv3x3_wino4h.hip carried over, nd_pointwise_gemm_f16x3_nhwc_f32):
-// an activation a = A1 + A2 and a weight 2^11 w = W1 + W2 as two f16 terms each, a w ~ 2^-11 (A1 W1 + A1 W2 + A2 W1) accumulated in fp32 -- the dropped
-// A2 W2 is 2^-22 of the product.  v_mfma_f32_32x32x8_f16 contracts the 8 channels of a group in one instruction of 32 cycles (the fp32 form: 4 x 64), and a
-// lane's four f16 of an operand are exactly the four channels its f32x4 held, so the 16-byte slots of the A tile and of the packed weight keep their place
-// and their size: {first terms ch0..3 | second terms ch0..3}.  The split of the activations happens in stage_write (v_cvt_pkrtz + v_fma_mix_f32: the
-// remainder is exact; nd_split4_f16); the weights are split by nd_pack_pointwise_weight_h; the epilogue multiplies by 2^-11.
-#define PWB_MFMA_H(acc, av, bv) asm volatile("v_mfma_f32_32x32x8_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-// ... and on the double-rate instruction (r4c, PWH_K16): v_mfma_f32_32x32x16_f16 contracts 16 channels in the same 32 cycles (tools/microbench/f16_mfma_32x32.hip); a lane then
-// holds 8 consecutive channels of an operand term, so a 16-channel group of the A tile is 64 bytes per pixel {A1 ch0..7 | A1 ch8..15 | A2 ch0..7 | A2 ch8..15} (written as two 8-byte
-// pieces per staged quad) and the packed weight is [cin/16][term][channel half][coutP] x 16 bytes.
-#define PWB_MFMA_H16(acc, av, bv) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv))
-#ifndef PWH_K16
-#define PWH_K16 1
-#endif
-#ifndef PWH_RS
-#define PWH_RS 4             // weight-fragment ring of the f16 form: slots (a power of two); PWH_RS - 1 groups of 8 channels in flight
-#endif
-#ifndef PWH_WG
-#define PWH_WG 4             // f16 form: the group of a chunk in front of which the next chunk's activations (requested at group 0) are written to LDS
-#endif
-template <int NB, int MODE, bool HF = false>
+template <int NB, int MODE>
 __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
-    constexpr int RS = HF ? PWH_RS : 4, RD = RS - 1;          // weight ring: slots, groups ahead
-    // f16 form on the double-rate instruction: groups of 16 channels, both terms as separate operands.  Not under the LayerNorm prologue: with the row statistics and the
-    // gamma / beta / vector constants live it needs 288 registers (one workgroup per CU: measured slower than the K = 8 form; with a two-slot weight ring it fits 256 and is
-    // 10-20 % faster, but produced sporadic wrong pixel rows at B = 16 that the K = 8 form and the four-slot ring never show -- not understood, not kept), so those layers
-    // keep the K = 8 form and packing
-    constexpr bool K16 = HF && PWH_K16 && MODE != ND_PRO_LAYERNORM;
-    constexpr int NT = K16 ? 2 : 1;     // (218 registers at NB = 2: two workgroups still share a CU)
+    constexpr int RS = 4, RD = RS - 1;                        // weight ring: slots, groups ahead
     constexpr int MB = 2, BM = 2 * MB * 32;                   // 128 pixels
     constexpr int SIT = BM / 16;                              // staging passes: 128 rows x 16 channel quads / 256 threads
     constexpr int ABUF = BM * BLDA;
@@ -419,22 +393,18 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
         }
     }
 
-    f32x4 bq[RS][NB][NT], av[2][MB][NT], raw[SIT];
+    f32x4 bq[RS][NB], av[2][MB], raw[SIT];
     f32x4 pA, pB, pC;                                          // per-chunk channel constants of the prologue
     auto load_b = [&](int slot, int cb, int g) {               // weight fragments of channels cb + 8g .. + 7
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int term = 0; term < NT; ++term)             // (K16: g counts 16-channel groups, a fragment per term)
-                bq[slot & (RS - 1)][nb][term] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    wrsrc, wvoff, __builtin_amdgcn_readfirstlane(K16 ? ((((cb >> 4) + g) * 2 + term) * 2 * a.coutP + nb * 32) * 16
-                                                                        : (((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 16), 0));
+            bq[slot & (RS - 1)][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wrsrc, wvoff, __builtin_amdgcn_readfirstlane((((cb >> 2) + 2 * g) * a.coutP + nb * 32) * 16), 0));
     };
     auto load_a = [&](int slot, const float* src, int g) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int term = 0; term < NT; ++term) av[slot & 1][mb][term] = nd_ld4(&src[a_off[mb] + (K16 ? g * 16 + term * 8 : g * 8)]);
+        av[slot & 1][mb] = nd_ld4(&src[a_off[mb] + g * 8]);
     };
     auto stage_load = [&](int cb) {
         const bool sec = cb >= s.c0;                          // wave-uniform: a 64-channel chunk never straddles the sources (host check)
@@ -468,12 +438,6 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
             else if (MODE == ND_PRO_LEAKY) v = nd_leaky4(v);
             const f32x4 zero = {0, 0, 0, 0};
             v = (p0 + r < HW) ? v : zero;
-            if (HF) v = nd_split4_f16(v);
-            if (K16) {                                        // quad -> (group of 16, channel half, low / high four): 8 bytes of first terms, 8 of second terms
-                float* p = &dst[r * BLDA + (quad >> 2) * 16 + ((quad >> 1) & 1) * 4 + (quad & 1) * 2];
-                *reinterpret_cast<f32x2*>(p) = f32x2{v.x, v.y};
-                *reinterpret_cast<f32x2*>(p + 8) = f32x2{v.z, v.w};
-            } else
             nd_st4(&dst[r * BLDA + quad * 4], v);
         }
     };
@@ -495,55 +459,21 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
         float* nxt = Ab + ((c + 1) & 1) * ABUF;
         const int cb = c * BKC, cbn = (c + 1 < n_chunks ? c + 1 : c) * BKC;      // behind the last chunk: a harmless re-stage of it
         load_a(0, cur, 0);
-        if (K16) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {                      // groups of 16 channels: 12 MFMAs of 32 cycles each
-                if (g + RD < 4) load_b(g + RD, cb, g + RD); else load_b(g + RD, cbn, g + RD - 4);
-                if (g + 1 < 4) load_a(g + 1, cur, g + 1);
-                if (g == 0) stage_load(cbn);
-                if (g == 2) stage_write(nxt);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int term = 0; term < 3; ++term)             // A1 W1, A1 W2, A2 W1
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            PWB_MFMA_H16(acc[mb][nb], av[g & 1][mb][term == 2 ? NT - 1 : 0], bq[g & (RS - 1)][nb][term == 1 ? NT - 1 : 0]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             // (no branch between a load and the MFMAs it overlaps, see above; sched_barriers pin load / MFMA order)
             if (g + RD < 8) load_b(g + RD, cb, g + RD); else load_b(g + RD, cbn, g + RD - 8);
             if (g + 1 < 8) load_a(g + 1, cur, g + 1);
             if (g == 0) stage_load(cbn);
-            if (g == (HF ? PWH_WG : 4)) stage_write(nxt);
+            if (g == 4) stage_write(nxt);
             __builtin_amdgcn_sched_barrier(0);
-            if (HF) {
 #pragma unroll
-                for (int term = 0; term < 3; ++term)                 // A1 W1, A1 W2, A2 W1
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const f32x4 av4 = av[g & 1][mb][0], bv4 = bq[g & (RS - 1)][nb][0];
-                            const f32x2 a1 = {av4.x, av4.y}, a2 = {av4.z, av4.w}, b1 = {bv4.x, bv4.y}, b2 = {bv4.z, bv4.w};
-                            if (term == 0) PWB_MFMA_H(acc[mb][nb], a1, b1);
-                            else if (term == 1) PWB_MFMA_H(acc[mb][nb], a1, b2);
-                            else PWB_MFMA_H(acc[mb][nb], a2, b1);
-                        }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) PWB_MFMA(acc[mb][nb], av[g & 1][mb][0][k], bq[g & 3][nb][0][k]);
-            }
+                    for (int nb = 0; nb < NB; ++nb) PWB_MFMA(acc[mb][nb], av[g & 1][mb][k], bq[g & 3][nb][k]);
             __builtin_amdgcn_sched_barrier(0);
-        }
         }
         __syncthreads();                                       // the other buffer is complete, this one has been consumed
     }
@@ -558,9 +488,9 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
         for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+a"(acc[mb][nb]));
 #ifdef PWB_STAMP
     unsigned long long ph[4];
-    pw_epilogue<MB, NB, 8, HF>(a, acc, Ab, b, p0, n0, ph);
+    pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0, ph);
 #else
-    pw_epilogue<MB, NB, 8, HF>(a, acc, Ab, b, p0, n0);
+    pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0);
 #endif
 #ifdef PWB_STAMP
     if (tid == 0) {                                           // (row 0, columns 0-7 of the tile are this wave's own stores: program order)
@@ -810,47 +740,6 @@ __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __rest
     }
 }
 
-// (cout, cin) -> 2^11 w as two f16 terms in the operand order of pointwise_big_kernel<.., HF>.  k16 (the double-rate instruction: every prologue but LayerNorm):
-// [cinP/16][term 2][channel half 2][coutP] slots of 16 bytes = 8 consecutive channels of one term; else (K = 8: the layers read through a LayerNorm prologue)
-// [cinP/4][coutP] slots {W1 ch0..3 | W2 ch0..3}
-__global__ void pack_pointwise_h_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int cinP, int coutP, int k16) {
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    const size_t total = (size_t)(cinP / 4) * coutP;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int n = i % coutP;
-        if (k16) {
-        size_t r = i / coutP;
-        const int h = r & 1, term = (r >> 1) & 1, G = (int)(r >> 2);
-        _Float16 t[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = G * 16 + h * 8 + e;
-            const float u = (n < cout && k < cin) ? w[(size_t)n * cin + k] * 2048.0f : 0.0f;
-            const _Float16 h1 = (_Float16)fminf(fmaxf(u, -65504.0f), 65504.0f);           // (a weight beyond 32 saturates the first term; the remainder carries on)
-            t[e] = term ? (_Float16)fminf(fmaxf(u - (float)h1, -65504.0f), 65504.0f) : h1;
-        }
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, h2v{t[2 * e], t[2 * e + 1]});
-        nd_st4(out + i * 4, v);
-        } else {
-        const int q = i / coutP;
-        _Float16 h1[4], h2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = q * 4 + e;
-            const float u = (n < cout && k < cin) ? w[(size_t)n * cin + k] * 2048.0f : 0.0f;
-            h1[e] = (_Float16)fminf(fmaxf(u, -65504.0f), 65504.0f);           // (a weight beyond 32 saturates the first term; the remainder carries on)
-            h2[e] = (_Float16)fminf(fmaxf(u - (float)h1[e], -65504.0f), 65504.0f);
-        }
-        f32x4 v;
-        v.x = __builtin_bit_cast(float, h2v{h1[0], h1[1]});  v.y = __builtin_bit_cast(float, h2v{h1[2], h1[3]});
-        v.z = __builtin_bit_cast(float, h2v{h2[0], h2[1]});  v.w = __builtin_bit_cast(float, h2v{h2[2], h2[3]});
-        nd_st4(out + i * 4, v);
-        }
-    }
-}
-
 template <int MB, int NB>
 void launch_pipe(const PwArgs& a, hipStream_t st) {
     const dim3 grid(a.total_wg), block(256);
@@ -863,15 +752,15 @@ void launch_pipe(const PwArgs& a, hipStream_t st) {
     }
 }
 
-template <int NB, bool HF = false>
+template <int NB>
 int launch_big(const PwArgs& a, hipStream_t st) {
     constexpr size_t lds = sizeof(float) * (2 * 128 * BLDA > 128 * (64 * NB + 4) ? 2 * 128 * BLDA : 128 * (64 * NB + 4));
     const dim3 grid(a.total_wg), block(256);
 #define PWB_LAUNCH(MODE)                                                                                                      \
     {                                                                                                                         \
         static nd_device_once configured;                                                                                     \
-        if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(pointwise_big_kernel<NB, MODE, HF>), lds, "nd_pointwise")) return e; \
-        hipLaunchKernelGGL((pointwise_big_kernel<NB, MODE, HF>), grid, block, lds, st, a);                                    \
+        if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(pointwise_big_kernel<NB, MODE>), lds, "nd_pointwise")) return e; \
+        hipLaunchKernelGGL((pointwise_big_kernel<NB, MODE>), grid, block, lds, st, a);                                    \
     }
     switch (a.d.src.mode) {
         case ND_PRO_LAYERNORM: PWB_LAUNCH(ND_PRO_LAYERNORM) break;
@@ -932,17 +821,16 @@ bool pw_pipe_takes(const nd_pointwise* d) {
     return use_pipe && d->cin % PKC == 0 && d->cin >= 2 * PKC && !s.unshuffle && (s.mode != ND_PRO_LAYERNORM || s.rowstats) && (s.c1 == 0 || nd_aligned16(s.p1));
 }
 // large tiles, one wave per SIMD: wide layers with enough 128-pixel tiles to fill the chip
-// (f16-split entry: `any_count` -- the product form must not depend on the batch a sample sits in, so that entry takes a layer by its geometry alone)
-long pw_big_tiles(const nd_pointwise* d, bool any_count = false) {          // 0: another kernel takes the layer
+long pw_big_tiles(const nd_pointwise* d) {                                  // 0: another kernel takes the layer
     static const int use_big = getenv("ND_PW_BIG") ? atoi(getenv("ND_PW_BIG")) : 1;            // A/B knob (tools/ only): 0 off
     const nd_src& s = d->src;
     if (!(pw_pipe_takes(d) && use_big && d->cin % BKC == 0 && d->cin >= 2 * BKC && d->cout % 128 == 0 && d->shuffle_c == 0 &&
           (s.c1 == 0 || s.c0 % BKC == 0) && (long)d->B * d->HW * s.ld0 * 4 < (1L << 32) && (long)d->B * d->HW * s.ld1 * 4 < (1L << 32))) return 0;
     const long tiles = (long)d->B * nd_cdiv(d->HW, 128) * (d->cout / 128);      // (256-cout tiles measured slower: 2429 vs 2318 us over the workload's wide layers)
-    return (any_count || tiles >= nd_device_cus()) ? tiles : 0;
+    return tiles >= nd_device_cus() ? tiles : 0;
 }
 
-int pw_run(const nd_pointwise* d, void* stream, bool hf) {
+int pw_run(const nd_pointwise* d, void* stream) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_pointwise: null descriptor");
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_pointwise: null tensor pointer");
@@ -1003,7 +891,7 @@ int pw_run(const nd_pointwise* d, void* stream, bool hf) {
     hipStream_t st = (hipStream_t)stream;
     // narrow outputs: a streaming dot product instead of an MFMA tile that is 15/16 padding (geometry only; A/B knob ND_PW_NARROW=0, tools/ only)
     static const bool use_narrow = !(getenv("ND_PW_NARROW") && atoi(getenv("ND_PW_NARROW")) == 0);
-    if (!hf && use_narrow && d->cout <= 8 && d->cout % 4 == 0 && d->cin <= 1024 && s.mode == ND_PRO_NONE && !s.unshuffle && d->shuffle_c == 0 && !d->gn_t && !d->vec &&
+    if (use_narrow && d->cout <= 8 && d->cout % 4 == 0 && d->cin <= 1024 && s.mode == ND_PRO_NONE && !s.unshuffle && d->shuffle_c == 0 && !d->gn_t && !d->vec &&
         (s.c1 == 0 || nd_aligned16(s.p1))) {
         const long blocks = ((long)d->B * d->HW + 63) / 64;
         const int grid = (int)(blocks < 8L * nd_device_cus() ? blocks : 8L * nd_device_cus());
@@ -1012,14 +900,13 @@ int pw_run(const nd_pointwise* d, void* stream, bool hf) {
         return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
     }
     const bool pipe = pw_pipe_takes(d);
-    const long tiles = pw_big_tiles(d, hf);
-    ND_REQUIRE(!hf || tiles > 0, ND_E_SHAPE, "nd_pointwise_gemm_f16x3: the layer is not one of the 128-pixel-tile kernel's (ask nd_pointwise_gemm_f16x3_takes first)");
+    const long tiles = pw_big_tiles(d);
     if (tiles > 0) {
         a.m_tiles = nd_cdiv(d->HW, 128);
         a.n_tiles = d->cout / 128;
         a.total_wg = (int)tiles;
-        if (int e = hf ? launch_big<2, true>(a, st) : launch_big<2>(a, st)) return e;
-        return nd_launch_status(hf ? "nd_pointwise_gemm_f16x3_nhwc_f32" : "nd_pointwise_gemm_nhwc_f32");
+        if (int e = launch_big<2>(a, st)) return e;
+        return nd_launch_status("nd_pointwise_gemm_nhwc_f32");
     }
     if (pipe) {
         if (mb == 2 && nb == 2) launch_pipe<2, 2>(a, st);
@@ -1036,21 +923,4 @@ int pw_run(const nd_pointwise* d, void* stream, bool hf) {
 }
 }  // namespace
 
-extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) { return pw_run(d, stream, false); }
-
-// The layers of the 128-pixel-tile kernel with every product as three f16 MFMAs (weights from nd_pack_pointwise_weight_h); any other layer is an error.
-extern "C" int nd_pointwise_gemm_f16x3_nhwc_f32(const nd_pointwise* d, void* stream) { return pw_run(d, stream, true); }
-
-// 1 if nd_pointwise_gemm_f16x3_nhwc_f32 accepts the layer: widths, strides, addressing and prologue of `d` only -- not the batch, not the device
-// (a sample's bits must not depend on the batch it is sharded into); no pointer is dereferenced.
-extern "C" int nd_pointwise_gemm_f16x3_takes(const nd_pointwise* d) { return d && pw_big_tiles(d, true) > 0 ? 1 : 0; }
-
-extern "C" int nd_pack_pointwise_weight_h(const float* w, float* packed, int cin, int cout, int layernorm_source, void* stream) {
-    ND_REQUIRE(w && packed, ND_E_BADARG, "nd_pack_pointwise_weight_h: null pointer");
-    ND_REQUIRE(cin > 0 && cout > 0, ND_E_BADARG, "nd_pack_pointwise_weight_h: non-positive size");
-    const int cinP = nd_round_up(cin, 8), coutP = nd_round_up(cout, 64);
-    const size_t total = (size_t)(cinP / 4) * coutP;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_pointwise_h_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, cinP, coutP, (PWH_K16 && !layernorm_source) ? 1 : 0);
-    return nd_launch_status("nd_pack_pointwise_weight_h");
-}
+extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) { return pw_run(d, stream); }

@@ -17,12 +17,6 @@
 // Weights (packed in operand order by nd_pack_chain_weight), biases and LayerNorm gamma/beta of all stages sit in LDS for
 // the lifetime of the persistent workgroup (80 KB at C = 64): an A fragment is one ds_read_b128 per four MFMAs.  Three or
 // four waves per SIMD (768 / 1024 threads) let one wave's activation VALU run under the others' MFMAs.
-//
-// HF (opt-in, nd_pointwise_chain_f16x3_nhwc_f32; the product form of conv3x3_wino4h.hip / pointwise_big_kernel<.., HF>): every product as three f16
-// MFMAs of two-term operands, fp32 accumulation.  v_mfma_f32_32x32x8_f16 takes lane (pixel, half)'s channels 8 jq + 4 half .. + 3 in one instruction --
-// the SAME four registers the fp32 form feeds one by one, so the register-to-register chain is untouched: the four activations of a K group are
-// split on the spot (nd_split4_f16), the weight fragment of a (tile, group) keeps its 16 bytes per lane as {W1 x 4 | W2 x 4} of 2^11 w
-// (nd_pack_chain_weight_h), the accumulators start at 2^11 bias and are scaled back once per stage.  3 x 32 MFMA cycles per group instead of 4 x 64.
 #include <type_traits>
 #include "nd_common.h"
 
@@ -34,11 +28,7 @@ struct ChainArgs {
     int tiles_per_sample;
 };
 
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-// IN_ACT (HF only): the activation of the PREVIOUS stage, applied to a K group's four operands right in front of that group's MFMAs instead of to the whole
-// accumulator tile before the loop -- the f16 MFMAs of group jq then run on the matrix pipe while the VALU works on group jq + 1 (with whole-tile phases the
-// waves of a SIMD march in step: all in their VALU phase, then all in their MFMA phase; measured 285 us per AttnBlock tail = the SUM of both)
-template <int K, int N, bool HF = false, int IN_ACT = ND_ACT_NONE>
+template <int K, int N>
 __device__ __forceinline__ void chain_gemm(const float (&in)[K / 2], const float* __restrict__ w, const float* __restrict__ bias,
                                            f32x16 (&acc)[N / 32], const int lane) {
     const int half = lane >> 5;
@@ -48,47 +38,16 @@ __device__ __forceinline__ void chain_gemm(const float (&in)[K / 2], const float
         for (int g = 0; g < 4; ++g) {
             const f32x4 b4 = nd_ld4(bias + 32 * nt + 8 * g + 4 * half);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = HF ? b4[i] * 2048.0f : b4[i];
+            for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = b4[i];
         }
 #pragma unroll
-    for (int jq = 0; jq < K / 8; ++jq) {
-        f16x4 x1, x2;
-        if (HF) {                                                        // the group's four activations as two f16 terms
-            f32x4 v = {in[4 * jq], in[4 * jq + 1], in[4 * jq + 2], in[4 * jq + 3]};
-            if (IN_ACT == ND_ACT_GELU) v = nd_gelu4(v);
-            else if (IN_ACT == ND_ACT_SILU) v = nd_silu4(v);
-            const f32x4 t = nd_split4_f16(v);
-            x1 = __builtin_bit_cast(f16x4, f32x2{t.x, t.y});
-            x2 = __builtin_bit_cast(f16x4, f32x2{t.z, t.w});
-        }
+    for (int jq = 0; jq < K / 8; ++jq)
 #pragma unroll
         for (int nt = 0; nt < N / 32; ++nt) {
             const f32x4 a4 = nd_ld4(w + ((nt * (K / 8) + jq) * 64 + lane) * 4);
-            if (HF) {
-                const f16x4 w1 = __builtin_bit_cast(f16x4, f32x2{a4.x, a4.y}), w2 = __builtin_bit_cast(f16x4, f32x2{a4.z, a4.w});
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x8f16(w1, x1, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x8f16(w2, x1, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x8f16(w1, x2, acc[nt], 0, 0, 0);
-            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[nt] = nd_mfma(a4[i], in[4 * jq + i], acc[nt]);
-            }
+            for (int i = 0; i < 4; ++i) acc[nt] = nd_mfma(a4[i], in[4 * jq + i], acc[nt]);
         }
-    }
-    if (HF) {
-#pragma unroll
-        for (int nt = 0; nt < N / 32; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] *= (1.0f / 2048.0f);
-    }
-}
-// (the previous stage's activation is a run-time field of the descriptor)
-template <int K, int N, bool HF>
-__device__ __forceinline__ void chain_gemm_act(const float (&in)[K / 2], const float* __restrict__ w, const float* __restrict__ bias,
-                                               f32x16 (&acc)[N / 32], const int lane, const int in_act) {
-    if (HF && in_act == ND_ACT_GELU) chain_gemm<K, N, HF, ND_ACT_GELU>(in, w, bias, acc, lane);
-    else if (HF && in_act == ND_ACT_SILU) chain_gemm<K, N, HF, ND_ACT_SILU>(in, w, bias, acc, lane);
-    else chain_gemm<K, N, HF>(in, w, bias, acc, lane);
 }
 
 template <int N>
@@ -140,14 +99,11 @@ __device__ __forceinline__ void chain_store(const f32x16 (&acc)[N / 32], float* 
 // K0: stage-0 input channels rounded up to 8; N1, N2, N3: stage widths rounded up to 32 (N3 = 0: two stages)
 // waves per workgroup: as many as the register budget of the widest stage allows (3 or 4 per SIMD) -- the activation
 // VALU of one wave runs under the MFMAs of the others
-#ifndef PWC_H_THREADS
-#define PWC_H_THREADS 512    // the f16-split form: two waves per SIMD (256 registers: the split terms of a stage's operands live next to the operands)
-#endif
-constexpr int chain_threads(int n1, bool hf = false) { return hf ? PWC_H_THREADS : n1 >= 128 ? 768 : 1024; }
+constexpr int chain_threads(int n1) { return n1 >= 128 ? 768 : 1024; }
 
-template <int K0, int N1, int N2, int N3, int MODE, bool HF = false>
-__global__ __launch_bounds__(chain_threads(N1, HF), 1) void chain_kernel(const ChainArgs a) {
-    constexpr int THREADS = chain_threads(N1, HF), WAVES = THREADS / 64;
+template <int K0, int N1, int N2, int N3, int MODE>
+__global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const ChainArgs a) {
+    constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w1 = lds;
     float* w2 = w1 + N1 * K0;
@@ -244,9 +200,9 @@ __global__ __launch_bounds__(chain_threads(N1, HF), 1) void chain_kernel(const C
 
         // ---- stage 0
         f32x16 H1[N1 / 32];
-        chain_gemm<K0, N1, HF>(in0, w1, b1, H1, lane);
+        chain_gemm<K0, N1>(in0, w1, b1, H1, lane);
         chain_res<K0, N1>(H1, X, s.vec ? myv : nullptr, a.d.st[0].res, half);
-        if (!HF) chain_act<N1>(H1, a.d.st[0].act);          // (HF: applied by the next stage, operand group by operand group)
+        chain_act<N1>(H1, a.d.st[0].act);
         // ---- stage 1: accumulator register r of n-tile nt is operand 16*nt + r
         float in1[N1 / 2];
 #pragma unroll
@@ -254,9 +210,9 @@ __global__ __launch_bounds__(chain_threads(N1, HF), 1) void chain_kernel(const C
 #pragma unroll
             for (int r = 0; r < 16; ++r) in1[16 * nt + r] = H1[nt][r];
         f32x16 H2[N2 / 32];
-        chain_gemm_act<N1, N2, HF>(in1, w2, b2, H2, lane, a.d.st[0].act);
+        chain_gemm<N1, N2>(in1, w2, b2, H2, lane);
         chain_res<K0, N2>(H2, X, s.vec ? myv : nullptr, a.d.st[1].res, half);
-        if (!HF || N3 == 0) chain_act<N2>(H2, a.d.st[1].act);
+        chain_act<N2>(H2, a.d.st[1].act);
         float* row = a.d.out + pix * a.d.ldo;
         if (N3 > 0) {
             float in2[N2 / 2];
@@ -265,7 +221,7 @@ __global__ __launch_bounds__(chain_threads(N1, HF), 1) void chain_kernel(const C
 #pragma unroll
                 for (int r = 0; r < 16; ++r) in2[16 * nt + r] = H2[nt][r];
             f32x16 H3[(N3 > 0 ? N3 : 32) / 32];
-            chain_gemm_act<N2, (N3 > 0 ? N3 : 32), HF>(in2, w3, b3, H3, lane, a.d.st[1].act);
+            chain_gemm<N2, (N3 > 0 ? N3 : 32)>(in2, w3, b3, H3, lane);
             chain_res<K0, (N3 > 0 ? N3 : 32)>(H3, X, s.vec ? myv : nullptr, a.d.st[2].res, half);
             chain_act<(N3 > 0 ? N3 : 32)>(H3, a.d.st[2].act);
             chain_store<(N3 > 0 ? N3 : 32)>(H3, row, cout_last, half);
@@ -286,47 +242,24 @@ __global__ void pack_chain_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-// ... the same fragments as two f16 terms of 2^11 w: lane l's 16 bytes = {W1 i = 0..3 | W2 i = 0..3}
-__global__ void pack_chain_h_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int KP, int NP) {
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    const int total = KP * NP / 4;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int l = idx & 63, rest = idx >> 6;
-        const int jq = rest % (KP / 8), nt = rest / (KP / 8);
-        const int n = 32 * nt + (l & 31);
-        _Float16 h1[4], h2[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = 8 * jq + i + 4 * (l >> 5);
-            const float u = (n < cout && k < cin) ? w[(size_t)n * cin + k] * 2048.0f : 0.0f;
-            h1[i] = (_Float16)fminf(fmaxf(u, -65504.0f), 65504.0f);
-            h2[i] = (_Float16)fminf(fmaxf(u - (float)h1[i], -65504.0f), 65504.0f);
-        }
-        f32x4 v;
-        v.x = __builtin_bit_cast(float, h2v{h1[0], h1[1]});  v.y = __builtin_bit_cast(float, h2v{h1[2], h1[3]});
-        v.z = __builtin_bit_cast(float, h2v{h2[0], h2[1]});  v.w = __builtin_bit_cast(float, h2v{h2[2], h2[3]});
-        nd_st4(out + (size_t)idx * 4, v);
-    }
-}
-
 static inline int device_cus() { return nd_device_cus(); }
 
-template <int K0, int N1, int N2, int N3, int MODE, bool HF>
+template <int K0, int N1, int N2, int N3, int MODE>
 int launch(const ChainArgs& a, hipStream_t st) {
     static nd_device_once configured;
-    constexpr int THREADS = chain_threads(N1, HF), WAVES = THREADS / 64;
+    constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
     const size_t lds = (size_t)(N1 * K0 + N2 * N1 + N3 * N2 + N1 + N2 + N3 + 2 * K0 + WAVES * K0) * sizeof(float);
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE, HF>), lds, "nd_pointwise_chain")) return e;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE>), lds, "nd_pointwise_chain")) return e;
     const int wgs = nd_cdiv(a.n_tiles, WAVES);
     const int grid = wgs < device_cus() ? wgs : device_cus();
-    hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE, HF>), dim3(grid), dim3(THREADS), lds, st, a);
+    hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE>), dim3(grid), dim3(THREADS), lds, st, a);
     return 0;
 }
 
-template <int K0, int N1, int N2, int N3, bool HF = false>
+template <int K0, int N1, int N2, int N3>
 int launch_mode(const ChainArgs& a, hipStream_t st) {
-    if (a.d.src.mode == ND_PRO_LAYERNORM) return launch<K0, N1, N2, N3, ND_PRO_LAYERNORM, HF>(a, st);
-    return launch<K0, N1, N2, N3, ND_PRO_NONE, HF>(a, st);
+    if (a.d.src.mode == ND_PRO_LAYERNORM) return launch<K0, N1, N2, N3, ND_PRO_LAYERNORM>(a, st);
+    return launch<K0, N1, N2, N3, ND_PRO_NONE>(a, st);
 }
 
 }  // namespace
@@ -356,16 +289,7 @@ extern "C" int nd_pointwise_chain_supported(int cin, int n1, int n2, int n3) {
     return 0;
 }
 
-// the f16-split instances: the chains of the d = 64 network at full and half resolution (the ones the fp32 matrix pipe bounds)
-extern "C" int nd_pointwise_chain_f16x3_supported(int cin, int n1, int n2, int n3) {
-    const int K0 = nd_round_up(cin, 8), N1 = nd_round_up(n1, 32), N2 = nd_round_up(n2, 32), N3 = n3 > 0 ? nd_round_up(n3, 32) : 0;
-    static const int table[][4] = {{64, 64, 64, 0}, {64, 128, 64, 64}, {8, 64, 64, 0}, {48, 64, 64, 0}, {48, 96, 64, 64}, {64, 64, 32, 0}};
-    for (const auto& e : table)
-        if (e[0] == K0 && e[1] == N1 && e[2] == N2 && e[3] == N3) return 1;
-    return 0;
-}
-
-static int chain_run(const nd_chain* d, void* stream, bool hf) {
+extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_pointwise_chain: null descriptor");
     const nd_src& s = d->src;
     ND_REQUIRE(d->n_stages == 2 || d->n_stages == 3, ND_E_BADARG, "nd_pointwise_chain: n_stages=%d (2 or 3)", d->n_stages);
@@ -403,22 +327,6 @@ static int chain_run(const nd_chain* d, void* stream, bool hf) {
     hipStream_t st = (hipStream_t)stream;
     const int K0 = nd_round_up(cin, 8), N1 = nd_round_up(d->st[0].cout, 32), N2 = nd_round_up(d->st[1].cout, 32), N3 = n3 ? nd_round_up(n3, 32) : 0;
     int rc = ND_E_SHAPE;
-    if (hf) {
-        ND_REQUIRE(nd_pointwise_chain_f16x3_supported(cin, d->st[0].cout, d->st[1].cout, n3), ND_E_SHAPE,
-                   "nd_pointwise_chain_f16x3: widths %d->%d->%d->%d are not instantiated in the f16-split form (nd_pointwise_chain_f16x3_supported)", cin,
-                   d->st[0].cout, d->st[1].cout, n3);
-#define ND_CHAIN_CASE_H(k0, n1, n2, n3) \
-    if (K0 == k0 && N1 == n1 && N2 == n2 && N3 == n3) rc = launch_mode<k0, n1, n2, n3, true>(a, st);
-        ND_CHAIN_CASE_H(64, 64, 64, 0)
-        ND_CHAIN_CASE_H(64, 128, 64, 64)
-        ND_CHAIN_CASE_H(8, 64, 64, 0)
-        ND_CHAIN_CASE_H(48, 64, 64, 0)
-        ND_CHAIN_CASE_H(48, 96, 64, 64)
-        ND_CHAIN_CASE_H(64, 64, 32, 0)
-#undef ND_CHAIN_CASE_H
-        if (rc) return rc;
-        return nd_launch_status("nd_pointwise_chain_f16x3_nhwc_f32");
-    }
 #define ND_CHAIN_CASE(k0, n1, n2, n3) \
     if (K0 == k0 && N1 == n1 && N2 == n2 && N3 == n3) rc = launch_mode<k0, n1, n2, n3>(a, st);
     ND_CHAIN_CASE(8, 32, 32, 0)
@@ -437,19 +345,4 @@ static int chain_run(const nd_chain* d, void* stream, bool hf) {
 #undef ND_CHAIN_CASE
     if (rc) return rc;
     return nd_launch_status("nd_pointwise_chain_nhwc_f32");
-}
-
-extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) { return chain_run(d, stream, false); }
-
-// The same chain with every product as three f16 MFMAs of two-term operands (fp32 accumulation): stage weights from nd_pack_chain_weight_h
-extern "C" int nd_pointwise_chain_f16x3_nhwc_f32(const nd_chain* d, void* stream) { return chain_run(d, stream, true); }
-
-extern "C" int nd_pack_chain_weight_h(const float* w, float* packed, int cin, int cout, int first_stage, void* stream) {
-    ND_REQUIRE(w && packed, ND_E_BADARG, "nd_pack_chain_weight_h: null pointer");
-    ND_REQUIRE(cin > 0 && cout > 0, ND_E_SHAPE, "nd_pack_chain_weight_h: non-positive size");
-    const int KP = nd_round_up(cin, first_stage ? 8 : 32), NP = nd_round_up(cout, 32);
-    const int total = KP * NP / 4;
-    hipLaunchKernelGGL(pack_chain_h_kernel, dim3(nd_cdiv(total, 256) < 1024 ? nd_cdiv(total, 256) : 1024), dim3(256), 0, (hipStream_t)stream,
-                       w, packed, cin, cout, KP, NP);
-    return nd_launch_status("nd_pack_chain_weight_h");
 }

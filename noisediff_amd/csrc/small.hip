@@ -136,12 +136,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 // Per 32 pixels x 32 channels: 49 LDS reads, 98 MFMAs, no VALU in the loop.
 constexpr int C7_TH = 16, C7_TW = 32, C7_HH = C7_TH + 6, C7_HW = C7_TW + 6;
 
-// HF (opt-in, nd_conv7x7_c4_f16x3_f32: the product form of conv3x3_wino4h.hip for the stem): v_mfma_f32_32x32x8_f16 contracts two taps x 4 channels -- lane half h takes
-// tap 2j + h --, both operands as two f16 terms, three products, fp32 accumulation.  The halo tile holds a pixel's four channels already split ({x1 x 4 | x2 x 4}: the same
-// 16 bytes), the wave splits its 2^11-scaled weights once at kernel start (25 groups x 2 terms x 2 registers), 25 LDS reads and 75 MFMAs of 32 cycles per 32 pixels x 32
-// channels instead of 49 and 98 of 64.
-typedef _Float16 c7_h4 __attribute__((ext_vector_type(4)));
-template <int NT, bool HF = false>   // n-tiles of 32 output channels (power of two, <= 8); 8 waves = NT n-tiles x 8/NT row groups
+template <int NT>   // n-tiles of 32 output channels (power of two, <= 8); 8 waves = NT n-tiles x 8/NT row groups
 __global__ __launch_bounds__(512, 1) void conv7x7_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                                                          float* __restrict__ out, int ldo, int B, int H, int W, int cout) {
     __shared__ __attribute__((aligned(16))) float tile[C7_HH * C7_HW * 4];
@@ -150,26 +145,11 @@ __global__ __launch_bounds__(512, 1) void conv7x7_kernel(const float* __restrict
     const int nt = wave % NT, rg = wave / NT;
     const int n = nt * 32 + col;
     // ---- this wave's weights: packed [tap*4 + c][cout]
-    float wr[HF ? 1 : 98];
-    c7_h4 wh[HF ? 25 : 1][2];                                // HF: group j = taps 2j, 2j + 1; this lane: tap 2j + half, channels 0..3, terms {W1, W2} of 2^11 w
-    if (HF) {
-#pragma unroll
-        for (int j = 0; j < 25; ++j) {
-            const int t = 2 * j + half;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float u = (n < cout && t < 49) ? wp[(size_t)(t * 4 + c) * cout + n] * 2048.0f : 0.0f;
-                const _Float16 h1 = (_Float16)fminf(fmaxf(u, -65504.0f), 65504.0f);
-                wh[j][0][c] = h1;
-                wh[j][1][c] = (_Float16)fminf(fmaxf(u - (float)h1, -65504.0f), 65504.0f);
-            }
-        }
-    } else {
+    float wr[98];
 #pragma unroll
     for (int t = 0; t < 49; ++t)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) wr[2 * t + jj] = n < cout ? wp[(size_t)(t * 4 + jj + 2 * half) * cout + n] : 0.0f;
-    }
     f32x4 bias4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -188,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void conv7x7_kernel(const float* __restrict
             const int y = ty0 + hy - 3, xx = tx0 + hx - 3;
             f32x4 v = {0, 0, 0, 0};
             if (y >= 0 && y < H && xx >= 0 && xx < W) v = nd_ld4(x + ((size_t)(b * H + y) * W + xx) * 4);
-            nd_st4(&tile[i * 4], HF ? nd_split4_f16(v) : v);
+            nd_st4(&tile[i * 4], v);
         }
         __syncthreads();
         for (int ly = rg; ly < C7_TH; ly += RG) {
@@ -196,22 +176,7 @@ __global__ __launch_bounds__(512, 1) void conv7x7_kernel(const float* __restrict
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[4 * g + i] = HF ? bias4[g][i] * 2048.0f : bias4[g][i];
-            if (HF) {
-                const float* base = &tile[(ly * C7_HW + col) * 4];
-#pragma unroll
-                for (int j = 0; j < 25; ++j) {               // the lane's tap of the pair: 2j (half 0) or 2j + 1 (half 1; the 50th tap is padding: zero weights, a valid address)
-                    const int t0 = 2 * j, t1 = 2 * j + 1 < 49 ? 2 * j + 1 : 48;
-                    const int o0 = ((t0 / 7) * C7_HW + t0 % 7) * 4, o1 = ((t1 / 7) * C7_HW + t1 % 7) * 4;
-                    const f32x4 v = nd_ld4(base + (half ? o1 : o0));
-                    const c7_h4 x1 = __builtin_bit_cast(c7_h4, f32x2{v.x, v.y}), x2 = __builtin_bit_cast(c7_h4, f32x2{v.z, v.w});
-                    acc = __builtin_amdgcn_mfma_f32_32x32x8f16(wh[j][0], x1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x8f16(wh[j][1], x1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x8f16(wh[j][0], x2, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] *= (1.0f / 2048.0f);
-            } else {
+                for (int i = 0; i < 4; ++i) acc[4 * g + i] = bias4[g][i];
             const float* base = &tile[(ly * C7_HW + col) * 4 + 2 * half];
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky)
@@ -221,7 +186,6 @@ __global__ __launch_bounds__(512, 1) void conv7x7_kernel(const float* __restrict
                     acc = nd_mfma(wr[2 * (ky * 7 + kx)], v.x, acc);
                     acc = nd_mfma(wr[2 * (ky * 7 + kx) + 1], v.y, acc);
                 }
-            }
             const int y = ty0 + ly, xx = tx0 + col;
             if (y < H && xx < W) {
                 float* o = out + ((size_t)(b * H + y) * W + xx) * ldo;
@@ -503,7 +467,8 @@ extern "C" int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout
     return nd_launch_status("nd_pack_conv7x7_weight");
 }
 
-static int conv7x7_run(const float* x, const float* wpacked, const float* bias, float* out, int ldo, int B, int H, int W, int cout, void* stream, bool hf) {
+extern "C" int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo, int B, int H, int W,
+                                 int cout, void* stream) {
     ND_REQUIRE(x && wpacked && bias && out, ND_E_BADARG, "nd_conv7x7_c4: null pointer");
     ND_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && ldo >= cout, ND_E_SHAPE, "nd_conv7x7_c4: bad shape");
     ND_REQUIRE(nd_aligned16(x), ND_E_ALIGN, "nd_conv7x7_c4: x must be 16-byte aligned");
@@ -513,26 +478,11 @@ static int conv7x7_run(const float* x, const float* wpacked, const float* bias, 
     const int cus = nd_device_cus();
     const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), block(512);
     const int ntiles = nd_cdiv(cout, 32);
-#define ND_C7_LAUNCH(NT)                                                                                                           \
-    {                                                                                                                              \
-        if (hf) hipLaunchKernelGGL((conv7x7_kernel<NT, true>), grid, block, 0, (hipStream_t)stream, x, wpacked, bias, out, ldo, B, H, W, cout); \
-        else hipLaunchKernelGGL((conv7x7_kernel<NT, false>), grid, block, 0, (hipStream_t)stream, x, wpacked, bias, out, ldo, B, H, W, cout);   \
-    }
-    if (ntiles <= 1) ND_C7_LAUNCH(1)
-    else if (ntiles <= 2) ND_C7_LAUNCH(2)
-    else if (ntiles <= 4) ND_C7_LAUNCH(4)
-    else ND_C7_LAUNCH(8)
+#define ND_C7_LAUNCH(NT) hipLaunchKernelGGL(conv7x7_kernel<NT>, grid, block, 0, (hipStream_t)stream, x, wpacked, bias, out, ldo, B, H, W, cout)
+    if (ntiles <= 1) ND_C7_LAUNCH(1);
+    else if (ntiles <= 2) ND_C7_LAUNCH(2);
+    else if (ntiles <= 4) ND_C7_LAUNCH(4);
+    else ND_C7_LAUNCH(8);
 #undef ND_C7_LAUNCH
-    return nd_launch_status(hf ? "nd_conv7x7_c4_f16x3_f32" : "nd_conv7x7_c4_f32");
-}
-
-extern "C" int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo, int B, int H, int W,
-                                 int cout, void* stream) {
-    return conv7x7_run(x, wpacked, bias, out, ldo, B, H, W, cout, stream, false);
-}
-
-// ... with every product as three f16 MFMAs of two-term operands (fp32 accumulation): same arguments, the SAME packed weights (the kernel splits them itself)
-extern "C" int nd_conv7x7_c4_f16x3_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo, int B, int H, int W,
-                                       int cout, void* stream) {
-    return conv7x7_run(x, wpacked, bias, out, ldo, B, H, W, cout, stream, true);
+    return nd_launch_status("nd_conv7x7_c4_f32");
 }

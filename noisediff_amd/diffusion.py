@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import threading
 from collections import namedtuple
 from typing import Dict, List, Optional
 
@@ -22,6 +23,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
+
+_SAMPLER_SWITCH = threading.RLock()          # p_sample_loop / ddim_sample switch the wrapper's sampler for one call (GaussianDiffusion._as_sampler)
 
 BUFFER_NAMES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
                 "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
@@ -208,7 +211,7 @@ class GaussianDiffusion(nn.Module):
         # ---- nn.DataParallel(net, device_ids=[...]) with several devices: the reference's --gpu_ids entry (models/modules.py:73-83).
         # The reference replicates the weights and scatters / gathers the batch on EVERY step (:332); here the batch rows are split
         # once, every device gets its own engine (arena copied device to device from the first), plan and captured step graph, and
-        # the host thread launches the graphs round-robin: no per-step traffic between the devices.  Row i of the batch draws the
+        # the host thread queues each device's whole chain of graph replays: no per-step traffic between the devices.  Row i of the batch draws the
         # same Philox noise (keyed by its global index) and runs the same kernels whatever the number of devices.
         from .shard import shard_bounds
         shards = []
@@ -225,9 +228,10 @@ class GaussianDiffusion(nn.Module):
         out_dev = self.device
         gather = lambda: torch.cat([p.read_nchw(p.x).to(out_dev) for _, p in shards], dim=0)
         if not return_all_timesteps:
-            for _ in range(n_steps):
-                for loop, _p in shards:
-                    loop.advance(1)
+            # every shard's whole chain is queued on its own device's stream at once (graph launches do not block the host): the devices then run
+            # their n_steps replays side by side without waiting for this thread between steps
+            for loop, _p in shards:
+                loop.advance(n_steps)
             return self.unnormalize(gather())
         frames = [gather()]
         for _ in range(n_steps):
@@ -319,25 +323,26 @@ class GaussianDiffusion(nn.Module):
     @contextlib.contextmanager
     def _as_sampler(self, ddim: bool):
         """Run sample() as the named sampler whatever the wrapper was configured with (p_sample_loop / ddim_sample are public in the reference)."""
-        saved = self.is_ddim_sampling
-        self.is_ddim_sampling = ddim
-        try:
-            yield
-        finally:
-            self.is_ddim_sampling = saved
+        with _SAMPLER_SWITCH:                       # (the attribute is read by sample() and its loops: another thread sampling on this wrapper waits here)
+            saved = self.is_ddim_sampling
+            self.is_ddim_sampling = ddim
+            try:
+                yield
+            finally:
+                self.is_ddim_sampling = saved
 
     def _check_shape(self, shape):
         if tuple(shape[1:]) != (self.channels, self.image_size, self.image_size):
             raise ValueError(f"shape {tuple(shape)} does not match (B, {self.channels}, {self.image_size}, {self.image_size})")
 
     @torch.inference_mode()
-    def p_sample_loop(self, shape, condition, return_all_timesteps=False, preset_mean=None, **kw):           # :375-402
+    def p_sample_loop(self, shape, condition=None, return_all_timesteps=False, preset_mean=None, **kw):           # :375-402
         self._check_shape(shape)
         with self._as_sampler(False):
             return self.sample(batch_size=shape[0], condition=condition, return_all_timesteps=return_all_timesteps, preset_mean=preset_mean, **kw)
 
     @torch.inference_mode()
-    def ddim_sample(self, shape, condition, return_all_timesteps=False, preset_mean=None, **kw):             # :404-444 (preset_mean accepted, ignored)
+    def ddim_sample(self, shape, condition=None, return_all_timesteps=False, preset_mean=None, **kw):             # :404-444 (preset_mean accepted, ignored)
         self._check_shape(shape)
         with self._as_sampler(True):
             return self.sample(batch_size=shape[0], condition=condition, return_all_timesteps=return_all_timesteps, preset_mean=preset_mean, **kw)

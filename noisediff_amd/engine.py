@@ -20,6 +20,7 @@ PyTorch is used for allocation and host<->device copies only.
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import math
 import os
 import threading
@@ -33,6 +34,7 @@ from .spec import (normalize_stage_attn, stage_attention_param_spec, ATTN_DIM_HE
                    arch_param_spec, arch_traits, attention_param_spec, stage_dims)
 
 GN_EPS = 1e-5
+_log = logging.getLogger("noisediff_amd")
 WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
 PREACT = os.environ.get("ND_PREACT", "1") != "0"         # A-B knob: 0 = GroupNorm+SiLU always fused into block2's conv prologue
 PREACT_MIN = int(os.environ.get("ND_PREACT_MIN", "256"))  # A-B knob: narrowest block2 that gets the separate activation pass
@@ -54,52 +56,15 @@ EIGHT_TILES_RULE = os.environ.get("ND_W4_EIGHT_TILES", "1") != "0"     # A-B kno
 # layer; "0": never.  Either way a function of the sample's geometry alone, and the same bits as the 16 x 32 form.
 WINO4_16 = os.environ.get("ND_WINO4_16", "narrow")
 WINO4_16_SPLIT = os.environ.get("ND_WINO4_16_SPLIT", "1") != "0"      # A-B knob: 0 = no K ranges on the 16 x 16-region form
-# r4: the step as a TWO-BRANCH graph.  The shot-noise branch of NoiseDiffNet.forward (Diffusion_arch.py:598-604: shot_mlp1 -> shot_attn -> shot_mlp2 -> shot_time ->
-# shot_mlp3) is independent of the U-Net until the final add (:644).  Its launches go to a second stream, forked from the trunk at the start of down stage
-# TWO_BRANCH - 1 (1: right behind the time embedding ... 4: at the H/8 stage) and joined in front of final_conv; captured, the two streams become two branches of
-# the step graph, and the branch's full-resolution work fills the kernel tails, the GroupNorm finalizes and the half-empty launches of the trunk's deep stages.
-# Same kernels on the same data: the bits do not change.  "0": one linear chain (r1-r3).
-# MEASURED (profiles/r4a_two_branch_ab.txt, cfg3 and cfg2, one box, alternating): 17.79 ms per step as one chain, 17.82-17.86 with the branch forked at any of
-# the four points; cfg2 5.77 vs 5.83.  The trunk's kernels are persistent one-workgroup-per-CU grids: a second grid only gets CUs as the first one's
-# workgroups retire, which the next trunk kernel would have taken at the same moment -- there is no idle capacity behind a step's 159 launches to fill
-# (tools/step_gaps.py: busy 17.60 of 17.61 ms).  So the default stays one chain; the branch form is kept, tested for identical bits, behind the knob.
-TWO_BRANCH = int(os.environ.get("ND_TWO_BRANCH", "0"))
-# r4 (opt-in): the F(4x4) position products on the f16 matrix instruction with both operands split into two f16 terms and three products accumulated in fp32
-# (nd_conv3x3_wino4h_nhwc_f32, conv3x3_wino4h.hip) for the layers of the 16 x 32-region form.  As accurate as the fp32 kernel against an fp64 convolution
-# (tests/test_hip_kernels.py::test_conv3x3_wino4h_*), not bit-identical to it; the fp32 MFMA shares the VALU's lanes on gfx950, the f16 one does not.
-CONV_F16X3 = os.environ.get("ND_CONV_F16X3", "0") != "0"
-# ... the layers of up to DIRECT_F16X3_MAX_CIN input channels as a DIRECT convolution in the same product form (nd_conv3x3_f16x3_nhwc_f32, conv3x3_f16x3.hip:
-# no Winograd transforms, the double-rate f16 instruction): at 64 / 128 channels the F(4x4) kernel spends most of a tile outside the matrix instructions.
-# ND_CONV_DIRECT_F16X3=<max cin> (0: off)
-DIRECT_F16X3_MAX_CIN = int(os.environ.get("ND_CONV_DIRECT_F16X3", "0")) if CONV_F16X3 else 0
-# ... and the wide 1x1 layers with it (nd_pointwise_gemm_f16x3_nhwc_f32, the 128-pixel-tile kernel of pointwise.hip); ND_PW_F16X3=0 keeps those on fp32 MFMAs (A/B knob)
-PW_F16X3 = CONV_F16X3 and os.environ.get("ND_PW_F16X3", "1") != "0"
-# ... and the fused Mlp / AttnBlock chains of the 48- and 64-channel stages (nd_pointwise_chain_f16x3_nhwc_f32, pwchain.hip); ND_CHAIN_F16X3=0: A/B knob
-CHAIN_F16X3 = CONV_F16X3 and os.environ.get("ND_CHAIN_F16X3", "1") != "0"
-
-
-def set_f16x3(on: bool) -> bool:
-    """Switch the opt-in f16-split product form (ND_CONV_F16X3) for engines built FROM NOW ON, the A/B knobs of its parts (ND_PW_F16X3, ND_CHAIN_F16X3,
-    ND_CONV_DIRECT_F16X3) kept; returns the previous setting.  bench.py times both forms in one process with it."""
-    global CONV_F16X3, PW_F16X3, CHAIN_F16X3, DIRECT_F16X3_MAX_CIN
-    prev, CONV_F16X3 = CONV_F16X3, bool(on)
-    PW_F16X3 = CONV_F16X3 and os.environ.get("ND_PW_F16X3", "1") != "0"
-    CHAIN_F16X3 = CONV_F16X3 and os.environ.get("ND_CHAIN_F16X3", "1") != "0"
-    DIRECT_F16X3_MAX_CIN = int(os.environ.get("ND_CONV_DIRECT_F16X3", "0")) if CONV_F16X3 else 0
-    return prev
-
-
-def _stem_entry() -> str:
-    """init_conv / cond_init_conv (7x7, 4 input channels): the f16-split form with ND_CONV_F16X3=1 (ND_STEM_F16X3=0: A/B knob)."""
-    return "nd_conv7x7_c4_f16x3_f32" if (CONV_F16X3 and os.environ.get("ND_STEM_F16X3", "1") != "0") else "nd_conv7x7_c4_f32"
-
-
-F16X3_SPLIT = os.environ.get("ND_F16X3_SPLIT", "1") != "0"       # A/B knob: the narrow layers' geometry-only K split on the f16 kernel too (ND_CONV_F16X3=1)
-F16X3_ENTRIES = ("nd_conv7x7_c4_f16x3_f32", "nd_conv3x3_wino4h_16_splitk_nhwc_f32", "nd_conv3x3_wino4h_nhwc_f32", "nd_conv3x3_f16x3_nhwc_f32", "nd_pointwise_gemm_f16x3_nhwc_f32", "nd_pointwise_chain_f16x3_nhwc_f32")
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
 PROJ_TABLE = os.environ.get("ND_PROJ_TABLE", "1") != "0"   # A-B knob: 0 = only the head is tabulated, the stacked projection is computed in every step
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
+
+
+def _few_items(H: int, W: int, cout: int) -> bool:
+    """At most eight (16 x 32-pixel region, 64-cout tile) items of the one-workgroup F(4x4) form per SAMPLE."""
+    return ((H + 15) // 16) * ((W + 31) // 32) * ((cout + 63) // 64) <= 8
 
 
 def _wino4_layer(cin: int, cout: int) -> bool:
@@ -171,10 +136,6 @@ class Engine:
             s = C.c_void_p()
             L.call("nd_stream_create", C.byref(s))
         self.stream = s
-        with torch.cuda.device(device):
-            s2 = C.c_void_p()
-            L.call("nd_stream_create", C.byref(s2))
-        self.stream2 = s2                          # the side branch of the step graph (TWO_BRANCH); ordered against `stream` by events only
         self.plans: Dict[Tuple[int, int, int], "Plan"] = {}
         self.loaded = False
         self.used: set = set()                     # arena slices the recorded plans read (Engine.p): what a broadcast has to carry
@@ -182,8 +143,7 @@ class Engine:
 
     def __del__(self):                      # the engine owns its HIP stream (plans and loops only borrow it)
         s, self.stream = getattr(self, "stream", None), None
-        s2, self.stream2 = getattr(self, "stream2", None), None
-        for q in (s2, s):
+        for q in (s,):
             if q:
                 try:
                     L.call("nd_stream_sync", q)
@@ -210,10 +170,6 @@ class Engine:
                 add(p.name + ".wino", self.lib.nd_pack_conv3x3_wino_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
                 if WINO4 and _wino4_layer(p.shape[1], p.shape[0]):
                     add(p.name + ".wino4", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
-                    if CONV_F16X3:
-                        add(p.name + ".wino4h", self.lib.nd_pack_conv3x3_wino4_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
-                    if DIRECT_F16X3_MAX_CIN and p.shape[1] <= DIRECT_F16X3_MAX_CIN and p.shape[1] % 16 == 0 and p.shape[0] % 64 == 0:
-                        add(p.name + ".f16x3", self.lib.nd_pack_conv3x3_f16x3_weight_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind in ("pw", "pw_unshuffle"):
                 n = self.lib.nd_pack_pointwise_weight_floats(p.shape[1], p.shape[0])
                 if p.name in _MAP_PRODUCERS and p.shape[0] % 32 == 0:
@@ -221,13 +177,9 @@ class Engine:
                     # the 16-channel-blocked layout the F(4x4,3x3) kernel reads one 128-byte line at a time (nd_src.map_blocked)
                     add(p.name + ".blk16", n, "derived", p.shape)
                     add(p.name[:-len("weight")] + "bias.blk16", p.shape[0], "derived", (p.shape[0],))
-                if kind == "pw" and PW_F16X3 and p.shape[1] % 64 == 0 and p.shape[1] >= 128 and p.shape[0] % 128 == 0:
-                    add(p.name + ".h", n, "derived", p.shape)        # the wide layers' f16-split packing (nd_pointwise_gemm_f16x3_nhwc_f32)
                 if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
                     first = int(p.name.endswith(_CHAIN_FIRST))
                     add(p.name + ".chain", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
-                    if CHAIN_F16X3:
-                        add(p.name + ".chain.h", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
             elif kind == "conv7":
                 n = 196 * p.shape[0]
             else:
@@ -292,15 +244,8 @@ class Engine:
                     L.call("nd_pack_conv3x3_wino_weight", t.data_ptr(), self.p(p.name + ".wino"), p.shape[1], p.shape[0], st)
                     if p.name + ".wino4" in self.slots:
                         L.call("nd_pack_conv3x3_wino4_weight", t.data_ptr(), self.p(p.name + ".wino4"), p.shape[1], p.shape[0], st)
-                    if p.name + ".wino4h" in self.slots:
-                        L.call("nd_pack_conv3x3_wino4h_weight", t.data_ptr(), self.p(p.name + ".wino4h"), p.shape[1], p.shape[0], st)
-                    if p.name + ".f16x3" in self.slots:
-                        L.call("nd_pack_conv3x3_f16x3_weight", t.data_ptr(), self.p(p.name + ".f16x3"), p.shape[1], p.shape[0], st)
                 elif kind == "pw":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], 0, st)
-                    if p.name + ".h" in self.slots:
-                        # (the layers read through a LayerNorm prologue -- FeedForward's first Linear -- have their own operand order: pw() checks the pairing)
-                        L.call("nd_pack_pointwise_weight_h", t.data_ptr(), self.p(p.name + ".h"), p.shape[1], p.shape[0], int(p.name.endswith(_CHAIN_FIRST[0])), st)
                     if p.name + ".blk16" in self.slots:
                         perm = _blocked_map_rows(p.shape[0] // 2).to(self.device)
                         tp = t[perm].contiguous()
@@ -310,9 +255,6 @@ class Engine:
                         self.view(bname + ".blk16").copy_(sd[bname].detach().to(device=self.device, dtype=torch.float32)[perm])
                     if p.name + ".chain" in self.slots:
                         L.call("nd_pack_chain_weight", t.data_ptr(), self.p(p.name + ".chain"), p.shape[1], p.shape[0],
-                               int(p.name.endswith(_CHAIN_FIRST)), st)
-                    if p.name + ".chain.h" in self.slots:
-                        L.call("nd_pack_chain_weight_h", t.data_ptr(), self.p(p.name + ".chain.h"), p.shape[1], p.shape[0],
                                int(p.name.endswith(_CHAIN_FIRST)), st)
                 elif kind == "pw_unshuffle":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], p.shape[1] // 4, st)
@@ -328,21 +270,32 @@ class Engine:
             e = math.log(10000) / (half - 1)
             self.view("time_freqs").copy_(torch.exp(torch.arange(half) * -e).to(torch.float32))
             torch.cuda.synchronize(self.device)
-            if self.time_table:
-                L.call("nd_cond_table_build_f32", self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"), self.p("time_mlp.3.weight"),
-                       self.p("time_mlp.3.bias"), self.p("time_table"), TIME_TABLE_ROWS, self.dim, st)
-                L.call("nd_stream_sync", st)
-                if "tproj_table" in self.slots:      # rows of the projection table = what the per-step launch computes for t = 0 .. rows-1 (same kernel code: same bits)
-                    ts = torch.arange(TIME_TABLE_ROWS, dtype=torch.int64, device=self.device)
-                    torch.cuda.synchronize(self.device)
-                    J = self.tproj_rows
-                    for t0 in range(0, TIME_TABLE_ROWS, 16):
-                        nb = min(16, TIME_TABLE_ROWS - t0)
-                        L.call("nd_cond_step_table_f32", ts.data_ptr() + 8 * t0, self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"),
-                               self.p("time_mlp.3.weight"), self.p("time_mlp.3.bias"), self.p("tproj.weight"), self.p("tproj.bias"),
-                               self.p("tproj_table") + 4 * t0 * J, J, nb, self.dim, J, self.p("time_table"), TIME_TABLE_ROWS, st)
-                    L.call("nd_stream_sync", st)
+            self._build_time_tables()
         self.loaded, self.valid, self.used = True, None, used
+
+    _DERIVED_TABLES = ("time_table", "tproj_table")       # pure functions of time_freqs, time_mlp.* and tproj.*: never shipped, rebuilt where those arrive
+
+    def _build_time_tables(self) -> None:
+        """time_mlp's result and the stacked ResnetBlock.mlp projection for every tabulated timestep, from the arena's own time_freqs / time_mlp / tproj slices
+        (the same kernel code the per-step launch runs: a lookup is the same bits).  Does not touch ``used``."""
+        if not self.time_table:
+            return
+        st, used = self.stream, set(self.used)
+        with torch.cuda.device(self.device):
+            L.call("nd_cond_table_build_f32", self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"), self.p("time_mlp.3.weight"),
+                   self.p("time_mlp.3.bias"), self.p("time_table"), TIME_TABLE_ROWS, self.dim, st)
+            L.call("nd_stream_sync", st)
+            if "tproj_table" in self.slots:      # rows of the projection table = what the per-step launch computes for t = 0 .. rows-1
+                ts = torch.arange(TIME_TABLE_ROWS, dtype=torch.int64, device=self.device)
+                torch.cuda.synchronize(self.device)
+                J = self.tproj_rows
+                for t0 in range(0, TIME_TABLE_ROWS, 16):
+                    nb = min(16, TIME_TABLE_ROWS - t0)
+                    L.call("nd_cond_step_table_f32", ts.data_ptr() + 8 * t0, self.p("time_freqs"), self.p("time_mlp.1.weight"), self.p("time_mlp.1.bias"),
+                           self.p("time_mlp.3.weight"), self.p("time_mlp.3.bias"), self.p("tproj.weight"), self.p("tproj.bias"),
+                           self.p("tproj_table") + 4 * t0 * J, J, nb, self.dim, J, self.p("time_table"), TIME_TABLE_ROWS, st)
+                L.call("nd_stream_sync", st)
+        self.used = used
 
     def broadcast_state_dict(self, sd: Optional[Dict[str, torch.Tensor]], src: int = 0, group=None) -> int:
         """The ONE collective of the sampling path in its smallest form: the network's own fp32 weights (150 MB at d=64, 598 MB at
@@ -384,7 +337,12 @@ class Engine:
                 dist.broadcast(self.arena, src=src, group=group)
                 nbytes = self.arena.numel() * 4
             else:
-                names = sorted(self.used, key=lambda n: self.slots[n].offset)
+                # (the per-timestep tables are functions of slices that travel anyway -- 41 MB at d=64 that every receiver rebuilds instead)
+                tables = [n for n in self._DERIVED_TABLES if n in self.used]
+                if tables:
+                    for dep in ("time_freqs", "time_mlp.1.weight", "time_mlp.1.bias", "time_mlp.3.weight", "time_mlp.3.bias", "tproj.weight", "tproj.bias"):
+                        self.used.add(dep)
+                names = sorted((n for n in self.used if n not in self._DERIVED_TABLES), key=lambda n: self.slots[n].offset)
                 every = [None] * dist.get_world_size(group)
                 dist.all_gather_object(every, names, group=group)      # control plane: every rank must have recorded the same plans
                 if any(e != names for e in every):
@@ -407,7 +365,10 @@ class Engine:
                     for lo, hi in ranges:
                         self.arena[lo:hi].copy_(stage[at:at + hi - lo])
                         at += hi - lo
-                    self.valid = set(names)
+                    self.valid = set(names) | set(tables)
+                    if tables:
+                        torch.cuda.synchronize(self.device)
+                        self._build_time_tables()
                 nbytes = stage.numel() * 4
             # the collective is asynchronous to the host and ordered only against torch's stream; the kernels that read the
             # arena run on the library's own non-blocking stream, so the arena must be complete before this returns
@@ -531,22 +492,46 @@ class Plan:
             setattr(s, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
         return s
 
+    def _conv_rows(self, H: int, W: int, up: int, ld0: int, ld1: int, cin: int, cout: int, mode: int, splits: int = 1) -> int:
+        """Samples ONE conv3x3 launch covers.  The Winograd kernels address their sources through 32-bit buffer offsets (sources below 1 GiB and 2^24 pixels,
+        outputs below 4 GiB, split-K partial sums below 2 GiB): a larger batch is cut into equal pieces of whole samples -- same kernel, same weights, same
+        summation order per sample, so a sample's bits do not depend on the batch (the reference takes any --batch_size, test_diffusion.py:23-78)."""
+        sh, sw, lim = H >> up, W >> up, (1 << 30) - (1 << 16)
+
+        def fits(b: int) -> bool:
+            px = b * sh * sw + sw + 2
+            return (px * 4 * max(ld0, ld1) < lim and px < (1 << 24) and b * H * W < (1 << 24) and b * H * W * cout * 4 < (1 << 32) - (1 << 16)
+                    and (mode != L.PRO_AFFINE_MAP_SILU or (b * H + 2) * W * 8 * cin < lim) and splits * b * H * W * cout * 4 < (1 << 31))
+        if fits(self.B):
+            return self.B
+        lo, hi = 1, self.B                         # largest b that fits (fits is monotone), then equal pieces
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            lo, hi = (mid, hi) if fits(mid) else (lo, mid - 1)
+        if not fits(lo):
+            raise L.HipError(f"conv3x3 at {H} x {W} x {max(ld0, ld1)}: one sample exceeds the kernels' 1 GiB source limit")
+        pieces = -(-self.B // lo)
+        return -(-self.B // pieces)
+
     def conv3(self, name: str, src: L.Src, cin: int, cout: int, H: int, W: int, stats: bool):
         """nn.Conv2d(cin, cout, 3, padding=1); returns (out, stats, slot_count, slots)."""
         e = self.e
         out = self._alloc(self.B, H, W, cout)
         # images of at least one 16x16 tile go through the Winograd F(2x2,3x3) kernel (2.25x fewer MFMAs)
         wino = WINOGRAD and H >= 16 and W >= 16
-        d = L.Conv3x3()
-        d.src, d.bias, d.out = src, e.p(name + ".bias"), out.data_ptr()
-        d.B, d.H, d.W, d.cin, d.cout, d.ldo = self.B, H, W, cin, cout, cout
+        up = 1 if src.upsample else 0
+        # rows per launch (the whole batch at the bench sizes).  Every kernel choice below looks at ONE launch's piece, and the pieces are equal for every
+        # batch beyond the limit: the choice is a function of the sample's geometry alone
+        rows = self._conv_rows(H, W, up, src.ld0, src.ld1, cin, cout, src.mode) if wino else self.B
         # both Winograd kernels share weights, statistics slots and descriptor; wino2 (one resident wave per SIMD,
         # all 16 position accumulators in registers) is the default, wino covers what it does not take
         wino2 = (wino and WINO2 and not (src.mode == L.PRO_AFFINE_MAP_SILU and src.upsample)
-                 and (src.c1 == 0 or src.c0 % 32 == 0) and self.B * H * W < (1 << 24)
-                 and self.B * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
-        w4kind = self._wino4_kind(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W) if wino else ""
+                 and (src.c1 == 0 or src.c0 % 32 == 0) and rows * H * W < (1 << 24)
+                 and rows * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
+        w4kind = self._wino4_kind(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W, rows) if wino else ""
         wino4 = bool(w4kind)
+        if wino and not wino4 and (name + ".weight.wino4") in e.slots and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU) and not _few_items(H, W, cout):
+            _log.warning("%s (%d -> %d at %d x %d, batch %d): not on the F(4x4) kernel", name, cin, cout, H, W, self.B)
         st = sc = None
         slots = 0
         if stats:     # per-(slot, channel) {sum, M2} partials for nd_groupnorm_finalize_f32: F(4x4) one slot per 16 x 16 tile, F(2x2) two
@@ -554,46 +539,57 @@ class Plan:
                      else e.lib.nd_conv3x3_stat_slots(H, W, cout, self.B))
             st = self._alloc(self.B, slots, cout, 2)
             sc = self._alloc(slots)
-            d.stats, d.slot_count = st.data_ptr(), sc.data_ptr()
         if src.map_blocked and not wino4:
             raise L.HipError(f"{name}: the scale / shift map was produced in the blocked layout but the layer does not run on conv3x3_wino4")
         # ONE packing of the weight is read (and marked for the weight broadcast): F(4x4), F(2x2) or the direct form
         lowlat_split = SPLIT_K and w4kind == "wino4" and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU) and int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) > 1
-        f16x3 = w4kind == "wino4" and (name + ".weight.wino4h") in e.slots and not lowlat_split      # (the opt-in low-latency split keeps the fp32 kernel)
-        # ... or the direct f16-split convolution (same statistics slots as the F(4x4) kernels, so it only stands in for them)
-        direct = wino4 and not lowlat_split and (name + ".weight.f16x3") in e.slots and bool(e.lib.nd_conv3x3_f16x3_takes(C.byref(d)))
-        f16x3 = f16x3 and not direct
-        d.weight = e.p(name + (".weight.f16x3" if direct else ".weight.wino4h" if f16x3 else ".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
-        if direct:
-            w4kind = "direct_f16x3"
-        entry = ("nd_conv3x3_f16x3_nhwc_f32" if direct else "nd_conv3x3_wino4h_nhwc_f32" if f16x3 else f"nd_conv3x3_{w4kind}_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
+        weight = e.p(name + (".weight.wino4" if wino4 else ".weight.wino" if wino else ".weight"))
+        entry = (f"nd_conv3x3_{w4kind}_nhwc_f32" if wino4 else "nd_conv3x3_wino2_nhwc_f32" if wino2 else
                  "nd_conv3x3_wino_nhwc_f32" if wino else "nd_conv3x3_nhwc_f32")
-        meta = {"layer": name, "B": self.B, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode),
-                "tiling": (9116 if direct else 9016 if w4kind == "wino4_16" else 9104 if f16x3 else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)}
-        splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if (SPLIT_K and w4kind == "wino4" and not f16x3 and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU)) else 1
+        tiling = (9016 if w4kind == "wino4_16" else 9004) if wino4 else 9002 if wino2 else 9001 if wino else e.lib.nd_conv3x3_tiling_id(self.B, H, W, cout)
+        splits = int(e.lib.nd_conv3x3_wino4_splitk_plan(self.B, H, W, cin, cout)) if lowlat_split else 1
         if w4kind == "wino4_16" and WINO4_16_SPLIT:      # few items per sample: K ranges by the SAMPLE's geometry (the batch never enters: a sample's bits stay batch-invariant)
             splits = int(e.lib.nd_conv3x3_wino4_16_splitk_plan(H, W, cin, cout))
-        if splits > 1 and splits * self.B * H * W * cout * 4 < (1 << 31):
-            ws = self._alloc(splits * self.B * H * W * cout)
-            meta["splits"] = splits
-            entry_s = "nd_conv3x3_wino4_16_splitk_nhwc_f32" if w4kind == "wino4_16" else "nd_conv3x3_wino4_splitk_nhwc_f32"
-            if w4kind == "wino4_16" and WINO4_16_SPLIT and (name + ".weight.wino4h") in e.slots and F16X3_SPLIT:      # opt-in form: the narrow layers' partial tensors from the f16 kernel
-                d.weight, entry_s = e.p(name + ".weight.wino4h"), "nd_conv3x3_wino4h_16_splitk_nhwc_f32"
-                meta["tiling"] = 9117
-            self._add(entry_s, C.byref(d), ws.data_ptr(), splits, e.stream, meta=meta)
+        if splits > 1:                                   # the partial sums of a launch stay below 2 GiB: smaller pieces, never another kernel
+            rows = self._conv_rows(H, W, up, src.ld0, src.ld1, cin, cout, src.mode, splits)
+        ws = self._alloc(splits * rows * H * W * cout) if splits > 1 else None
+        sh, sw, ctot = H >> up, W >> up, src.c0 + src.c1
+        for b0 in range(0, self.B, rows):                # one launch per piece of `rows` samples (one piece at the bench sizes)
+            nb = min(rows, self.B - b0)
+            d = L.Conv3x3()
+            s = L.Src.from_buffer_copy(src)
+            if b0:                                       # the piece's rows of every per-sample operand
+                s.p0 = src.p0 + 4 * b0 * sh * sw * src.ld0
+                if src.p1:
+                    s.p1 = src.p1 + 4 * b0 * sh * sw * src.ld1
+                if src.mad:
+                    s.mad = src.mad + 4 * b0 * 3 * ctot
+                if src.map:
+                    s.map = src.map + 4 * b0 * H * W * 2 * ctot
+            d.src, d.weight, d.bias, d.out = s, weight, e.p(name + ".bias"), out.data_ptr() + 4 * b0 * H * W * cout
+            d.B, d.H, d.W, d.cin, d.cout, d.ldo = nb, H, W, cin, cout, cout
+            if stats:
+                d.stats, d.slot_count = st.data_ptr() + 4 * b0 * slots * cout * 2, sc.data_ptr()
+            meta = {"layer": name, "B": nb, "H": H, "W": W, "cin": cin, "cout": cout, "mode": int(src.mode), "tiling": tiling}
+            if splits > 1:
+                meta["splits"] = splits
+                entry_s = "nd_conv3x3_wino4_16_splitk_nhwc_f32" if w4kind == "wino4_16" else "nd_conv3x3_wino4_splitk_nhwc_f32"
+                self._add(entry_s, C.byref(d), ws.data_ptr(), splits, e.stream, meta=meta)
+            else:
+                self._add(entry, C.byref(d), e.stream, meta=meta)
+            self._keep.append(d)
+        if ws is not None:
             self._release(ws)
-        else:
-            self._add(entry, C.byref(d), e.stream, meta=meta)
-        self._keep.append(d)
         return out, st, sc, slots
 
-    def _wino4_kind(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int) -> str:
+    def _wino4_kind(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int, rows: Optional[int] = None) -> str:
         """"wino4" (16 x 32-pixel regions, one workgroup per CU), "wino4_16" (16 x 16-pixel regions, two per CU) or "" (another kernel).
         F(4x4,3x3) (1.78x fewer MFMAs than F(2x2,3x3); 16-channel K chunks) wherever a form of its kernel takes the
         layer: plain / GroupNorm-affine (+ per-pixel map) + SiLU inputs, concat on a chunk boundary, images that fill its regions,
         sources below 1 GiB and 2^24 pixels (the host checks of nd_conv3x3_wino4_nhwc_f32)."""
         up = 1 if upsample else 0
-        src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
+        rows = self.B if rows is None else rows                          # samples of one launch (conv3 cuts a batch beyond the kernels' limits into pieces)
+        src_px = rows * (H >> up) * (W >> up) + (W >> up) + 2            # the kernel's buffer resource starts one row + one pixel in front of the tensor
         src_bytes = src_px * 4 * max(ld0, ld1)
         common = (WINOGRAD and WINO4 and H >= 16 and W >= 16 and cout <= 2048 and (name + ".weight.wino4") in self.e.slots
                   and W <= 2048 and (c1 == 0 or (c0 % 16 == 0 and not up)) and src_bytes < (1 << 30) - (1 << 16) and src_px < (1 << 24)
@@ -602,12 +598,12 @@ class Plan:
             return ""
         # the 16 x 16-region form: plain and affine + SiLU sources; regions of any image are at least half used from W = 16 on (W % 16 == 0 or W >= 48)
         takes16 = WINO4_16 != "0" and mode in (L.PRO_NONE, L.PRO_AFFINE_SILU) and (W % 16 == 0 or W >= 48)
-        few = ((H + 15) // 16) * ((W + 31) // 32) * ((cout + 63) // 64) <= 8       # <= 8 items of the 16 x 32 form per SAMPLE
+        few = _few_items(H, W, cout)                                     # <= 8 items of the 16 x 32 form per SAMPLE
         if takes16 and (WINO4_16 == "all" or W < 32 or (few and EIGHT_TILES_RULE and not SPLIT_K)):
             return "wino4_16"
-        return "wino4" if self._wino4_takes(name, mode, upsample, c0, c1, ld0, ld1, cin, cout, H, W) else ""
+        return "wino4" if self._wino4_takes(name, mode, upsample, c0, c1, ld0, ld1, cin, cout, H, W, rows) else ""
 
-    def _wino4_takes(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int) -> bool:
+    def _wino4_takes(self, name: str, mode: int, upsample: bool, c0: int, c1: int, ld0: int, ld1: int, cin: int, cout: int, H: int, W: int, rows: Optional[int] = None) -> bool:
         """The 16 x 32-region form."""
         up = 1 if upsample else 0
         # Layers with at most eight F(4x4) workgroup tiles (16 x 32 pixels x 64 couts) per SAMPLE -- 256 -> 256 at 32 x 32 -- fill half of an
@@ -617,11 +613,12 @@ class Plan:
         if (WINO2 and not SPLIT_K and EIGHT_TILES_RULE and ((H + 15) // 16) * ((W + 31) // 32) * ((cout + 63) // 64) <= 8 and (c1 == 0 or c0 % 32 == 0)
                 and not (mode == L.PRO_AFFINE_MAP_SILU and up)):
             return False
-        src_px = self.B * (H >> up) * (W >> up) + (W >> up) + 2          # the kernel's buffer resource starts one row + one pixel in front of the tensor
+        rows = self.B if rows is None else rows
+        src_px = rows * (H >> up) * (W >> up) + (W >> up) + 2            # the kernel's buffer resource starts one row + one pixel in front of the tensor
         src_bytes = src_px * 4 * max(ld0, ld1)
         return (WINOGRAD and WINO4 and H >= 16 and W >= 16 and cout <= 2048 and (name + ".weight.wino4") in self.e.slots
                 and mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU)
-                and not (mode == L.PRO_AFFINE_MAP_SILU and (up or (self.B * H + 2) * W * 8 * cin >= (1 << 30) - (1 << 16)))
+                and not (mode == L.PRO_AFFINE_MAP_SILU and (up or (rows * H + 2) * W * 8 * cin >= (1 << 30) - (1 << 16)))
                 and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (c1 == 0 or (c0 % 16 == 0 and not up))
                 and src_bytes < (1 << 30) - (1 << 16) and src_px < (1 << 24)
                 and (not up or (H % 2 == 0 and W % 2 == 0)))
@@ -644,11 +641,7 @@ class Plan:
             d.vec = vec.data_ptr()
         if gn_t is not None:
             d.gn_t, d.ldt, d.gn_mad = gn_t.data_ptr(), gn_t.shape[-1], gn_mad.data_ptr()
-        entry = "nd_pointwise_gemm_nhwc_f32"
-        if (not variant and (name + ".weight.h") in e.slots and e.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d))
-                and (src.mode == L.PRO_LAYERNORM) == (name + ".weight").endswith(_CHAIN_FIRST[0])):      # opt-in (CONV_F16X3): the wide layers' products as f16 splits; the packing matches the prologue
-            d.weight, entry = e.p(name + ".weight.h"), "nd_pointwise_gemm_f16x3_nhwc_f32"
-        self._add(entry, C.byref(d), e.stream, meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout})
+        self._add("nd_pointwise_gemm_nhwc_f32", C.byref(d), e.stream, meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout})
         self._keep.append(d)
         return out
 
@@ -708,12 +701,10 @@ class Plan:
         out = self._alloc(self.B, HW, stages[-1][2])
         d = L.Chain()
         d.src, d.out, d.n_stages, d.B, d.HW, d.ldo = src, out.data_ptr(), len(stages), self.B, HW, stages[-1][2]
-        widths = [stages[0][1]] + [st_[2] for st_ in stages] + [0] * (3 - len(stages))
-        hf = (all((layer + ".weight.chain.h") in e.slots for layer, *_ in stages) and bool(e.lib.nd_pointwise_chain_f16x3_supported(*widths)))    # opt-in (CONV_F16X3)
         for i, (layer, cin, cout, act, res) in enumerate(stages):
-            d.st[i].weight, d.st[i].bias = e.p(layer + (".weight.chain.h" if hf else ".weight.chain")), e.p(layer + ".bias")
+            d.st[i].weight, d.st[i].bias = e.p(layer + ".weight.chain"), e.p(layer + ".bias")
             d.st[i].cin, d.st[i].cout, d.st[i].act, d.st[i].res = cin, cout, act, res
-        self._add("nd_pointwise_chain_f16x3_nhwc_f32" if hf else "nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
+        self._add("nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
                   meta={"layer": name, "B": self.B, "HW": HW, "cin": stages[0][1], "cout": stages[-1][2],
                         "flop_per_px": 2.0 * sum(c_in * c_out for _, c_in, c_out, _, _ in stages)})
         self._keep.append(d)
@@ -787,7 +778,7 @@ class Plan:
         if tr.cond_branch:
             # clean-image encoding of the UNet_PosEmbV2* nets (others_arch.py:491-492): step-invariant, so it runs here
             ce = self._alloc(B, H, W, e.dim)
-            self._add(_stem_entry(), self.clean.data_ptr(), e.p("cond_init_conv.weight"), e.p("cond_init_conv.bias"),
+            self._add("nd_conv7x7_c4_f32", self.clean.data_ptr(), e.p("cond_init_conv.weight"), e.p("cond_init_conv.bias"),
                       ce.data_ptr(), e.dim, B, H, W, e.dim, st)
             self.clean_emb = self._tap("clean_emb", self.resnet("cond_res_block1", ce, None, e.dim, H, W, RESNET_GROUPS))
             self._release(ce)                  # clean_emb itself is never released: every step reads it
@@ -816,11 +807,7 @@ class Plan:
         e, B, H, W, d = self.e, self.B, self.H, self.W, self.e.dim
         G, tr = RESNET_GROUPS, self.e.traits
         shot_noise = None
-        two = TWO_BRANCH > 0 and tr.shot_branch and not self.debug
-        trunk_ops, main_free = self._ops, self._free
         if tr.shot_branch:
-            if two:      # the branch records into its own list and allocates from its own pool: the trunk must not recycle a buffer the branch may still be using
-                self._ops, self._free = [], {}
             # ---- shot-noise branch, full resolution (:598-604)
             r_shot = self.mlp("shot_mlp1", self._src(self.clean, self.x), 2 * e.inp_dim, d, d, H, W)
             s = self.attn_block("shot_attn", r_shot, H, W)
@@ -830,12 +817,9 @@ class Plan:
             for nm, tt in (("shot_mlp1", r_shot), ("shot_attn", s), ("shot_mlp2", s2), ("shot_time", s3)):
                 self._tap(nm, tt)
             self._release(r_shot, s, s2, s3)
-        shot_ops, fork_at = self._ops, {}
-        self._ops, self._free = trunk_ops, main_free
-        fork_at[1] = len(self._ops)                # right behind the time embedding
         # ---- trunk
         x0 = self._alloc(B, H, W, d)
-        self._add(_stem_entry(), self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
+        self._add("nd_conv7x7_c4_f32", self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
                   B, H, W, d, e.stream)
         self._tap("init_conv", x0)
         xin = x0
@@ -851,7 +835,6 @@ class Plan:
         h, w = H, W
         for i, (cin, cout) in enumerate(stage_dims(d)):
             p = f"downs.{i}"
-            fork_at[i + 1] = fork_at.get(i + 1, len(self._ops))        # fork point i + 1: the start of down stage i
             x1 = self.resnet(p + ".0", x, None, cin, h, w, G)
             self._release(x)
             x2 = self.resnet(p + ".1", x1, None, cin, h, w, G)
@@ -900,36 +883,11 @@ class Plan:
         self._release(x)
         xf = self._tap("final_res_block", self.resnet("final_res_block", xp, x0, d, H, W, G))
         self._release(xp, x0)
-        if two:
-            self._splice_branch(shot_ops, fork_at[min(max(TWO_BRANCH, 1), 4)])
         # NoiseDiffNet: shot + read (:644); the ablation nets return final_conv(x) alone
         self.pw("final_conv", self._src(xf), d, e.inp_dim, H * W, W, res0=shot_noise, out=self.model_out)
         self._release(xf)
-        if shot_noise is not None and not two:     # (two branches: the branch's buffers stay out of the trunk's pool for the plan's life)
+        if shot_noise is not None:
             self._release(shot_noise)
-
-    def _splice_branch(self, branch_ops: List[Op], at: int) -> None:
-        """Put `branch_ops` on the engine's second stream: fork from the main stream in front of recorded op `at`, join at the current end of the list.
-        Eagerly the events order the two streams; under hipStreamBeginCapture the same calls make the branch a second branch of the graph."""
-        e = self.e
-        main, side = e.stream, e.stream2
-        fork, join = C.c_void_p(), C.c_void_p()
-        with torch.cuda.device(self.dev):
-            L.call("nd_event_create_untimed", C.byref(fork))
-            L.call("nd_event_create_untimed", C.byref(join))
-        self._events = getattr(self, "_events", []) + [fork, join]
-        lib = e.lib
-        moved = []
-        for fn, args, name, meta in branch_ops:        # the recorded launches carry the main stream: the same launches on the side stream
-            args2 = tuple(side if a is main else a for a in args)
-            assert any(a is side for a in args2), name
-            self._keep.append(args2)
-            moved.append((fn, args2, name, None if meta is None else dict(meta, _stream=side)))
-        head = [(lib.nd_event_record, (fork, main), "nd_event_record", None), (lib.nd_stream_wait_event, (side, fork), "nd_stream_wait_event", None)]
-        tail = [(lib.nd_event_record, (join, side), "nd_event_record", None)]
-        self._ops[at:at] = head + moved + tail
-        self._ops.append((lib.nd_stream_wait_event, (main, join), "nd_stream_wait_event", None))
-        self.branch_ops = len(moved)
 
     def _mid_attention(self, x: torch.Tensor, h: int, w: int, prefix: str = "mid_attn") -> torch.Tensor:
         """x = Attention(x) + x (Diffusion_arch.py:237-266): between the mid blocks (BASELINE config 4) or as a stage's full attention."""

@@ -177,15 +177,12 @@ class NoiseDiffNet(nn.Module):
         3x3 convolutions, GroupNorm (+ modulation + SiLU) and LayerNorm forward and backward and the Linear / 1x1 weight gradients on
         the HIP library -- over the reference graph of trainable.py.  The fused sampling engine has no backward, so this path does
         not go through it; like it, it has no CPU fallback."""
-        if self.ARCH != "NoiseDiffNet" or self.has_mid_attn or self.stage_attn:
-            raise NotImplementedError(
-                f"noisediff_amd.{self.ARCH}{' with mid_attn / stage_attn' if self.has_mid_attn or self.stage_attn else ''} implements the inference (sampling) path only; "
-                "call it under torch.no_grad()/inference_mode().  Only the NoiseDiffNet graph has a differentiable HIP path.")
         if x.device.type != "cuda":
             raise L.HipError(f"{self.ARCH} runs on the HIP library only; tensor is on {x.device} and there is no CPU path")
         L.load()
         from .trainable import _Ops, _forward
-        return _forward(_Ops(self._parameter_table(), True), x, time, condition)
+        # (the ablation nets, the mid-block Attention and the per-stage attention wiring train the same way -- others_arch.py:364-985 go through the same p_losses)
+        return _forward(_Ops(self._parameter_table(), True), x, time, condition, arch=self.ARCH, mid_attn=self.has_mid_attn, stage_attn=self.stage_attn)
 
     def _parameter_table(self) -> Dict[str, torch.Tensor]:
         """name -> tensor for the differentiable forward.  An nn.DataParallel replica holds no Parameters: ``replicate`` leaves the

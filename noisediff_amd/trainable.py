@@ -180,17 +180,56 @@ class _Ops:
         return self.conv(name + ".proj_out", t.transpose(1, 2).reshape(b, c, h, w)) + x
 
 
-def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """NoiseDiffNet.forward (:577-646): shot-noise branch on cat(clean, x) + the U-Net's read-noise branch."""
+    # ---- the attention modules the reference defines next to the network (Diffusion_arch.py:84-90,198-266): BASELINE config 4's mid-block Attention and
+    #      upstream's per-stage LinearAttention / Attention wiring.  Plain differentiable PyTorch around the library's 1x1 convolutions.
+    def rms_norm(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        """RMSNorm (:84-90): F.normalize over the channels * g * sqrt(C)."""
+        return F.normalize(x, dim=1) * self.p[name + ".g"] * (x.shape[1] ** 0.5)
+
+    def attention(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        """Attention (:237-266) with Attend's explicit path (models/attend.py:101-116): RMSNorm -> to_qkv -> softmax(q k^T / sqrt(d)) v -> to_out."""
+        b, c, h, w = x.shape
+        q, k, v = (t.reshape(b, HEADS, -1, h * w).transpose(-1, -2) for t in self.conv(name + ".to_qkv", self.rms_norm(name + ".norm", x)).chunk(3, dim=1))   # b h (xy) d
+        out = F.scaled_dot_product_attention(q, k, v)                            # scale d^-1/2, no mask, no dropout
+        return self.conv(name + ".to_out", out.transpose(-1, -2).reshape(b, -1, h, w))
+
+    def linear_attention(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        """LinearAttention (:198-235): q softmax over d (scaled), k softmax over the pixels, context = k v^T, out = context^T q -> to_out.0 -> RMSNorm."""
+        b, c, h, w = x.shape
+        q, k, v = (t.reshape(b, HEADS, -1, h * w) for t in self.conv(name + ".to_qkv", self.rms_norm(name + ".norm", x)).chunk(3, dim=1))    # b h d (xy)
+        q = q.softmax(dim=-2) * (q.shape[2] ** -0.5)
+        k = k.softmax(dim=-1)
+        ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+        out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b, -1, h, w)
+        return self.rms_norm(name + ".to_out.1", self.conv(name + ".to_out.0", out))
+
+    def stage_attention(self, name: str, kind, x: torch.Tensor) -> torch.Tensor:
+        if not kind:
+            return x
+        return (self.attention(name, x) if kind == "full" else self.linear_attention(name, x)) + x
+
+
+def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition, arch: str = "NoiseDiffNet", mid_attn: bool = False, stage_attn=None) -> torch.Tensor:
+    """NoiseDiffNet.forward (Diffusion_arch.py:577-646: shot-noise branch on cat(clean, x) + the U-Net's read-noise branch) and the forward of the
+    ``UNet_PosEmbV2*`` ablation nets (others_arch.py:483-537, :655-707, :919-985: no shot branch; the clean image through cond_init_conv -> cond_res_block1 ->
+    cond_concat_conv; ``_NoPosition`` without the position inputs, ``_CameraCond`` with the ISO AttnBlocks).  ``mid_attn``: ``x = Attention(x) + x`` between
+    the mid blocks (BASELINE config 4); ``stage_attn``: four entries 'linear' / 'full' / None, upstream's per-stage wiring (modules down_attns.{i} / up_attns.{i})."""
+    from .spec import arch_traits
+    tr = arch_traits(arch)
     p = o.p
     dim = p["init_conv.weight"].shape[0]
     if x.shape[-1] % 8 or x.shape[-2] % 8:
-        raise ValueError(f"NoiseDiffNet needs image sides that are multiples of 8, got {tuple(x.shape[-2:])}")
-    clean = condition["clean_img"]
+        raise ValueError(f"{arch} needs image sides that are multiples of 8, got {tuple(x.shape[-2:])}")
+    clean = condition["clean_img"] if isinstance(condition, dict) else condition           # (_NoPosition takes the clean image itself, others_arch.py:658)
+    kinds = tuple(stage_attn) if stage_attn else (None,) * 4
     # condition embeddings: learned sinusoidal position features -> Mlp; ISO table row as a one-token context; time MLP
-    w = o.conv("pos_enc.weights", condition["position"])
-    pos = o.mlp("pos_mlp", torch.cat((w, (2 * math.pi * w).sin(), (2 * math.pi * w).cos()), dim=1))
-    iso = F.embedding(condition["iso_ratio_idx"].long().to(x.device), p["iso_embed.weight"])[:, None]      # (the trainer keeps the index on the CPU, trainer_diffusion.py:135)
+    pos = None
+    if tr.position:
+        w = o.conv("pos_enc.weights", condition["position"])
+        pos = o.mlp("pos_mlp", torch.cat((w, (2 * math.pi * w).sin(), (2 * math.pi * w).cos()), dim=1))
+    iso = None
+    if tr.iso_attn:
+        iso = F.embedding(condition["iso_ratio_idx"].long().to(x.device), p["iso_embed.weight"])[:, None]      # (the trainer keeps the index on the CPU, trainer_diffusion.py:135)
     half = dim // 2
     freqs = torch.exp(torch.arange(half, device=x.device) * -(math.log(10000.0) / (half - 1)))
     ang = time[:, None] * freqs[None]
@@ -198,51 +237,83 @@ def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, 
 
     # ResnetBlock.mlp / ResnetBlock2.mlp = Sequential(SiLU, Linear / Conv2d) of the SAME embedding in all 20 (2) blocks: one activation each, not 20
     # forward + 20 backward + 19 gradient accumulations of launch-bound (4, 256) kernels (and two full-resolution SiLUs of the position embedding)
-    t, pos = F.silu(t), F.silu(pos)
+    t = F.silu(t)
+    if pos is not None:
+        pos = F.silu(pos)
     o.time_projections(t)
-    s0 = o.mlp("shot_mlp1", torch.cat((clean, x), dim=1))
-    s = o.mlp("shot_mlp2", o.attn_block("shot_attn", s0, iso))
-    shot = o.mlp("shot_mlp3", o.resnet("shot_time", s, t, POS_GROUPS) + s0)
+    shot = None
+    if tr.shot_branch:
+        s0 = o.mlp("shot_mlp1", torch.cat((clean, x), dim=1))
+        s = o.mlp("shot_mlp2", o.attn_block("shot_attn", s0, iso))
+        shot = o.mlp("shot_mlp3", o.resnet("shot_time", s, t, POS_GROUPS) + s0)
 
-    x = o.conv("init_conv", x, 3)
-    if o.hip and x.is_cuda:                     # MIOpen answers the 4-channel NCHW input in NCHW: one conversion here instead of one in every consumer of the stem
-        x = x.contiguous(memory_format=torch.channels_last)       # (pos_block1's conv, its shortcut, the final concat and both of that concat's readers)
+    def stem7(name: str, v: torch.Tensor) -> torch.Tensor:
+        v = o.conv(name, v, 3)
+        if o.hip and v.is_cuda:                 # MIOpen answers the 4-channel NCHW input in NCHW: one conversion here instead of one in every consumer of the stem
+            v = v.contiguous(memory_format=torch.channels_last)   # (pos_block1's conv, its shortcut, the final concat and both of that concat's readers)
+        return v
+
+    x = stem7("init_conv", x)
     stem = x
-    x = o.resnet("pos_block1", x, pos, POS_GROUPS, per_pixel=True)
+    if tr.cond_branch:                          # x = cond_concat_conv(cat[init_conv(x), cond_res_block1(cond_init_conv(clean))])   others_arch.py:491-498
+        clean_emb = o.resnet("cond_res_block1", stem7("cond_init_conv", clean), None, GROUPS)
+        x = o.conv("cond_concat_conv", torch.cat((x, clean_emb), dim=1), 1)
+    pos_block = (lambda n, v: o.resnet(n, v, pos, POS_GROUPS, per_pixel=True)) if tr.position else (lambda n, v: o.resnet(n, v, None, POS_GROUPS))
+    x = pos_block("pos_block1", x)
+    rs = 3 if tr.iso_attn else 2                # index of a stage's resampling layer
     skips: List[torch.Tensor] = []
     for i in range(4):
         n = f"downs.{i}"
         x = o.resnet(n + ".0", x, t, GROUPS); skips.append(x)
-        x = o.resnet(n + ".1", x, t, GROUPS); skips.append(x)
-        x = o.attn_block(n + ".2", x, iso)
-        x = o.conv(n + ".3", x, 1) if i == 3 else o.conv(n + ".3.1", F.pixel_unshuffle(x, 2))
-    x = o.resnet("mid_block2", o.resnet("mid_block1", x, t, GROUPS), t, GROUPS)
+        x = o.stage_attention(f"down_attns.{i}", kinds[i], o.resnet(n + ".1", x, t, GROUPS)); skips.append(x)
+        if tr.iso_attn:
+            x = o.attn_block(n + ".2", x, iso)
+        x = o.conv(f"{n}.{rs}", x, 1) if i == 3 else o.conv(f"{n}.{rs}.1", F.pixel_unshuffle(x, 2))
+    x = o.resnet("mid_block1", x, t, GROUPS)
+    if mid_attn:
+        x = o.attention("mid_attn", x) + x
+    x = o.resnet("mid_block2", x, t, GROUPS)
     for i in range(4):
         n = f"ups.{i}"
         x = o.resnet(n + ".0", torch.cat((x, skips.pop()), dim=1), t, GROUPS)
-        x = o.resnet(n + ".1", torch.cat((x, skips.pop()), dim=1), t, GROUPS)
-        x = o.attn_block(n + ".2", x, iso)
-        x = o.conv(n + ".3", x, 1) if i == 3 else o.conv(n + ".3.1", F.interpolate(x, scale_factor=2, mode="nearest"), 1)
-    x = o.resnet("pos_block2", x, pos, POS_GROUPS, per_pixel=True)
+        x = o.stage_attention(f"up_attns.{i}", kinds[3 - i], o.resnet(n + ".1", torch.cat((x, skips.pop()), dim=1), t, GROUPS))
+        if tr.iso_attn:
+            x = o.attn_block(n + ".2", x, iso)
+        x = o.conv(f"{n}.{rs}", x, 1) if i == 3 else o.conv(f"{n}.{rs}.1", F.interpolate(x, scale_factor=2, mode="nearest"), 1)
+    x = pos_block("pos_block2", x)
     x = o.resnet("final_res_block", torch.cat((x, stem), dim=1), t, GROUPS)
-    return shot + o.conv("final_conv", x)
+    out = o.conv("final_conv", x)
+    return out if shot is None else shot + out
 
 
 class TrainableNoiseDiffNet(nn.Module):
     """``TrainableNoiseDiffNet(args)``: args.dim (default 64), the other fields of the reference's argument object are accepted and
-    must describe the configuration this package implements (4 input channels, no self-conditioning)."""
+    must describe the configuration this package implements (4 input channels, no self-conditioning).  Optional: ``args.arch`` (one of the
+    ``UNet_PosEmbV2*`` ablation nets of others_arch.py instead of NoiseDiffNet), ``args.mid_attn`` (BASELINE config 4's mid-block Attention),
+    ``args.stage_attn`` (upstream's per-stage attention wiring: True or four entries) -- the extensions of noisediff_amd.NoiseDiffNet, under its names."""
     channels = out_dim = 4
     self_condition = False
     random_or_learned_sinusoidal_cond = False
 
     def __init__(self, args=None, seed: int = 0):
         super().__init__()
+        from .spec import arch_param_spec, attention_param_spec, normalize_stage_attn, stage_attention_param_spec
         dim = int(getattr(args, "dim", 64))
         if getattr(args, "self_condition", False) or int(getattr(args, "inp_dim", 4)) != 4 or int(getattr(args, "cond_dim", 4)) != 4:
             raise ValueError("TrainableNoiseDiffNet implements the reference's configuration: inp_dim = cond_dim = 4, self_condition = False")
         self.dim = dim
+        self.arch = str(getattr(args, "arch", "NoiseDiffNet"))
+        self.has_mid_attn = bool(getattr(args, "mid_attn", False))
+        self.stage_attn = normalize_stage_attn(getattr(args, "stage_attn", None))
+        if self.arch != "NoiseDiffNet" and (self.has_mid_attn or self.stage_attn):
+            raise ValueError("mid_attn / stage_attn extend NoiseDiffNet only")
         self._hip = False
-        for name, value in synth.make_state_dict(noisediff_param_spec(dim), seed).items():      # PyTorch's default-init statistics
+        spec = list(arch_param_spec(self.arch, dim, 4))
+        if self.has_mid_attn:
+            spec += attention_param_spec("mid_attn", 8 * dim)
+        if self.stage_attn:
+            spec += stage_attention_param_spec(dim, self.stage_attn)
+        for name, value in synth.make_state_dict(spec, seed).items():      # PyTorch's default-init statistics
             parts, m = name.split("."), self
             for part in parts[:-1]:
                 if part not in m._modules:
@@ -261,4 +332,4 @@ class TrainableNoiseDiffNet(nn.Module):
     def forward(self, x: torch.Tensor, time: torch.Tensor, condition: Dict[str, torch.Tensor], x_self_cond: Optional[torch.Tensor] = None):
         if x_self_cond is not None:
             raise ValueError("self-conditioning is not part of this configuration")
-        return _forward(_Ops(dict(self.named_parameters()), self._hip), x, time, condition)
+        return _forward(_Ops(dict(self.named_parameters()), self._hip), x, time, condition, arch=self.arch, mid_attn=self.has_mid_attn, stage_attn=self.stage_attn)

@@ -63,16 +63,12 @@ def pack_conv3(ctx, w):
     return out
 
 
-def pack_pw(ctx, w, unshuffle_c=0, f16x3=False, layernorm_source=False):
-    """f16x3: the two-f16-term packing of nd_pointwise_gemm_f16x3_nhwc_f32 (same size); layernorm_source: for a layer read through the LayerNorm prologue."""
+def pack_pw(ctx, w, unshuffle_c=0):
     w = w.reshape(w.shape[0], -1)
     cout, cin = w.shape
     n = ctx.lib.nd_pack_pointwise_weight_floats(cin, cout)
     wd, out = dev(w), torch.empty(n, device=DEV)
-    if f16x3:
-        L.call("nd_pack_pointwise_weight_h", wd.data_ptr(), out.data_ptr(), cin, cout, int(layernorm_source), ctx.stream)
-    else:
-        L.call("nd_pack_pointwise_weight", wd.data_ptr(), out.data_ptr(), cin, cout, unshuffle_c, ctx.stream)
+    L.call("nd_pack_pointwise_weight", wd.data_ptr(), out.data_ptr(), cin, cout, unshuffle_c, ctx.stream)
     ctx.sync()
     return out
 

@@ -246,18 +246,12 @@ CHAIN_CASES = {  # (B, HW, [widths]): Mlp chains (two stages) and AttnBlock tail
 }
 
 
-def _chain_forms(case):
-    w = CHAIN_CASES[case][2]
-    return ["fp32", "f16x3"] if tuple(w) in ((64, 64, 64), (64, 128, 64, 64), (8, 64, 64), (48, 48, 48), (48, 96, 48, 48), (64, 64, 4)) else ["fp32"]
-
-
-@pytest.mark.parametrize("case,form", [(c, f) for c in sorted(CHAIN_CASES) for f in _chain_forms(c)])
-def test_pointwise_chain_matches_layer_by_layer(ctx, case, form):
-    """nd_pointwise_chain_nhwc_f32 == the same Linear layers applied one by one (Mlp :340-356, AttnBlock tail :405-443).
-    form f16x3: nd_pointwise_chain_f16x3_nhwc_f32 (every product three f16 MFMAs of two-term operands) on the widths it instantiates, same tolerance."""
+@pytest.mark.parametrize("case", sorted(CHAIN_CASES))
+def test_pointwise_chain_matches_layer_by_layer(ctx, case):
+    """nd_pointwise_chain_nhwc_f32 == the same Linear layers applied one by one (Mlp :340-356, AttnBlock tail :405-443)."""
     import hiputil as hu
     B, HW, widths = CHAIN_CASES[case]
-    pack, entry = ("nd_pack_chain_weight_h", "nd_pointwise_chain_f16x3_nhwc_f32") if form == "f16x3" else ("nd_pack_chain_weight", "nd_pointwise_chain_nhwc_f32")
+    pack, entry = "nd_pack_chain_weight", "nd_pointwise_chain_nhwc_f32"
     n = len(widths) - 1
     x = U(case + ".x", (B, HW, widths[0]), -1.5, 1.5)
     ws = [U(f"{case}.w{i}", (widths[i + 1], widths[i]), -0.3, 0.3) for i in range(n)]
@@ -384,21 +378,16 @@ def test_pointwise_pipelined_chunks_concat_and_prologues(ctx, cin):
     assert rel_err(hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
 
 
-PW_FORMS = {"fp32": "nd_pointwise_gemm_nhwc_f32", "f16x3": "nd_pointwise_gemm_f16x3_nhwc_f32"}
-
-
-@pytest.mark.parametrize("form", sorted(PW_FORMS))
-def test_pointwise_large_tile_kernel(ctx, form):
+def test_pointwise_large_tile_kernel(ctx):
     """The one-wave-per-SIMD form of the 1x1 GEMM (pointwise_big_kernel: cin % 64 == 0, cout % 128 == 0 and at least one 128-pixel
-    tile per CU): 3 chunks of 64 channels, a ragged last pixel tile, concat on a chunk boundary, every prologue, all epilogue operands.
-    form f16x3: the opt-in entry that runs every product as three f16 MFMAs of two-term operands -- the same cases at the same tolerance."""
+    tile per CU): 3 chunks of 64 channels, a ragged last pixel tile, concat on a chunk boundary, every prologue, all epilogue operands."""
     import hiputil as hu
     import functools
     B, HW, W, cin, cout = 2, 8200, 100, 192, 256              # 2 x 65 x 2 = 260 workgroups
-    pwf = functools.partial(hu.pointwise, entry=PW_FORMS[form])
+    pwf = functools.partial(hu.pointwise, entry="nd_pointwise_gemm_nhwc_f32")
     x = U("big.x", (B, HW, cin), -1.5, 1.5)
     w, b = U("big.w", (cout, cin), -0.2, 0.2), U("big.b", (cout,))
-    wp, xd, bd = hu.pack_pw(ctx, w, f16x3=form == "f16x3"), hu.dev(x), hu.dev(b)
+    wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
     lin = F.linear(x, w, b)
     assert rel_err(pwf(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
     xa, xb = hu.dev(x[..., :128].contiguous()), hu.dev(x[..., 128:].contiguous())
@@ -414,7 +403,7 @@ def test_pointwise_large_tile_kernel(ctx, form):
     ctx.sync()
     s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
     ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
-    wpl = hu.pack_pw(ctx, w, f16x3=form == "f16x3", layernorm_source=True)      # (f16x3: a layer behind the LayerNorm prologue has its own operand order)
+    wpl = wp
     assert rel_err(pwf(ctx, s, wpl, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
     # epilogue operands: two residuals, a per-sample vector, the fused ResnetBlock tail silu(GroupNorm-affine(t))
     r0, r1, ov, t = U("big.r0", (B, HW, cout)), U("big.r1", (B, HW, cout)), U("big.ov", (B, cout)), U("big.t", (B, HW, cout), -1.5, 1.5)
@@ -425,8 +414,7 @@ def test_pointwise_large_tile_kernel(ctx, form):
 
 
 @pytest.mark.parametrize("cin,cout", [(1024, 2048), (2048, 1024), (1024, 1024)])
-@pytest.mark.parametrize("form", sorted(PW_FORMS))
-def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout, form):
+def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout):
     """pointwise_big_kernel at BASELINE config 4's widths (d=128: FeedForward 1024 -> 2048 -> 1024 and proj_out 1024 -> 1024 on the
     32 x 32 = 1024 tokens of the H/8 stage; 16 / 32 K chunks of 64): LayerNorm prologue + GELU, plain, residual + per-sample vector."""
     import hiputil as hu
@@ -434,9 +422,9 @@ def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout, form):
     bound = 1.0 / np.sqrt(cin)
     x = U(f"c4pw.x.{cin}", (B, HW, cin), -1.5, 1.5)
     w, b = U(f"c4pw.w.{cin}.{cout}", (cout, cin), -bound, bound), U(f"c4pw.b.{cout}", (cout,), -bound, bound)
-    wp, xd, bd = hu.pack_pw(ctx, w, f16x3=form == "f16x3"), hu.dev(x), hu.dev(b)
+    wp, xd, bd = hu.pack_pw(ctx, w), hu.dev(x), hu.dev(b)
     lin = F.linear(x, w, b)
-    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, entry=PW_FORMS[form]).cpu(), lin) < TOL
+    assert rel_err(hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout).cpu(), lin) < TOL
     if cin <= 1024:                                           # LayerNorm feeds ff.net.0.0 only (its rows are at most 8 d = 1024 wide)
         vec, g, be = U(f"c4pw.v.{cin}", (B, cin)), U(f"c4pw.g.{cin}", (cin,), 0.5, 1.5), U(f"c4pw.be.{cin}", (cin,))
         rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
@@ -444,61 +432,11 @@ def test_pointwise_large_tile_kernel_config4_widths(ctx, cin, cout, form):
         ctx.sync()
         s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
         ref = F.gelu(F.linear(F.layer_norm(x + vec[:, None], (cin,), g, be, eps=1e-5), w, b))
-        wpl = hu.pack_pw(ctx, w, f16x3=form == "f16x3", layernorm_source=True)
-        assert rel_err(hu.pointwise(ctx, s, wpl, bd, B, HW, W, cin, cout, act=L.ACT_GELU, entry=PW_FORMS[form]).cpu(), ref) < TOL
+        wpl = hu.pack_pw(ctx, w)
+        assert rel_err(hu.pointwise(ctx, s, wpl, bd, B, HW, W, cin, cout, act=L.ACT_GELU).cpu(), ref) < TOL
     r0, ov = U(f"c4pw.r0.{cout}", (B, HW, cout)), U(f"c4pw.ov.{cout}", (B, cout))
-    out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), vec=hu.dev(ov), entry=PW_FORMS[form])
+    out = hu.pointwise(ctx, hu.src(xd), wp, bd, B, HW, W, cin, cout, res0=hu.dev(r0), vec=hu.dev(ov))
     assert rel_err(out.cpu(), lin + r0 + ov[:, None]) < TOL
-
-
-@pytest.mark.parametrize("cin,cout,ln", [(128, 128, False), (256, 128, False), (128, 256, True)])
-def test_pointwise_f16x3_at_bench_size_is_repeatable(ctx, cin, cout, ln):
-    """The f16-split 128-pixel-tile kernel at the bench workload's size (16 samples x 128 x 128 pixels: 4096 workgroups, two per CU): five launches must leave the
-    same bits, and every element must be right (fp64 product on the device).  A two-slot weight ring tried for the LayerNorm form passed the small cases and put a
-    few hundred wrong elements into outputs of this size: races of that kind show here."""
-    import hiputil as hu
-    B, HW, W = 16, 128 * 128, 128
-    g = torch.Generator().manual_seed(cin + cout)
-    x = torch.randn(B, HW, cin, generator=g); w = torch.randn(cout, cin, generator=g) / cin ** 0.5; b = torch.randn(cout, generator=g)
-    xd, bd = hu.dev(x), hu.dev(b)
-    wp = hu.pack_pw(ctx, w, f16x3=True, layernorm_source=ln)
-    if ln:
-        vec, gm, be = torch.randn(B, cin, generator=g), torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
-        rs, vd = hu.full((B, HW, 2)), hu.dev(vec)
-        L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
-        ctx.sync()
-        s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(gm), beta=hu.dev(be), rowstats=rs)
-        ref = F.gelu(F.linear(F.layer_norm(xd.double() + vd.double()[:, None], (cin,), hu.dev(gm).double(), hu.dev(be).double(), eps=1e-5), hu.dev(w).double(), bd.double()))
-        act = L.ACT_GELU
-    else:
-        s, act = hu.src(xd), L.ACT_NONE
-        ref = F.linear(xd.double(), hu.dev(w).double(), bd.double())
-    first = None
-    for _ in range(5):
-        out = hu.pointwise(ctx, s, wp, bd, B, HW, W, cin, cout, act=act, entry="nd_pointwise_gemm_f16x3_nhwc_f32")
-        assert float((out.double() - ref).abs().max()) < TOL * max(1.0, float(ref.abs().max()))
-        if first is None:
-            first = out.clone()
-        assert torch.equal(out, first)
-
-
-def test_pointwise_f16x3_entry_refuses_layers_of_the_other_kernels(ctx):
-    """nd_pointwise_gemm_f16x3_nhwc_f32 is the 128-pixel-tile kernel only: a narrow layer (cin = 64) or a cout that is not whole 128-wide tiles is an error
-    (ND_E_SHAPE), and nd_pointwise_gemm_f16x3_takes says so beforehand -- never a silent change of kernel or product form.  The batch does not enter:
-    a layer with two tiles is taken like one with thousands (a sample's bits must not depend on the batch it sits in)."""
-    import hiputil as hu
-    for (B, HW, cin, cout, takes) in [(2, 8200, 192, 256, 1), (2, 8200, 64, 128, 0), (1, 256, 128, 128, 1), (2, 8200, 192, 192, 0)]:
-        x, w = hu.dev(U(f"pwh.x.{cin}", (B, HW, cin))), U(f"pwh.w.{cin}.{cout}", (cout, cin), -0.2, 0.2)
-        wp, out = hu.pack_pw(ctx, w, f16x3=True), hu.full((B, HW, cout))
-        d = L.Pointwise()
-        d.src, d.weight, d.out = hu.src(x), wp.data_ptr(), out.data_ptr()
-        d.B, d.HW, d.W, d.cin, d.cout, d.ldo = B, HW, 1, cin, cout, cout
-        assert ctx.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d)) == takes
-        rc = ctx.lib.nd_pointwise_gemm_f16x3_nhwc_f32(C.byref(d), ctx.stream)
-        ctx.sync()
-        assert (rc == 0) == bool(takes)
-        if not takes:
-            assert b"f16x3" in ctx.lib.nd_last_error()
 
 
 def test_affine_silu_add_and_rmsnorm(ctx):
@@ -565,17 +503,16 @@ def test_small_ops(ctx):
     assert torch.equal(a.cpu(), x4.permute(0, 2, 3, 1)) and torch.equal(bb.cpu(), x4)
 
 
-@pytest.mark.parametrize("entry", ["nd_conv7x7_c4_f32", "nd_conv7x7_c4_f16x3_f32"])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 40, 24, 48), (2, 64, 64, 64), (1, 19, 45, 128), (1, 16, 32, 20)])
-def test_conv7x7(ctx, shape, entry):
-    """init_conv (Diffusion_arch.py:478); entry ..._f16x3: the same layer as three f16 products of two-term operands, same packed weights, same tolerance."""
+def test_conv7x7(ctx, shape):
+    """init_conv (Diffusion_arch.py:478)."""
     import hiputil as hu
     B, H, W, cout = shape
     x, w, b = U("c7.x", (B, 4, H, W), -1.5, 1.5), U("c7.w", (cout, 4, 7, 7), -0.1, 0.1), U("c7.b", (cout,))
     wp, out = torch.empty(196 * cout, device=hu.DEV), torch.empty(B, H, W, cout, device=hu.DEV)
     xd, wd, bd = hu.nhwc(x), hu.dev(w), hu.dev(b)
     L.call("nd_pack_conv7x7_weight", wd.data_ptr(), wp.data_ptr(), cout, ctx.stream)
-    L.call(entry, xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, B, H, W, cout, ctx.stream)
+    L.call("nd_conv7x7_c4_f32", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, B, H, W, cout, ctx.stream)
     ctx.sync()
     assert rel_err(hu.nchw(out), F.conv2d(x, w, b, padding=3)) < TOL
 
@@ -935,11 +872,9 @@ W16_CASES = {**{k: v + (0, 0) for k, v in WINO_CASES.items()}, **{k: HEADLINE_CA
              **CFG2_CASES, "ragged_17x33": (2, 17, 33, 48, 80, 0, 0), "odd_rows_50x18": (1, 50, 18, 32, 64, 16, 0)}
 
 
-@pytest.mark.parametrize("entry", ["nd_conv3x3_wino4_16_nhwc_f32", "nd_conv3x3_wino4_8w_nhwc_f32"])
 @pytest.mark.parametrize("case", sorted(W16_CASES))
-def test_conv3x3_wino4_two_waves_per_simd_forms_equal_the_one_workgroup_form(ctx, case, entry):
-    """nd_conv3x3_wino4_16_nhwc_f32 (16 x 16-pixel regions, two co-resident workgroups per CU) and nd_conv3x3_wino4_8w_nhwc_f32 (16 x 32-pixel regions,
-    eight waves per workgroup) against nn.Conv2d AND against
+def test_conv3x3_wino4_16_region_form_equals_the_one_workgroup_form(ctx, case, entry="nd_conv3x3_wino4_16_nhwc_f32"):
+    """nd_conv3x3_wino4_16_nhwc_f32 (16 x 16-pixel regions, two co-resident workgroups per CU) against nn.Conv2d AND against
     nd_conv3x3_wino4_nhwc_f32 bit for bit wherever that kernel takes the shape -- output and GroupNorm partials, plain / concat / nearest-x2 /
     affine + SiLU sources, ragged images, images narrower than 32 pixels, partial K chunks and cout tiles; bitwise repeat."""
     import hiputil as hu
@@ -984,163 +919,14 @@ def test_conv3x3_wino4_two_waves_per_simd_forms_equal_the_one_workgroup_form(ctx
         assert getattr(ctx.lib, entry)(C.byref(d), ctx.stream) != 0
 
 
-W4H_CASES = {**{k: v + (0, 0) for k, v in WINO_CASES.items()}, **HEADLINE_CASES}
-
-
-@pytest.mark.parametrize("case", sorted(W4H_CASES))
-def test_conv3x3_wino4h_f16_split_products_match_conv2d_at_the_fp32_kernels_tolerance(ctx, case):
-    """nd_conv3x3_wino4h_nhwc_f32 -- F(4x4) with the position products as a three-product split on the f16 matrix instruction (V = V1 + V2, U 2^11 = U1 + U2,
-    fp32 accumulation) -- against nn.Conv2d at the SAME 5e-5 as the fp32 F(4x4) kernel, with a float64 convolution as the yardstick for both kernels' errors
-    (the split's must not exceed 1.5x the fp32 kernel's + 2e-6); GroupNorm partials, concat / nearest-x2 / affine + SiLU / LeakyReLU sources, bitwise repeat,
-    large activations (x 200: the first f16 term near its range)."""
-    import hiputil as hu
-    B, H, W, cin, cout, c0, up = W4H_CASES[case]
-    cin = max(cin, 24)
-    hs, ws = (H // 2, W // 2) if up else (H, W)
-    bound = 1.0 / np.sqrt(9 * cin)
-    x = U(case + ".x", (B, cin, hs, ws), -1.5, 1.5)
-    w = U(case + ".w", (cout, cin, 3, 3), -bound, bound)
-    b = U(case + ".b", (cout,), -bound, bound)
-    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
-    ref64 = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
-    ref = ref64.float()
-    wd, bd = hu.dev(w), hu.dev(b)
-    n = ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout)
-    wph, wp4 = hu.full((n,)), hu.full((n,))
-    L.call("nd_pack_conv3x3_wino4h_weight", wd.data_ptr(), wph.data_ptr(), cin, cout, ctx.stream)
-    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp4.data_ptr(), cin, cout, ctx.stream)
-    ctx.sync()
-    runh = lambda s, stats=True: _run_wino4(ctx, s, wph, bd, B, H, W, cin, cout, stats, entry="nd_conv3x3_wino4h_nhwc_f32")
-    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
-    out, st, sc, slots = runh(s)
-    assert rel_err(hu.nchw(out), ref) < 5e-5
-    _check_gn(ctx, case, ref, st, sc, slots, B, cout, 5e-5)
-    out2, st2, *_ = runh(s)
-    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
-    o16r, s16r, *_ = _run_wino4(ctx, s, wph, bd, B, H, W, cin, cout, entry="nd_conv3x3_wino4h_16_nhwc_f32")      # its 16 x 16-region form: the same bits
-    assert torch.equal(out.cpu(), o16r.cpu()) and torch.equal(st.cpu(), s16r.cpu())
-    o32, *_ = _run_wino4(ctx, s, wp4, bd, B, H, W, cin, cout)
-    scale = max(1.0, float(ref64.abs().max()))
-    e16 = float((hu.nchw(out).double() - ref64).abs().max()) / scale
-    e32 = float((hu.nchw(o32).double() - ref64).abs().max()) / scale
-    assert e16 < 1.5 * e32 + 2e-6, (e16, e32)
-    if not up:
-        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
-        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
-        mad = hu.dev(torch.stack((M, A, D), 1))
-        sa = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:]), L.PRO_AFFINE_SILU, mad=mad) if c0 else hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=mad)
-        out, *_ = runh(sa, stats=False)
-        assert rel_err(hu.nchw(out), F.conv2d(act, w, b, padding=1)) < 5e-5
-        if not c0:
-            out, *_ = runh(hu.src(hu.nhwc(x), None, L.PRO_LEAKY), stats=False)
-            assert rel_err(hu.nchw(out), F.conv2d(F.leaky_relu(x, 0.2), w, b, padding=1)) < 5e-5
-            xb = x * 200.0                                               # |V| up to ~3e4: the first f16 term near the top of its range
-            out, *_ = runh(hu.src(hu.nhwc(xb)), stats=False)
-            assert rel_err(hu.nchw(out), F.conv2d(xb.double(), w.double(), b.double(), padding=1).float()) < 5e-5
-
-
-D16_CASES = {  # (B, H, W, cin, cout, c0 of a concat, nearest-x2 source)
-    "h1_64_64": (2, 64, 96, 64, 64, 0, 0),                  # 2 x 4 x 3 = 24 items on 256 CUs: every workgroup has one tile
-    "h1_64_64_many": (3, 256, 256, 64, 64, 0, 0),           # 384 items: workgroups with two tiles (the pipeline across tiles)
-    "h1_128cat_64": (2, 64, 64, 128, 64, 64, 0),
-    "h2_128_128": (2, 32, 64, 128, 128, 0, 0),              # two cout tiles per region
-    "h2_up_256_128": (1, 32, 64, 256, 128, 0, 1),
-    "one_chunk": (1, 16, 32, 16, 64, 0, 0),
-    "h4_48cat_192": (1, 16, 32, 48, 192, 32, 0),
-}
-
-
-@pytest.mark.parametrize("case", sorted(D16_CASES))
-def test_conv3x3_f16x3_direct_split_products_match_conv2d(ctx, case):
-    """nd_conv3x3_f16x3_nhwc_f32 -- the direct convolution on the double-rate f16 matrix instruction, every product a three-product split of two-term
-    operands with fp32 accumulation -- against nn.Conv2d at the 2e-5 of the direct fp32 kernel (no Winograd transform amplifies anything), with a float64
-    convolution as the yardstick (its error must not exceed 1.5x the fp32 F(4x4) kernel's + 2e-6); GroupNorm partials in the F(4x4) kernels' slots,
-    concat / nearest-x2 / affine + SiLU sources, bitwise repeat, statistics on and off, large activations (x 200), a padded output row."""
-    import hiputil as hu
-    B, H, W, cin, cout, c0, up = D16_CASES[case]
-    hs, ws = (H // 2, W // 2) if up else (H, W)
-    bound = 1.0 / np.sqrt(9 * cin)
-    x = U(case + ".dx", (B, cin, hs, ws), -1.5, 1.5)
-    w = U(case + ".dw", (cout, cin, 3, 3), -bound, bound)
-    b = U(case + ".db", (cout,), -bound, bound)
-    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
-    ref64 = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
-    ref = ref64.float()
-    wd, bd = hu.dev(w), hu.dev(b)
-    wph = hu.full((ctx.lib.nd_pack_conv3x3_f16x3_weight_floats(cin, cout),))
-    L.call("nd_pack_conv3x3_f16x3_weight", wd.data_ptr(), wph.data_ptr(), cin, cout, ctx.stream)
-    ctx.sync()
-    runh = lambda s, stats=True: _run_wino4(ctx, s, wph, bd, B, H, W, cin, cout, stats, entry="nd_conv3x3_f16x3_nhwc_f32")
-    s = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:])) if c0 else hu.src(hu.nhwc(x), upsample=up)
-    out, st, sc, slots = runh(s)
-    assert rel_err(hu.nchw(out), ref) < TOL
-    _check_gn(ctx, case, ref, st, sc, slots, B, cout, TOL)
-    assert torch.equal(sc.cpu(), torch.full((slots,), 256.0))
-    out2, st2, *_ = runh(s)
-    assert torch.equal(out.cpu(), out2.cpu()) and torch.equal(st.cpu(), st2.cpu())
-    out_ns, *_ = runh(s, stats=False)
-    assert torch.equal(out.cpu(), out_ns.cpu())
-    if cin > 16:                                                          # the fp32 F(4x4) kernel as the error yardstick (it needs two K chunks)
-        wp4 = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
-        L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp4.data_ptr(), cin, cout, ctx.stream)
-        ctx.sync()
-        o32, *_ = _run_wino4(ctx, s, wp4, bd, B, H, W, cin, cout)
-        scale = max(1.0, float(ref64.abs().max()))
-        e16 = float((hu.nchw(out).double() - ref64).abs().max()) / scale
-        e32 = float((hu.nchw(o32).double() - ref64).abs().max()) / scale
-        assert e16 < 1.5 * e32 + 2e-6, (e16, e32)
-    if not up:
-        M, A, D = U(case + ".M", (B, cin)), U(case + ".A", (B, cin), 0.5, 1.5), U(case + ".D", (B, cin))
-        act = F.silu((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None])
-        mad = hu.dev(torch.stack((M, A, D), 1))
-        sa = hu.src(hu.nhwc(x[:, :c0]), hu.nhwc(x[:, c0:]), L.PRO_AFFINE_SILU, mad=mad) if c0 else hu.src(hu.nhwc(x), None, L.PRO_AFFINE_SILU, mad=mad)
-        refa = F.conv2d(act, w, b, padding=1)
-        out, st, sc, slots = runh(sa)
-        assert rel_err(hu.nchw(out), refa) < TOL
-        _check_gn(ctx, case + ".a", refa, st, sc, slots, B, cout, TOL)
-        if not c0:
-            xb = x * 200.0                                               # the first f16 term near the top of its range
-            out, *_ = runh(hu.src(hu.nhwc(xb)), stats=False)
-            assert rel_err(hu.nchw(out), F.conv2d(xb.double(), w.double(), b.double(), padding=1).float()) < TOL
-            # a padded output row (ldo > cout): the padding keeps its bits
-            outp = torch.full((B, H, W, cout + 8), 7.0, device=hu.DEV)
-            d = L.Conv3x3()
-            d.src, d.weight, d.bias, d.out = hu.src(hu.nhwc(x)), wph.data_ptr(), bd.data_ptr(), outp.data_ptr()
-            d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout + 8
-            torch.cuda.synchronize()
-            L.call("nd_conv3x3_f16x3_nhwc_f32", C.byref(d), ctx.stream)
-            ctx.sync()
-            assert rel_err(hu.nchw(outp[..., :cout].contiguous()), ref) < TOL and bool((outp[..., cout:] == 7.0).all())
-
-
-def test_conv3x3_f16x3_refuses_what_it_does_not_cover(ctx):
-    """nd_conv3x3_f16x3_takes / the entry's ND_E_SHAPE: ragged regions (H % 16, W % 32), cin % 16, cout % 64, the map / LeakyReLU prologues."""
-    import hiputil as hu
-    x = hu.full((1, 32, 64, 64))
-    wph, out = hu.full((ctx.lib.nd_pack_conv3x3_f16x3_weight_floats(64, 64),)), hu.full((1, 32, 64, 64))
-    for (H, W, cin, cout, mode, takes) in [(32, 64, 64, 64, L.PRO_NONE, 1), (24, 64, 64, 64, L.PRO_NONE, 0), (32, 48, 64, 64, L.PRO_NONE, 0),
-                                           (32, 64, 24, 64, L.PRO_NONE, 0), (32, 64, 64, 32, L.PRO_NONE, 0), (32, 64, 64, 64, L.PRO_LEAKY, 0)]:
-        d = L.Conv3x3()
-        d.src, d.weight, d.out = hu.src(x, None, mode), wph.data_ptr(), out.data_ptr()
-        d.src.c0 = cin
-        d.B, d.H, d.W, d.cin, d.cout, d.ldo = 1, H, W, cin, cout, 64
-        assert ctx.lib.nd_conv3x3_f16x3_takes(C.byref(d)) == takes
-        rc = ctx.lib.nd_conv3x3_f16x3_nhwc_f32(C.byref(d), ctx.stream)
-        ctx.sync()
-        assert (rc == 0) == bool(takes)
-
-
-@pytest.mark.parametrize("form", ["fp32", "f16x3"])
 @pytest.mark.parametrize("case", sorted(CFG2_CASES))
-def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case, form):
+def test_conv3x3_wino4_16_split_k_for_sampling(ctx, case):
     """nd_conv3x3_wino4_16_splitk_nhwc_f32 with the split count of nd_conv3x3_wino4_16_splitk_plan (the sample's geometry only) on BASELINE config 2's
     narrow stages: output against nn.Conv2d and against the unsplit kernel, the GroupNorm partials the reduction leaves, the affine + SiLU prologue,
-    bitwise repeat, and the same bits for a sample whatever batch it sits in.  form f16x3: nd_conv3x3_wino4h_16_splitk_nhwc_f32 (the partial tensors from the
-    f16-split kernel, the same plan, workspace and reduction), the same checks at the same tolerances."""
+    bitwise repeat, and the same bits for a sample whatever batch it sits in."""
     import hiputil as hu
     B, H, W, cin, cout, c0, up = CFG2_CASES[case]
-    pack, entry, plain_entry = (("nd_pack_conv3x3_wino4h_weight", "nd_conv3x3_wino4h_16_splitk_nhwc_f32", "nd_conv3x3_wino4h_16_nhwc_f32") if form == "f16x3" else
-                                ("nd_pack_conv3x3_wino4_weight", "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32"))
+    pack, entry, plain_entry = "nd_pack_conv3x3_wino4_weight", "nd_conv3x3_wino4_16_splitk_nhwc_f32", "nd_conv3x3_wino4_16_nhwc_f32"
     B = min(B, 4)
     hs, ws = (H // 2, W // 2) if up else (H, W)
     bound = 1.0 / np.sqrt(9 * cin)

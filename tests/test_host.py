@@ -154,14 +154,14 @@ def test_shard_bounds_and_synthetic_shards():
     assert torch.equal(synth.make_noise(2, "x_T", 6, 4, 16)[3:5], synth.make_noise(2, "x_T", 2, 4, 16, first_sample=3))
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, total=3):
     import torch.distributed as dist
     from noisediff_amd.shard import sample_sharded
     from oracle import noisediff_oracle as O
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    dim, H, T, total = 16, 16, 3, 3
+    dim, H, T = 16, 16, 3
     # the one collective: weights root -> all (a flat fp32 arena on the GPU path)
     flat = torch.cat([v.reshape(-1) for v in state_dict(dim).values()]) if rank == 0 else torch.zeros(sum(np.prod(p.shape) for p in noisediff_param_spec(dim)), dtype=torch.float32)
     dist.broadcast(flat, src=0)
@@ -185,21 +185,23 @@ def _gloo_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_sampling_equals_single_rank_gloo():
-    """world_size 2 on CPU (gloo): broadcast weights once, shard rows, gather -> same patches as one rank."""
+@pytest.mark.parametrize("world,total", [(2, 3), (8, 19)])
+def test_n_rank_sharded_sampling_equals_single_rank_gloo(world, total):
+    """world_size 2 and 8 on CPU (gloo; SURVEY section 4: "8-rank shard == 1-rank full-batch"): broadcast the weights once, shard the rows (8 ranks, 19 patches:
+    ragged 3 + 3 + 3 + 2 + ...), gather -> the same patches as one rank, in parity-noise mode."""
     import torch.multiprocessing as mp
     from oracle import noisediff_oracle as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + world) % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q, total)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    got = q.get(timeout=600)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    dim, H, T, total = 16, 16, 3, 3
+    dim, H, T = 16, 16, 3
     ref = O.sample(state_dict(dim), synth.make_condition(total, H, seed=1), image_size=H, batch_size=total, timesteps=T,
                    x_T=synth.make_noise(2, "x_T", total, 4, H), noise=lambda i, shape: synth.make_noise(2, f"noise.{i}", total, 4, H))
     assert got.shape == (total, 4, H, H)

@@ -78,6 +78,94 @@ def test_loss_and_gradients_match_the_reference(golden):
     assert len(dead) == 9 * 4 and all(float(grads[k].abs().max()) == 0.0 for k in dead)
 
 
+ARCH_CASES = {      # case of tests/golden/training_archs.npz -> (args of the network, gradients the fixture holds)
+    "UNet_PosEmbV2": (dict(arch="UNet_PosEmbV2"), ["final_conv.weight", "cond_init_conv.weight", "cond_concat_conv.weight", "downs.0.0.block1.proj.weight",
+                                                    "time_mlp.1.weight", "mid_block1.block2.norm.weight", "pos_block1.block1.proj.weight"]),
+    "UNet_PosEmbV2_NoPosition": (dict(arch="UNet_PosEmbV2_NoPosition"), ["final_conv.weight", "cond_init_conv.weight", "cond_concat_conv.weight",
+                                                                          "downs.0.0.block1.proj.weight", "time_mlp.1.weight", "pos_block1.block1.proj.weight"]),
+    "UNet_PosEmbV2_CameraCond": (dict(arch="UNet_PosEmbV2_CameraCond"), ["final_conv.weight", "cond_concat_conv.weight", "downs.1.2.ff.net.2.weight", "iso_embed.weight",
+                                                                          "time_mlp.1.weight"]),
+    "mid_attn": (dict(mid_attn=True), ["final_conv.weight", "downs.3.1.block2.proj.weight", "mid_block2.block1.proj.weight", "mid_attn.to_qkv.weight",
+                                       "mid_attn.to_out.weight", "mid_attn.norm.g"]),
+    "stage_attn": (dict(stage_attn=True), ["final_conv.weight", "downs.3.1.block2.proj.weight", "down_attns.0.to_qkv.weight", "down_attns.3.to_out.weight",
+                                           "up_attns.0.to_qkv.weight", "up_attns.3.to_out.1.g"]),
+}
+
+
+def _arch_net(case, cls=TrainableNoiseDiffNet):
+    kw, _ = ARCH_CASES[case]
+    net = cls(SimpleNamespace(dim=DIM, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, phase="train", **kw))
+    net.load_state_dict(_arch_state_dict(net), strict=True)
+    return net
+
+
+def _arch_state_dict(net):
+    """The synthetic weights of the capture script: every tensor from its own hash stream (seed 0), keyed by its state-dict name."""
+    from noisediff_amd.spec import arch_param_spec, attention_param_spec, stage_attention_param_spec
+    spec = list(arch_param_spec(net.arch if hasattr(net, "arch") else net.ARCH, DIM, 4))
+    if net.has_mid_attn:
+        spec += attention_param_spec("mid_attn", 8 * DIM)
+    if net.stage_attn:
+        spec += stage_attention_param_spec(DIM, net.stage_attn)
+    return synth.make_state_dict(spec, 0)
+
+
+def _check_arch_loss_and_gradients(golden, case, net, loss, loss_rel, grad_tol, sq_rel):
+    assert float(loss.detach()) == pytest.approx(float(golden("training_archs", f"{case}.loss")), rel=loss_rel)
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    assert sum(1 for g in grads.values() if g is not None) == int(golden("training_archs", f"{case}.n_params_with_grad"))
+    for k in ARCH_CASES[case][1]:
+        ref = golden("training_archs", f"{case}.grad.{k}")
+        got = sub(grads[k].cpu(), 2048)
+        assert np.abs(got - ref).max() <= grad_tol * max(1.0, np.abs(ref).max()), (case, k)
+    sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
+    assert sq == pytest.approx(float(golden("training_archs", f"{case}.grad_sq_norm")), rel=sq_rel)
+
+
+@pytest.mark.parametrize("case", sorted(ARCH_CASES))
+def test_other_architectures_loss_and_gradients_match_the_reference(golden, case):
+    """The ``UNet_PosEmbV2*`` ablation nets (others_arch.py:364-985), NoiseDiffNet with the mid-block Attention of BASELINE config 4 and NoiseDiffNet with
+    upstream's per-stage LinearAttention / Attention wiring under ``p_losses`` (denoising_diffusion_pytorch.py:481-531): loss, the squared norm of the
+    whole gradient, the number of parameters that receive one and samples of parameter gradients equal the reference's (tests/golden/training_archs.npz,
+    captured from the reference's own classes by tests/golden/capture_training_archs.py)."""
+    x0, noise, t, cond = _inputs()
+    net = _arch_net(case)
+    gd = GaussianDiffusion(nn.DataParallel(net), image_size=H, timesteps=T, beta_schedule="sigmoid2", objective="pred_v")
+    ref_cond = cond["clean_img"] if case == "UNet_PosEmbV2_NoPosition" else cond      # others_arch.py:658
+    loss = gd.p_losses(x0, t, ref_cond, noise=noise.clone())
+    loss.backward()
+    _check_arch_loss_and_gradients(golden, case, net, loss, 2e-5, 2e-5, 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(ARCH_CASES))
+def test_the_drop_in_networks_of_every_architecture_train_under_autograd(golden, case):
+    """``noisediff_amd.UNet_PosEmbV2*`` and ``noisediff_amd.NoiseDiffNet`` with ``mid_attn`` / ``stage_attn`` under autograd on the differentiable HIP operators
+    (the modules the registry hands to define_G: they sample on the fused engine and train through the same ``forward``): loss and gradients against the
+    reference's, and the differentiable forward equals the fused engine's."""
+    import noisediff_amd
+    dev = torch.device("cuda", 0)
+    x0, noise, t, cond = _inputs()
+    x0, noise, t = x0.to(dev), noise.to(dev), t.to(dev)
+    cond_dev = {k: (v if k == "iso_ratio_idx" else v.to(dev)) for k, v in cond.items()}
+    kw, _ = ARCH_CASES[case]
+    cls = getattr(noisediff_amd, kw.get("arch", "NoiseDiffNet"))
+    net = cls(SimpleNamespace(dim=DIM, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False, phase="train",
+                              **{k: v for k, v in kw.items() if k != "arch"}))
+    net.load_state_dict(_arch_state_dict(net), strict=True)
+    net = net.to(dev).train()
+    ref_cond = cond_dev["clean_img"] if case == "UNet_PosEmbV2_NoPosition" else cond_dev
+    gd = GaussianDiffusion(nn.DataParallel(net, device_ids=[0]), image_size=H, timesteps=T, beta_schedule="sigmoid2", objective="pred_v").to(dev)
+    with torch.no_grad():
+        fused = net(x0, t, ref_cond).clone()                                   # the sampling engine
+    loss = gd.p_losses(x0, t, ref_cond, noise=noise.clone())
+    loss.backward()
+    _check_arch_loss_and_gradients(golden, case, net, loss, 5e-5, 2e-4, 1e-3)
+    with torch.enable_grad():
+        y = net(x0, t, ref_cond)
+    assert y.requires_grad and rel_err(y.detach().cpu().numpy(), fused.cpu().numpy()) < 2e-4
+
+
 def test_cross_attention_general_form_equals_the_one_token_identity():
     from noisediff_amd.trainable import _Ops
     net = _net()

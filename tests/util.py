@@ -30,3 +30,27 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+
+ELEM_RTOL = 1e-3          # the north-star's "1e-3 relative fp32 tolerance", element by element ...
+ELEM_ATOL = 1e-5          # ... with this floor where the reference crosses zero: |a - b| <= ELEM_ATOL + ELEM_RTOL * |b| for EVERY element
+
+
+def elem_excess(a, b, rtol=ELEM_RTOL):
+    """max over the elements of |a - b| - rtol * |b|: the absolute floor the element-wise criterion |a - b| <= atol + rtol * |b| would need to hold everywhere."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) - rtol * np.abs(b)))
+
+
+def close(a, b, tol, atol=ELEM_ATOL, rtol=ELEM_RTOL):
+    """Both parity criteria of DESIGN section 6: rel_err(a, b) < tol (max |a - b| / max(1, max |b|)) AND zero elements outside |a - b| <= atol + rtol * |b|.
+    Set ND_TEST_ELEM_LOG=<file> to log the measured figures of every call."""
+    import os
+    r, x = rel_err(a, b), elem_excess(a, b, rtol)
+    if os.environ.get("ND_TEST_ELEM_LOG"):
+        with open(os.environ["ND_TEST_ELEM_LOG"], "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?')}: rel_err {r:.3e} (tol {tol:g}), element-wise floor needed {x:.3e} (atol {atol:g})\n")
+    assert r < tol, f"rel_err {r:.3e} >= {tol:g}"
+    assert x <= atol or os.environ.get("ND_TEST_ELEM_LOG_ONLY"), f"element-wise: |a - b| exceeds {rtol:g} * |b| by {x:.3e} > atol {atol:g}"
+    return True

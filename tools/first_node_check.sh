@@ -15,15 +15,13 @@ if [ "$N" -ge 2 ]; then
   echo "== two physical devices in one process (nn.DataParallel device_ids=[0,1]) and the stream-device guards"
   python -m pytest tests/test_hip_net.py -q -m gpu -k "two_physical_devices or streams_device or device_ids" || exit 1
   echo "== two ranks, product path (weight broadcast over RCCL, sharded sampler, all-gather == one rank == oracle)"
-  python -m pytest tests/test_hip_net.py -q -m gpu -k "two_rank or rccl" || exit 1
+  python -m pytest tests/test_hip_net.py -q -m gpu -k "n_rank or rccl" || exit 1
 fi
 for n in 2 4 8; do
   [ "$n" -le "$N" ] || break
   echo "== $n GPUs (weak scaling: 16 patches per GPU)"
   python bench.py --gpus $n --steps 20 --warmup 3 --no-cpu | tee gpurun_out/first_node_n$n.jsonl | python tools/bench_line.py || exit 1
 done
-echo "== the opt-in f16-split product form at the largest device count (ND_CONV_F16X3=1: same sharding, same single weight broadcast)"
-ND_CONV_F16X3=1 python bench.py --gpus $N --steps 20 --warmup 3 --no-cpu --no-alt | tee gpurun_out/first_node_f16x3_n$N.jsonl | python tools/bench_line.py || exit 1
 python - <<'PY'
 import glob, json
 base = None
@@ -33,5 +31,5 @@ for f in sorted(glob.glob("gpurun_out/first_node_n[0-9]*.jsonl"), key=lambda s: 
     base = base or j["value"] / n
     mg = j.get("multi_gpu") or {}
     print(f"n={n}: {j['value']:.4f} {j['unit']}  per GPU {j['value'] / n:.4f}  efficiency vs n=1 {j['value'] / n / base:.3f}  "
-          f"broadcast {mg.get('broadcast_ms')} ms / {mg.get('broadcast_bytes')} B  checksum equal {mg.get('arena_checksum_equal_on_all_ranks')}")
+          f"broadcast {mg.get('broadcast_and_pack_ms')} ms / {mg.get('broadcast_bytes')} B  checksum equal {mg.get('arena_checksum_equal_on_all_ranks')}")
 PY

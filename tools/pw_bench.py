@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """nd_pointwise_gemm_nhwc_f32 on the bench workload's wide 1x1 layers: correctness against torch and us / TF per layer.
 ND_PW_BIG=0 (pipelined 64-pixel tiles) / 1 (large tiles, one wave per SIMD) / 2 (large tiles, 128 couts only): run once per value.
-Both product forms of the large-tile kernel per layer: fp32 MFMAs (nd_pointwise_gemm_nhwc_f32) and the f16 three-product split
-(nd_pointwise_gemm_f16x3_nhwc_f32, where it takes the layer); errors are against an fp64 product, relative to the output's largest magnitude."""
+Errors are against an fp64 product, relative to the output's largest magnitude."""
 import os, sys, ctypes as C
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -19,13 +18,12 @@ LAYERS = [(1024, 768, 512, 512, 0, 0), (1024, 512, 1024, 0, 1, 0), (1024, 1024, 
           (4096, 384, 256, 256, 0, 0), (4096, 256, 512, 0, 1, 0), (4096, 512, 256, 0, 0, 1), (4096, 256, 256, 0, 0, 1),
           (16384, 192, 128, 128, 0, 0), (16384, 128, 256, 0, 1, 0), (16384, 256, 128, 0, 0, 1), (16384, 128, 128, 0, 0, 1),
           (65536, 128, 128, 0, 0, 0)]
-tot = {"fp32": 0.0, "f16x3": 0.0}
+tot = {"fp32": 0.0}
 for (HW, cin, cout, c0, ln, res) in LAYERS:
     g = torch.Generator().manual_seed(HW + cin)
     x = torch.randn(B, HW, cin, generator=g); w = torch.randn(cout, cin, generator=g) / cin ** 0.5; b = torch.randn(cout, generator=g)
     xd, wp, bd = hu.dev(x), hu.pack_pw(ctx, w), hu.dev(b)
-    wh = torch.empty_like(wp); wdev = hu.dev(w)
-    L.call("nd_pack_pointwise_weight_h", wdev.data_ptr(), wh.data_ptr(), cin, cout, int(bool(ln)), ctx.stream); ctx.sync()
+    wdev = hu.dev(w)
     x64, w64, b64 = xd.double(), wdev.double(), bd.double()          # fp64 reference on the device, from the operands the kernel reads
     r = torch.randn(B, HW, cout, generator=g) if res else None
     rd = hu.dev(r) if res else None
@@ -45,10 +43,8 @@ for (HW, cin, cout, c0, ln, res) in LAYERS:
     d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = B, HW, int(HW ** 0.5), cin, cout, cout, (L.ACT_GELU if ln else 0)
     if res: d.res0, d.ldr0 = rd.data_ptr(), cout
     cells = []
-    for form, entry, wt in (("fp32", "nd_pointwise_gemm_nhwc_f32", wp), ("f16x3", "nd_pointwise_gemm_f16x3_nhwc_f32", wh)):
+    for form, entry, wt in (("fp32", "nd_pointwise_gemm_nhwc_f32", wp),):
         d.weight = wt.data_ptr()
-        if form == "f16x3" and not ctx.lib.nd_pointwise_gemm_f16x3_takes(C.byref(d)):
-            cells.append("f16x3: not taken"); continue
         out.zero_(); torch.cuda.synchronize()        # (zero_ runs on torch's stream, the kernel on ctx.stream)
         L.call(entry, C.byref(d), ctx.stream); ctx.sync()
         err = float((out.double() - ref).abs().max() / ref.abs().max())

@@ -9,7 +9,7 @@ O=noisediff_amd/csrc/build
 flags="-O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function"
 case $src in
   conv3x3_wino2) flags="$flags -mllvm -pragma-unroll-threshold=1000000" ;;
-  conv3x3_wino4|conv3x3_wino4h|conv3x3_f16x3) ;;
+  conv3x3_wino4) ;;
   *) flags="$flags -mllvm -amdgpu-mfma-vgpr-form=1" ;;
 esac
 hipcc $flags "$@" -c noisediff_amd/csrc/$src.hip -o tools/_build/${src}_$tag.o

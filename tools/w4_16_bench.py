@@ -14,11 +14,9 @@ if os.environ.get("ND_LIB"):
 import hiputil as hu
 ctx = hu.Ctx()
 ROUNDS = int(os.environ.get("ROUNDS", "5"))
-ENTRIES = [e for e in os.environ.get("ENTRIES", "wino2,wino4,wino4_16,wino4_8w").split(",")]
+ENTRIES = [e for e in os.environ.get("ENTRIES", "wino2,wino4,wino4_16").split(",")]
 NAMES = {"wino2": ("nd_conv3x3_wino2_nhwc_f32", "nd_pack_conv3x3_wino_weight"), "wino4": ("nd_conv3x3_wino4_nhwc_f32", "nd_pack_conv3x3_wino4_weight"),
-         "wino4_16": ("nd_conv3x3_wino4_16_nhwc_f32", "nd_pack_conv3x3_wino4_weight"), "wino4_8w": ("nd_conv3x3_wino4_8w_nhwc_f32", "nd_pack_conv3x3_wino4_weight"),
-         "f16x3": ("nd_conv3x3_f16x3_nhwc_f32", "nd_pack_conv3x3_f16x3_weight"),          # direct convolution, f16 split (whole 16 x 32 regions, cin % 16, cout % 64)
-         "wino4h": ("nd_conv3x3_wino4h_nhwc_f32", "nd_pack_conv3x3_wino4h_weight"), "wino4h_16": ("nd_conv3x3_wino4h_16_nhwc_f32", "nd_pack_conv3x3_wino4h_weight")}       # f16 split: its own packing of the same size
+         "wino4_16": ("nd_conv3x3_wino4_16_nhwc_f32", "nd_pack_conv3x3_wino4_weight")}
 
 SHAPES = [  # (B, H, W, cin, cout, mode)
     (16, 256, 256, 64, 64, 0), (16, 256, 256, 64, 64, 1), (16, 256, 256, 128, 64, 0), (16, 128, 128, 128, 128, 0), (16, 128, 128, 128, 128, 1),
@@ -34,7 +32,7 @@ def bench(kind, B, H, W, cin, cout, mode):
     entry, pack = NAMES[kind]
     g = torch.Generator().manual_seed(1)
     x = hu.dev(torch.randn(B, H, W, cin, generator=g)); w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
-    wd = hu.dev(w); wp = torch.empty(getattr(ctx.lib, pack.replace("wino4h", "wino4") + "_floats")(cin, cout), device=hu.DEV)
+    wd = hu.dev(w); wp = torch.empty(getattr(ctx.lib, pack + "_floats")(cin, cout), device=hu.DEV)
     L.call(pack, wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream); ctx.sync()
     b = hu.dev(torch.randn(cout, generator=g))
     out = torch.zeros(B, H, W, cout, device=hu.DEV)
@@ -68,17 +66,11 @@ for sh in SHAPES:
         us, out, st = bench(kind, *sh)
         tot[kind] += us
         outs[kind] = (out, st)
-        frac = 18.0 * cin * cout * H * W * B / (us * 1e-6) / (1.0 if kind == "f16x3" else 4.0 if kind != "wino2" else 2.25) / 157.3e12
+        frac = 18.0 * cin * cout * H * W * B / (us * 1e-6) / (4.0 if kind != "wino2" else 2.25) / 157.3e12
         cells.append(f"{kind} {us:8.1f} us ({frac:.3f})")
     same = ""
-    if "wino4h" in outs and "wino4h_16" in outs:
-        same += " | wino4h_16 bits " + ("EQUAL" if torch.equal(outs["wino4h"][0], outs["wino4h_16"][0]) and torch.equal(outs["wino4h"][1], outs["wino4h_16"][1]) else "DIFFER")
-    if "wino4" in outs and "f16x3" in outs:
-        same += f" | f16x3 vs wino4 max diff {float((outs['wino4'][0] - outs['f16x3'][0]).abs().max()):.2e}"
-    if "wino4" in outs and "wino4h" in outs:
-        same += f" | wino4h vs wino4 max diff {float((outs['wino4'][0] - outs['wino4h'][0]).abs().max()):.2e}"
     if "wino4" in outs:
-        for other in ("wino4_16", "wino4_8w"):
+        for other in ("wino4_16",):
             if other in outs:
                 same += f" | {other} bits " + ("EQUAL" if torch.equal(outs["wino4"][0], outs[other][0]) and torch.equal(outs["wino4"][1], outs[other][1]) else "DIFFER")
     print(sh, " | ".join(cells) + same, flush=True)

@@ -9,8 +9,8 @@ L.load(os.environ["ND_LIB"])
 import hiputil as hu
 ctx = hu.Ctx()
 ENTRY = os.environ.get("W4_ENTRY", "nd_conv3x3_wino4_nhwc_f32")     # nd_conv3x3_wino4_16_nhwc_f32: 16 x 16-pixel regions, two workgroups per CU
-MFMA_CHUNK = 4608 if "_16_" in ENTRY else 3910 if "wino4h" in ENTRY else 9216      # MFMA issue cycles per wave and 16-channel chunk (f16 split: 216 x 18.1)
-PACK = "nd_pack_conv3x3_wino4h_weight" if "wino4h" in ENTRY else "nd_pack_conv3x3_wino4_weight"
+MFMA_CHUNK = 4608 if "_16_" in ENTRY else 9216      # MFMA issue cycles per wave and 16-channel chunk
+PACK = "nd_pack_conv3x3_wino4_weight"
 SHAPES = [(16, 256, 256, 64, 64), (16, 32, 32, 512, 512)]
 if os.environ.get("W4_SHAPES"):          # e.g. W4_SHAPES="1,256,256,64,64;2,256,256,64,64"
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["W4_SHAPES"].split(";")]
