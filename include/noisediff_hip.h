@@ -271,6 +271,16 @@ int nd_pack_pointwise_weight(const float* w, float* packed, int cin, int cout, i
  * Diffusion_arch.py:156,345-347,410-419), read in place from its forward weight
  * `w_t` ((cin, cout) row-major here = torch's (out_features, in_features) of the forward layer; cin = the forward layer's cout). */
 int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cout, void* stream);
+/* Many packings in ONE launch (training: the forward and the data-gradient packing of every Linear / 1x1 weight once per optimizer step;
+ * noisediff_amd/train.py keeps the table).  `items_dev`: n_items records in DEVICE memory; item i packs `w` ((cout, cin) row-major, or with
+ * `transposed` the forward weight (cin, cout) of the layer whose data gradient this packing serves) into `packed` (nd_pack_pointwise_weight_floats
+ * floats), exactly as nd_pack_pointwise_weight / nd_pack_pointwise_weight_t do. */
+typedef struct nd_pack_item {
+    const float* w;
+    float*       packed;
+    int32_t      cin, cout, transposed, reserved;
+} nd_pack_item;
+int nd_pack_pointwise_weights_batch(const nd_pack_item* items_dev, int n_items, void* stream);
 
 /* ------------------------------------------------------------------ chained pointwise layers
  * Two or three per-pixel Linear layers in one kernel, the intermediate activations never leaving registers:

@@ -31,6 +31,10 @@ class Src(C.Structure):
                 ("mad", fptr), ("map", fptr), ("vec", fptr), ("gamma", fptr), ("beta", fptr), ("rowstats", fptr)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", fptr), ("packed", fptr), ("cin", C.c_int32), ("cout", C.c_int32), ("transposed", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Conv3x3(C.Structure):
     _fields_ = [("src", Src), ("weight", fptr), ("bias", fptr), ("out", fptr), ("stats", fptr), ("slot_count", fptr),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("ldo", C.c_int32)]
@@ -115,6 +119,7 @@ SIGNATURES = {
     "nd_pack_pointwise_weight_floats": (i64, [i32, i32]),
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
+    "nd_pack_pointwise_weights_batch": (i32, [vp, i32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
     "nd_groupnorm_finalize_train_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),

@@ -270,11 +270,13 @@ template <int G>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ y, int ldy, float* __restrict__ stats, long N, int C, float eps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane % G, rw = lane / G, RPW = 64 / G, QL = C / (4 * G);
+    // a row's C / 4 channel quads over the G lanes of its group: quad g + k G for k < QL; a width that is not 4 G QL (C = 48, 96, 192, 384: the d = 48 network)
+    // leaves the last lanes of the group without a quad in the last round -- they load nothing and add zeros to the row sums
+    const int g = lane % G, rw = lane / G, RPW = 64 / G, CQ = C / 4, QL = (CQ + G - 1) / G;
     f32x4 gm[LT_MAXQ], bt[LT_MAXQ];
 #pragma unroll
     for (int k = 0; k < LT_MAXQ; ++k)
-        if (k < QL) { gm[k] = nd_ld4(gamma + 4 * (g + k * G)); bt[k] = nd_ld4(beta + 4 * (g + k * G)); }
+        if (k < QL && g + k * G < CQ) { gm[k] = nd_ld4(gamma + 4 * (g + k * G)); bt[k] = nd_ld4(beta + 4 * (g + k * G)); }
     const float inv = 1.0f / (float)C;
     for (long row = ((long)blockIdx.x * 4 + wave) * RPW + rw; row < N + rw; row += (long)gridDim.x * 4 * RPW) {
         const bool ok = row < N;                                         // (all lanes of a wave stay in the loop together: the sums are wave-wide instructions)
@@ -283,17 +285,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < LT_MAXQ; ++k)
-            if (k < QL) { v[k] = nd_ld4(x + (size_t)rr * ldx + 4 * (g + k * G)); s += v[k].x + v[k].y + v[k].z + v[k].w; }
+            if (k < QL && g + k * G < CQ) { v[k] = nd_ld4(x + (size_t)rr * ldx + 4 * (g + k * G)); s += v[k].x + v[k].y + v[k].z + v[k].w; }
         const float mean = lt_group_sum<G>(s) * inv;
         float q = 0.0f;
 #pragma unroll
         for (int k = 0; k < LT_MAXQ; ++k)
-            if (k < QL) { v[k] = v[k] - mean; q += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w; }
+            if (k < QL && g + k * G < CQ) { v[k] = v[k] - mean; q += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w; }
         const float rstd = rsqrtf(lt_group_sum<G>(q) * inv + eps);
         if (ok) {
 #pragma unroll
             for (int k = 0; k < LT_MAXQ; ++k)
-                if (k < QL) nd_st4(y + (size_t)row * ldy + 4 * (g + k * G), v[k] * rstd * gm[k] + bt[k]);
+                if (k < QL && g + k * G < CQ) nd_st4(y + (size_t)row * ldy + 4 * (g + k * G), v[k] * rstd * gm[k] + bt[k]);
             if (g == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
         }
     }
@@ -305,12 +307,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                     float* __restrict__ part, long N, int C, long rows_per_wg) {
     __shared__ __attribute__((aligned(16))) float red[2][256][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane % G, rw = lane / G, RPW = 64 / G, QL = C / (4 * G);
+    const int g = lane % G, rw = lane / G, RPW = 64 / G, CQ = C / 4, QL = (CQ + G - 1) / G;
     f32x4 gm[LT_MAXQ], dg[LT_MAXQ], db[LT_MAXQ];
 #pragma unroll
     for (int k = 0; k < LT_MAXQ; ++k) {
         dg[k] = f32x4{0, 0, 0, 0};  db[k] = f32x4{0, 0, 0, 0};
-        if (k < QL) gm[k] = nd_ld4(gamma + 4 * (g + k * G));
+        if (k < QL && g + k * G < CQ) gm[k] = nd_ld4(gamma + 4 * (g + k * G));
     }
     const float inv = 1.0f / (float)C;
     const long r_begin = (long)blockIdx.x * rows_per_wg, r_end = min(r_begin + rows_per_wg, N);
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < LT_MAXQ; ++k)
-            if (k < QL) {
+            if (k < QL && g + k * G < CQ) {
                 const f32x4 d = nd_ld4(dy + (size_t)rr * lddy + 4 * (g + k * G));
                 xh[k] = (nd_ld4(x + (size_t)rr * ldx + 4 * (g + k * G)) - mean) * rstd;
                 a[k] = d * gm[k];
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (ok) {
 #pragma unroll
             for (int k = 0; k < LT_MAXQ; ++k)
-                if (k < QL) nd_st4(dx + (size_t)row * lddx + 4 * (g + k * G), (a[k] - s2 - xh[k] * s1) * rstd);
+                if (k < QL && g + k * G < CQ) nd_st4(dx + (size_t)row * lddx + 4 * (g + k * G), (a[k] - s2 - xh[k] * s1) * rstd);
         }
     }
     // the workgroup's column sums: the 4 * RPW row lanes of every channel quad meet in LDS, in lane order
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             *reinterpret_cast<f32x4*>(red[0][tid]) = dg[k];
             *reinterpret_cast<f32x4*>(red[1][tid]) = db[k];
             __syncthreads();
-            if (tid < G) {
+            if (tid < G && tid + k * G < CQ) {
                 f32x4 sg = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
                 for (int w = 0; w < 4; ++w)
                     for (int r = 0; r < RPW; ++r) {
@@ -392,8 +394,8 @@ __global__ __launch_bounds__(256) void ln_dparam_kernel(const float* __restrict_
 
 constexpr int LT_BWD_WGS = 1024;                                         // fixed: the summation order must not depend on the device
 
-inline int lt_group(int C) { return C >= 256 ? 64 : C / 4; }
-inline bool lt_ok(int C) { return C == 64 || C == 128 || (C % 256 == 0 && C <= 1024); }
+inline int lt_group(int C) { return C > 128 ? 64 : C > 64 ? 32 : 16; }             // lanes per row: 16, 32 or 64 (C / 4 quads over them, up to LT_MAXQ rounds)
+inline bool lt_ok(int C) { return C % 4 == 0 && C >= 16 && C <= 1024; }
 
 }  // namespace
 
@@ -402,7 +404,7 @@ extern "C" int64_t nd_layernorm_train_workspace_floats(int64_t N, int C) { retur
 extern "C" int nd_layernorm_train_forward_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* stats,
                                               int64_t N, int C, float eps, void* stream) {
     ND_REQUIRE(x && gamma && beta && y && stats, ND_E_BADARG, "nd_layernorm_train_forward: null pointer");
-    ND_REQUIRE(N > 0 && lt_ok(C), ND_E_SHAPE, "nd_layernorm_train_forward: C=%d (64, 128 or a multiple of 256 up to 1024)", C);
+    ND_REQUIRE(N > 0 && lt_ok(C), ND_E_SHAPE, "nd_layernorm_train_forward: C=%d (a multiple of 4 in 16 .. 1024)", C);
     ND_REQUIRE(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && nd_aligned16(x) && nd_aligned16(y) && nd_aligned16(gamma) && nd_aligned16(beta),
                ND_E_ALIGN, "nd_layernorm_train_forward: strides must be multiples of 4 floats >= C, pointers 16-byte aligned");
     const int G = lt_group(C), rows_per_pass = 4 * (64 / G);
@@ -418,7 +420,7 @@ extern "C" int nd_layernorm_train_forward_f32(const float* x, int ldx, const flo
 extern "C" int nd_layernorm_train_backward_f32(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* stats,
                                                float* dx, int lddx, float* dgamma, float* dbeta, float* workspace, int64_t N, int C, void* stream) {
     ND_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta && workspace, ND_E_BADARG, "nd_layernorm_train_backward: null pointer");
-    ND_REQUIRE(N > 0 && lt_ok(C), ND_E_SHAPE, "nd_layernorm_train_backward: C=%d (64, 128 or a multiple of 256 up to 1024)", C);
+    ND_REQUIRE(N > 0 && lt_ok(C), ND_E_SHAPE, "nd_layernorm_train_backward: C=%d (a multiple of 4 in 16 .. 1024)", C);
     ND_REQUIRE(lddy >= C && ldx >= C && lddx >= C && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && nd_aligned16(dy) && nd_aligned16(x) &&
                nd_aligned16(dx) && nd_aligned16(gamma) && nd_aligned16(workspace), ND_E_ALIGN,
                "nd_layernorm_train_backward: strides must be multiples of 4 floats >= C, pointers 16-byte aligned");

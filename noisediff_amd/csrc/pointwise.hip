@@ -740,6 +740,22 @@ __global__ void pack_pointwise_kernel(const float* __restrict__ w, float* __rest
     }
 }
 
+// The same packing for MANY weights in one launch (training: every Linear / 1x1 weight and its transposed data-gradient packing once per optimizer
+// step -- 356 packings of a few microseconds each at d = 64 would otherwise be 356 launches).  blockIdx.y = item; `items` lives in device memory.
+__global__ void pack_pointwise_batch_kernel(const nd_pack_item* __restrict__ items) {
+    const nd_pack_item it = items[blockIdx.y];
+    const int cinP = (it.cin + 7) / 8 * 8, coutP = (it.cout + 63) / 64 * 64;
+    const size_t total = (size_t)cinP * coutP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3;
+        const size_t r = i >> 2;
+        const int n = r % coutP, kp = (int)(r / coutP) * 4 + e;
+        float v = 0.0f;
+        if (n < it.cout && kp < it.cin) v = it.transposed ? it.w[(size_t)kp * it.cout + n] : it.w[(size_t)n * it.cin + kp];
+        it.packed[i] = v;
+    }
+}
+
 template <int MB, int NB>
 void launch_pipe(const PwArgs& a, hipStream_t st) {
     const dim3 grid(a.total_wg), block(256);
@@ -811,6 +827,12 @@ extern "C" int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int c
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_pointwise_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_t, packed, cin, cout, cinP, coutP, 0, 1);
     return nd_launch_status("nd_pack_pointwise_weight_t");
+}
+
+extern "C" int nd_pack_pointwise_weights_batch(const nd_pack_item* items_dev, int n_items, void* stream) {
+    ND_REQUIRE(items_dev && n_items > 0 && n_items <= 65535, ND_E_BADARG, "nd_pack_pointwise_weights_batch: needs 1 .. 65535 items in device memory");
+    hipLaunchKernelGGL(pack_pointwise_batch_kernel, dim3(32, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    return nd_launch_status("nd_pack_pointwise_weights_batch");
 }
 
 namespace {

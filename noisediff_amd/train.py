@@ -387,10 +387,69 @@ def _hip_norm_forward(self: nn.GroupNorm, x: torch.Tensor) -> torch.Tensor:
     return group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
 
 
-# Output and data gradient of Linears / 1x1 convolutions: the library GEMM by default.  ND_TRAIN_PW=1 (or train._PW_GEMM = True) sends them to the
-# sampling path's pointwise kernels instead (weights packed per call).  Measured r3, B=4 256x256, d=64: 178 GEMMs per step take 4.23 ms on the
-# library against 4.36 ms + 0.77 ms of packing here -- unfused and with weights that change every step, the pointwise kernels have nothing to win.
-_PW_GEMM = __import__("os").environ.get("ND_TRAIN_PW", "0") != "0"
+# Output and data gradient of Linears / 1x1 convolutions: the sampling path's pointwise kernels (nd_pointwise_gemm_nhwc_f32), since r5 by default --
+# no library GEMM (rocBLAS / hipBLASLt) is left in a training step.  The packed operands are cached per weight and refreshed when the parameter's
+# version changes: ONE launch per optimizer step packs every stale weight (nd_pack_pointwise_weights_batch), where r3 packed per call (178 GEMMs,
+# 0.77 ms of 4-microsecond launches per step -- that, not the GEMMs, was what lost to the library then).  ND_TRAIN_PW=0 (or train._PW_GEMM = False):
+# the library GEMM, as an A/B knob.
+_PW_GEMM = __import__("os").environ.get("ND_TRAIN_PW", "1") != "0"
+
+
+class _PackCache:
+    """Packed operands of the Linear / 1x1 weights of one device.  An entry belongs to a leaf tensor (a parameter): key (data_ptr, shape, transposed),
+    valid while the tensor's version counter stands.  The first stale entry a step meets repacks EVERY stale entry in one launch over a descriptor
+    table kept in device memory.  Weights that are not leaves (the per-step torch.cat of the stacked time projections, nn.DataParallel's broadcast
+    copies) are packed per call and never cached."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.entries: Dict[tuple, list] = {}        # key -> [weight tensor (kept alive), packed buffer, version packed, cin, cout, transposed]
+        self.table: Optional[torch.Tensor] = None   # device copy of the nd_pack_item records, in the order of `order`
+        self.order: list = []
+
+    def get(self, w: torch.Tensor, cin: int, cout: int, transposed: bool, st) -> int:
+        lib = L.load()
+        key = (w.data_ptr(), tuple(w.shape), transposed)
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= 4096:            # (a model is a few hundred weights: anything beyond is a leak of temporaries -- start over)
+                self.entries.clear(); self.order = []; self.table = None
+            buf = torch.empty(int(lib.nd_pack_pointwise_weight_floats(cin, cout)), dtype=torch.float32, device=self.device)
+            e = self.entries[key] = [w, buf, -1, cin, cout, transposed]
+            self.order.append(key)
+            self.table = None
+        if e[2] != w._version:
+            self._repack_stale(st)
+        return e[1].data_ptr()
+
+    def _repack_stale(self, st) -> None:
+        stale = [k for k in self.order if self.entries[k][2] != self.entries[k][0]._version]
+        if (self.table is None or len(stale) != len(self.order)) and torch.cuda.is_current_stream_capturing():
+            # a new descriptor table would need a host-to-device copy, which a capturing stream refuses: one capturable launch per stale weight instead
+            for k in stale:
+                w, buf, _, cin, cout, tr = self.entries[k]
+                L.call("nd_pack_pointwise_weight_t" if tr else "nd_pack_pointwise_weight", w.data_ptr(), buf.data_ptr(), cin, cout, *(() if tr else (0,)), st)
+                self.entries[k][2] = w._version
+            return
+        if self.table is None or len(stale) != len(self.order):
+            # first use, or only part of the table is stale (a partially frozen model): a table of the stale entries only
+            items = (L.PackItem * len(stale))()
+            for i, k in enumerate(stale):
+                w, buf, _, cin, cout, tr = self.entries[k]
+                items[i].w, items[i].packed, items[i].cin, items[i].cout, items[i].transposed = w.data_ptr(), buf.data_ptr(), cin, cout, int(tr)
+            host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+            table = host.to(self.device)                     # (synchronous copy of a few KB)
+            if len(stale) == len(self.order):
+                self.table = table
+        else:
+            table = self.table
+        L.call("nd_pack_pointwise_weights_batch", table.data_ptr(), len(stale), st)
+        self._last_table = table                             # alive until the next repack (the launch is asynchronous)
+        for k in stale:
+            self.entries[k][2] = self.entries[k][0]._version
+
+
+_PACK_CACHES: Dict[int, _PackCache] = {}
 
 
 def _tokens(t: torch.Tensor, c: int) -> torch.Tensor:
@@ -410,15 +469,22 @@ def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     st = _stream(x2.device)
     with _on(x2.device):
         y = torch.empty((N, cout), dtype=torch.float32, device=x2.device)
-        wp = torch.empty(int(lib.nd_pack_pointwise_weight_floats(cin, cout)), dtype=torch.float32, device=x2.device)
-        w32 = w.detach().float().contiguous()
-        if transposed:
-            L.call("nd_pack_pointwise_weight_t", w32.data_ptr(), wp.data_ptr(), cin, cout, st)
+        if w.is_leaf and w.dtype == torch.float32 and w.is_contiguous():      # a parameter: its packing is cached until the optimizer changes it
+            cache = _PACK_CACHES.get(x2.device.index)
+            if cache is None:
+                cache = _PACK_CACHES[x2.device.index] = _PackCache(x2.device)
+            wptr = cache.get(w, cin, cout, transposed, st)
         else:
-            L.call("nd_pack_pointwise_weight", w32.data_ptr(), wp.data_ptr(), cin, cout, 0, st)
+            wp = torch.empty(int(lib.nd_pack_pointwise_weight_floats(cin, cout)), dtype=torch.float32, device=x2.device)
+            w32 = w.detach().float().contiguous()
+            if transposed:
+                L.call("nd_pack_pointwise_weight_t", w32.data_ptr(), wp.data_ptr(), cin, cout, st)
+            else:
+                L.call("nd_pack_pointwise_weight", w32.data_ptr(), wp.data_ptr(), cin, cout, 0, st)
+            wptr = wp.data_ptr()
         d = L.Pointwise()
         d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x2.data_ptr(), cin, cin, L.PRO_NONE
-        d.weight, d.out = wp.data_ptr(), y.data_ptr()
+        d.weight, d.out = wptr, y.data_ptr()
         if bias is not None:
             b32 = bias.detach().float().contiguous()
             d.bias = b32.data_ptr()
@@ -493,6 +559,62 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
     return y.permute(0, 3, 1, 2)                                           # NCHW-shaped, channels_last in memory
 
 
+class Conv7x7Function(torch.autograd.Function):
+    """The 7x7 stem over a 4-channel image (init_conv / cond_init_conv: Diffusion_arch.py:478, others_arch.py:394-398): forward on nd_conv7x7_c4_f32 (the sampling
+    path's kernel), weight and bias gradient as the Linear weight gradient of the unfolded image -- dW[co, (ci, ky, kx)] = sum over the pixels of
+    dy[pixel, co] * patch[pixel, (ci, ky, kx)] on nd_linear_wgrad_f32 (fixed summation order).  The input is an image, not an activation: its gradient is asked for
+    only by callers outside the reference's training loop and then comes from PyTorch's transposed convolution."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = L.load()
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        xn = x.detach().permute(0, 2, 3, 1).contiguous().float()          # NHWC, 4 channels
+        st = _stream(x.device)
+        with _on(x.device):
+            wp = torch.empty(196 * cout, dtype=torch.float32, device=x.device)
+            w32 = weight.detach().float().contiguous()
+            L.call("nd_pack_conv7x7_weight", w32.data_ptr(), wp.data_ptr(), cout, st)
+            b32 = bias.detach().float().contiguous() if bias is not None else torch.zeros(cout, dtype=torch.float32, device=x.device)
+            y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+            L.call("nd_conv7x7_c4_f32", xn.data_ptr(), wp.data_ptr(), b32.data_ptr(), y.data_ptr(), cout, B, H, W, cout, st)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y.permute(0, 3, 1, 2)                                       # NCHW-shaped, channels_last in memory
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_x = torch.nn.grad.conv2d_input(x.shape, weight, grad_out, padding=3)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            g2 = _tokens(grad_out.permute(0, 2, 3, 1), cout)                # (pixels, cout)
+            cols = torch.nn.functional.unfold(x.detach().float(), kernel_size=7, padding=3)      # (B, cin * 49, H W): index ci * 49 + ky * 7 + kx == weight.flatten(1)'s
+            x2 = cols.transpose(1, 2).reshape(B * H * W, cin * 49).contiguous()
+            N, K = x2.shape
+            with _on(x2.device):
+                gw = torch.empty((cout, K), dtype=torch.float32, device=x2.device)
+                grad_b = torch.empty(cout, dtype=torch.float32, device=x2.device) if ctx.has_bias else None
+                ws = torch.empty(int(lib.nd_linear_wgrad_workspace_floats(N, K, cout)), dtype=torch.float32, device=x2.device)
+                L.call("nd_linear_wgrad_f32", x2.data_ptr(), K, g2.data_ptr(), cout, gw.data_ptr(),
+                       grad_b.data_ptr() if grad_b is not None else None, ws.data_ptr(), N, K, cout, _stream(x2.device))
+            grad_w = gw.view(weight.shape)
+        return grad_x, grad_w, grad_b
+
+
+def conv7x7_c4(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable F.conv2d(x, weight, bias, padding=3) for the 7x7 stem of a 4-channel image (cout a multiple of 4) on the HIP library."""
+    if x.dim() != 4 or tuple(weight.shape[1:]) != (4, 7, 7) or x.shape[1] != 4 or weight.shape[0] % 4:
+        raise ValueError(f"conv7x7_c4: x {tuple(x.shape)} / weight {tuple(weight.shape)}: a 7x7 convolution of a 4-channel image, cout a multiple of 4")
+    return Conv7x7Function.apply(x, weight, bias)
+
+
 def _eligible_linear(m: nn.Module) -> bool:
     if isinstance(m, nn.Linear):
         return _linear_ok(m.in_features, m.out_features)
@@ -507,7 +629,7 @@ def _hip_linear_forward(self, x: torch.Tensor) -> torch.Tensor:
 
 
 def _layer_norm_ok(C_: int) -> bool:
-    return C_ in (64, 128) or (C_ % 256 == 0 and C_ <= 1024)
+    return C_ % 4 == 0 and 16 <= C_ <= 1024          # (r5: any multiple of 4 -- the d = 48 network's 48 / 96 / 192 / 384 included)
 
 
 class LayerNormFunction(torch.autograd.Function):

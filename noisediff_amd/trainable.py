@@ -70,8 +70,17 @@ class _Ops:
         if self.hip and x.is_cuda and w.shape[2:] == (1, 1) and padding == 0 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
             from . import train
             return train.conv1x1(x, w, b)
+        if self.hip and x.is_cuda and tuple(w.shape[1:]) == (4, 7, 7) and padding == 3 and w.shape[0] % 4 == 0:
+            from . import train
+            return train.conv7x7_c4(x, w, b)                                    # the stem (init_conv / cond_init_conv)
+        if self.hip and x.is_cuda and w.shape[2:] == (1, 1) and padding == 0 and w.shape[0] % 4 == 0 and w.shape[1] < 4:
+            # pos_enc.weights (2 -> 8 channels, Diffusion_arch.py:328): as a 4-channel 1x1 convolution with two zero input channels -- the zero weight columns
+            # receive gradients that the slice drops
+            from . import train
+            pad = 4 - w.shape[1]
+            return train.conv1x1(F.pad(x, (0, 0, 0, 0, 0, pad)), F.pad(w, (0, 0, 0, 0, 0, pad)), b)
         if x.is_cuda:
-            self._left_library(name, f"conv{w.shape[2]}x{w.shape[3]}", f"{w.shape[1]} -> {w.shape[0]} channels: the library's differentiable convolutions are 3x3 (channels % 8) and 1x1 (channels % 4)")
+            self._left_library(name, f"conv{w.shape[2]}x{w.shape[3]}", f"{w.shape[1]} -> {w.shape[0]} channels: the library's differentiable convolutions are 3x3 (channels % 8), 1x1 (cout % 4) and the 7x7 stem of a 4-channel image")
         return F.conv2d(x, w, b, padding=padding)
 
     def linear(self, name: str, x: torch.Tensor) -> torch.Tensor:

@@ -42,6 +42,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(L.Pointwise) == C.sizeof(L.Src) + 8 * 8 + 13 * 4 + 4     # 13 int32 + tail padding to 8
     assert C.sizeof(L.SamplerState) == 6 * 8 + 2 * 4
     assert C.sizeof(L.ChainStage) == 2 * 8 + 4 * 4
+    assert C.sizeof(L.PackItem) == 2 * 8 + 4 * 4
     assert C.sizeof(L.Chain) == C.sizeof(L.Src) + 3 * C.sizeof(L.ChainStage) + 8 + 4 * 4
 
 

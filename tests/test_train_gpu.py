@@ -463,7 +463,29 @@ def test_conv1x1_and_accelerated_linears():
     assert rel_err(tok_hip.bias.grad.cpu().numpy(), tok.bias.grad.cpu().numpy()) < 2e-5
 
 
-LN_CASES = {"c64": (3001, 64), "c128": (1000, 128), "c256": (515, 256), "c512": (300, 512), "c1024": (70, 1024), "many": (262144, 64)}
+@pytest.mark.parametrize("shape", [(2, 32, 48, 64), (1, 40, 24, 48), (3, 16, 16, 16)])
+def test_stem_conv7x7_autograd_matches_pytorch(shape):
+    """train.conv7x7_c4 (init_conv / cond_init_conv: forward on nd_conv7x7_c4_f32, weight + bias gradient through nd_linear_wgrad_f32 over the unfolded image)
+    == F.conv2d(padding=3) and its autograd; the image's own gradient (not needed by the reference's training loop) comes from PyTorch's transposed convolution."""
+    B, H, W, cout = shape
+    x = U("stem.x", (B, 4, H, W), -1.5, 1.5).to(DEV)
+    w, b = U("stem.w", (cout, 4, 7, 7), -0.1, 0.1).to(DEV), U("stem.b", (cout,)).to(DEV)
+    gy = U("stem.gy", (B, cout, H, W)).to(DEV)
+    outs = []
+    for hip in (False, True, True):
+        xa, wa, ba = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        y = train.conv7x7_c4(xa, wa, ba) if hip else F.conv2d(xa, wa, ba, padding=3)
+        y.backward(gy)
+        outs.append([t.detach().cpu() for t in (y, xa.grad, wa.grad, ba.grad)])
+    for got, ref, name in zip(outs[1], outs[0], ("y", "dx", "dw", "db")):
+        assert rel_err(got.numpy(), ref.numpy()) < 2e-5 * max(1.0, (B * H * W / 4096) ** 0.5), name
+    assert all(torch.equal(p, q) for p, q in zip(outs[1], outs[2]))              # bitwise repeatable
+    with pytest.raises(ValueError):
+        train.conv7x7_c4(x[:, :3], w[:, :3], b)
+
+
+LN_CASES = {"c64": (3001, 64), "c128": (1000, 128), "c256": (515, 256), "c512": (300, 512), "c1024": (70, 1024), "many": (262144, 64),
+            "c48": (3001, 48), "c96": (1000, 96), "c192": (777, 192), "c384": (301, 384), "c20": (513, 20), "c1000": (65, 1000)}      # (d = 48: 48 / 96 / 192 / 384; ragged widths)
 
 
 @pytest.mark.parametrize("case", sorted(LN_CASES))
@@ -489,7 +511,7 @@ def test_layer_norm_autograd_matches_a_float64_reference(case):
     for got, ref, name in zip(outs[0], (y, xa.grad, wa.grad, ba.grad), ("y", "dx", "dgamma", "dbeta")):
         assert rel_err(got.numpy(), ref.detach().numpy()) < tol, (case, name)
     with pytest.raises(ValueError):
-        train.layer_norm(x[:, :48].contiguous(), gamma[:48], beta[:48])      # C = 48: not taken
+        train.layer_norm(x[:, :14].contiguous(), gamma[:14], beta[:14])      # C = 14: not a multiple of 4, not taken
     ln = nn.LayerNorm(C_).to(DEV)
     train.accelerate(ln)
     assert getattr(ln.forward, "__func__", None) is train._hip_layer_norm_forward
