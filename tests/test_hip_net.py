@@ -95,7 +95,7 @@ def test_net_forward_non_square_and_wrapped(golden):
     assert close(got.cpu().numpy(), ref.numpy(), NET_TOL)
 
 
-def test_net_refuses_cpu_and_variants_refuse_autograd():
+def test_net_refuses_cpu_and_every_architecture_runs_under_autograd():
     from noisediff_amd._lib import HipError
     from noisediff_amd import UNet_PosEmbV2_NoPosition
     net = make_net(16)
@@ -103,10 +103,14 @@ def test_net_refuses_cpu_and_variants_refuse_autograd():
     x = torch.zeros(1, 4, 16, 16)
     with torch.no_grad(), pytest.raises(HipError):
         net(x, torch.zeros(1, dtype=torch.long), cond)                   # CPU tensor: no fallback
-    with pytest.raises(NotImplementedError):                             # autograd requested: only the NoiseDiffNet graph is differentiable
-        make_net(16, mid_attn=True)(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), to_dev(cond))
-    with pytest.raises(NotImplementedError):
-        UNet_PosEmbV2_NoPosition(SimpleNamespace(dim=16, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False)).to(DEV)(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), x.to(DEV))
+    with pytest.raises(HipError):                                        # ... under autograd neither
+        net.cpu()(x, torch.zeros(1, dtype=torch.long), cond)
+    # autograd requested: since r5 every architecture has the differentiable path (tests/test_trainable.py pins loss and gradients to the reference's)
+    y = make_net(16, mid_attn=True)(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), to_dev(cond))
+    assert y.requires_grad and y.shape == (1, 4, 16, 16)
+    v = UNet_PosEmbV2_NoPosition(SimpleNamespace(dim=16, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False)).to(DEV)
+    y = v(x.to(DEV), torch.zeros(1, dtype=torch.long, device=DEV), x.to(DEV))
+    assert y.requires_grad and y.shape == (1, 4, 16, 16)
 
 
 def _sample(dim, B, H, T, S, eta=0.0, return_all=False, sched="sigmoid2", objective="pred_v", mid=False, preset=False):

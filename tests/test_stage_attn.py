@@ -89,8 +89,9 @@ def test_stage_attention_hip_forward_and_sampler(golden):
         steps = torch.stack([synth.make_noise(2, f"noise.{i}", B, 4, S) for i in range(5)])
         res = gd.sample(batch_size=B, condition=cond_d, noise={"x_T": synth.make_noise(2, "x_T", B, 4, S), "steps": steps})
     assert rel_err(res.cpu().numpy(), golden("stage_attn", "sa.samp.ddim6")) < 1e-3             # north-star tolerance
-    with pytest.raises(NotImplementedError):                                                   # inference only, like mid_attn
-        net(x.to(dev), torch.zeros(B, dtype=torch.long, device=dev), cond_d)
+    # under autograd the same module runs the differentiable graph (r5; loss and gradients against the reference: tests/test_trainable.py) -- the same function
+    y = net(x.to(dev), torch.full((B,), 500, dtype=torch.long, device=dev), cond_d)
+    assert y.requires_grad and rel_err(y.detach().cpu().numpy(), golden("stage_attn", "sa.fwd.t500")) < 2e-4
 
 
 @pytest.mark.gpu
