@@ -36,29 +36,29 @@ from .spec import (normalize_stage_attn, stage_attention_param_spec, ATTN_DIM_HE
 GN_EPS = 1e-5
 _log = logging.getLogger("noisediff_amd")
 WINOGRAD = os.environ.get("ND_WINOGRAD", "1") != "0"     # tuning / A-B knob: 0 = direct conv3x3 kernel everywhere
-PREACT = os.environ.get("ND_PREACT", "1") != "0"         # A-B knob: 0 = GroupNorm+SiLU always fused into block2's conv prologue
-PREACT_MIN = int(os.environ.get("ND_PREACT_MIN", "256"))  # A-B knob: narrowest block2 that gets the separate activation pass
-CHAIN = os.environ.get("ND_CHAIN", "1") != "0"           # A-B knob: 0 = one pointwise GEMM launch per Linear layer
+PREACT = True            # wide block2 inputs get a separate GroupNorm + SiLU pass instead of the conv prologue (settled r1e; was ND_PREACT)
+PREACT_MIN = 256         # ... from this width on (r1e: 128 / 256 / 512 measured the same within 0.1 %; was ND_PREACT_MIN)
+CHAIN = True             # fused per-pixel Linear chains where pwchain.hip has the widths (was ND_CHAIN)
 _CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that can open / continue a fused chain (pwchain.hip)
 _CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
 WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two-waves-per-SIMD Winograd kernel (conv3x3_wino.hip)
-MAP_BLOCKED = os.environ.get("ND_MAP_BLOCKED", "1") != "0"   # A-B knob: 0 = ResnetBlock2 scale / shift maps in the planar [scale C | shift C] layout
-COND_STEP = os.environ.get("ND_COND_STEP", "1") != "0"   # A-B knob: 0 = time embedding / time_mlp / projections as four launches
+MAP_BLOCKED = True       # ResnetBlock2 scale / shift maps in the 16-channel-blocked layout the F(4x4) kernel reads (was ND_MAP_BLOCKED)
+COND_STEP = True         # time embedding / time_mlp / projections in one launch where it fits the LDS (was ND_COND_STEP)
 WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel (conv3x3_wino4.hip)
 # Low-latency mode for SMALL batches (opt-in: ND_SPLIT_K=1 or engine.SPLIT_K = True before the plans are recorded): plain-source F(4x4) layers whose
 # (sample, region, cout tile) items fill a fraction of the chip run on the split-K form (nd_conv3x3_wino4_splitk_nhwc_f32: one sample at 256 x 256 has 16
 # items for the 512 -> 512 layers at 32 x 32).  Off by default: the split count depends on the batch size, and with it the summation order over cin --
 # a sample's bits would depend on the batch it is sharded into, which the default path rules out (see _wino4_takes).  16 patches per GPU never split.
 SPLIT_K = os.environ.get("ND_SPLIT_K", "0") != "0"
-EIGHT_TILES_RULE = os.environ.get("ND_W4_EIGHT_TILES", "1") != "0"     # A-B knob (tools/): 0 = F(4x4) also for layers with <= 8 workgroup tiles per sample
+EIGHT_TILES_RULE = True  # layers with <= 8 tiles of the 16 x 32 form per sample go to the 16 x 16-region form (profiles/r3_eight_tiles_rule_ab.txt; was ND_W4_EIGHT_TILES)
 # r4: the F(4x4) kernel on 16 x 16-pixel regions with two co-resident workgroups per CU (nd_conv3x3_wino4_16_nhwc_f32).  "narrow" (default): where the
 # 16 x 32 form has too few regions per sample or the image is narrower than 32 pixels (those layers ran on F(2x2) before); "all": wherever it takes the
 # layer; "0": never.  Either way a function of the sample's geometry alone, and the same bits as the 16 x 32 form.
 WINO4_16 = os.environ.get("ND_WINO4_16", "narrow")
-WINO4_16_SPLIT = os.environ.get("ND_WINO4_16_SPLIT", "1") != "0"      # A-B knob: 0 = no K ranges on the 16 x 16-region form
+WINO4_16_SPLIT = True    # geometry-only K ranges on the 16 x 16-region form (profiles/r4a_cfg2_cfg3_sampling_split_k_ab.txt; was ND_WINO4_16_SPLIT)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
-TIME_TABLE = os.environ.get("ND_TIME_TABLE", "1") != "0"   # A-B knob: 0 = the time embedding's head is computed in every step
-PROJ_TABLE = os.environ.get("ND_PROJ_TABLE", "1") != "0"   # A-B knob: 0 = only the head is tabulated, the stacked projection is computed in every step
+TIME_TABLE = True        # the time embedding's head looked up per timestep (r3; was ND_TIME_TABLE)
+PROJ_TABLE = True        # ... and the stacked ResnetBlock.mlp projection (r4e; was ND_PROJ_TABLE)
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
 
 
