@@ -14,6 +14,7 @@
 // read as one conflict-free ds_read_b32 each.  The split over pixel tiles is fixed by the shape alone, partial sums go to a
 // workspace and a second kernel adds them in a fixed order: bitwise repeatable, no atomics.  The bias gradient (sum of dY over the
 // pixels) falls out of the staged dY tiles of the first cin block's workgroups.
+#include <type_traits>
 #include <stdlib.h>
 #include "nd_common.h"
 
@@ -273,14 +274,16 @@ void plan(int B, int H, int W, int cin, int cout, WgradArgs& a) {
 // Taken when H % 8 == 0, W % 16 == 0 and both channel counts are multiples of 32 (every Block.proj of the d = 64 network at the training sizes);
 // anything else keeps the nine-tap kernel above.  ND_WGRAD_WINO=0: A/B knob.
 constexpr int WW_CB = 32;                                            // channels per block, both sides
-constexpr int WW_TY = 2, WW_TX = 4, WW_NT = WW_TY * WW_TX;           // tile group: 2 x 4 tiles of 4 x 4 pixels
-constexpr int WW_GH = 4 * WW_TY, WW_GW = 4 * WW_TX;                  // 8 x 16 pixels
-constexpr int WW_HR = WW_GH + 2, WW_HC = WW_GW + 2;                  // halo 10 x 18
+constexpr int WW_NT = 4;                                             // tile group: one row of four 4 x 4 tiles
+constexpr int WW_GH = 4, WW_GW = 16;                                 // = 4 x 16 pixels of dY
+constexpr int WW_HR = WW_GH + 2, WW_HC = WW_GW + 2;                  // input halo 6 x 18
+constexpr int WW_PS = 36;                                            // floats per staged pixel: 32 channels + 4 (the four tiles of a wave's 8-byte reads land on distinct bank halves)
+constexpr int WW_XF = WW_HR * WW_HC * WW_PS, WW_YF = WW_GH * WW_GW * WW_PS, WW_RAWF = WW_XF + WW_YF;     // one raw buffer: halo, then the dY block
+constexpr int WW_VDF = 36 * WW_NT * WW_CB;                           // one operand image [pos][tile][channel]
+constexpr size_t WW_LDS = (size_t)(2 * WW_RAWF + 4 * WW_VDF) * sizeof(float);      // two raw buffers + two (V, D) pairs: 123264 bytes
 constexpr int WW_TARGET_WGS = 256;                                   // fixed: the summation order must not depend on the device
-constexpr int WW_X_IT = (WW_HR * WW_HC * (WW_CB / 4) + 255) / 256;   // 6 float4 per thread
-constexpr int WW_Y_IT = WW_GH * WW_GW * (WW_CB / 4) / 256;           // 4 float4 per thread
-constexpr int WW_LDT = 12;                                           // floats per (position, channel) row of the operand images: 8 tiles + pad (16-byte reads, conflict-free)
-constexpr size_t WW_LDS = (size_t)(WW_HR * WW_HC + WW_GH * WW_GW + 2 * 36 * WW_LDT) * WW_CB * sizeof(float);   // 150016 bytes
+constexpr int WW_X_IT = (WW_HR * WW_HC * (WW_CB / 4) + 127) / 128;   // 7 float4 of the halo per thread of the two D waves
+constexpr int WW_Y_IT = WW_GH * WW_GW * (WW_CB / 4) / 128;           // 4 float4 of the dY block per thread of the two V waves
 
 struct WwArgs {
     const float* x; const float* dy; float* ws; float* wsb;
@@ -289,18 +292,57 @@ struct WwArgs {
 };
 
 typedef float ww_f2 __attribute__((ext_vector_type(2)));
-template <typename T>
-__device__ __forceinline__ void ww_bt6(const T (&d)[6], T (&t)[6]) {      // one row of B^T applied to six values (float2: two channels at once, packed instructions)
+#ifdef WW_DIAG_NOMFMA
+#define WW_DIAG_MFMA_ASM(k) asm volatile("" :: "v"(a_), "v"(b_));
+#else
+#define WW_DIAG_MFMA_ASM(k) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(accr[(k) % 9]) : "v"(a_), "v"(b_));
+#endif
+#ifdef WW_DIAG_NOWRITE
+#define WW_ST2(p, v) asm volatile("" :: "v"(v))
+#else
+#define WW_ST2(p, v) *reinterpret_cast<ww_f2*>(p) = (v)
+#endif
+// Rows 3 RH .. 3 RH + 2 of B^T applied to six values / all six rows (float2: two channels at once, packed instructions)
+template <int RH>
+__device__ __forceinline__ void ww_bt3(const ww_f2 (&d)[6], ww_f2 (&t)[3]) {
+    if constexpr (RH == 0) {
+        const ww_f2 p = d[4] - 4.0f * d[2], q = d[3] - 4.0f * d[1];
+        t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+        t[1] = p + q;
+        t[2] = p - q;
+    } else {
+        const ww_f2 p = d[4] - d[2], q = d[3] - d[1];
+        t[0] = p + 2.0f * q;
+        t[1] = p - 2.0f * q;
+        t[2] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+    }
+}
+__device__ __forceinline__ void ww_bt6(const ww_f2 (&d)[6], ww_f2 (&t)[6]) {
+    const ww_f2 p = d[4] - 4.0f * d[2], q = d[3] - 4.0f * d[1], r = d[4] - d[2], s = d[3] - d[1];
     t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
-    t[1] = -4.0f * (d[1] + d[2]) + d[3] + d[4];
-    t[2] = 4.0f * (d[1] - d[2]) - d[3] + d[4];
-    t[3] = 2.0f * (d[3] - d[1]) + d[4] - d[2];
-    t[4] = 2.0f * (d[1] - d[3]) + d[4] - d[2];
+    t[1] = p + q;
+    t[2] = p - q;
+    t[3] = r + 2.0f * s;
+    t[4] = r - 2.0f * s;
     t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
 }
-template <typename T>
-__device__ __forceinline__ void ww_a4(const T (&y)[4], T (&o)[6]) {       // A (6 x 4) applied to four values
-    const T e = y[0] + y[2], f = y[1] + y[3], g4 = y[0] + 4.0f * y[2], h = 2.0f * y[1] + 8.0f * y[3];
+// Rows 3 RH .. 3 RH + 2 of A (6 x 4) applied to four values / all six rows
+template <int RH>
+__device__ __forceinline__ void ww_a3(const ww_f2 (&y)[4], ww_f2 (&o)[3]) {
+    if constexpr (RH == 0) {
+        const ww_f2 e = y[0] + y[2], f = y[1] + y[3];
+        o[0] = y[0];
+        o[1] = e + f;
+        o[2] = e - f;
+    } else {
+        const ww_f2 g4 = y[0] + 4.0f * y[2], h = 2.0f * y[1] + 8.0f * y[3];
+        o[0] = g4 + h;
+        o[1] = g4 - h;
+        o[2] = y[3];
+    }
+}
+__device__ __forceinline__ void ww_a6(const ww_f2 (&y)[4], ww_f2 (&o)[6]) {
+    const ww_f2 e = y[0] + y[2], f = y[1] + y[3], g4 = y[0] + 4.0f * y[2], h = 2.0f * y[1] + 8.0f * y[3];
     o[0] = y[0];
     o[1] = e + f;
     o[2] = e - f;
@@ -309,130 +351,218 @@ __device__ __forceinline__ void ww_a4(const T (&y)[4], T (&o)[6]) {       // A (
     o[5] = y[3];
 }
 
-__global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WwArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Xs = sm;                                                  // [10][18][32]
-    float* Ys = Xs + WW_HR * WW_HC * WW_CB;                          // [8][16][32]
-    float* Vs = Ys + WW_GH * WW_GW * WW_CB;                          // [36][32 cins][8 tiles + 4]
-    float* Ds = Vs + 36 * WW_CB * WW_LDT;                            // [36][32 couts][8 tiles + 4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One wave of the Winograd-domain kernel.  ISV: the wave transforms input patches (V) and stages the dY block; otherwise it transforms dY blocks (D),
+// stages the input halo and (RH == 0) collects the bias gradient.  RH: which three of the six transform rows it produces.  Every wave also owns nine
+// of the 36 positions' accumulators.  An iteration i of the pipeline holds, as ONE instruction stream of 18 slots -- an MFMA (64 cycles of the matrix
+// pipe) followed by the few VALU / LDS instructions that fit beside it (an LDS write issued right behind an MFMA costs ~2 cycles instead of its 32;
+// on its own the transforms' LDS writes alone take as long as the MFMAs: profiles/r5_wgrad_wino.txt):
+//     M(i)    the 18 MFMAs of group i on the operand images VD[i & 1]
+//     X(i+1)  this thread's half transform of group i + 1: raw[(i + 1) & 1] -> VD[(i + 1) & 1]
+//     W(i+2)  its staged float4s of group i + 2: registers -> raw[i & 1]
+//     L(i+3)  the requests for group i + 3
+// and ends in one barrier.  Iterations -2 and -1 fill the pipeline (no MFMAs); past the last group X / W / L run on clamped, unused data.
+template <bool ISV, int RH>
+__device__ __forceinline__ void ww_wave(const WwArgs& a, float* sm, const int wave, const int lane) {
+    constexpr int NIT = ISV ? WW_Y_IT : WW_X_IT;
     const int col = lane & 31, half = lane >> 5;
     int bid = blockIdx.x;
     const int s = bid % a.S;  bid /= a.S;
     const int cib = bid % a.n_ci, cob = bid / a.n_ci;
     const int co0 = cob * WW_CB, ci0 = cib * WW_CB;
-    const int g_lo = (int)((long)s * a.n_groups / a.S), g_hi = (int)((long)(s + 1) * a.n_groups / a.S);
+    const int g_lo = (int)((long)s * a.n_groups / a.S), g_hi = (int)((long)(s + 1) * a.n_groups / a.S), n = g_hi - g_lo;
 
     f32x16 acc[9];
 #pragma unroll
     for (int p = 0; p < 9; ++p) acc[p] = nd_zero16();
-    const bool do_bias = a.wsb != nullptr && cib == 0;
-    ww_f2 bsum2 = {0.0f, 0.0f};                                      // D-transform threads: their (tile, cout pair) share of the bias gradient
-    // transform roles: waves 0, 1 the input patches (V), waves 2, 3 the dY blocks (D); a thread = (tile, channel PAIR), packed float2 arithmetic
-    const int t_tile = (tid & 127) >> 4, t_cp = tid & 15, t_ch = 2 * t_cp;
-    const int t_ty = t_tile / WW_TX, t_tx = t_tile % WW_TX;
-    const bool t_isV = tid < 128;
+    const bool do_bias = !ISV && RH == 0 && a.wsb != nullptr && cib == 0;
+    ww_f2 bsum2 = {0.0f, 0.0f};
 
-    f32x4 xr[WW_X_IT], yr[WW_Y_IT];
-    auto issue = [&](int g) {                                        // the group's halo and dY block -> registers (zero outside the image)
-        const int gxy = a.gx * a.gy;
-        const int b = g / gxy, r_ = g - b * gxy, gyi = r_ / a.gx, gxi = r_ - gyi * a.gx;
-        const int y0 = gyi * WW_GH, x0 = gxi * WW_GW;
-        const f32x4 zero = {0, 0, 0, 0};
+    // ---- staging: the V waves (threads 0..127) the dY block, the D waves (threads 128..255) the halo; float4 = (pixel, channel quad)
+    const int u = (wave & 1) * 64 + lane;                            // 0..127 within the wave pair
+    int voff[NIT], xc[NIT], soff_l[NIT];
 #pragma unroll
-        for (int it = 0; it < WW_X_IT; ++it) {
-            const int idx = tid + 256 * it, q = idx & 7, px = idx >> 3, r = px / WW_HC, c = px - r * WW_HC;
-            const int y = y0 - 1 + r, x = x0 - 1 + c;
-            const bool ok = px < WW_HR * WW_HC && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            xr[it] = ok ? nd_ld4(a.x + ((size_t)(b * a.H + y) * a.W + x) * a.ldx + ci0 + 4 * q) : zero;
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = u + 128 * it, q = idx & 7, px = idx >> 3;
+        if constexpr (ISV) {
+            const int r = px / WW_GW, c = px - r * WW_GW;
+            voff[it] = ((r * a.W + c) * a.ldy + co0 + 4 * q) * 4;
+            xc[it] = 0;
+            soff_l[it] = (WW_XF + px * WW_PS + 4 * q);
+        } else {
+            const int r = px / WW_HC, c = px - r * WW_HC;
+            voff[it] = (((r - 1) * a.W + (c - 1)) * a.ldx + ci0 + 4 * q) * 4;
+            xc[it] = px < WW_HR * WW_HC ? c - 1 : (1 << 30);        // past the halo: always out of range (the register is never written to LDS)
+            soff_l[it] = px * WW_PS + 4 * q;
         }
+    }
+    const int ld = ISV ? a.ldy : a.ldx;
+    const float* const src = ISV ? a.dy : a.x;
+    const int sample_bytes = a.H * a.W * ld * 4;
+    // the group the next request is for (scalar state; past the last group it stays there)
+    int lg = g_lo, lb, lgy, lgx;
+    {
+        const int gxy = a.gx * a.gy;
+        lb = lg / gxy;  const int r_ = lg - lb * gxy;  lgy = r_ / a.gx;  lgx = r_ - lgy * a.gx;
+    }
+    f32x4 sr[NIT];
+    auto request = [&]() {
+#ifdef WW_DIAG_NOREQ
+        if (lg > g_lo) return;
+#endif
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) + (size_t)lb * a.H * a.W * ld, 0, sample_bytes, 0x00020000);
+        const int base = ((lgy * WW_GH) * a.W + lgx * WW_GW) * ld * 4;
+        const int x0 = lgx * WW_GW;
 #pragma unroll
-        for (int it = 0; it < WW_Y_IT; ++it) {
-            const int idx = tid + 256 * it, q = idx & 7, px = idx >> 3, r = px / WW_GW, c = px - r * WW_GW;
-            yr[it] = nd_ld4(a.dy + ((size_t)(b * a.H + y0 + r) * a.W + x0 + c) * a.ldy + co0 + 4 * q);
+        for (int it = 0; it < NIT; ++it) {
+            int vo = voff[it] + base;
+            if constexpr (!ISV) vo = (unsigned)(x0 + xc[it]) < (unsigned)a.W ? vo : (int)0x80000000;      // rows outside the image are out of range by themselves
+            sr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+        }
+        if (lg + 1 < g_hi) {
+            ++lg;
+            if (++lgx == a.gx) { lgx = 0;  if (++lgy == a.gy) { lgy = 0;  ++lb; } }
         }
     };
-    if (g_lo < g_hi) issue(g_lo);
-    for (int g = g_lo; g < g_hi; ++g) {
+
+    // ---- transform role: thread (tile t, channel pair cp) of the wave's row half
+    const int t = lane >> 4, cp = lane & 15;
+    const int rd_off = (ISV ? 0 : WW_XF) + 4 * t * WW_PS + 2 * cp;   // in a raw buffer
+    const int wr_off = (ISV ? 0 : WW_VDF) + t * WW_CB + 2 * cp;      // in a (V, D) pair: + pos * 128
+    const int op_off = (9 * wave * WW_NT + half) * WW_CB + col;      // operands of this wave's positions: + p * 128 (+ 64: the second tile of the lane's K slot)
+
+#ifdef WW_STAMP                  // diagnostic (tools/wgrad_clock.py): shader-clock stamps per wave -> operand wait / the 18 slots / barrier wait per iteration, clock under load
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_a = 0, st_b = 0, st_c = 0;
+#endif
+    int par = 0;
+    auto iteration = [&](auto with_mfma, const int i) {
+        constexpr bool MF = decltype(with_mfma)::value;
+#ifdef WW_STAMP
+        if constexpr (MF) st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        const float* const rbuf = sm + (par ^ 1) * WW_RAWF + rd_off;
+        float* const wbuf = sm + par * WW_RAWF;
+        const float* const opv = sm + 2 * WW_RAWF + par * (2 * WW_VDF) + op_off;
+        float* const vdw = sm + 2 * WW_RAWF + (par ^ 1) * (2 * WW_VDF) + wr_off;
+        f32x2 av[9], bv[9];
+        if constexpr (MF) {
 #pragma unroll
-        for (int it = 0; it < WW_X_IT; ++it) {
-            const int idx = tid + 256 * it;
-            if (idx < WW_HR * WW_HC * 8) nd_st4(Xs + (idx >> 3) * WW_CB + 4 * (idx & 7), xr[it]);
-        }
-#pragma unroll
-        for (int it = 0; it < WW_Y_IT; ++it) {
-            const int idx = tid + 256 * it;
-            nd_st4(Ys + (idx >> 3) * WW_CB + 4 * (idx & 7), yr[it]);
-        }
-        __syncthreads();                                             // the group's raw data is in LDS (and every wave is done with the previous group's MFMAs)
-        if (g + 1 < g_hi) issue(g + 1);                              // the next group's loads fly over this group's transforms and MFMAs
-        if (t_isV) {    // V = B^T d B of this thread's (tile, cin pair): 36 8-byte reads, two packed passes, 72 writes
-            ww_f2 T[6][6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                ww_f2 d[6], t[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const ww_f2*>(Xs + ((4 * t_ty + i) * WW_HC + 4 * t_tx + j) * WW_CB + t_ch);
-                ww_bt6(d, t);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) T[i][j] = t[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                ww_f2 v[6];
-                ww_bt6(T[i], v);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    float* o = Vs + ((i * 6 + j) * WW_CB + t_ch) * WW_LDT + t_tile;
-                    o[0] = v[j].x;  o[WW_LDT] = v[j].y;
-                }
-            }
-        } else {        // D = A dY A^T of this thread's (tile, cout pair): 16 reads, 72 writes; the bias gradient's share on the way
-            ww_f2 U[6][4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                ww_f2 y[4], o[6];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) y[m] = *reinterpret_cast<const ww_f2*>(Ys + ((4 * t_ty + m) * WW_GW + 4 * t_tx + n) * WW_CB + t_ch);
-                if (do_bias) bsum2 += (y[0] + y[1]) + (y[2] + y[3]);
-                ww_a4(y, o);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) U[i][n] = o[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                ww_f2 o6[6];
-                ww_a4(U[i], o6);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    float* o = Ds + ((i * 6 + j) * WW_CB + t_ch) * WW_LDT + t_tile;
-                    o[0] = o6[j].x;  o[WW_LDT] = o6[j].y;
-                }
+            for (int p = 0; p < 9; ++p) {
+                av[p][0] = opv[WW_VDF + p * 128];  av[p][1] = opv[WW_VDF + p * 128 + 64];
+                bv[p][0] = opv[p * 128];           bv[p][1] = opv[p * 128 + 64];
             }
         }
-        __syncthreads();                                             // V and D of the group are complete
-        // all operands of the wave's nine positions first (one LDS round trip for the lot: left next to their MFMAs, hipcc waits for every read in
-        // front of its MFMA -- 36 exposed LDS latencies per group), then 36 MFMAs back to back.  K step k of an instruction = tiles {k, 4 + k}: lane
-        // (channel, half) holds tiles 4 half .. 4 half + 3 of its channel -- 16 contiguous bytes per operand and position.
-        f32x4 av[9], bv[9];
-#pragma unroll
-        for (int p = 0; p < 9; ++p) {
-            const int o = ((wave * 9 + p) * WW_CB + col) * WW_LDT + 4 * half;
-            av[p] = *reinterpret_cast<const f32x4*>(Ds + o);
-            bv[p] = *reinterpret_cast<const f32x4*>(Vs + o);
+        f32x16 (&accr)[9] = acc;                                     // (an asm operand alone does not capture)
+#define WW_MFMA(k)                                                                                                             \
+        if constexpr (MF) {                                                                                                    \
+            const float a_ = av[(k) % 9][(k) / 9], b_ = bv[(k) % 9][(k) / 9];                                                  \
+            WW_DIAG_MFMA_ASM(k)                                                                                                \
         }
-        __builtin_amdgcn_sched_barrier(0);
+        auto commit = [&](auto ii) {                                 // W: one staged float4 -> the raw buffer
+            constexpr int it = decltype(ii)::value;
+            if (ISV || it < NIT - 1 || u < WW_HR * WW_HC * 8 - 128 * (NIT - 1)) nd_st4(wbuf + soff_l[it], sr[it]);
+        };
+        const bool count_bias = do_bias && i + 1 >= 0 && i + 1 < n;
+#define WW_K(k) std::integral_constant<int, (k)>{}
+#ifdef WW_STAMP
+#define WW_STAMP1(k) if constexpr (MF && (k) == 0) st_t1 = __builtin_amdgcn_s_memtime();
+#else
+#define WW_STAMP1(k)
+#endif
+#define WW_SB() __builtin_amdgcn_sched_barrier(0)
+        if constexpr (ISV) {
+            ww_f2 X6[6][6], T[3][6];
 #pragma unroll
-        for (int p = 0; p < 9; ++p)
-#pragma unroll
-            for (int k = 0; k < WW_NT / 2; ++k) {
-                const float a_ = av[p][k], b_ = bv[p][k];                // (element k of the float4s)
-                // accumulators pinned to the AGPR half by the constraint (the file is built with hipcc's VGPR-form switch for the nine-tap kernel: left to the
-                // builtin, 144 accumulator registers + the transforms' values overflow the VGPR half and hipcc shuttles them through v_accvgpr_mov / read / write)
-                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[p]) : "v"(a_), "v"(b_));
+            for (int r = 0; r < 6; ++r) X6[0][r] = *reinterpret_cast<const ww_f2*>(rbuf + (r * WW_HC) * WW_PS);
+            WW_SB();
+            // slots 0..5: column k of the patch through the wave's three rows of B^T (the next column's six reads in flight)
+#define WW_COL(k)                                                                                                              \
+            WW_MFMA((k));  WW_STAMP1(k)                                                                                       \
+            if constexpr ((k) < 5) {                                                                                           \
+                _Pragma("unroll") for (int r = 0; r < 6; ++r) X6[(k) + 1][r] = *reinterpret_cast<const ww_f2*>(rbuf + (r * WW_HC + (k) + 1) * WW_PS); \
+            }                                                                                                                  \
+            { ww_f2 t3[3];  ww_bt3<RH>(X6[k], t3);  T[0][k] = t3[0];  T[1][k] = t3[1];  T[2][k] = t3[2]; }                      \
+            WW_SB();
+            WW_COL(0) WW_COL(1) WW_COL(2) WW_COL(3) WW_COL(4) WW_COL(5)
+#undef WW_COL
+            // slots 6..17: row r through all of B^T, its six 8-byte writes spread over four slots; the staged float4s and the next requests beside them
+#define WW_ROW(r, E0, E1)                                                                                                      \
+            {                                                                                                                  \
+                ww_f2 v[6];                                                                                                    \
+                float* const o = vdw + ((3 * RH + (r)) * 6) * 128;                                                             \
+                WW_MFMA((6 + 4 * (r)));  ww_bt6(T[r], v);                                                                     \
+                WW_ST2(o, v[0]);  WW_ST2(o + 128, v[1]);  WW_SB();                     \
+                WW_MFMA((7 + 4 * (r)));                                                                                       \
+                WW_ST2(o + 256, v[2]);  WW_ST2(o + 384, v[3]);  WW_SB();               \
+                WW_MFMA((8 + 4 * (r)));  WW_ST2(o + 512, v[4]);  E0;  WW_SB();                            \
+                WW_MFMA((9 + 4 * (r)));  WW_ST2(o + 640, v[5]);  E1;  WW_SB();                            \
             }
-        __builtin_amdgcn_sched_barrier(0);
+            WW_ROW(0, commit(WW_K(0)), commit(WW_K(1)))
+            WW_ROW(1, commit(WW_K(2)), commit(WW_K(3)))
+            WW_ROW(2, (void)0, request())
+#undef WW_ROW
+        } else {
+            ww_f2 Y4[4][4], U[3][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Y4[0][m] = *reinterpret_cast<const ww_f2*>(rbuf + (m * WW_GW) * WW_PS);
+            WW_SB();
+            // slots 0..3: column k of the dY tile through the wave's three rows of A, one staged float4 each
+#define WW_COL(k)                                                                                                              \
+            WW_MFMA((k));  WW_STAMP1(k)                                                                                       \
+            if constexpr ((k) < 3) {                                                                                           \
+                _Pragma("unroll") for (int m = 0; m < 4; ++m) Y4[(k) + 1][m] = *reinterpret_cast<const ww_f2*>(rbuf + (m * WW_GW + (k) + 1) * WW_PS); \
+            }                                                                                                                  \
+            { ww_f2 o3[3];  ww_a3<RH>(Y4[k], o3);  U[0][k] = o3[0];  U[1][k] = o3[1];  U[2][k] = o3[2]; }                       \
+            if (count_bias) bsum2 += (Y4[k][0] + Y4[k][1]) + (Y4[k][2] + Y4[k][3]);                                            \
+            commit(WW_K(k));                                                                                                   \
+            WW_SB();
+            WW_COL(0) WW_COL(1) WW_COL(2) WW_COL(3)
+#undef WW_COL
+#define WW_ROW(r, E0, E1)                                                                                                      \
+            {                                                                                                                  \
+                ww_f2 v[6];                                                                                                    \
+                float* const o = vdw + ((3 * RH + (r)) * 6) * 128;                                                             \
+                WW_MFMA((4 + 4 * (r)));  ww_a6(U[r], v);                                                                      \
+                WW_ST2(o, v[0]);  WW_ST2(o + 128, v[1]);  WW_SB();                     \
+                WW_MFMA((5 + 4 * (r)));                                                                                       \
+                WW_ST2(o + 256, v[2]);  WW_ST2(o + 384, v[3]);  WW_SB();               \
+                WW_MFMA((6 + 4 * (r)));  WW_ST2(o + 512, v[4]);  E0;  WW_SB();                            \
+                WW_MFMA((7 + 4 * (r)));  WW_ST2(o + 640, v[5]);  E1;  WW_SB();                            \
+            }
+            WW_ROW(0, commit(WW_K(4)), commit(WW_K(5)))
+            WW_ROW(1, commit(WW_K(6)), (void)0)
+            WW_ROW(2, (void)0, (void)0)
+#undef WW_ROW
+            WW_MFMA((16));  request();  WW_SB();
+            WW_MFMA((17));  WW_SB();
+        }
+#undef WW_K
+#undef WW_STAMP1
+#undef WW_MFMA
+#undef WW_SB
+#ifdef WW_STAMP
+        if constexpr (MF) st_t2 = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS writes have landed (its global requests stay in flight) ...
+        __builtin_amdgcn_s_barrier();                                // ... and so have every other wave's; all operand reads of the iteration are done
+#ifdef WW_STAMP
+        if constexpr (MF) { const unsigned long long t3 = __builtin_amdgcn_s_memtime();  st_a += st_t1 - st_t0;  st_b += st_t2 - st_t1;  st_c += t3 - st_t2; }
+#endif
+        par ^= 1;
+    };
+
+    request();                                                       // group 0
+    iteration(std::false_type{}, -2);
+    iteration(std::false_type{}, -1);
+    for (int i = 0; i < n; ++i) iteration(std::true_type{}, i);
+
+#ifdef WW_STAMP
+    if (lane == 0) {
+        float* dbg = a.ws + (size_t)a.S * 36 * a.cout * a.cin + (size_t)a.S * a.cout + ((size_t)blockIdx.x * 4 + wave) * 8;
+        dbg[0] = (float)(__builtin_amdgcn_s_memtime() - st_c0);  dbg[1] = (float)(__builtin_amdgcn_s_memrealtime() - st_r0);
+        dbg[2] = (float)n;  dbg[3] = (float)st_a;  dbg[4] = (float)st_b;  dbg[5] = (float)st_c;
     }
+#endif
     // ---- this workgroup's partial sums: ws[s][pos][co][ci]  (the MFMAs are asm statements: hipcc does not know their results are still in flight)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
@@ -445,17 +575,25 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WwArgs a) {
             const int co = co0 + nd_acc_row(r, lane), ci = ci0 + col;
             a.ws[(((size_t)s * 36 + wave * 9 + p) * coP + co) * ciP + ci] = acc[p][r];
         }
-    if (do_bias) {                                                   // the eight tile threads of a cout pair meet in a fixed order
+    if (a.wsb != nullptr && cib == 0) {                              // the four tile threads of a cout pair meet in a fixed order (every wave passes both barriers)
+        if (do_bias) { sm[(t * 16 + cp) * 2] = bsum2.x;  sm[(t * 16 + cp) * 2 + 1] = bsum2.y; }
         __syncthreads();
-        if (!t_isV) { Xs[(t_tile * 16 + t_cp) * 2] = bsum2.x;  Xs[(t_tile * 16 + t_cp) * 2 + 1] = bsum2.y; }
-        __syncthreads();
-        if (tid < WW_CB) {
-            float v = Xs[tid];
+        if (wave == 0 && lane < WW_CB) {
+            float v = sm[lane];
 #pragma unroll
-            for (int t = 1; t < WW_NT; ++t) v += Xs[t * WW_CB + tid];
-            a.wsb[(size_t)s * coP + co0 + tid] = v;
+            for (int tt = 1; tt < WW_NT; ++tt) v += sm[tt * WW_CB + lane];
+            a.wsb[(size_t)s * coP + co0 + lane] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;     // scalar: the four roles are wave-uniform branches
+    if (wave == 0) ww_wave<true, 0>(a, sm, wave, lane);
+    else if (wave == 1) ww_wave<true, 1>(a, sm, wave, lane);
+    else if (wave == 2) ww_wave<false, 0>(a, sm, wave, lane);
+    else ww_wave<false, 1>(a, sm, wave, lane);
 }
 
 // The S partials [s][pos][co][ci] (+ the bias partials [s][co]) summed in split order into the split-0 slot: a thread owns one element -- 36 cout cin
@@ -552,7 +690,7 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
     ND_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx >= cin && ldy >= cout && ldx % 4 == 0 && ldy % 4 == 0, ND_E_SHAPE,
                "nd_conv3x3_wgrad: cin=%d, cout=%d and the pixel strides must be multiples of 4", cin, cout);
     ND_REQUIRE(nd_aligned16(x) && nd_aligned16(dy), ND_E_ALIGN, "nd_conv3x3_wgrad: x and dy must be 16-byte aligned");
-    if (ww_takes(B, H, W, cin, cout)) {                                  // F(4x4) Winograd-domain form (a quarter of the MFMAs)
+    if (ww_takes(B, H, W, cin, cout) && (long)H * W * ldx * 4 < (1L << 30) && (long)H * W * ldy * 4 < (1L << 30)) {     // F(4x4) Winograd-domain form (a quarter of the MFMAs); 32-bit offsets within a sample
         WwArgs w;
         ww_plan(B, H, W, cin, cout, w);
         w.x = x; w.dy = dy; w.ws = workspace; w.ldx = ldx; w.ldy = ldy;

@@ -45,10 +45,11 @@ def test_conv3x3_autograd_matches_torch(case):
     assert rel_err(wa.grad.cpu().numpy(), outs[0][2].numpy()) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 32, 64, 128), (2, 48, 24, 64, 128), (4, 64, 64, 32, 32), (1, 16, 16, 512, 256), (3, 40, 48, 96, 64), (2, 48, 32, 48, 64)])
+@pytest.mark.parametrize("shape", [(2, 48, 32, 64, 128), (2, 48, 24, 64, 128), (4, 64, 64, 32, 32), (1, 16, 16, 512, 256), (3, 40, 48, 96, 64), (2, 48, 32, 48, 64),
+                                   (1, 4, 16, 32, 64), (2, 12, 16, 32, 32), (1, 6, 16, 32, 32)])
 def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum(shape):
-    """nd_conv3x3_wgrad_nhwc_f32 in both of its forms: the Winograd-domain F(4x4) kernel (H % 8 == 0, W % 16 == 0, channel counts % 32 == 0: r5) and the
-    nine-tap kernel (everything else: here W = 24 and cin = 48) against a float64 weight gradient; bitwise repeatable, bias gradient, argument checks."""
+    """nd_conv3x3_wgrad_nhwc_f32 in both of its forms: the Winograd-domain F(4x4) kernel (H % 4 == 0, W % 16 == 0, channel counts % 32 == 0: r5; down to a
+    single tile group per workgroup) and the nine-tap kernel (everything else: here W = 24, H = 6 and cin = 48) against a float64 weight gradient; bitwise repeatable, bias gradient, argument checks."""
     lib = L.load()
     B, H, W, cin, cout = shape
     x = U("wg.x", (B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
