@@ -265,25 +265,26 @@ void plan(int B, int H, int W, int cin, int cout, WgradArgs& a) {
 // 36 multiplies per 16 pixels instead of 144 -- a quarter of the nine-tap form's MFMAs.  fp32 error against an fp64 sum: ~3-5e-6 of max|dW|
 // (the nine-tap form: 4e-7; tests/test_train_gpu.py holds both to 2e-5).
 //
-// A workgroup owns a (32 couts x 32 cins) block of all 36 positions -- wave w the positions 9 w .. 9 w + 8, nine 32 x 32 accumulators -- and walks
-// its share of the tile groups (2 x 4 tiles = 8 x 16 pixels).  Per group: the 10 x 18 x 32 input halo and the 8 x 16 x 32 dY block go to LDS
-// (requested one group ahead, in registers), thread (tile, channel) transforms one patch of each into V[pos][tile][ch] / D[pos][tile][ch]
-// (the MFMA operands: lane (ch, tile parity) reads one dword each, conflict-free), then 36 MFMAs per wave (v_mfma_f32_32x32x2_f32, K = two
-// tiles).  The split over tile groups is fixed by the shape alone; partials [split][pos][co][ci] and the bias partials go to the workspace and
-// wgrad_wino_reduce_kernel adds them in split order and applies G^T . G.  Bitwise repeatable, no atomics.
-// Taken when H % 8 == 0, W % 16 == 0 and both channel counts are multiples of 32 (every Block.proj of the d = 64 network at the training sizes);
-// anything else keeps the nine-tap kernel above.  ND_WGRAD_WINO=0: A/B knob.
+// A workgroup owns a (32 couts x 32 cins) block of all 36 positions -- wave w the positions 9 w .. 9 w + 8, nine 32 x 32 accumulators pinned in
+// AGPRs -- and walks its share of the tile groups (one row of four tiles = 4 x 16 pixels).  Per group: the 6 x 18 x 32 input halo and the
+// 4 x 16 x 32 dY block go to LDS (requested two groups ahead, in registers), thread (tile, channel pair) transforms half a patch of each into
+// V[pos][tile][ch] / D[pos][tile][ch] (the MFMA operands: lane (ch, tile parity) reads two dwords, conflict-free), then 18 MFMAs per wave
+// (v_mfma_f32_32x32x2_f32, K = two tiles) -- all of it ONE software-pipelined instruction stream per wave (ww_wave below).  The split over tile
+// groups is fixed by the shape alone; partials [split][pos][co][ci] and the bias partials go to the workspace, wgrad_wino_sum_kernel adds them
+// in split order and wgrad_wino_reduce_kernel applies G^T . G.  Bitwise repeatable, no atomics.
+// Taken when H % 4 == 0, W % 16 == 0 and both channel counts are multiples of 32 (every Block.proj of the d = 64 network at the training sizes);
+// anything else keeps the nine-tap kernel above.  ND_WGRAD_WINO=0: A/B knob.  Cycle split and what was tried: profiles/r5_wgrad_wino.txt.
 constexpr int WW_CB = 32;                                            // channels per block, both sides
 constexpr int WW_NT = 4;                                             // tile group: one row of four 4 x 4 tiles
 constexpr int WW_GH = 4, WW_GW = 16;                                 // = 4 x 16 pixels of dY
 constexpr int WW_HR = WW_GH + 2, WW_HC = WW_GW + 2;                  // input halo 6 x 18
-constexpr int WW_PS = 36;                                            // floats per staged pixel: 32 channels + 4 (the four tiles of a wave's 8-byte reads land on distinct bank halves)
+constexpr int WW_PS = 40;                                            // floats per staged pixel: 32 channels + 8 (tiles t, t + 1 of a half wave's 8-byte reads on opposite bank halves)
 constexpr int WW_XF = WW_HR * WW_HC * WW_PS, WW_YF = WW_GH * WW_GW * WW_PS, WW_RAWF = WW_XF + WW_YF;     // one raw buffer: halo, then the dY block
 constexpr int WW_VDF = 36 * WW_NT * WW_CB;                           // one operand image [pos][tile][channel]
-constexpr size_t WW_LDS = (size_t)(2 * WW_RAWF + 4 * WW_VDF) * sizeof(float);      // two raw buffers + two (V, D) pairs: 123264 bytes
+constexpr size_t WW_LDS = (size_t)(2 * WW_RAWF + 4 * WW_VDF) * sizeof(float);      // two raw buffers + two (V, D) pairs: 128768 bytes
 constexpr int WW_TARGET_WGS = 256;                                   // fixed: the summation order must not depend on the device
-constexpr int WW_X_IT = (WW_HR * WW_HC * (WW_CB / 4) + 127) / 128;   // 7 float4 of the halo per thread of the two D waves
-constexpr int WW_Y_IT = WW_GH * WW_GW * (WW_CB / 4) / 128;           // 4 float4 of the dY block per thread of the two V waves
+constexpr int WW_X_IT = 7;                                           // float4s of the halo per thread of the two D waves: six rows of 16 columns, the two last columns
+constexpr int WW_Y_IT = 4;                                           // float4s of the dY block per thread of the two V waves: its four rows
 
 struct WwArgs {
     const float* x; const float* dy; float* ws; float* wsb;
@@ -292,16 +293,10 @@ struct WwArgs {
 };
 
 typedef float ww_f2 __attribute__((ext_vector_type(2)));
-#ifdef WW_DIAG_NOMFMA
-#define WW_DIAG_MFMA_ASM(k) asm volatile("" :: "v"(a_), "v"(b_));
-#else
-#define WW_DIAG_MFMA_ASM(k) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(accr[(k) % 9]) : "v"(a_), "v"(b_));
-#endif
-#ifdef WW_DIAG_NOWRITE
-#define WW_ST2(p, v) asm volatile("" :: "v"(v))
-#else
+// (s_nop 1: hipcc places no wait states between a VALU / v_accvgpr_write it put in front of an asm statement and the MFMA reading that register; free next to a 64-cycle MFMA)
+#define WW_MFMA_ASM(k) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(accr[(k) % 9]) : "v"(a_), "v"(b_));
+#define WW_LDRAW(p) (*reinterpret_cast<const ww_f2*>(p))
 #define WW_ST2(p, v) *reinterpret_cast<ww_f2*>(p) = (v)
-#endif
 // Rows 3 RH .. 3 RH + 2 of B^T applied to six values / all six rows (float2: two channels at once, packed instructions)
 template <int RH>
 __device__ __forceinline__ void ww_bt3(const ww_f2 (&d)[6], ww_f2 (&t)[3]) {
@@ -351,16 +346,18 @@ __device__ __forceinline__ void ww_a6(const ww_f2 (&y)[4], ww_f2 (&o)[6]) {
     o[5] = y[3];
 }
 
-// One wave of the Winograd-domain kernel.  ISV: the wave transforms input patches (V) and stages the dY block; otherwise it transforms dY blocks (D),
-// stages the input halo and (RH == 0) collects the bias gradient.  RH: which three of the six transform rows it produces.  Every wave also owns nine
-// of the 36 positions' accumulators.  An iteration i of the pipeline holds, as ONE instruction stream of 18 slots -- an MFMA (64 cycles of the matrix
+// One wave of the Winograd-domain kernel.  ISV: the wave transforms input patches (V) and stages the dY block; otherwise it transforms dY blocks (D)
+// and stages the input halo.  RH: which three of the six transform rows it produces.  Every wave also owns nine of the 36 positions' accumulators.
+// The pipeline runs in PHASES from barrier to barrier; phase p holds, as ONE instruction stream of 18 slots -- an MFMA (64 cycles of the matrix
 // pipe) followed by the few VALU / LDS instructions that fit beside it (an LDS write issued right behind an MFMA costs ~2 cycles instead of its 32;
-// on its own the transforms' LDS writes alone take as long as the MFMAs: profiles/r5_wgrad_wino.txt):
-//     M(i)    the 18 MFMAs of group i on the operand images VD[i & 1]
-//     X(i+1)  this thread's half transform of group i + 1: raw[(i + 1) & 1] -> VD[(i + 1) & 1]
-//     W(i+2)  its staged float4s of group i + 2: registers -> raw[i & 1]
-//     L(i+3)  the requests for group i + 3
-// and ends in one barrier.  Iterations -2 and -1 fill the pipeline (no MFMAs); past the last group X / W / L run on clamped, unused data.
+// on their own the transforms' LDS writes alone take as long as the MFMAs: profiles/r5_wgrad_wino.txt):
+//     MFMAs 15..17 of group p - 1 (operand registers of set (p - 1) & 1), then MFMAs 0..14 of group p (set p & 1)
+//     R(p)    the operands of group p: VD[p & 1] -> register set p & 1, three slots ahead of their first MFMA
+//     X(p+1)  this thread's half transform of group p + 1: raw[(p + 1) & 1] -> VD[(p + 1) & 1]
+//     W(p+2)  its staged float4s of group p + 2: staging set p & 1 -> raw[p & 1]
+//     L(p+3)  the requests for group p + 3 into staging set (p + 1) & 1 (a whole phase in flight)
+// Everything indexed by the parity of p is a compile-time constant of the two copies of the phase (register sets, LDS offsets as immediates).
+// Phases -2 and -1 fill the pipeline (no MFMAs); past the last group X / W / L run on clamped, unused data.
 template <bool ISV, int RH>
 __device__ __forceinline__ void ww_wave(const WwArgs& a, float* sm, const int wave, const int lane) {
     constexpr int NIT = ISV ? WW_Y_IT : WW_X_IT;
@@ -374,49 +371,52 @@ __device__ __forceinline__ void ww_wave(const WwArgs& a, float* sm, const int wa
     f32x16 acc[9];
 #pragma unroll
     for (int p = 0; p < 9; ++p) acc[p] = nd_zero16();
-    const bool do_bias = !ISV && RH == 0 && a.wsb != nullptr && cib == 0;
-    ww_f2 bsum2 = {0.0f, 0.0f};
+    // the bias gradient rides on the operands: position (1, 1) of D = A dY A^T is the plain sum of the tile's 16 values (row 1 of A is all ones), and
+    // wave 0 reads D[7][cout][its two tiles] as an MFMA operand anyway
+    const bool do_bias = ISV && RH == 0 && a.wsb != nullptr && cib == 0;
+    float bsum = 0.0f;
 
-    // ---- staging: the V waves (threads 0..127) the dY block, the D waves (threads 128..255) the halo; float4 = (pixel, channel quad)
+    // ---- staging: a thread of the V waves = (column c of the 4 x 16 dY block, channel quad), its items the four rows; a thread of the D waves =
+    // (column c < 16 of the 6 x 18 halo, quad), items 0..5 the rows, item 6 = the two last columns as (row, column, quad) on 96 lanes.  The row goes
+    // into the scalar offset of the request, the group into the resource's base, so the lane offsets are constants; what lies outside the image is
+    // requested out of range (-> zeros): one select for the left edge, one each for the top and the bottom row, a mask test for item 6.
     const int u = (wave & 1) * 64 + lane;                            // 0..127 within the wave pair
-    int voff[NIT], xc[NIT], soff_l[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = u + 128 * it, q = idx & 7, px = idx >> 3;
-        if constexpr (ISV) {
-            const int r = px / WW_GW, c = px - r * WW_GW;
-            voff[it] = ((r * a.W + c) * a.ldy + co0 + 4 * q) * 4;
-            xc[it] = 0;
-            soff_l[it] = (WW_XF + px * WW_PS + 4 * q);
-        } else {
-            const int r = px / WW_HC, c = px - r * WW_HC;
-            voff[it] = (((r - 1) * a.W + (c - 1)) * a.ldx + ci0 + 4 * q) * 4;
-            xc[it] = px < WW_HR * WW_HC ? c - 1 : (1 << 30);        // past the halo: always out of range (the register is never written to LDS)
-            soff_l[it] = px * WW_PS + 4 * q;
-        }
-    }
     const int ld = ISV ? a.ldy : a.ldx;
     const float* const src = ISV ? a.dy : a.x;
-    const int sample_bytes = a.H * a.W * ld * 4;
-    // the group the next request is for (scalar state; past the last group it stays there)
-    int lg = g_lo, lb, lgy, lgx;
+    const int sc = u >> 3, sq = u & 7;
+    const int OOB = (int)0x80000000;
+    const int vl = (sc * ld + (ISV ? co0 : ci0) + 4 * sq) * 4;
+    const int vl_left = (!ISV && sc == 0) ? OOB : vl;                // left image edge: halo column 0 is padding
+    const int r6 = u >> 4, c6 = 16 + ((u >> 3) & 1);
+    const int v6 = ((r6 * a.W + c6) * ld + ci0 + 4 * sq) * 4;
+    const int code6 = (c6 == 17 ? 1 : 0) | (r6 == 0 ? 2 : 0) | (r6 == 5 ? 4 : 0) | (u >= 96 ? 8 : 0);
+    const int lds_c = (ISV ? WW_XF : 0) + sc * WW_PS + 4 * sq;       // + row * (16 | 18) * WW_PS
+    const int lds_6 = (r6 * WW_HC + c6) * WW_PS + 4 * sq;
+    const int row_bytes = a.W * ld * 4;
+    int lg = g_lo, lb, lgy, lgx;                                     // the group the next request is for (scalar state; past the last group it stays there)
     {
         const int gxy = a.gx * a.gy;
         lb = lg / gxy;  const int r_ = lg - lb * gxy;  lgy = r_ / a.gx;  lgx = r_ - lgy * a.gx;
     }
-    f32x4 sr[NIT];
-    auto request = [&]() {
-#ifdef WW_DIAG_NOREQ
-        if (lg > g_lo) return;
-#endif
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) + (size_t)lb * a.H * a.W * ld, 0, sample_bytes, 0x00020000);
-        const int base = ((lgy * WW_GH) * a.W + lgx * WW_GW) * ld * 4;
-        const int x0 = lgx * WW_GW;
+    f32x4 sr[2][NIT];
+    auto request = [&](auto set_) {
+        constexpr int SET = decltype(set_)::value;
+        const int y0 = lgy * WW_GH, x0 = lgx * WW_GW;
+        const long org = ((long)(lb * a.H + y0 - (ISV ? 0 : 1)) * a.W + x0 - (ISV ? 0 : 1)) * ld;      // (for the halo: may lie in front of the tensor; never dereferenced there)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) + org, 0, 0x7fffffff, 0x00020000);
+        if constexpr (ISV) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            int vo = voff[it] + base;
-            if constexpr (!ISV) vo = (unsigned)(x0 + xc[it]) < (unsigned)a.W ? vo : (int)0x80000000;      // rows outside the image are out of range by themselves
-            sr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+            for (int it = 0; it < NIT; ++it) sr[SET][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vl, it * row_bytes, 0));
+        } else {
+            const bool left = x0 == 0, right = x0 + WW_GW == a.W, top = y0 == 0, bottom = y0 + WW_GH == a.H;
+            const int vm = left ? vl_left : vl;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int vo = (it == 0 && top) || (it == 5 && bottom) ? OOB : vm;
+                sr[SET][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, it * row_bytes, 0));
+            }
+            const int edge = (right ? 1 : 0) | (top ? 2 : 0) | (bottom ? 4 : 0) | 8;
+            sr[SET][6] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (code6 & edge) ? OOB : v6, 0, 0));
         }
         if (lg + 1 < g_hi) {
             ++lg;
@@ -430,160 +430,170 @@ __device__ __forceinline__ void ww_wave(const WwArgs& a, float* sm, const int wa
     const int wr_off = (ISV ? 0 : WW_VDF) + t * WW_CB + 2 * cp;      // in a (V, D) pair: + pos * 128
     const int op_off = (9 * wave * WW_NT + half) * WW_CB + col;      // operands of this wave's positions: + p * 128 (+ 64: the second tile of the lane's K slot)
 
-#ifdef WW_STAMP                  // diagnostic (tools/wgrad_clock.py): shader-clock stamps per wave -> operand wait / the 18 slots / barrier wait per iteration, clock under load
+    f32x2 av[2][9], bv[2][9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) { av[1][p] = f32x2{0.0f, 0.0f};  bv[1][p] = f32x2{0.0f, 0.0f}; }       // phase 0 runs "MFMAs 15..17 of group -1" on these
+    f32x16 (&accr)[9] = acc;                                         // (an asm operand alone does not capture)
+#ifdef WW_STAMP                  // diagnostic (tools/wgrad_clock.py): shader-clock stamps per wave -> slots / barrier wait per phase, clock under load
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_a = 0, st_b = 0, st_c = 0;
+    unsigned long long st_t0 = 0, st_t2 = 0, st_b = 0, st_c = 0;
 #endif
-    int par = 0;
-    auto iteration = [&](auto with_mfma, const int i) {
+
+#define WW_MFMA(set, k)                                                                                                        \
+        if constexpr (MF) {                                                                                                    \
+            const float a_ = av[set][(k) % 9][(k) / 9], b_ = bv[set][(k) % 9][(k) / 9];                                        \
+            WW_MFMA_ASM(k)                                                                                                     \
+        }
+#define WW_SB() __builtin_amdgcn_sched_barrier(0)
+    auto phase = [&](auto par_, auto with_mfma) {
+        constexpr int P = decltype(par_)::value, Q = P ^ 1;
         constexpr bool MF = decltype(with_mfma)::value;
+        const float* const rbuf = sm + Q * WW_RAWF + rd_off;                                         // X(p+1) reads raw[(p+1) & 1]
+        float* const wbuf = sm + P * WW_RAWF;                                                         // W(p+2) writes raw[p & 1]
+        const float* const opv = sm + 2 * WW_RAWF + P * (2 * WW_VDF) + op_off;                        // R(p) reads VD[p & 1]
+        float* const vdw = sm + 2 * WW_RAWF + Q * (2 * WW_VDF) + wr_off + (3 * RH * 6) * 128;        // X(p+1) writes its rows of VD[(p+1) & 1]
+        auto commit = [&](auto ii, auto hh) {                        // W: half of one staged float4 -> the raw buffer.  8-byte writes: behind an MFMA a ds_write_b64
+            constexpr int it = decltype(ii)::value, h = decltype(hh)::value;      // costs the wave ~2 cycles, a ds_write_b128 ~80 (tools/wgrad_clock.py)
+            const ww_f2 v = h ? ww_f2{sr[P][it][2], sr[P][it][3]} : ww_f2{sr[P][it][0], sr[P][it][1]};
+            float* d;
+            if constexpr (ISV) d = wbuf + lds_c + it * WW_GW * WW_PS;
+            else if constexpr (it < 6) d = wbuf + lds_c + it * WW_HC * WW_PS;
+            else d = wbuf + lds_6;
+            if (ISV || it < 6 || u < 96) *reinterpret_cast<ww_f2*>(d + 2 * h) = v;
+        };
+#define WW_I(k) std::integral_constant<int, (k)>{}
+#define WW_C(it, h) commit(WW_I(it), WW_I(h))
 #ifdef WW_STAMP
         if constexpr (MF) st_t0 = __builtin_amdgcn_s_memtime();
 #endif
-        const float* const rbuf = sm + (par ^ 1) * WW_RAWF + rd_off;
-        float* const wbuf = sm + par * WW_RAWF;
-        const float* const opv = sm + 2 * WW_RAWF + par * (2 * WW_VDF) + op_off;
-        float* const vdw = sm + 2 * WW_RAWF + (par ^ 1) * (2 * WW_VDF) + wr_off;
-        f32x2 av[9], bv[9];
+        // ---- slots 15..17 of the previous group: this group's operands, the first staged float4s, the first raw reads, the next requests
+        WW_MFMA(Q, 15)
         if constexpr (MF) {
 #pragma unroll
             for (int p = 0; p < 9; ++p) {
-                av[p][0] = opv[WW_VDF + p * 128];  av[p][1] = opv[WW_VDF + p * 128 + 64];
-                bv[p][0] = opv[p * 128];           bv[p][1] = opv[p * 128 + 64];
+                av[P][p][0] = opv[WW_VDF + p * 128];  av[P][p][1] = opv[WW_VDF + p * 128 + 64];
+                bv[P][p][0] = opv[p * 128];           bv[P][p][1] = opv[p * 128 + 64];
             }
         }
-        f32x16 (&accr)[9] = acc;                                     // (an asm operand alone does not capture)
-#define WW_MFMA(k)                                                                                                             \
-        if constexpr (MF) {                                                                                                    \
-            const float a_ = av[(k) % 9][(k) / 9], b_ = bv[(k) % 9][(k) / 9];                                                  \
-            WW_DIAG_MFMA_ASM(k)                                                                                                \
-        }
-        auto commit = [&](auto ii) {                                 // W: one staged float4 -> the raw buffer
-            constexpr int it = decltype(ii)::value;
-            if (ISV || it < NIT - 1 || u < WW_HR * WW_HC * 8 - 128 * (NIT - 1)) nd_st4(wbuf + soff_l[it], sr[it]);
-        };
-        const bool count_bias = do_bias && i + 1 >= 0 && i + 1 < n;
-#define WW_K(k) std::integral_constant<int, (k)>{}
-#ifdef WW_STAMP
-#define WW_STAMP1(k) if constexpr (MF && (k) == 0) st_t1 = __builtin_amdgcn_s_memtime();
-#else
-#define WW_STAMP1(k)
-#endif
-#define WW_SB() __builtin_amdgcn_sched_barrier(0)
+        if constexpr (ISV) { WW_C(0, 0); } else { WW_C(0, 0);  WW_C(3, 1); }
+        WW_SB();
         if constexpr (ISV) {
             ww_f2 X6[6][6], T[3][6];
+            WW_MFMA(Q, 16)  WW_C(0, 1);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) X6[0][r] = *reinterpret_cast<const ww_f2*>(rbuf + (r * WW_HC) * WW_PS);
+            for (int r = 0; r < 6; ++r) X6[0][r] = WW_LDRAW(rbuf + (r * WW_HC) * WW_PS);
             WW_SB();
+            WW_MFMA(Q, 17)  WW_C(1, 0);  request(WW_I(Q));  WW_SB();
             // slots 0..5: column k of the patch through the wave's three rows of B^T (the next column's six reads in flight)
-#define WW_COL(k)                                                                                                              \
-            WW_MFMA((k));  WW_STAMP1(k)                                                                                       \
+#define WW_COL(k, E)                                                                                                           \
+            WW_MFMA(P, k)                                                                                                      \
             if constexpr ((k) < 5) {                                                                                           \
-                _Pragma("unroll") for (int r = 0; r < 6; ++r) X6[(k) + 1][r] = *reinterpret_cast<const ww_f2*>(rbuf + (r * WW_HC + (k) + 1) * WW_PS); \
+                _Pragma("unroll") for (int r = 0; r < 6; ++r) X6[(k) + 1][r] = WW_LDRAW(rbuf + (r * WW_HC + (k) + 1) * WW_PS); \
             }                                                                                                                  \
             { ww_f2 t3[3];  ww_bt3<RH>(X6[k], t3);  T[0][k] = t3[0];  T[1][k] = t3[1];  T[2][k] = t3[2]; }                      \
-            WW_SB();
-            WW_COL(0) WW_COL(1) WW_COL(2) WW_COL(3) WW_COL(4) WW_COL(5)
+            E;  WW_SB();
+            WW_COL(0, WW_C(1, 1)) WW_COL(1, WW_C(2, 0)) WW_COL(2, WW_C(2, 1)) WW_COL(3, WW_C(3, 0)) WW_COL(4, WW_C(3, 1))
+            WW_COL(5, if (MF && do_bias) bsum += av[P][7][0] + av[P][7][1])
 #undef WW_COL
-            // slots 6..17: row r through all of B^T, its six 8-byte writes spread over four slots; the staged float4s and the next requests beside them
-#define WW_ROW(r, E0, E1)                                                                                                      \
+            // slots 6..14: row r through all of B^T, its six 8-byte writes two per slot
+#define WW_ROW(r)                                                                                                              \
             {                                                                                                                  \
                 ww_f2 v[6];                                                                                                    \
-                float* const o = vdw + ((3 * RH + (r)) * 6) * 128;                                                             \
-                WW_MFMA((6 + 4 * (r)));  ww_bt6(T[r], v);                                                                     \
-                WW_ST2(o, v[0]);  WW_ST2(o + 128, v[1]);  WW_SB();                     \
-                WW_MFMA((7 + 4 * (r)));                                                                                       \
-                WW_ST2(o + 256, v[2]);  WW_ST2(o + 384, v[3]);  WW_SB();               \
-                WW_MFMA((8 + 4 * (r)));  WW_ST2(o + 512, v[4]);  E0;  WW_SB();                            \
-                WW_MFMA((9 + 4 * (r)));  WW_ST2(o + 640, v[5]);  E1;  WW_SB();                            \
+                float* const o = vdw + ((r) * 6) * 128;                                                                        \
+                WW_MFMA(P, 6 + 3 * (r))  ww_bt6(T[r], v);  WW_ST2(o, v[0]);  WW_ST2(o + 128, v[1]);  WW_SB();                  \
+                WW_MFMA(P, 7 + 3 * (r))  WW_ST2(o + 256, v[2]);  WW_ST2(o + 384, v[3]);  WW_SB();                              \
+                WW_MFMA(P, 8 + 3 * (r))  WW_ST2(o + 512, v[4]);  WW_ST2(o + 640, v[5]);  WW_SB();                              \
             }
-            WW_ROW(0, commit(WW_K(0)), commit(WW_K(1)))
-            WW_ROW(1, commit(WW_K(2)), commit(WW_K(3)))
-            WW_ROW(2, (void)0, request())
+            WW_ROW(0) WW_ROW(1) WW_ROW(2)
 #undef WW_ROW
         } else {
             ww_f2 Y4[4][4], U[3][4];
+            WW_MFMA(Q, 16)  WW_C(1, 0);  WW_C(4, 1);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) Y4[0][m] = *reinterpret_cast<const ww_f2*>(rbuf + (m * WW_GW) * WW_PS);
+            for (int m = 0; m < 4; ++m) Y4[0][m] = WW_LDRAW(rbuf + (m * WW_GW) * WW_PS);
             WW_SB();
+            WW_MFMA(Q, 17)  WW_C(2, 0);  WW_C(5, 1);  request(WW_I(Q));  WW_SB();
             // slots 0..3: column k of the dY tile through the wave's three rows of A, one staged float4 each
 #define WW_COL(k)                                                                                                              \
-            WW_MFMA((k));  WW_STAMP1(k)                                                                                       \
+            WW_MFMA(P, k)                                                                                                      \
             if constexpr ((k) < 3) {                                                                                           \
-                _Pragma("unroll") for (int m = 0; m < 4; ++m) Y4[(k) + 1][m] = *reinterpret_cast<const ww_f2*>(rbuf + (m * WW_GW + (k) + 1) * WW_PS); \
+                _Pragma("unroll") for (int m = 0; m < 4; ++m) Y4[(k) + 1][m] = WW_LDRAW(rbuf + (m * WW_GW + (k) + 1) * WW_PS); \
             }                                                                                                                  \
             { ww_f2 o3[3];  ww_a3<RH>(Y4[k], o3);  U[0][k] = o3[0];  U[1][k] = o3[1];  U[2][k] = o3[2]; }                       \
-            if (count_bias) bsum2 += (Y4[k][0] + Y4[k][1]) + (Y4[k][2] + Y4[k][3]);                                            \
-            commit(WW_K(k));                                                                                                   \
-            WW_SB();
+            WW_C(3 + (k), 0);  WW_C(((k) + 6) % 7, 1);  WW_SB();
             WW_COL(0) WW_COL(1) WW_COL(2) WW_COL(3)
 #undef WW_COL
-#define WW_ROW(r, E0, E1)                                                                                                      \
+            // slots 4..12: row r through all of A, its six 8-byte writes two per slot; 13, 14: MFMAs only
+#define WW_ROW(r)                                                                                                              \
             {                                                                                                                  \
                 ww_f2 v[6];                                                                                                    \
-                float* const o = vdw + ((3 * RH + (r)) * 6) * 128;                                                             \
-                WW_MFMA((4 + 4 * (r)));  ww_a6(U[r], v);                                                                      \
-                WW_ST2(o, v[0]);  WW_ST2(o + 128, v[1]);  WW_SB();                     \
-                WW_MFMA((5 + 4 * (r)));                                                                                       \
-                WW_ST2(o + 256, v[2]);  WW_ST2(o + 384, v[3]);  WW_SB();               \
-                WW_MFMA((6 + 4 * (r)));  WW_ST2(o + 512, v[4]);  E0;  WW_SB();                            \
-                WW_MFMA((7 + 4 * (r)));  WW_ST2(o + 640, v[5]);  E1;  WW_SB();                            \
+                float* const o = vdw + ((r) * 6) * 128;                                                                        \
+                WW_MFMA(P, 4 + 3 * (r))  ww_a6(U[r], v);  WW_ST2(o, v[0]);  WW_ST2(o + 128, v[1]);  WW_SB();                   \
+                WW_MFMA(P, 5 + 3 * (r))  WW_ST2(o + 256, v[2]);  WW_ST2(o + 384, v[3]);  WW_SB();                              \
+                WW_MFMA(P, 6 + 3 * (r))  WW_ST2(o + 512, v[4]);  WW_ST2(o + 640, v[5]);  WW_SB();                              \
             }
-            WW_ROW(0, commit(WW_K(4)), commit(WW_K(5)))
-            WW_ROW(1, commit(WW_K(6)), (void)0)
-            WW_ROW(2, (void)0, (void)0)
+            WW_ROW(0) WW_ROW(1) WW_ROW(2)
 #undef WW_ROW
-            WW_MFMA((16));  request();  WW_SB();
-            WW_MFMA((17));  WW_SB();
+            WW_MFMA(P, 13)  WW_SB();
+            WW_MFMA(P, 14)  WW_SB();
         }
-#undef WW_K
-#undef WW_STAMP1
-#undef WW_MFMA
-#undef WW_SB
+#undef WW_I
+#undef WW_C
 #ifdef WW_STAMP
         if constexpr (MF) st_t2 = __builtin_amdgcn_s_memtime();
 #endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS writes have landed (its global requests stay in flight) ...
-        __builtin_amdgcn_s_barrier();                                // ... and so have every other wave's; all operand reads of the iteration are done
+        __builtin_amdgcn_s_barrier();                                // ... and so have every other wave's; all LDS reads of the phase are done
 #ifdef WW_STAMP
-        if constexpr (MF) { const unsigned long long t3 = __builtin_amdgcn_s_memtime();  st_a += st_t1 - st_t0;  st_b += st_t2 - st_t1;  st_c += t3 - st_t2; }
+        if constexpr (MF) { const unsigned long long t3 = __builtin_amdgcn_s_memtime();  st_b += st_t2 - st_t0;  st_c += t3 - st_t2; }
 #endif
-        par ^= 1;
     };
 
-    request();                                                       // group 0
-    iteration(std::false_type{}, -2);
-    iteration(std::false_type{}, -1);
-    for (int i = 0; i < n; ++i) iteration(std::true_type{}, i);
+    request(std::integral_constant<int, 0>{});                       // group 0
+    phase(std::integral_constant<int, 0>{}, std::false_type{});
+    phase(std::integral_constant<int, 1>{}, std::false_type{});
+    int p = 0;
+    for (; p + 1 < n; p += 2) {
+        phase(std::integral_constant<int, 0>{}, std::true_type{});
+        phase(std::integral_constant<int, 1>{}, std::true_type{});
+        // leaving the loop hipcc may move accumulators between register files for the code behind it -- and it does not know that the asm MFMAs'
+        // results are still in flight (n = 3 read stale accumulators there): let them land first
+        if (p + 3 >= n) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    }
+    {
+        constexpr bool MF = true;
+        if (p < n) {
+            phase(std::integral_constant<int, 0>{}, std::true_type{});
+            WW_MFMA(0, 15) WW_MFMA(0, 16) WW_MFMA(0, 17)
+        } else {
+            WW_MFMA(1, 15) WW_MFMA(1, 16) WW_MFMA(1, 17)
+        }
+    }
+#undef WW_MFMA
+#undef WW_SB
 
 #ifdef WW_STAMP
     if (lane == 0) {
         float* dbg = a.ws + (size_t)a.S * 36 * a.cout * a.cin + (size_t)a.S * a.cout + ((size_t)blockIdx.x * 4 + wave) * 8;
         dbg[0] = (float)(__builtin_amdgcn_s_memtime() - st_c0);  dbg[1] = (float)(__builtin_amdgcn_s_memrealtime() - st_r0);
-        dbg[2] = (float)n;  dbg[3] = (float)st_a;  dbg[4] = (float)st_b;  dbg[5] = (float)st_c;
+        dbg[2] = (float)n;  dbg[3] = 0.0f;  dbg[4] = (float)st_b;  dbg[5] = (float)st_c;
     }
 #endif
     // ---- this workgroup's partial sums: ws[s][pos][co][ci]  (the MFMAs are asm statements: hipcc does not know their results are still in flight)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-    for (int p = 0; p < 9; ++p) asm volatile("" : "+a"(acc[p]));
+    for (int p9 = 0; p9 < 9; ++p9) asm volatile("" : "+a"(acc[p9]));
     const int coP = a.n_co * WW_CB, ciP = a.n_ci * WW_CB;
 #pragma unroll
-    for (int p = 0; p < 9; ++p)
+    for (int p9 = 0; p9 < 9; ++p9)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + nd_acc_row(r, lane), ci = ci0 + col;
-            a.ws[(((size_t)s * 36 + wave * 9 + p) * coP + co) * ciP + ci] = acc[p][r];
+            a.ws[(((size_t)s * 36 + wave * 9 + p9) * coP + co) * ciP + ci] = acc[p9][r];
         }
-    if (a.wsb != nullptr && cib == 0) {                              // the four tile threads of a cout pair meet in a fixed order (every wave passes both barriers)
-        if (do_bias) { sm[(t * 16 + cp) * 2] = bsum2.x;  sm[(t * 16 + cp) * 2 + 1] = bsum2.y; }
-        __syncthreads();
-        if (wave == 0 && lane < WW_CB) {
-            float v = sm[lane];
-#pragma unroll
-            for (int tt = 1; tt < WW_NT; ++tt) v += sm[tt * WW_CB + lane];
-            a.wsb[(size_t)s * coP + co0 + lane] = v;
-        }
+    if (do_bias) {                                                   // lane (cout, half) holds the sum over its two tiles of every group: the halves meet in lane order
+        const float other = __shfl_down(bsum, 32);
+        if (lane < WW_CB) a.wsb[(size_t)s * coP + co0 + lane] = bsum + other;
     }
 }
 
