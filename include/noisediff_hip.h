@@ -170,7 +170,11 @@ int nd_conv3x3_wino4_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, i
  * GaussianDiffusion.p_losses (models/denoising_diffusion_pytorch.py:481-531; loss.backward() at models/trainer_diffusion.py:187).
  * Exact-fp32 MFMA; the split over pixel tiles depends on the shape only and the partial sums are added in a fixed order, so the
  * result is bitwise repeatable.  `workspace`: nd_conv3x3_wgrad_workspace_floats(...) floats.  `dbias` (may be NULL): the bias
- * gradient db[co] = sum_{b,y,x} dy[b][y][x][co], from the same staged dy tiles (same fixed order).
+ * gradient db[co] = sum_{b,y,x} dy[b][y][x][co], from the same dy tiles (same fixed order).
+ * Two forms, chosen by the shape alone.  H % 4 == 0, W % 16 == 0 and both channel counts multiples of 32: the Winograd-domain F(4x4,3x3)
+ * form -- per 4 x 4 pixel tile the 6 x 6 transforms of the input patch and of the dY block, 36 position-wise products (a quarter of the
+ * nine-tap form's MFMAs), one back-transform G^T M G at the end; error ~4e-6 of max|dW| against a float64 sum.  Anything else: nine tap
+ * GEMMs over the pixels (4e-7).  ND_WGRAD_WINO=0 forces the nine-tap form (A/B).
  * The DATA gradient of the same layer is the forward operator itself: nd_conv3x3_*_nhwc_f32 on weights packed by
  * nd_pack_conv3x3_*_weight_dgrad (taps flipped, channel roles swapped) -- see noisediff_amd/train.py. */
 int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout);
@@ -448,6 +452,27 @@ int nd_rmsnorm_nhwc_f32(const float* x, int ldx, const float* g, float* out, int
                         int B, int HW, int C, void* stream);
 /* out = RMSNorm(x) * g + res: LinearAttention's closing RMSNorm (Diffusion_arch.py:213-216) with the residual of the per-stage wiring */
 int nd_rmsnorm_add_nhwc_f32(const float* x, int ldx, const float* g, const float* res, int ldr, float* out, int ldo, int B, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ optimizer step of the training path
+ * torch.optim.Adam's update (the reference's optimizer: models/trainer_diffusion.py:94; L2 weight decay added to the gradient, no amsgrad)
+ * for all parameters of a group in ONE launch -- PyTorch's foreach form makes ~10 passes over the parameters.  `items_dev`: n_items records
+ * in DEVICE memory, one per parameter: p, m (exp_avg), v (exp_avg_sq) are updated in place from g; step_size = lr / (1 - beta1^t) and
+ * bias2_sqrt = sqrt(1 - beta2^t) with the parameter's own step count t (after the increment), computed by the caller in double precision;
+ * vec4 != 0 promises that the four tensors are 16-byte aligned.  `chunks_dev`: n_chunks pairs (item index, chunk index) of int32 in device
+ * memory, one per nd_adam_chunk_elements() elements of a parameter (the last chunk of a parameter may be short).  noisediff_amd.train.Adam
+ * is the host side (a torch.optim.Adam subclass with the same state dict). */
+typedef struct nd_adam_item {
+    float*       p;
+    const float* g;
+    float*       m;
+    float*       v;
+    int64_t      n;
+    float        step_size, bias2_sqrt;
+    int32_t      vec4, reserved;
+} nd_adam_item;
+int nd_adam_chunk_elements(void);
+int nd_adam_step_f32(const nd_adam_item* items_dev, int n_items, const int32_t* chunks_dev, int n_chunks, float beta1, float beta2, float eps,
+                     float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------ HIP graph helpers */
 int nd_stream_create(void** stream);

@@ -31,6 +31,11 @@ class Src(C.Structure):
                 ("mad", fptr), ("map", fptr), ("vec", fptr), ("gamma", fptr), ("beta", fptr), ("rowstats", fptr)]
 
 
+class AdamItem(C.Structure):
+    _fields_ = [("p", fptr), ("g", fptr), ("m", fptr), ("v", fptr), ("n", C.c_int64), ("step_size", C.c_float), ("bias2_sqrt", C.c_float),
+                ("vec4", C.c_int32), ("reserved", C.c_int32)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("w", fptr), ("packed", fptr), ("cin", C.c_int32), ("cout", C.c_int32), ("transposed", C.c_int32), ("reserved", C.c_int32)]
 
@@ -120,6 +125,8 @@ SIGNATURES = {
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_pointwise_weights_batch": (i32, [vp, i32, vp]),
+    "nd_adam_chunk_elements": (i32, []),
+    "nd_adam_step_f32": (i32, [vp, i32, vp, i32, f32, f32, f32, f32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
     "nd_groupnorm_finalize_train_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),

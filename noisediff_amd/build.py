@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnoisediff_hip.so")
 SOURCES = ["runtime", "conv3x3", "conv3x3_wino", "conv3x3_wino2", "conv3x3_wino4", "conv3x3_wgrad", "linear_wgrad", "pointwise", "pwchain", "norm", "norm_train", "small", "sampler",
-           "attention", "linattn"]
+           "attention", "linattn", "adam"]
 ARCH = "gfx950"
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified file); without it hipcc 7.2 parks
 # them in AGPRs and wraps every v_mfma_f32_32x32x2_f32 in v_accvgpr_read/write copies (8 VALU per MFMA, measured)

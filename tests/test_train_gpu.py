@@ -589,3 +589,51 @@ def test_accelerate_fuses_the_tail_of_block_shaped_modules():
             res.append([y.detach().cpu(), xa.grad.cpu()] + [p.grad.detach().cpu() for p in net.parameters()] + ([sa.grad.cpu()] if sa is not None else []))
         for got, want in zip(res[1], res[0]):
             assert rel_err(got.numpy(), want.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_adam_one_launch_step_matches_torch_optim_adam(weight_decay):
+    """train.Adam (nd_adam_step_f32: all parameters of a group in one launch) against torch.optim.Adam over several steps on parameters of awkward
+    sizes (one element, not a multiple of 4, several chunks, an unaligned view-backed tensor), with a parameter that has no gradient, a state dict
+    moved from one class to the other in the middle, and bitwise repeatability."""
+    shapes = [(1,), (7,), (3, 5, 3, 3), (64, 64, 3, 3), (20000,), (130, 257)]
+
+    def make():
+        torch.manual_seed(3)
+        ps = [nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+        big = torch.randn(4099, device=DEV)
+        ps.append(nn.Parameter(big[1:4098].clone()))                  # (a fresh allocation: aligned; the vec4 path also needs whole chunks)
+        ps.append(nn.Parameter(torch.randn(5, device=DEV)))           # never receives a gradient
+        return ps
+
+    def grads(ps, step):
+        g = torch.Generator(device="cpu").manual_seed(100 + step)
+        for p in ps[:-1]:
+            p.grad = (torch.randn(p.shape, generator=g) * (0.5 + step)).to(DEV)
+
+    runs = []
+    for cls in (torch.optim.Adam, train.Adam, train.Adam):
+        ps = make()
+        opt = cls(ps, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+        for step in range(4):
+            grads(ps, step)
+            opt.step()
+            if step == 1:                                             # the state dict of one class loads into the other
+                other = (train.Adam if cls is torch.optim.Adam else torch.optim.Adam)(ps, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+                other.load_state_dict(opt.state_dict())
+                opt = other
+        torch.cuda.synchronize()
+        runs.append(([p.detach().cpu() for p in ps], opt.state_dict()))
+    ref, got, again = runs
+    for a, b, c in zip(ref[0], got[0], again[0]):
+        assert torch.equal(b, c)                                      # no reductions: the same bits
+        assert rel_err(b.numpy(), a.numpy()) < 2e-6
+    assert torch.equal(got[0][-1], make()[-1].detach().cpu())         # no gradient: untouched
+    for k in ref[1]["state"]:
+        for name in ("exp_avg", "exp_avg_sq"):
+            assert rel_err(got[1]["state"][k][name].cpu().numpy(), ref[1]["state"][k][name].cpu().numpy()) < 2e-6
+        assert float(got[1]["state"][k]["step"]) == float(ref[1]["state"][k]["step"]) == 4.0
+    with pytest.raises(NotImplementedError):
+        train.Adam(make(), amsgrad=True)
+    with pytest.raises(L.HipError):
+        L.call("nd_adam_step_f32", None, 1, None, 1, 0.9, 0.99, 1e-8, 0.0, None)

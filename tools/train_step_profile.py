@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One configuration of the training step (GaussianDiffusion.p_losses forward + backward + Adam on the NoiseDiffNet graph with the HIP operators)
 for rocprofv3:  rocprofv3 --kernel-trace --stats -d gpurun_out/train_prof -- python3 tools/train_step_profile.py
-Env: B (4), S (256), STEPS (6), HIP (1: .hip() operators, 0: PyTorch), NET (trainable | dropin: noisediff_amd.NoiseDiffNet under autograd), ADAM_FUSED (0)."""
+Env: B (4), S (256), STEPS (6), HIP (1: .hip() operators, 0: PyTorch), NET (trainable | dropin: noisediff_amd.NoiseDiffNet under autograd),
+ADAM (hip: noisediff_amd.train.Adam, one launch per step -- the default | torch: torch.optim.Adam's foreach form | fused: PyTorch's single-kernel Adam)."""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -20,7 +21,12 @@ if os.environ.get("NET", "trainable") == "dropin":
 else:
     net = TrainableNoiseDiffNet(SimpleNamespace(dim=64)).to(dev).hip(HIP)
 gd = GaussianDiffusion(net, image_size=S, timesteps=1000, beta_schedule="sigmoid2", objective="pred_v").to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=1e-4, **({"fused": True} if os.environ.get("ADAM_FUSED", "0") != "0" else {}))   # ADAM_FUSED=1: PyTorch's single-kernel Adam (an explicit fused=False would also switch the foreach default off)
+_adam = os.environ.get("ADAM", "hip")
+if _adam == "hip":
+    from noisediff_amd.train import Adam
+    opt = Adam(net.parameters(), lr=1e-4)
+else:
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, **({"fused": True} if _adam == "fused" else {}))   # (an explicit fused=False would also switch the foreach default off)
 
 
 def one():
