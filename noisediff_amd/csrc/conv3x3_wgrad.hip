@@ -270,8 +270,8 @@ void plan(int B, int H, int W, int cin, int cout, WgradArgs& a) {
 // 4 x 16 x 32 dY block go to LDS (requested two groups ahead, in registers), thread (tile, channel pair) transforms half a patch of each into
 // V[pos][tile][ch] / D[pos][tile][ch] (the MFMA operands: lane (ch, tile parity) reads two dwords, conflict-free), then 18 MFMAs per wave
 // (v_mfma_f32_32x32x2_f32, K = two tiles) -- all of it ONE software-pipelined instruction stream per wave (ww_wave below).  The split over tile
-// groups is fixed by the shape alone; partials [split][pos][co][ci] and the bias partials go to the workspace, wgrad_wino_sum_kernel adds them
-// in split order and wgrad_wino_reduce_kernel applies G^T . G.  Bitwise repeatable, no atomics.
+// groups is fixed by the shape alone; partials [split][pos][co][ci] and the bias partials go to the workspace, wgrad_wino_finish_kernel adds
+// them in split order and applies G^T . G.  Bitwise repeatable, no atomics.
 // Taken when H % 4 == 0, W % 16 == 0 and both channel counts are multiples of 32 (every Block.proj of the d = 64 network at the training sizes);
 // anything else keeps the nine-tap kernel above.  ND_WGRAD_WINO=0: A/B knob.  Cycle split and what was tried: profiles/r5_wgrad_wino.txt.
 constexpr int WW_CB = 32;                                            // channels per block, both sides
@@ -661,6 +661,56 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __r
     }
 }
 
+// Both steps in one launch, for the planes wide enough to fill the chip that way (cout cin / 32 >= 512 workgroups): a workgroup owns one cout x 32 cins, thread
+// (position triple, cin) adds the S partials of its three positions (eight loads in flight, every load a 128-byte row) into LDS, then thread
+// (tap, cin) forms its tap of G^T M G.  The last workgroups add the bias partials [s][co].  (r5 first form: a sum launch + a transform launch,
+// 14 us of a 128 -> 128 layer's 89.  Same additions in the same order: the same bits as the two launches.)
+__global__ __launch_bounds__(384) void wgrad_wino_finish_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw,
+                                                                float* __restrict__ db, int S, int cin, int cout) {
+    constexpr float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                               {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    __shared__ float M[36][32];
+    const int tid = threadIdx.x, n_cb = cin / 32, n_main = cout * n_cb;
+    auto sum_splits = [&](const float* p, size_t stride) {
+        float sum = p[0];
+        int s_ = 1;
+        for (; s_ + 8 <= S; s_ += 8) {                                   // eight loads in flight, added in split order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s_ + k) * stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[k];
+        }
+        for (; s_ < S; ++s_) sum += p[(size_t)s_ * stride];
+        return sum;
+    };
+    if ((int)blockIdx.x >= n_main) {                                 // bias rows
+        const int co = ((int)blockIdx.x - n_main) * 384 + tid;
+        if (db && co < cout) db[co] = sum_splits(wsb + co, (size_t)cout);
+        return;
+    }
+    const int co = blockIdx.x / n_cb, ci0 = (blockIdx.x % n_cb) * 32, cl = tid & 31, pg = tid >> 5;
+    const size_t plane = (size_t)cout * cin;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int pos = 3 * pg + q;
+        M[pos][cl] = sum_splits(ws + (size_t)pos * plane + (size_t)co * cin + ci0 + cl, 36 * plane);
+    }
+    __syncthreads();
+    if (tid < 288) {
+        const int r = pg / 3, c = pg % 3;
+        float v = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            float rj = 0.0f;                                             // (G^T M)[r][jj]
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rj += G[i][r] * M[i * 6 + jj][cl];
+            v += rj * G[jj][c];
+        }
+        dw[((size_t)co * cin + ci0 + cl) * 9 + pg] = v;
+    }
+}
+
 bool ww_takes(int B, int H, int W, int cin, int cout) {
     static const bool on = !(getenv("ND_WGRAD_WINO") && atoi(getenv("ND_WGRAD_WINO")) == 0);       // A/B knob
     return on && H % WW_GH == 0 && W % WW_GW == 0 && cin % WW_CB == 0 && cout % WW_CB == 0 && (long)B * H * W < (1L << 30);
@@ -671,9 +721,17 @@ void ww_plan(int B, int H, int W, int cin, int cout, WwArgs& a) {
     a.n_co = cout / WW_CB;  a.n_ci = cin / WW_CB;
     a.gx = W / WW_GW;  a.gy = H / WW_GH;
     a.n_groups = B * a.gx * a.gy;
-    int S = WW_TARGET_WGS / (a.n_co * a.n_ci);                       // fixed by the shape: the summation order never depends on the device
-    if (S < 1) S = 1;
-    if (S > a.n_groups) S = a.n_groups;
+    // The split over the tile groups: fixed by the shape (the summation order never depends on the device).  Workgroups run in rounds of
+    // WW_TARGET_WGS, one per CU; a round costs its groups + ~14 groups' worth of pipeline fill, partial-sum stores and their summation: the cheapest split wins
+    // (768 -> 512 at 32 x 32: 384 blocks, two rounds unsplit, three rounds of half the length split in two).
+    const int blocks = a.n_co * a.n_ci;
+    long best = -1;
+    int S = 1;
+    for (int c = 1; c <= a.n_groups && c <= 4 * WW_TARGET_WGS; ++c) {
+        const long rounds = ((long)blocks * c + WW_TARGET_WGS - 1) / WW_TARGET_WGS, cost = rounds * ((a.n_groups + c - 1) / c + 14);
+        if (best < 0 || cost < best) { best = cost;  S = c; }
+        if (rounds > 8) break;
+    }
     a.S = S;
 }
 
@@ -710,6 +768,11 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)(w.n_co * w.n_ci * w.S)), dim3(256), WW_LDS, st, w);
         if (int e = nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (Winograd domain)")) return e;
+        const int n_main = cout * (cin / 32), n_bias = dbias ? (cout + 383) / 384 : 0;
+        if (w.S > 1 && n_main >= 512) {
+            hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((unsigned)(n_main + n_bias)), dim3(384), 0, st, workspace, w.wsb, dw_oihw, dbias, w.S, cin, cout);
+            return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (Winograd-domain sum + reduce)");
+        }
         const size_t n_w = (size_t)36 * cout * cin;
         if (w.S > 1) {
             const size_t tot = n_w + (dbias ? cout : 0);

@@ -25,7 +25,7 @@ for (B, H, W, cin, cout) in SHAPES:
     torch.cuda.synchronize()
     blocks = (cin // 32) * (cout // 32)
     groups = B * (H // 4) * (W // 16)
-    S = max(1, min(256 // blocks, groups)) if blocks <= 256 else 1
+    S = min((-(-blocks * c // 256) * (-(-groups // c) + 14), c) for c in range(1, min(groups, 1024) + 1) if -(-blocks * c // 256) <= 9)[1]      # ww_plan
     base = S * 36 * cout * cin + S * cout
     d = ws[base: base + blocks * S * 32].cpu().view(-1, 4, 8).double()
     cyc, real, n, a, b, c = (d[:, :, i] for i in range(6))
