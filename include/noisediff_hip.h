@@ -145,6 +145,16 @@ int nd_conv3x3_wino4_stat_slots(int H, int W);
 int64_t nd_pack_conv3x3_wino4_weight_floats(int cin, int cout);
 int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, int cin, int cout, void* stream);
 int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream);
+/* Many weights in one launch (the training path repacks every Block.proj weight, forward and data-gradient form, once per optimizer step):
+ * nd_pack_item records in DEVICE memory (shared with nd_pack_pointwise_weights_batch below); item.w = OIHW weight (the FORWARD layer's when
+ * item.transposed != 0, which selects the _dgrad form; cin / cout are then the data-gradient operator's), item.packed = its
+ * nd_pack_conv3x3_wino4_weight_floats(cin, cout) floats. */
+typedef struct nd_pack_item {
+    const float* w;
+    float*       packed;
+    int32_t      cin, cout, transposed, reserved;
+} nd_pack_item;
+int nd_pack_conv3x3_wino4_weights_batch(const nd_pack_item* items_dev, int n_items, void* stream);
 /* Split-K form of nd_conv3x3_wino4_nhwc_f32 for plain and GroupNorm-affine + SiLU sources -- the forward and data-gradient convolutions of
  * Block.proj under GaussianDiffusion.p_losses (models/archs/Diffusion_arch.py:128-144; models/denoising_diffusion_pytorch.py:481-531) at
  * training batch sizes (512 -> 512 at
@@ -279,11 +289,6 @@ int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cou
  * noisediff_amd/train.py keeps the table).  `items_dev`: n_items records in DEVICE memory; item i packs `w` ((cout, cin) row-major, or with
  * `transposed` the forward weight (cin, cout) of the layer whose data gradient this packing serves) into `packed` (nd_pack_pointwise_weight_floats
  * floats), exactly as nd_pack_pointwise_weight / nd_pack_pointwise_weight_t do. */
-typedef struct nd_pack_item {
-    const float* w;
-    float*       packed;
-    int32_t      cin, cout, transposed, reserved;
-} nd_pack_item;
 int nd_pack_pointwise_weights_batch(const nd_pack_item* items_dev, int n_items, void* stream);
 
 /* ------------------------------------------------------------------ chained pointwise layers

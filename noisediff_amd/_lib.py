@@ -125,6 +125,7 @@ SIGNATURES = {
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_pointwise_weights_batch": (i32, [vp, i32, vp]),
+    "nd_pack_conv3x3_wino4_weights_batch": (i32, [vp, i32, vp]),
     "nd_adam_chunk_elements": (i32, []),
     "nd_adam_step_f32": (i32, [vp, i32, vp, i32, f32, f32, f32, f32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),

@@ -1013,7 +1013,7 @@ int launch4_split(const Wino4Args& a, hipStream_t st) {
 // dgrad: `w` is the FORWARD layer's OIHW weight (cin_fwd = cout, cout_fwd = cin) and the packed operator is the data gradient's --
 // taps flipped, channel roles swapped: g'[co][ch][r][s] = w[ch][co][2 - r][2 - s] -- read in place (no flipped / transposed copy).
 template <bool DGRAD>
-__global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int n_c8, int n_cg) {
+__device__ __forceinline__ void pack_wino4_body(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int n_c8, int n_cg) {
     // One thread = one lane slot (block (c8, cg), lane l): the two channels' nine taps are read once and all 18 position pairs leave as
     // float4s -- 64 lanes x 16 bytes contiguous per store.  (One thread per output float re-read every 3 x 3 filter 36 times from
     // addresses a whole filter row apart: 150 us for a 512 -> 512 layer, 1.3 ms of a training step's 98 packings.)
@@ -1053,6 +1053,20 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
             nd_st4(o + pp * 256, v);
         }
     }
+}
+
+template <bool DGRAD>
+__global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int n_c8, int n_cg) {
+    pack_wino4_body<DGRAD>(w, out, cin, cout, n_c8, n_cg);
+}
+
+// The same packing for MANY weights in one launch (training: every Block.proj weight and its data-gradient packing once per optimizer step --
+// 98 launches of 4-17 microseconds at d = 64 otherwise).  blockIdx.y = item; `items` lives in device memory; item.transposed = data-gradient form.
+__global__ void pack_wino4_batch_kernel(const nd_pack_item* __restrict__ items) {
+    const nd_pack_item it = items[blockIdx.y];
+    const int n_c8 = (((it.cin + 7) / 8) + 1) / 2 * 2, n_cg = (it.cout + 63) / 64 * 4;
+    if (it.transposed) pack_wino4_body<true>(it.w, it.packed, it.cin, it.cout, n_c8, n_cg);
+    else pack_wino4_body<false>(it.w, it.packed, it.cin, it.cout, n_c8, n_cg);
 }
 
 template <int MODE, bool STREAM, int NTG = 2, int NW = 4>
@@ -1097,6 +1111,12 @@ extern "C" int nd_pack_conv3x3_wino4_weight(const float* oihw, float* packed, in
 
 extern "C" int nd_pack_conv3x3_wino4_weight_dgrad(const float* oihw_fwd, float* packed, int cin, int cout, void* stream) {
     return pack_wino4(oihw_fwd, packed, cin, cout, 1, stream);
+}
+
+extern "C" int nd_pack_conv3x3_wino4_weights_batch(const nd_pack_item* items_dev, int n_items, void* stream) {
+    ND_REQUIRE(items_dev && n_items > 0 && n_items <= 65535, ND_E_BADARG, "nd_pack_conv3x3_wino4_weights_batch: needs 1 .. 65535 items in device memory");
+    hipLaunchKernelGGL(pack_wino4_batch_kernel, dim3(64, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    return nd_launch_status("nd_pack_conv3x3_wino4_weights_batch");
 }
 
 extern "C" int nd_conv3x3_wino4_stat_slots(int H, int W) { return nd_cdiv(W, 16) * nd_cdiv(H, 16); }

@@ -84,6 +84,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
     if cin % 4 or cout % 4:
         raise L.HipError(f"conv3x3 on the HIP library needs channel counts that are multiples of 4 (cin={cin}, cout={cout})")
     st = _stream(x.device)
+    cached = _PackCache.cacheable(w_oihw)             # a parameter: the packing lives until the optimizer changes it, all stale ones repacked in one launch
     w_oihw = w_oihw.detach().to(torch.float32).contiguous()
     with _on(x.device):
         out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
@@ -100,11 +101,15 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
             pack, entry = "nd_pack_conv3x3_weight", "nd_conv3x3_nhwc_f32"
             if cin % 8:
                 raise L.HipError(f"conv3x3 on the HIP library needs cin % 8 == 0 (cin={cin})")
-        wp = torch.empty(int(getattr(lib, pack + "_floats")(cin, cout)), dtype=torch.float32, device=x.device)
-        L.call(pack + ("_dgrad" if dgrad else ""), w_oihw.data_ptr(), wp.data_ptr(), cin, cout, st)
+        if wino4 and cached:
+            wptr = _pack_cache(x.device).get(w_oihw, cin, cout, dgrad, st, kind="w4")
+        else:
+            wp = torch.empty(int(getattr(lib, pack + "_floats")(cin, cout)), dtype=torch.float32, device=x.device)
+            L.call(pack + ("_dgrad" if dgrad else ""), w_oihw.data_ptr(), wp.data_ptr(), cin, cout, st)
+            wptr = wp.data_ptr()
         d = L.Conv3x3()
         d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x.data_ptr(), cin, cin, L.PRO_NONE
-        d.weight, d.out = wp.data_ptr(), out.data_ptr()
+        d.weight, d.out = wptr, out.data_ptr()
         if bias is not None:
             b = bias.detach().to(torch.float32).contiguous()
             d.bias = b.data_ptr()
@@ -396,60 +401,85 @@ _PW_GEMM = __import__("os").environ.get("ND_TRAIN_PW", "1") != "0"
 
 
 class _PackCache:
-    """Packed operands of the Linear / 1x1 weights of one device.  An entry belongs to a leaf tensor (a parameter): key (data_ptr, shape, transposed),
-    valid while the tensor's version counter stands.  The first stale entry a step meets repacks EVERY stale entry in one launch over a descriptor
-    table kept in device memory.  Weights that are not leaves (the per-step torch.cat of the stacked time projections, nn.DataParallel's broadcast
-    copies) are packed per call and never cached."""
+    """Packed operands of one device's weights: the Linear / 1x1 weights (kind "pw": nd_pack_pointwise_weight, ``flag`` = the transposed data-gradient
+    packing) and the 3x3 weights on the F(4x4) kernels (kind "w4": nd_pack_conv3x3_wino4_weight, ``flag`` = the data-gradient form).  An entry belongs
+    to a parameter (or a view of one: ``weight.flatten(1)`` of a 1x1 convolution): key (kind, data_ptr, shape, flag), valid while the tensor's
+    version counter stands.  The first stale entry of a kind that a step meets repacks EVERY stale entry of that kind in one launch over a descriptor
+    table kept in device memory.  Weights that are not parameters (the per-step torch.cat of the stacked time projections, nn.DataParallel's
+    broadcast copies) are packed per call and never cached."""
+    _FLOATS = {"pw": "nd_pack_pointwise_weight_floats", "w4": "nd_pack_conv3x3_wino4_weight_floats"}
+    _BATCH = {"pw": "nd_pack_pointwise_weights_batch", "w4": "nd_pack_conv3x3_wino4_weights_batch"}
 
     def __init__(self, device: torch.device):
         self.device = device
-        self.entries: Dict[tuple, list] = {}        # key -> [weight tensor (kept alive), packed buffer, version packed, cin, cout, transposed]
-        self.table: Optional[torch.Tensor] = None   # device copy of the nd_pack_item records, in the order of `order`
-        self.order: list = []
+        self.entries: Dict[tuple, list] = {}        # key -> [weight tensor (kept alive), packed buffer, version packed, cin, cout, flag]
+        self.tables: Dict[str, Optional[torch.Tensor]] = {"pw": None, "w4": None}     # device copies of the nd_pack_item records, in the order of `order`
+        self.order: Dict[str, list] = {"pw": [], "w4": []}
 
-    def get(self, w: torch.Tensor, cin: int, cout: int, transposed: bool, st) -> int:
+    @staticmethod
+    def cacheable(w: torch.Tensor) -> bool:
+        return (w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
+                and (w.is_leaf or (w._is_view() and w._base is not None and w._base.is_leaf)))
+
+    def get(self, w: torch.Tensor, cin: int, cout: int, flag: bool, st, kind: str = "pw") -> int:
         lib = L.load()
-        key = (w.data_ptr(), tuple(w.shape), transposed)
+        key = (kind, w.data_ptr(), tuple(w.shape), flag)
         e = self.entries.get(key)
         if e is None:
             if len(self.entries) >= 4096:            # (a model is a few hundred weights: anything beyond is a leak of temporaries -- start over)
-                self.entries.clear(); self.order = []; self.table = None
-            buf = torch.empty(int(lib.nd_pack_pointwise_weight_floats(cin, cout)), dtype=torch.float32, device=self.device)
-            e = self.entries[key] = [w, buf, -1, cin, cout, transposed]
-            self.order.append(key)
-            self.table = None
+                self.entries.clear(); self.order = {"pw": [], "w4": []}; self.tables = {"pw": None, "w4": None}
+            buf = torch.empty(int(getattr(lib, self._FLOATS[kind])(cin, cout)), dtype=torch.float32, device=self.device)
+            e = self.entries[key] = [w, buf, -1, cin, cout, flag]
+            self.order[kind].append(key)
+            self.tables[kind] = None
         if e[2] != w._version:
-            self._repack_stale(st)
+            e[0] = w                                 # (the same storage and version counter; keeps the newest tensor object alive)
+            self._repack_stale(kind, st)
         return e[1].data_ptr()
 
-    def _repack_stale(self, st) -> None:
-        stale = [k for k in self.order if self.entries[k][2] != self.entries[k][0]._version]
-        if (self.table is None or len(stale) != len(self.order)) and torch.cuda.is_current_stream_capturing():
+    def _pack_one(self, kind: str, w, buf, cin, cout, flag, st) -> None:
+        if kind == "pw":
+            L.call("nd_pack_pointwise_weight_t" if flag else "nd_pack_pointwise_weight", w.data_ptr(), buf.data_ptr(), cin, cout, *(() if flag else (0,)), st)
+        else:
+            L.call("nd_pack_conv3x3_wino4_weight" + ("_dgrad" if flag else ""), w.data_ptr(), buf.data_ptr(), cin, cout, st)
+
+    def _repack_stale(self, kind: str, st) -> None:
+        order = self.order[kind]
+        stale = [k for k in order if self.entries[k][2] != self.entries[k][0]._version]
+        if (self.tables[kind] is None or len(stale) != len(order)) and torch.cuda.is_current_stream_capturing():
             # a new descriptor table would need a host-to-device copy, which a capturing stream refuses: one capturable launch per stale weight instead
             for k in stale:
-                w, buf, _, cin, cout, tr = self.entries[k]
-                L.call("nd_pack_pointwise_weight_t" if tr else "nd_pack_pointwise_weight", w.data_ptr(), buf.data_ptr(), cin, cout, *(() if tr else (0,)), st)
+                w, buf, _, cin, cout, flag = self.entries[k]
+                self._pack_one(kind, w, buf, cin, cout, flag, st)
                 self.entries[k][2] = w._version
             return
-        if self.table is None or len(stale) != len(self.order):
+        if self.tables[kind] is None or len(stale) != len(order):
             # first use, or only part of the table is stale (a partially frozen model): a table of the stale entries only
             items = (L.PackItem * len(stale))()
             for i, k in enumerate(stale):
-                w, buf, _, cin, cout, tr = self.entries[k]
-                items[i].w, items[i].packed, items[i].cin, items[i].cout, items[i].transposed = w.data_ptr(), buf.data_ptr(), cin, cout, int(tr)
+                w, buf, _, cin, cout, flag = self.entries[k]
+                items[i].w, items[i].packed, items[i].cin, items[i].cout, items[i].transposed = w.data_ptr(), buf.data_ptr(), cin, cout, int(flag)
             host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
             table = host.to(self.device)                     # (synchronous copy of a few KB)
-            if len(stale) == len(self.order):
-                self.table = table
+            if len(stale) == len(order):
+                self.tables[kind] = table
         else:
-            table = self.table
-        L.call("nd_pack_pointwise_weights_batch", table.data_ptr(), len(stale), st)
-        self._last_table = table                             # alive until the next repack (the launch is asynchronous)
+            table = self.tables[kind]
+        L.call(self._BATCH[kind], table.data_ptr(), len(stale), st)
+        self._last_table = getattr(self, "_last_table", {})
+        self._last_table[kind] = table                       # alive until the next repack (the launch is asynchronous)
         for k in stale:
             self.entries[k][2] = self.entries[k][0]._version
 
 
 _PACK_CACHES: Dict[int, _PackCache] = {}
+
+
+def _pack_cache(device: torch.device) -> _PackCache:
+    cache = _PACK_CACHES.get(device.index)
+    if cache is None:
+        cache = _PACK_CACHES[device.index] = _PackCache(device)
+    return cache
 
 
 def _tokens(t: torch.Tensor, c: int) -> torch.Tensor:
@@ -469,11 +499,8 @@ def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     st = _stream(x2.device)
     with _on(x2.device):
         y = torch.empty((N, cout), dtype=torch.float32, device=x2.device)
-        if w.is_leaf and w.dtype == torch.float32 and w.is_contiguous():      # a parameter: its packing is cached until the optimizer changes it
-            cache = _PACK_CACHES.get(x2.device.index)
-            if cache is None:
-                cache = _PACK_CACHES[x2.device.index] = _PackCache(x2.device)
-            wptr = cache.get(w, cin, cout, transposed, st)
+        if _PackCache.cacheable(w):                   # a parameter (or a view of one): its packing is cached until the optimizer changes it
+            wptr = _pack_cache(x2.device).get(w, cin, cout, transposed, st)
         else:
             wp = torch.empty(int(lib.nd_pack_pointwise_weight_floats(cin, cout)), dtype=torch.float32, device=x2.device)
             w32 = w.detach().float().contiguous()
@@ -841,4 +868,9 @@ class Adam(torch.optim.Adam):
                 L.call("nd_adam_step_f32", table.data_ptr(), len(ps), tab[0].data_ptr(), tab[1], float(beta1), float(beta2), float(group["eps"]),
                        float(group["weight_decay"]), _stream(dev))
             self._nd_keep = (table, keep)                                # alive until the next step (the launch is asynchronous)
+            for p in ps:                                                 # the kernel wrote through raw pointers: tell autograd (and the packing caches, which
+                st = self.state[p]                                       # compare version counters) that these tensors changed
+                torch.autograd.graph.increment_version(p)
+                torch.autograd.graph.increment_version(st["exp_avg"])
+                torch.autograd.graph.increment_version(st["exp_avg_sq"])
         return loss

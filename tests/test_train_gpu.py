@@ -637,3 +637,30 @@ def test_adam_one_launch_step_matches_torch_optim_adam(weight_decay):
         train.Adam(make(), amsgrad=True)
     with pytest.raises(L.HipError):
         L.call("nd_adam_step_f32", None, 1, None, 1, 0.9, 0.99, 1e-8, 0.0, None)
+
+
+def test_training_with_the_one_launch_adam_follows_torch_adam_step_by_step():
+    """The packed-operand caches (3x3 weights on F(4x4), Linear / 1x1 weights, views of parameters) are keyed on version counters: an optimizer that
+    writes through raw pointers must bump them, or every forward after the first step runs on the initial weights.  Five steps of a block-shaped net
+    (3x3 convs wide enough for the F(4x4) kernels, a 1x1 conv, GroupNorm) with train.Adam against the same net under torch.optim.Adam."""
+    torch.manual_seed(0)
+    net = nn.Sequential(_Block(32, 64), _Block(64, 64), nn.Conv2d(64, 4, 1)).to(DEV)
+    train.accelerate(net)
+    x = U("adamnet.x", (2, 32, 32, 64)).to(DEV)
+    target = U("adamnet.t", (2, 4, 32, 64)).to(DEV)
+    curves = []
+    for cls in (torch.optim.Adam, train.Adam):
+        m = copy.deepcopy(net)
+        opt = cls(m.parameters(), lr=2e-3)
+        v0 = [p._version for p in m.parameters()]
+        losses = []
+        for _ in range(5):
+            opt.zero_grad(set_to_none=True)
+            loss = F.mse_loss(m(x), target)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        assert all(p._version > v for p, v in zip(m.parameters(), v0))
+        curves.append(losses)
+    assert curves[0][-1] < 0.9 * curves[0][0]                                    # it does train
+    assert curves[1] == pytest.approx(curves[0], rel=2e-4)

@@ -12,6 +12,7 @@ def family(n):
     if n.startswith("Cijk"): return "library GEMM (rocBLAS / hipBLASLt)"
     if any(k in n for k in ("gs_", "gn_", "ln_fwd", "ln_bwd", "ln_dparam", "token_sum", "modsilu", "affine3", "affine_silu_add")): return "GroupNorm / LayerNorm / modulation forward + backward, token sums (HIP)"
     if "pack_" in n: return "weight packing (HIP)"
+    if "adam_kernel" in n: return "Adam (HIP, one launch)"
     if "multi_tensor" in n: return "Adam (ATen foreach)"
     if "CUDAFunctor_add" in n: return "ATen add"
     if "direct_copy" in n: return "ATen copy"
@@ -22,10 +23,10 @@ def family(n):
 
 
 def steps_from_trace(path, want):
-    """The last `want` complete training steps of a ..._kernel_trace.csv: a step ends with the optimizer's multi_tensor_apply kernels.  (The first
+    """The last `want` complete training steps of a ..._kernel_trace.csv: a step ends with the optimizer's kernels (adam_kernel, or ATen's multi_tensor_apply cluster).  (The first
     steps of a fresh box carry MIOpen's algorithm search for the 7x7 stem -- naive / CK candidates of hundreds of ms -- and stay out.)"""
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))), key=lambda e: e[0])
-    adam = [i for i in range(len(ev)) if "multi_tensor_apply" in ev[i][2]]
+    adam = [i for i in range(len(ev)) if "multi_tensor_apply" in ev[i][2] or "adam_kernel" in ev[i][2]]
     ends = [i for i, j in zip(adam, adam[1:] + [len(ev) + 1000]) if j - i > 100]      # the optimizer's kernels come in one cluster per step
     ends = ends[-(want + 1):]
     return ev[ends[0] + 1: ends[-1] + 1], len(ends) - 1
