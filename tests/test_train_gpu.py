@@ -664,3 +664,26 @@ def test_training_with_the_one_launch_adam_follows_torch_adam_step_by_step():
         curves.append(losses)
     assert curves[0][-1] < 0.9 * curves[0][0]                                    # it does train
     assert curves[1] == pytest.approx(curves[0], rel=2e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 32, 64), (2, 16, 24, 32, 64)])
+def test_wgrad_reads_channel_slices_of_wider_tensors(shape):
+    """x and dy as channel slices of wider NHWC tensors (pixel strides ldx > cin, ldy > cout: the halves of a concat, a gradient that is a view), both
+    forms of the kernel (W = 32: Winograd domain, W = 24: nine taps), against the gradient computed from contiguous copies -- the same bits."""
+    lib = L.load()
+    B, H, W, cin, cout = shape
+    xw = U("wgs.x", (B, H, W, cin + 32)).to(DEV)
+    gw = U("wgs.g", (B, H, W, cout + 16)).to(DEV)
+    xs, gs = xw[..., 32:], gw[..., 8:8 + cout]                       # 16-byte aligned starts
+    ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, cin, cout)), device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = []
+    for x_, ldx, g_, ldy in ((xs, cin + 32, gs, cout + 16), (xs.contiguous(), cin, gs.contiguous(), cout)):
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        db = torch.full((cout,), float("nan"), device=DEV)
+        L.call("nd_conv3x3_wgrad_nhwc_f32", x_.data_ptr(), ldx, g_.data_ptr(), ldy, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, W, cin, cout, st)
+        torch.cuda.synchronize()
+        res.append((dw.cpu(), db.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    ref = torch.nn.grad.conv2d_weight(xs.permute(0, 3, 1, 2).double().cpu(), (cout, cin, 3, 3), gs.permute(0, 3, 1, 2).double().cpu(), padding=1)
+    assert rel_err(res[0][0].numpy(), ref.numpy()) < 2e-5
