@@ -289,7 +289,7 @@ constexpr int WW_Y_IT = 4;                                           // float4s 
 struct WwArgs {
     const float* x; const float* dy; float* ws; float* wsb;
     int ldx, ldy, B, H, W, cin, cout;
-    int n_co, n_ci, S, gx, gy, n_groups;
+    int n_co, n_ci, S, gx, gy, n_groups, wide;
 };
 
 typedef float ww_f2 __attribute__((ext_vector_type(2)));
@@ -606,6 +606,276 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WwArgs a) {
     else ww_wave<false, 1>(a, sm, wave, lane);
 }
 
+// ---- the same pipeline for a (64 couts x 32 cins) block on EIGHT waves, two per SIMD (taken when cout % 64 == 0).  What bounds the four-wave form
+// is the LDS pipe (profiles/r5_wgrad_wino.txt): per tile group ~1.16 k cycles of LDS transfers that a lone wave per SIMD cannot overlap with its own
+// 1.15 k cycles of MFMAs.  Here a group carries twice the MFMAs for 1.5x the LDS bytes (the V side is shared by both cout halves) and a wave's LDS
+// waits are covered by its SIMD partner's MFMAs.  Wave w multiplies positions 9 (w & 3) .. + 8 of cout half w >> 2; roles besides: waves 0, 1
+// transform the input patches (rows 0-2 / 3-5), waves 2, 3, 6, 7 the dY blocks (cout half x row half) and stage dY, waves 4, 5 stage the input halo.
+// The accumulator volume per CU -- and with it the split and the partial sums -- is the four-wave form's.  256 registers per wave: eight
+// accumulators in AGPRs, the ninth in ordinary registers (hipcc splits the file 128 / 128 when asm statements use AGPRs).  LDS: two raw buffers +
+// ONE (V, D) pair (126720 bytes), so a phase p has two barriers:
+//   [A]  the two MFMAs of position 8 of group p - 1 (operands still in registers), then all operands of group p -> registers
+//   [B]  (the images may be overwritten) the sixteen MFMAs of positions 0..7 of group p; behind them the transform of group p + 1 -> the images,
+//        the staged float4s of group p + 2 -> raw[p & 1], the requests for group p + 3
+constexpr int W8_CO = 64;
+constexpr int W8_PSY = 72;                                           // floats per staged dY pixel: 64 channels + 8
+constexpr int W8_XF = WW_HR * WW_HC * WW_PS, W8_YF = WW_GH * WW_GW * W8_PSY, W8_RAWF = W8_XF + W8_YF;
+constexpr int W8_VF = 36 * WW_NT * WW_CB, W8_DF = 36 * WW_NT * W8_CO, W8_VDF = W8_VF + W8_DF;
+constexpr size_t W8_LDS = (size_t)(2 * W8_RAWF + W8_VDF) * sizeof(float);
+
+enum { W8_V = 0, W8_D = 1, W8_S = 2 };
+
+template <int ROLE, int RH>
+__device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int wave, const int lane) {
+    constexpr int NIT = ROLE == W8_S ? WW_X_IT : ROLE == W8_D ? WW_Y_IT : 1;
+    const int col = lane & 31, half = lane >> 5;
+    const int pa = wave & 3, cb = wave >> 2;                         // MFMA role: positions 9 pa .., cout half cb
+    int bid = blockIdx.x;
+    const int s = bid % a.S;  bid /= a.S;
+    const int cib = bid % a.n_ci, cob = bid / a.n_ci;
+    const int co0 = cob * W8_CO, ci0 = cib * WW_CB;
+    const int g_lo = (int)((long)s * a.n_groups / a.S), g_hi = (int)((long)(s + 1) * a.n_groups / a.S), n = g_hi - g_lo;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) acc[p] = nd_zero16();
+    // the bias gradient rides on the operands (position (1, 1) of D = the plain sum of the tile): the waves that own position 7, one per cout half
+    const bool do_bias = pa == 0 && a.wsb != nullptr && cib == 0;
+    float bsum = 0.0f;
+
+    // ---- staging (ROLE S: the halo, as the D waves of the four-wave form; ROLE D: the 4 x 16 x 64 dY block, thread = (column, quad), items = rows)
+    const int OOB = (int)0x80000000;
+    const int u = ROLE == W8_D ? ((wave >> 2) * 2 + (wave & 1)) * 64 + lane : (wave & 1) * 64 + lane;      // 0..255 over the D waves, 0..127 over the S waves
+    const int ld = ROLE == W8_D ? a.ldy : a.ldx;
+    const float* const src = ROLE == W8_D ? a.dy : a.x;
+    const int sc = ROLE == W8_D ? u >> 4 : u >> 3, sq = ROLE == W8_D ? u & 15 : u & 7;
+    const int vl = (sc * ld + (ROLE == W8_D ? co0 : ci0) + 4 * sq) * 4;
+    const int vl_left = (ROLE == W8_S && sc == 0) ? OOB : vl;
+    const int r6 = u >> 4, c6 = 16 + ((u >> 3) & 1);
+    const int v6 = ((r6 * a.W + c6) * ld + ci0 + 4 * (u & 7)) * 4;
+    const int code6 = (c6 == 17 ? 1 : 0) | (r6 == 0 ? 2 : 0) | (r6 == 5 ? 4 : 0) | (u >= 96 ? 8 : 0);
+    const int st_c = ROLE == W8_D ? W8_XF + sc * W8_PSY + 4 * sq : sc * WW_PS + 4 * sq;      // staged float4s in a raw buffer: + row * (16 PSY | 18 PS)
+    const int st_6 = (r6 * WW_HC + c6) * WW_PS + 4 * (u & 7);
+    const int row_bytes = a.W * ld * 4;
+    int lg = g_lo, lb, lgy, lgx;
+    {
+        const int gxy = a.gx * a.gy;
+        lb = lg / gxy;  const int r_ = lg - lb * gxy;  lgy = r_ / a.gx;  lgx = r_ - lgy * a.gx;
+    }
+    f32x4 sr[NIT];
+    auto request = [&]() {
+        if constexpr (ROLE != W8_V) {
+            const int y0 = lgy * WW_GH, x0 = lgx * WW_GW;
+            const long org = ((long)(lb * a.H + y0 - (ROLE == W8_S ? 1 : 0)) * a.W + x0 - (ROLE == W8_S ? 1 : 0)) * ld;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) + org, 0, 0x7fffffff, 0x00020000);
+            if constexpr (ROLE == W8_D) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) sr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vl, it * row_bytes, 0));
+            } else {
+                const bool left = x0 == 0, right = x0 + WW_GW == a.W, top = y0 == 0, bottom = y0 + WW_GH == a.H;
+                const int vm = left ? vl_left : vl;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int vo = (it == 0 && top) || (it == 5 && bottom) ? OOB : vm;
+                    sr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, it * row_bytes, 0));
+                }
+                const int edge = (right ? 1 : 0) | (top ? 2 : 0) | (bottom ? 4 : 0) | 8;
+                sr[6] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (code6 & edge) ? OOB : v6, 0, 0));
+            }
+            if (lg + 1 < g_hi) {
+                ++lg;
+                if (++lgx == a.gx) { lgx = 0;  if (++lgy == a.gy) { lgy = 0;  ++lb; } }
+            }
+        }
+    };
+    // ---- transform role: thread (tile t, channel pair cp) of the wave's row half (D: of its cout half as well)
+    const int t = lane >> 4, cp = lane & 15;
+    const int rd_off = ROLE == W8_D ? W8_XF + 4 * t * W8_PSY + 32 * (wave >> 2) + 2 * cp : 4 * t * WW_PS + 2 * cp;      // its patch in a raw buffer
+    constexpr int WSTEP = WW_NT * (ROLE == W8_D ? W8_CO : WW_CB);    // floats between two positions of the image this wave writes
+    const int wr_off = (ROLE == W8_D ? W8_VF + t * W8_CO + 32 * (wave >> 2) : t * WW_CB) + 2 * cp + (3 * RH * 6) * WSTEP;
+    const int opv_off = (9 * pa * WW_NT + half) * WW_CB + col;                     // V operands of this wave's positions: + p * 128 (+ 64)
+    const int opd_off = W8_VF + (9 * pa * WW_NT + half) * W8_CO + 32 * cb + col;   // D operands: + p * 256 (+ 128)
+
+    f32x2 oa[9], ob[9];                                              // the group's operands
+    oa[8] = f32x2{0.0f, 0.0f};  ob[8] = f32x2{0.0f, 0.0f};           // phase 0 runs "position 8 of group -1" on these
+    f32x16 (&accr)[9] = acc;                                         // (an asm operand alone does not capture)
+
+#define W8_MFMA(p, j)                                                                                                          \
+        if constexpr (MF) {                                                                                                    \
+            const float a_ = oa[p][j], b_ = ob[p][j];                                                                          \
+            if constexpr ((p) == 8) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accr[8]) : "v"(a_), "v"(b_));     \
+            else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(accr[p]) : "v"(a_), "v"(b_));         \
+        }
+#define W8_LDOP(p)                                                                                                             \
+        if constexpr (MF) {                                                                                                    \
+            oa[p][0] = sm[opd_off + (p) * 256];  oa[p][1] = sm[opd_off + (p) * 256 + 128];                                     \
+            ob[p][0] = sm[opv_off + (p) * 128];  ob[p][1] = sm[opv_off + (p) * 128 + 64];                                      \
+        }
+#define WW_SB() __builtin_amdgcn_sched_barrier(0)
+#define W8_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  __builtin_amdgcn_s_barrier(); }
+#define W8_I(k) std::integral_constant<int, (k)>{}
+#ifdef WW_STAMP                  // diagnostic (tools/wgrad_clock.py): cycles per phase = segment 1 / wait at B / segment 2 / wait at A
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_s1 = 0, st_wb = 0, st_s2 = 0, st_wa = 0;
+#endif
+    int par = 0;
+    auto phase = [&](auto with_mfma) {
+        constexpr bool MF = decltype(with_mfma)::value;
+#ifdef WW_STAMP
+        if constexpr (MF) st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        const float* const rd = sm + W8_VDF + (par ^ 1) * W8_RAWF + rd_off;      // X(p+1) reads raw[(p+1) & 1]  (the images sit at LDS address 0: 16-bit offsets reach all of them)
+        float* const wbuf = sm + W8_VDF + par * W8_RAWF;             // W(p+2) writes raw[p & 1]
+        float* const vdw = sm + wr_off;                              // X(p+1) writes its rows of the images
+        auto commit = [&](auto ii) {                                 // one staged float4 -> the raw buffer
+            constexpr int it = decltype(ii)::value;
+            if constexpr (ROLE == W8_D) nd_st4(wbuf + st_c + it * WW_GW * W8_PSY, sr[it]);
+            else if constexpr (ROLE == W8_S && it < 6) nd_st4(wbuf + st_c + it * WW_HC * WW_PS, sr[it]);
+            else if constexpr (ROLE == W8_S) { if (u < 96) nd_st4(wbuf + st_6, sr[6]); }
+        };
+        // ================= segment 1 (behind barrier A): position 8 of the previous group, then this group's operands
+        W8_MFMA(8, 0)  W8_MFMA(8, 1)
+        W8_LDOP(0) W8_LDOP(1) W8_LDOP(2) W8_LDOP(3) W8_LDOP(4) W8_LDOP(5) W8_LDOP(6) W8_LDOP(7) W8_LDOP(8)
+#ifdef WW_STAMP
+        if constexpr (MF) st_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        W8_BARRIER()                                                 // B: every wave holds its operands -- the images may be overwritten
+#ifdef WW_STAMP
+        if constexpr (MF) st_t2 = __builtin_amdgcn_s_memtime();
+#endif
+        if (MF && do_bias) bsum += oa[7][0] + oa[7][1];
+        // ================= segment 2: sixteen MFMAs (K step 0 of positions 0..7, then K step 1); slot m = MFMA m + what fits behind it
+#define W8_M(m) W8_MFMA((m) % 8, (m) / 8)
+        ww_f2 T[3][ROLE == W8_V ? 6 : 4];
+        if constexpr (ROLE == W8_V) {
+            ww_f2 X6[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) X6[0][r] = WW_LDRAW(rd + (r * WW_HC) * WW_PS);
+            WW_SB();
+#define W8_COL(k)                                                                                                              \
+            W8_M(k)                                                                                                            \
+            { ww_f2 t3[3];  ww_bt3<RH>(X6[k], t3);  T[0][k] = t3[0];  T[1][k] = t3[1];  T[2][k] = t3[2]; }                      \
+            asm volatile("" ::: "memory");                                                                                     \
+            if constexpr ((k) < 5) {                                                                                           \
+                _Pragma("unroll") for (int r = 0; r < 6; ++r) X6[(k) + 1][r] = WW_LDRAW(rd + (r * WW_HC + (k) + 1) * WW_PS);   \
+            }                                                                                                                  \
+            WW_SB();
+            W8_COL(0) W8_COL(1) W8_COL(2) W8_COL(3) W8_COL(4) W8_COL(5)
+#undef W8_COL
+#define W8_ROW(r, m0)                                                                                                          \
+            {                                                                                                                  \
+                ww_f2 v[6];                                                                                                    \
+                float* const o = vdw + ((r) * 6) * WSTEP;                                                                      \
+                W8_M(m0)  ww_bt6(T[r], v);  WW_ST2(o, v[0]);  WW_ST2(o + WSTEP, v[1]);  WW_SB();                               \
+                W8_M((m0) + 1)  WW_ST2(o + 2 * WSTEP, v[2]);  WW_ST2(o + 3 * WSTEP, v[3]);  WW_SB();                           \
+                W8_M((m0) + 2)  WW_ST2(o + 4 * WSTEP, v[4]);  WW_ST2(o + 5 * WSTEP, v[5]);  WW_SB();                           \
+            }
+            W8_ROW(0, 6) W8_ROW(1, 9) W8_ROW(2, 12)
+#undef W8_ROW
+            W8_M(15)  WW_SB();
+        } else if constexpr (ROLE == W8_D) {
+            ww_f2 Y4[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Y4[0][m] = WW_LDRAW(rd + (m * WW_GW) * W8_PSY);
+            WW_SB();
+#define W8_COL(k)                                                                                                              \
+            W8_M(k)                                                                                                            \
+            if constexpr ((k) < 3) {                                                                                           \
+                _Pragma("unroll") for (int m = 0; m < 4; ++m) Y4[(k) + 1][m] = WW_LDRAW(rd + (m * WW_GW + (k) + 1) * W8_PSY);  \
+            }                                                                                                                  \
+            { ww_f2 o3[3];  ww_a3<RH>(Y4[k], o3);  T[0][k] = o3[0];  T[1][k] = o3[1];  T[2][k] = o3[2]; }                       \
+            commit(W8_I(k));  WW_SB();
+            W8_COL(0) W8_COL(1) W8_COL(2) W8_COL(3)
+#undef W8_COL
+#define W8_ROW(r, m0)                                                                                                          \
+            {                                                                                                                  \
+                ww_f2 v[6];                                                                                                    \
+                float* const o = vdw + ((r) * 6) * WSTEP;                                                                      \
+                W8_M(m0)  ww_a6(T[r], v);  WW_ST2(o, v[0]);  WW_ST2(o + WSTEP, v[1]);  WW_SB();                                \
+                W8_M((m0) + 1)  WW_ST2(o + 2 * WSTEP, v[2]);  WW_ST2(o + 3 * WSTEP, v[3]);  WW_SB();                           \
+                W8_M((m0) + 2)  WW_ST2(o + 4 * WSTEP, v[4]);  WW_ST2(o + 5 * WSTEP, v[5]);  WW_SB();                           \
+            }
+            W8_ROW(0, 4) W8_ROW(1, 7) W8_ROW(2, 10)
+#undef W8_ROW
+            W8_M(13)  request();  WW_SB();
+            W8_M(14)  WW_SB();
+            W8_M(15)  WW_SB();
+        } else {
+            W8_M(0)  commit(W8_I(0));  WW_SB();
+            W8_M(1)  commit(W8_I(1));  WW_SB();
+            W8_M(2)  commit(W8_I(2));  WW_SB();
+            W8_M(3)  commit(W8_I(3));  WW_SB();
+            W8_M(4)  commit(W8_I(4));  WW_SB();
+            W8_M(5)  commit(W8_I(5));  WW_SB();
+            W8_M(6)  commit(W8_I(6));  WW_SB();
+            W8_M(7)  request();  WW_SB();
+            W8_M(8) WW_SB(); W8_M(9) WW_SB(); W8_M(10) WW_SB(); W8_M(11) WW_SB(); W8_M(12) WW_SB(); W8_M(13) WW_SB(); W8_M(14) WW_SB(); W8_M(15) WW_SB();
+        }
+#undef W8_M
+#ifdef WW_STAMP
+        if constexpr (MF) st_t3 = __builtin_amdgcn_s_memtime();
+#endif
+        W8_BARRIER()                                                 // A: the images of the next group and the raw buffer of the one after it are complete
+#ifdef WW_STAMP
+        if constexpr (MF) { const unsigned long long t4 = __builtin_amdgcn_s_memtime();  st_s1 += st_t1 - st_t0;  st_wb += st_t2 - st_t1;  st_s2 += st_t3 - st_t2;  st_wa += t4 - st_t3; }
+#endif
+        par ^= 1;
+    };
+
+    request();                                                       // group 0
+    phase(std::false_type{});                                        // phase -2: stages group 0, requests group 1 (its transform works on nothing yet)
+    phase(std::false_type{});                                        // phase -1: transforms group 0, stages group 1, requests group 2
+    for (int p = 0; p < n; ++p) {
+        phase(std::true_type{});
+        // leaving the loop hipcc may move accumulators between register files -- and it does not know that the asm MFMAs' results are still in flight
+        if (p + 1 >= n) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    }
+    {
+        constexpr bool MF = true;
+        W8_MFMA(8, 0) W8_MFMA(8, 1)
+    }
+#undef W8_MFMA
+#undef W8_LDOP
+#undef WW_SB
+#undef W8_BARRIER
+#undef W8_I
+
+#ifdef WW_STAMP
+    if (lane == 0) {
+        float* dbg = a.ws + (size_t)a.S * 36 * a.cout * a.cin + (size_t)a.S * a.cout + ((size_t)blockIdx.x * 8 + wave) * 8;
+        dbg[0] = (float)(__builtin_amdgcn_s_memtime() - st_c0);  dbg[1] = (float)(__builtin_amdgcn_s_memrealtime() - st_r0);
+        dbg[2] = (float)n;  dbg[3] = (float)st_s1;  dbg[4] = (float)st_wb;  dbg[5] = (float)st_s2;  dbg[6] = (float)st_wa;
+    }
+#endif
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int p9 = 0; p9 < 8; ++p9) asm volatile("" : "+a"(acc[p9]));
+    asm volatile("" : "+v"(acc[8]));
+#pragma unroll
+    for (int p9 = 0; p9 < 9; ++p9)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * cb + nd_acc_row(r, lane), ci = ci0 + col;
+            a.ws[(((size_t)s * 36 + pa * 9 + p9) * a.cout + co) * a.cin + ci] = acc[p9][r];
+        }
+    if (do_bias) {
+        const float other = __shfl_down(bsum, 32);
+        if (lane < WW_CB) a.wsb[(size_t)s * a.cout + co0 + 32 * cb + lane] = bsum + other;
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_wino8_kernel(const WwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    switch (wave) {
+        case 0: ww8_wave<W8_V, 0>(a, sm, wave, lane); break;
+        case 1: ww8_wave<W8_V, 1>(a, sm, wave, lane); break;
+        case 4: case 5: ww8_wave<W8_S, 0>(a, sm, wave, lane); break;
+        case 2: case 6: ww8_wave<W8_D, 0>(a, sm, wave, lane); break;
+        default: ww8_wave<W8_D, 1>(a, sm, wave, lane); break;
+    }
+}
+
 // The S partials [s][pos][co][ci] (+ the bias partials [s][co]) summed in split order into the split-0 slot: a thread owns one element -- 36 cout cin
 // of them, every load coalesced.  (One thread per (co, ci) doing all 36 S-deep sums had 4096 threads reading 38 MB for a 64 -> 64 layer.)
 __global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(float* __restrict__ ws, float* __restrict__ wsb, int S, size_t n_w, int n_b) {
@@ -718,7 +988,11 @@ bool ww_takes(int B, int H, int W, int cin, int cout) {
 
 void ww_plan(int B, int H, int W, int cin, int cout, WwArgs& a) {
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
-    a.n_co = cout / WW_CB;  a.n_ci = cin / WW_CB;
+    static const bool eight = !(getenv("ND_WGRAD_WINO8") && atoi(getenv("ND_WGRAD_WINO8")) == 0);      // A/B knob: 0 = the four-wave form for every shape
+    // the eight-wave form ((64 couts x 32 cins) blocks): 20 % fewer cycles per tile group and block, but twice the accumulators per CU -- twice the
+    // partial sums to write and add.  It pays where the groups x blocks product is large (measured over the d = 64 layers: profiles/r5_wgrad_wino.txt)
+    a.wide = eight && cout % W8_CO == 0 && (long)B * (H / WW_GH) * (W / WW_GW) * (cin / WW_CB) * (cout / WW_CB) >= 20000;
+    a.n_co = cout / (a.wide ? W8_CO : WW_CB);  a.n_ci = cin / WW_CB;
     a.gx = W / WW_GW;  a.gy = H / WW_GH;
     a.n_groups = B * a.gx * a.gy;
     // The split over the tile groups: fixed by the shape (the summation order never depends on the device).  Workgroups run in rounds of
@@ -766,6 +1040,11 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
         static nd_device_once configured_w;
         if (int e = nd_reserve_lds(configured_w, reinterpret_cast<const void*>(wgrad_wino_kernel), WW_LDS, "nd_conv3x3_wgrad (Winograd domain)")) return e;
         hipStream_t st = (hipStream_t)stream;
+        if (w.wide) {
+            static nd_device_once configured_w8;
+            if (int e = nd_reserve_lds(configured_w8, reinterpret_cast<const void*>(wgrad_wino8_kernel), W8_LDS, "nd_conv3x3_wgrad (Winograd domain, eight waves)")) return e;
+            hipLaunchKernelGGL(wgrad_wino8_kernel, dim3((unsigned)(w.n_co * w.n_ci * w.S)), dim3(512), W8_LDS, st, w);
+        } else
         hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)(w.n_co * w.n_ci * w.S)), dim3(256), WW_LDS, st, w);
         if (int e = nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (Winograd domain)")) return e;
         const int n_main = cout * (cin / 32), n_bias = dbias ? (cout + 383) / 384 : 0;
