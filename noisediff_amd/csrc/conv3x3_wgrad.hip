@@ -697,7 +697,7 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
     const int opd_off = W8_VF + (9 * pa * WW_NT + half) * W8_CO + 32 * cb + col;   // D operands: + p * 256 (+ 128)
 
     f32x2 oa[9], ob[9];                                              // the group's operands
-    oa[8] = f32x2{0.0f, 0.0f};  ob[8] = f32x2{0.0f, 0.0f};           // phase 0 runs "position 8 of group -1" on these
+    oa[7] = oa[8] = f32x2{0.0f, 0.0f};  ob[7] = ob[8] = f32x2{0.0f, 0.0f};      // phase 0 runs "positions 7, 8 of group -1" on these
     f32x16 (&accr)[9] = acc;                                         // (an asm operand alone does not capture)
 
 #define W8_MFMA(p, j)                                                                                                          \
@@ -733,8 +733,8 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
             else if constexpr (ROLE == W8_S && it < 6) nd_st4(wbuf + st_c + it * WW_HC * WW_PS, sr[it]);
             else if constexpr (ROLE == W8_S) { if (u < 96) nd_st4(wbuf + st_6, sr[6]); }
         };
-        // ================= segment 1 (behind barrier A): position 8 of the previous group, then this group's operands
-        W8_MFMA(8, 0)  W8_MFMA(8, 1)
+        // ================= segment 1 (behind barrier A): positions 7, 8 of the previous group, then this group's operands
+        W8_MFMA(7, 0)  W8_MFMA(8, 0)  W8_MFMA(7, 1)  W8_MFMA(8, 1)
         W8_LDOP(0) W8_LDOP(1) W8_LDOP(2) W8_LDOP(3) W8_LDOP(4) W8_LDOP(5) W8_LDOP(6) W8_LDOP(7) W8_LDOP(8)
 #ifdef WW_STAMP
         if constexpr (MF) st_t1 = __builtin_amdgcn_s_memtime();
@@ -744,8 +744,8 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
         if constexpr (MF) st_t2 = __builtin_amdgcn_s_memtime();
 #endif
         if (MF && do_bias) bsum += oa[7][0] + oa[7][1];
-        // ================= segment 2: sixteen MFMAs (K step 0 of positions 0..7, then K step 1); slot m = MFMA m + what fits behind it
-#define W8_M(m) W8_MFMA((m) % 8, (m) / 8)
+        // ================= segment 2: fourteen MFMAs (K step 0 of positions 0..6, then K step 1); slot m = MFMA m + what fits behind it
+#define W8_M(m) if constexpr ((m) < 14) { W8_MFMA((m) % 7, (m) / 7) }
         ww_f2 T[3][ROLE == W8_V ? 6 : 4];
         if constexpr (ROLE == W8_V) {
             ww_f2 X6[6][6];
@@ -772,7 +772,6 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
             }
             W8_ROW(0, 6) W8_ROW(1, 9) W8_ROW(2, 12)
 #undef W8_ROW
-            W8_M(15)  WW_SB();
         } else if constexpr (ROLE == W8_D) {
             ww_f2 Y4[4][4];
 #pragma unroll
@@ -798,8 +797,6 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
             W8_ROW(0, 4) W8_ROW(1, 7) W8_ROW(2, 10)
 #undef W8_ROW
             W8_M(13)  request();  WW_SB();
-            W8_M(14)  WW_SB();
-            W8_M(15)  WW_SB();
         } else {
             W8_M(0)  commit(W8_I(0));  WW_SB();
             W8_M(1)  commit(W8_I(1));  WW_SB();
@@ -809,7 +806,7 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
             W8_M(5)  commit(W8_I(5));  WW_SB();
             W8_M(6)  commit(W8_I(6));  WW_SB();
             W8_M(7)  request();  WW_SB();
-            W8_M(8) WW_SB(); W8_M(9) WW_SB(); W8_M(10) WW_SB(); W8_M(11) WW_SB(); W8_M(12) WW_SB(); W8_M(13) WW_SB(); W8_M(14) WW_SB(); W8_M(15) WW_SB();
+            W8_M(8) WW_SB(); W8_M(9) WW_SB(); W8_M(10) WW_SB(); W8_M(11) WW_SB(); W8_M(12) WW_SB(); W8_M(13) WW_SB();
         }
 #undef W8_M
 #ifdef WW_STAMP
@@ -832,7 +829,7 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
     }
     {
         constexpr bool MF = true;
-        W8_MFMA(8, 0) W8_MFMA(8, 1)
+        W8_MFMA(7, 0) W8_MFMA(8, 0) W8_MFMA(7, 1) W8_MFMA(8, 1)
     }
 #undef W8_MFMA
 #undef W8_LDOP
