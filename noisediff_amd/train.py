@@ -806,7 +806,7 @@ class Adam(torch.optim.Adam):
     all parameters of a group in ONE launch of nd_adam_step_f32 (adam.hip) instead of PyTorch's ~10 foreach passes: 1.14 -> 0.3 ms of the d = 64
     network's 28 ms step.  Same constructor, same state (``step`` -- a CPU tensor per parameter --, ``exp_avg``, ``exp_avg_sq``), so state dicts move
     between the two classes (``--resume_optim``); the same update in fp32 up to the rounding of one fused pass.  What the kernel does not do is refused:
-    amsgrad, maximize, capturable, differentiable, sparse gradients, parameters that are not fp32 on a GPU."""
+    amsgrad, maximize, capturable (and a step under stream capture), differentiable, sparse gradients, parameters that are not fp32 on a GPU."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kw):
         for k in ("amsgrad", "maximize", "capturable", "differentiable", "fused"):
@@ -822,6 +822,9 @@ class Adam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("noisediff_amd.train.Adam computes its step sizes on the host and uploads a pointer table per step: it cannot be captured "
+                               "into a CUDA graph (torch.optim.Adam(capturable=True) can)")
         lib = L.load()
         per = int(lib.nd_adam_chunk_elements())
         for gi, group in enumerate(self.param_groups):
