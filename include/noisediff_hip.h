@@ -184,10 +184,13 @@ int nd_conv3x3_wino4_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, i
  * Two forms, chosen by the shape alone.  H % 4 == 0, W % 16 == 0 and both channel counts multiples of 32: the Winograd-domain F(4x4,3x3)
  * form -- per 4 x 4 pixel tile the 6 x 6 transforms of the input patch and of the dY block, 36 position-wise products (a quarter of the
  * nine-tap form's MFMAs), one back-transform G^T M G at the end; error ~4e-6 of max|dW| against a float64 sum.  Anything else: nine tap
- * GEMMs over the pixels (4e-7).  ND_WGRAD_WINO=0 forces the nine-tap form (A/B).
+ * GEMMs over the pixels (4e-7).  ND_WGRAD_WINO=0 forces the nine-tap form (A/B); nd_conv3x3_wgrad_form pins any of them.
  * The DATA gradient of the same layer is the forward operator itself: nd_conv3x3_*_nhwc_f32 on weights packed by
  * nd_pack_conv3x3_*_weight_dgrad (taps flipped, channel roles swapped) -- see noisediff_amd/train.py. */
 int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout);
+/* Tests and A/B tools: pin the form -- 0 by the shape (default), 1 nine taps, 2 Winograd domain on four waves, 3 on eight waves (cout % 64 == 0;
+ * else four); anything else only queries.  Returns the previous setting.  Process-wide; ask for the workspace size AFTER setting it. */
+int nd_conv3x3_wgrad_form(int form);
 int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace,
                               int B, int H, int W, int cin, int cout, void* stream);
 

@@ -978,17 +978,23 @@ __global__ __launch_bounds__(384) void wgrad_wino_finish_kernel(const float* __r
     }
 }
 
+// Which form runs: 0 = by the shape (the product), 1 = nine taps everywhere, 2 = Winograd domain on four waves wherever it applies, 3 = on eight waves
+// wherever cout % 64 == 0 (else four).  Set by nd_conv3x3_wgrad_form (tests, tools); the environment gives the start value: ND_WGRAD_WINO=0 -> 1,
+// ND_WGRAD_WINO8=0 -> 2.  The result of a form never depends on anything but the shape.
+int& ww_form() {
+    static int form = (getenv("ND_WGRAD_WINO") && atoi(getenv("ND_WGRAD_WINO")) == 0) ? 1 : (getenv("ND_WGRAD_WINO8") && atoi(getenv("ND_WGRAD_WINO8")) == 0) ? 2 : 0;
+    return form;
+}
+
 bool ww_takes(int B, int H, int W, int cin, int cout) {
-    static const bool on = !(getenv("ND_WGRAD_WINO") && atoi(getenv("ND_WGRAD_WINO")) == 0);       // A/B knob
-    return on && H % WW_GH == 0 && W % WW_GW == 0 && cin % WW_CB == 0 && cout % WW_CB == 0 && (long)B * H * W < (1L << 30);
+    return ww_form() != 1 && H % WW_GH == 0 && W % WW_GW == 0 && cin % WW_CB == 0 && cout % WW_CB == 0 && (long)B * H * W < (1L << 30);
 }
 
 void ww_plan(int B, int H, int W, int cin, int cout, WwArgs& a) {
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
-    static const bool eight = !(getenv("ND_WGRAD_WINO8") && atoi(getenv("ND_WGRAD_WINO8")) == 0);      // A/B knob: 0 = the four-wave form for every shape
     // the eight-wave form ((64 couts x 32 cins) blocks): 20 % fewer cycles per tile group and block, but twice the accumulators per CU -- twice the
     // partial sums to write and add.  It pays where the groups x blocks product is large (measured over the d = 64 layers: profiles/r5_wgrad_wino.txt)
-    a.wide = eight && cout % W8_CO == 0 && (long)B * (H / WW_GH) * (W / WW_GW) * (cin / WW_CB) * (cout / WW_CB) >= 20000;
+    a.wide = ww_form() != 2 && cout % W8_CO == 0 && (ww_form() == 3 || (long)B * (H / WW_GH) * (W / WW_GW) * (cin / WW_CB) * (cout / WW_CB) >= 20000);
     a.n_co = cout / (a.wide ? W8_CO : WW_CB);  a.n_ci = cin / WW_CB;
     a.gx = W / WW_GW;  a.gy = H / WW_GH;
     a.n_groups = B * a.gx * a.gy;
@@ -1007,6 +1013,12 @@ void ww_plan(int B, int H, int W, int cin, int cout, WwArgs& a) {
 }
 
 }  // namespace
+
+extern "C" int nd_conv3x3_wgrad_form(int form) {
+    const int was = ww_form();
+    if (form >= 0 && form <= 3) ww_form() = form;
+    return was;
+}
 
 extern "C" int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout) {
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return -1;

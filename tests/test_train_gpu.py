@@ -45,12 +45,28 @@ def test_conv3x3_autograd_matches_torch(case):
     assert rel_err(wa.grad.cpu().numpy(), outs[0][2].numpy()) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 32, 64, 128), (2, 48, 24, 64, 128), (4, 64, 64, 32, 32), (1, 16, 16, 512, 256), (3, 40, 48, 96, 64), (2, 48, 32, 48, 64),
-                                   (1, 4, 16, 32, 64), (2, 12, 16, 32, 32), (1, 6, 16, 32, 32)])
-def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum(shape):
-    """nd_conv3x3_wgrad_nhwc_f32 in both of its forms: the Winograd-domain F(4x4) kernel (H % 4 == 0, W % 16 == 0, channel counts % 32 == 0: r5; down to a
-    single tile group per workgroup) and the nine-tap kernel (everything else: here W = 24, H = 6 and cin = 48) against a float64 weight gradient; bitwise repeatable, bias gradient, argument checks."""
+WGRAD_FORMS = {1: "nine taps", 2: "Winograd domain, four waves", 3: "Winograd domain, eight waves"}
+
+
+@pytest.fixture
+def wgrad_form():
+    """Pins a form of nd_conv3x3_wgrad_nhwc_f32 for a test and restores the product's choice (by the shape) afterwards."""
     lib = L.load()
+    was = lib.nd_conv3x3_wgrad_form(-1)
+    yield lib.nd_conv3x3_wgrad_form
+    lib.nd_conv3x3_wgrad_form(was)
+
+
+@pytest.mark.parametrize("form", sorted(WGRAD_FORMS))
+@pytest.mark.parametrize("shape", [(2, 48, 32, 64, 128), (2, 48, 24, 64, 128), (4, 64, 64, 32, 32), (1, 16, 16, 512, 256), (3, 40, 48, 96, 64), (2, 48, 32, 48, 64),
+                                   (1, 4, 16, 32, 64), (2, 12, 16, 32, 32), (1, 6, 16, 32, 32), (3, 64, 256, 32, 64)])
+def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum(shape, form, wgrad_form):
+    """nd_conv3x3_wgrad_nhwc_f32 in each of its forms -- nine taps (any shape), the Winograd-domain F(4x4) kernel on four waves (H % 4 == 0, W % 16 == 0,
+    channel counts % 32 == 0; down to a single tile group per workgroup, 1 / 2 / 3 groups: the three exits of its pipeline) and on eight waves
+    (cout % 64 == 0 as well) -- against a float64 weight gradient; bitwise repeatable, bias gradient, argument checks.  A form that does not take the
+    shape leaves it to the next one, as the product does; the product's own choice (by the shape) is one of them."""
+    lib = L.load()
+    wgrad_form(form)
     B, H, W, cin, cout = shape
     x = U("wg.x", (B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
     gy = U("wg.gy", (B, cout, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
@@ -69,10 +85,27 @@ def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum(shape):
     assert bool(bouts[0].isnan().all()) and torch.equal(bouts[1], bouts[2])           # NULL dbias: untouched
     ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (cout, cin, 3, 3), gy.double().cpu(), padding=1)
     assert rel_err(outs[0].numpy(), ref.numpy()) < 2e-5
-    assert rel_err(bouts[1].numpy(), gy.double().cpu().sum(dim=(0, 2, 3)).numpy()) < 2e-6
+    assert rel_err(bouts[1].numpy(), gy.double().cpu().sum(dim=(0, 2, 3)).numpy()) < (2e-6 if form == 1 else 5e-6)      # (Winograd forms: the bias rides on a transformed operand)
     assert lib.nd_conv3x3_wgrad_workspace_floats(0, 8, 8, 8, 8) == -1
     with pytest.raises(L.HipError):
         L.call("nd_conv3x3_wgrad_nhwc_f32", x.data_ptr(), cin, gy.data_ptr(), cout, dw.data_ptr(), None, ws.data_ptr(), B, H, W, 6, cout, None)
+
+
+def test_wgrad_forms_are_chosen_by_the_shape_alone():
+    """The product's choice (form 0): the workspace asked for tells which form a shape gets -- per form S x cout x (36 cin + 1) or the nine-tap layout."""
+    lib = L.load()
+    assert lib.nd_conv3x3_wgrad_form(-1) == 0
+    sizes = {}
+    for shape in [(4, 128, 128, 192, 128), (4, 128, 128, 64, 64), (2, 48, 24, 64, 128)]:
+        per = []
+        for form in (0, 1, 2, 3):
+            lib.nd_conv3x3_wgrad_form(form)
+            per.append(int(lib.nd_conv3x3_wgrad_workspace_floats(*shape)))
+        lib.nd_conv3x3_wgrad_form(0)
+        sizes[shape] = per
+    assert sizes[(4, 128, 128, 192, 128)][0] == sizes[(4, 128, 128, 192, 128)][3]            # large: eight waves
+    assert sizes[(4, 128, 128, 64, 64)][0] == sizes[(4, 128, 128, 64, 64)][2]                # small: four waves
+    assert len(set(sizes[(2, 48, 24, 64, 128)])) == 1                                       # W % 16 != 0: nine taps whatever is asked
 
 
 @pytest.mark.parametrize("case", [
