@@ -391,6 +391,13 @@ int nd_embedding_rows_f32(const int64_t* idx, const float* table, float* out, in
  * weight packed [7*7*4][cout] by nd_pack_conv7x7_weight. */
 int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const float* bias, float* out, int ldo,
                       int B, int H, int W, int cout, void* stream);
+/* training: weight and bias gradient of that stem, dw (cout, 4, 7, 7) OIHW = sum over the pixels of dy[p][co] x[p + tap][ci] (zero padding) and
+ * db[co] = sum dy[p][co]; x NHWC with 4 channels, dy NHWC with pixel stride ldy.  The patch matrix is never built (GEMM with K = pixels straight from a
+ * halo tile in LDS); fixed summation order (bitwise repeatable).  Taken for H % 4 == 0, W % 32 == 0, cout in {32, 48, 64, 96, 128}:
+ * nd_conv7x7_c4_wgrad_workspace_floats returns -1 otherwise (unfold the image and use nd_linear_wgrad_f32).  dbias may be NULL. */
+int64_t nd_conv7x7_c4_wgrad_workspace_floats(int B, int H, int W, int cout);
+int nd_conv7x7_c4_wgrad_f32(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace, int B, int H, int W, int cout,
+                            void* stream);
 int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout, void* stream);
 /* LearnedSinusoidalPosEmb (:331-337): position NCHW (B,2,H,W) -> NHWC (B,H,W,3*hid):
  * w = conv1x1(position); cat(w, sin(2 pi w), cos(2 pi w)). */

@@ -127,6 +127,8 @@ SIGNATURES = {
     "nd_pack_pointwise_weights_batch": (i32, [vp, i32, vp]),
     "nd_pack_conv3x3_wino4_weights_batch": (i32, [vp, i32, vp]),
     "nd_conv3x3_wgrad_form": (i32, [i32]),
+    "nd_conv7x7_c4_wgrad_workspace_floats": (i64, [i32, i32, i32, i32]),
+    "nd_conv7x7_c4_wgrad_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_adam_chunk_elements": (i32, []),
     "nd_adam_step_f32": (i32, [vp, i32, vp, i32, f32, f32, f32, f32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
@@ -174,7 +176,7 @@ SIGNATURES = {
     "nd_stream_device": (i32, [vp]),
 }
 
-_UNCHECKED = {"nd_version", "nd_last_error", "nd_stream_device", "nd_conv3x3_wgrad_form", "nd_adam_chunk_elements", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
+_UNCHECKED = {"nd_version", "nd_last_error", "nd_stream_device", "nd_conv3x3_wgrad_form", "nd_adam_chunk_elements", "nd_conv7x7_c4_wgrad_workspace_floats", "nd_conv3x3_stat_slots", "nd_conv3x3_tiling_id", "nd_pack_conv3x3_weight_floats",
               "nd_pack_pointwise_weight_floats", "nd_linear_attention_workspace_floats", "nd_conv3x3_wino_stat_slots", "nd_conv3x3_wino4_stat_slots",
               "nd_pack_conv3x3_wino_weight_floats", "nd_pack_conv3x3_wino4_weight_floats", "nd_conv3x3_wino4_splitk_plan", "nd_conv3x3_wino4_16_splitk_plan", "nd_conv3x3_wino4_splitk_workspace_floats", "nd_token_sum_workspace_floats", "nd_cond_step_lds_bytes", "nd_conv3x3_wgrad_workspace_floats",
               "nd_groupnorm_train_workspace_floats", "nd_linear_wgrad_workspace_floats",

@@ -486,3 +486,181 @@ extern "C" int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const flo
 #undef ND_C7_LAUNCH
     return nd_launch_status("nd_conv7x7_c4_f32");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Weight (and bias) gradient of the 7x7 stem over a 4-channel image (init_conv / cond_init_conv: Diffusion_arch.py:478; training path, SURVEY
+// 8f-4): dw[co][ci][ky][kx] = sum over the pixels of dy[p][co] x[p + (ky - 3, kx - 3)][ci], zero padding.  A GEMM with K = pixels, M = cout,
+// N = 196 = (tap, ci): the patch matrix is never built (r5 first form: F.unfold + a transposed copy, 205 MB and 330 us per step for the one layer).
+// A workgroup walks tiles of 4 x 32 pixels: the 10 x 38 x 4 halo of x and the 128 x cout block of dy in LDS, v_mfma_f32_16x16x4_f32 with K = four
+// consecutive pixels of a row -- A = dy (lane (cout, pixel)), B = x[pixel + tap][ci] gathered from the halo (lane (n, pixel); n >= 196 reads zeros).
+// The 13 column blocks of 16 go to the four waves as 4 + 3 + 3 + 3, the heavy share rotating with the workgroup; accumulators stay in registers over
+// all tiles of the workgroup, partial sums [workgroup][cout][208] + [workgroup][cout] to the workspace, summed in workgroup order by the second kernel.
+namespace {
+constexpr int C7W_TH = 4, C7W_TW = 32, C7W_PX = C7W_TH * C7W_TW;     // pixels per tile
+constexpr int C7W_HR = C7W_TH + 6, C7W_HC = C7W_TW + 6;              // halo 10 x 38
+constexpr int C7W_NB = 13, C7W_N = 16 * C7W_NB;                      // column blocks, padded N
+constexpr int C7W_WGS = 512;                                         // fixed: the summation order must not depend on the device
+
+struct C7wArgs {
+    const float* x; const float* dy; float* ws; float* wsb;
+    int ldy, B, H, W, cout, tiles_x, tiles_y, n_tiles, n_wg;
+};
+
+__host__ __device__ constexpr int c7w_stride(int MB) { return (16 * MB + 63) / 64 * 64 + 16; }      // floats per dy pixel in LDS: = 16 mod 64 (the four pixels of a K step on distinct banks)
+
+template <int MB>
+__global__ __launch_bounds__(256) void c7_wgrad_kernel(const C7wArgs a) {
+    constexpr int YS = c7w_stride(MB);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Xs = sm;                                                  // [10][38][4] (+ 8 zeros: what a lane of a padded column reads)
+    float* Ys = sm + C7W_HR * C7W_HC * 4 + 8;                        // [128][YS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, k = lane >> 4;
+    const int role = (wave + (int)blockIdx.x / 256) & 3;             // which share of the column blocks: role, role + 4, role + 8 (+ 12 for role 0)
+    const int nblk = role == 0 ? 4 : 3;
+    int boff[4];                                                     // halo offset of this lane's column n = 16 (role + 4 j) + m: ((ky 38 + kx) 4 + ci) floats
+    bool bok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = 16 * (role + 4 * j) + m, tap = n >> 2, ci = n & 3;
+        bok[j] = j < nblk && tap < 49;
+        boff[j] = bok[j] ? ((tap / 7) * C7W_HC + tap % 7) * 4 + ci : 0;
+    }
+    f32x4 acc[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mb][j] = f32x4{0, 0, 0, 0};
+    float bs[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) bs[mb] = 0.0f;
+    const bool do_bias = a.wsb != nullptr && wave == 0;
+
+    const int t_lo = (int)((long)blockIdx.x * a.n_tiles / a.n_wg), t_hi = (int)((long)(blockIdx.x + 1) * a.n_tiles / a.n_wg);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int per = a.tiles_x * a.tiles_y, b = tile / per, r_ = tile - b * per, ty = r_ / a.tiles_x, tx = r_ - ty * a.tiles_x;
+        const int y0 = ty * C7W_TH, x0 = tx * C7W_TW;
+        __syncthreads();                                             // the previous tile's operands are consumed
+        for (int idx = tid; idx < C7W_HR * C7W_HC; idx += 256) {     // halo: one float4 (the pixel's four channels) per item, zero outside the image
+            const int r = idx / C7W_HC, c = idx - r * C7W_HC, y = y0 - 3 + r, xx = x0 - 3 + c;
+            const f32x4 zero = {0, 0, 0, 0};
+            nd_st4(Xs + idx * 4, ((unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? nd_ld4(a.x + ((size_t)(b * a.H + y) * a.W + xx) * 4) : zero);
+        }
+        for (int idx = tid; idx < C7W_PX * 4 * MB; idx += 256) {     // dy block: float4 = (pixel, channel quad)
+            const int p = idx / (4 * MB), q = idx - p * (4 * MB), py = p >> 5, px = p & 31;
+            nd_st4(Ys + p * YS + 4 * q, nd_ld4(a.dy + ((size_t)(b * a.H + y0 + py) * a.W + x0 + px) * a.ldy + 4 * q));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < C7W_PX / 4; ++kk) {                    // K step = pixels 4 kk .. 4 kk + 3 of the tile (one row segment)
+            const int pbase = ((kk >> 3) * C7W_HC + 4 * (kk & 7)) * 4;       // halo offset of pixel 4 kk's patch origin
+            float av[MB], bv[4];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = Ys[(4 * kk + k) * YS + 16 * mb + m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = Xs[pbase + 4 * k + boff[j]];
+                bv[j] = bok[j] ? v : 0.0f;
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) bs[mb] += av[mb];
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < 3 || role == 0) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[j], acc[mb][j], 0, 0, 0);
+        }
+    }
+    // partial sums: ws[wg][co][n] (n = 16 (role + 4 j) + (lane & 15); rows 4 (lane >> 4) + r of the block), wsb[wg][co]
+    float* o = a.ws + (size_t)blockIdx.x * a.cout * C7W_N;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nblk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(size_t)(16 * mb + 4 * k + r) * C7W_N + 16 * (role + 4 * j) + m] = acc[mb][j][r];
+    if (do_bias) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float v = bs[mb];                                        // lanes (m, k): the four pixel slots of a K step meet in a fixed order
+            v += __shfl_down(v, 32);
+            v += __shfl_down(v, 16);
+            if (lane < 16) a.wsb[(size_t)blockIdx.x * a.cout + 16 * mb + m] = v;
+        }
+    }
+}
+
+// dw (cout, 4, 7, 7) and db from the partial sums, in workgroup order
+__global__ __launch_bounds__(256) void c7_wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw, float* __restrict__ db,
+                                                              int n_wg, int cout) {
+    const int total = cout * 196 + (db ? cout : 0);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const bool bias = i >= cout * 196;
+        const int co = bias ? i - cout * 196 : i / 196, e = bias ? 0 : i - co * 196;                  // e = ci 49 + tap in dw
+        const int ci = e / 49, tap = e - ci * 49;
+        const float* p = bias ? wsb + co : ws + (size_t)co * C7W_N + tap * 4 + ci;
+        const size_t stride = bias ? (size_t)cout : (size_t)cout * C7W_N;
+        float sum = 0.0f;
+        int s = 0;
+        for (; s + 8 <= n_wg; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(s + q) * stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += v[q];
+        }
+        for (; s < n_wg; ++s) sum += p[(size_t)s * stride];
+        if (bias) db[co] = sum; else dw[i] = sum;
+    }
+}
+
+bool c7w_takes(int B, int H, int W, int cout) {
+    return B > 0 && H % C7W_TH == 0 && W % C7W_TW == 0 && (cout == 32 || cout == 48 || cout == 64 || cout == 96 || cout == 128) && (long)B * H * W < (1L << 28);
+}
+int c7w_wgs(int B, int H, int W) {
+    const int tiles = B * (H / C7W_TH) * (W / C7W_TW);
+    return tiles < C7W_WGS ? tiles : C7W_WGS;
+}
+
+template <int MB>
+int c7w_launch(const C7wArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(C7W_HR * C7W_HC * 4 + 8 + C7W_PX * c7w_stride(MB)) * sizeof(float);
+    static nd_device_once configured;
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(c7_wgrad_kernel<MB>), lds, "nd_conv7x7_c4_wgrad_f32")) return e;
+    hipLaunchKernelGGL(c7_wgrad_kernel<MB>, dim3((unsigned)a.n_wg), dim3(256), lds, st, a);
+    return nd_launch_status("nd_conv7x7_c4_wgrad_f32");
+}
+}  // namespace
+
+extern "C" int64_t nd_conv7x7_c4_wgrad_workspace_floats(int B, int H, int W, int cout) {
+    if (!c7w_takes(B, H, W, cout)) return -1;                        // the shape is not taken (callers unfold the image and use nd_linear_wgrad_f32)
+    return (int64_t)c7w_wgs(B, H, W) * cout * (C7W_N + 1);
+}
+
+extern "C" int nd_conv7x7_c4_wgrad_f32(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace, int B, int H, int W,
+                                       int cout, void* stream) {
+    ND_REQUIRE(x && dy && dw_oihw && workspace, ND_E_BADARG, "nd_conv7x7_c4_wgrad_f32: null pointer");
+    ND_REQUIRE(c7w_takes(B, H, W, cout), ND_E_SHAPE, "nd_conv7x7_c4_wgrad_f32: needs H %% 4 == 0, W %% 32 == 0 and cout in {32, 48, 64, 96, 128} (H=%d W=%d cout=%d): "
+               "unfold the image and use nd_linear_wgrad_f32", H, W, cout);
+    ND_REQUIRE(ldy >= cout && ldy % 4 == 0 && nd_aligned16(x) && nd_aligned16(dy), ND_E_ALIGN, "nd_conv7x7_c4_wgrad_f32: dy rows must be 16-byte aligned, ldy >= cout");
+    C7wArgs a;
+    a.x = x; a.dy = dy; a.ldy = ldy; a.B = B; a.H = H; a.W = W; a.cout = cout;
+    a.tiles_x = W / C7W_TW; a.tiles_y = H / C7W_TH; a.n_tiles = B * a.tiles_x * a.tiles_y; a.n_wg = c7w_wgs(B, H, W);
+    a.ws = workspace; a.wsb = dbias ? workspace + (size_t)a.n_wg * cout * C7W_N : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    int e;
+    switch (cout / 16) {
+        case 2: e = c7w_launch<2>(a, st); break;
+        case 3: e = c7w_launch<3>(a, st); break;
+        case 4: e = c7w_launch<4>(a, st); break;
+        case 6: e = c7w_launch<6>(a, st); break;
+        default: e = c7w_launch<8>(a, st); break;
+    }
+    if (e) return e;
+    const int total = cout * 196 + (dbias ? cout : 0);
+    hipLaunchKernelGGL(c7_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, a.wsb, dw_oihw, dbias, a.n_wg, cout);
+    return nd_launch_status("nd_conv7x7_c4_wgrad_f32 (reduce)");
+}

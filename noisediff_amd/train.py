@@ -588,8 +588,9 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] 
 
 class Conv7x7Function(torch.autograd.Function):
     """The 7x7 stem over a 4-channel image (init_conv / cond_init_conv: Diffusion_arch.py:478, others_arch.py:394-398): forward on nd_conv7x7_c4_f32 (the sampling
-    path's kernel), weight and bias gradient as the Linear weight gradient of the unfolded image -- dW[co, (ci, ky, kx)] = sum over the pixels of
-    dy[pixel, co] * patch[pixel, (ci, ky, kx)] on nd_linear_wgrad_f32 (fixed summation order).  The input is an image, not an activation: its gradient is asked for
+    path's kernel), weight and bias gradient on nd_conv7x7_c4_wgrad_f32 (H % 4 == 0, W % 32 == 0, cout in {32, 48, 64, 96, 128}; r5) or, for other
+    shapes, as the Linear weight gradient of the unfolded image -- dW[co, (ci, ky, kx)] = sum over the pixels of dy[pixel, co] * patch[pixel, (ci, ky, kx)] on
+    nd_linear_wgrad_f32 (both: fixed summation order).  The input is an image, not an activation: its gradient is asked for
     only by callers outside the reference's training loop and then comes from PyTorch's transposed convolution."""
 
     @staticmethod
@@ -620,7 +621,18 @@ class Conv7x7Function(torch.autograd.Function):
         grad_x = grad_w = grad_b = None
         if ctx.needs_input_grad[0]:
             grad_x = torch.nn.grad.conv2d_input(x.shape, weight, grad_out, padding=3)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and cin == 4 and \
+                int(lib.nd_conv7x7_c4_wgrad_workspace_floats(B, H, W, cout)) >= 0:
+            # nd_conv7x7_c4_wgrad_f32: the GEMM over the pixels straight from halo tiles (no unfolded image: 205 MB and two copies at B = 4, 256 x 256)
+            g = _tokens(grad_out.permute(0, 2, 3, 1), cout)                 # (pixels, cout)
+            xn = x.detach().permute(0, 2, 3, 1).contiguous().float()
+            with _on(xn.device):
+                grad_w = torch.empty(weight.shape, dtype=torch.float32, device=xn.device)
+                grad_b = torch.empty(cout, dtype=torch.float32, device=xn.device) if ctx.has_bias else None
+                ws = torch.empty(int(lib.nd_conv7x7_c4_wgrad_workspace_floats(B, H, W, cout)), dtype=torch.float32, device=xn.device)
+                L.call("nd_conv7x7_c4_wgrad_f32", xn.data_ptr(), g.data_ptr(), cout, grad_w.data_ptr(), grad_b.data_ptr() if grad_b is not None else None,
+                       ws.data_ptr(), B, H, W, cout, _stream(xn.device))
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             g2 = _tokens(grad_out.permute(0, 2, 3, 1), cout)                # (pixels, cout)
             cols = torch.nn.functional.unfold(x.detach().float(), kernel_size=7, padding=3)      # (B, cin * 49, H W): index ci * 49 + ky * 7 + kx == weight.flatten(1)'s
             x2 = cols.transpose(1, 2).reshape(B * H * W, cin * 49).contiguous()

@@ -500,9 +500,11 @@ def test_conv1x1_and_accelerated_linears():
     assert rel_err(tok_hip.bias.grad.cpu().numpy(), tok.bias.grad.cpu().numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 48, 64), (1, 40, 24, 48), (3, 16, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 32, 48, 64), (1, 40, 24, 48), (3, 16, 16, 16), (2, 32, 64, 64), (1, 40, 32, 48), (3, 16, 96, 128), (2, 64, 128, 96), (1, 8, 32, 32),
+                                   (5, 128, 128, 64)])
 def test_stem_conv7x7_autograd_matches_pytorch(shape):
-    """train.conv7x7_c4 (init_conv / cond_init_conv: forward on nd_conv7x7_c4_f32, weight + bias gradient through nd_linear_wgrad_f32 over the unfolded image)
+    """train.conv7x7_c4 (init_conv / cond_init_conv: forward on nd_conv7x7_c4_f32, weight + bias gradient on nd_conv7x7_c4_wgrad_f32 -- H % 4 == 0, W % 32 == 0,
+    cout in {32, 48, 64, 96, 128}; one and several tiles per workgroup -- or, for the other shapes, through nd_linear_wgrad_f32 over the unfolded image)
     == F.conv2d(padding=3) and its autograd; the image's own gradient (not needed by the reference's training loop) comes from PyTorch's transposed convolution."""
     B, H, W, cout = shape
     x = U("stem.x", (B, 4, H, W), -1.5, 1.5).to(DEV)
@@ -516,7 +518,9 @@ def test_stem_conv7x7_autograd_matches_pytorch(shape):
         outs.append([t.detach().cpu() for t in (y, xa.grad, wa.grad, ba.grad)])
     for got, ref, name in zip(outs[1], outs[0], ("y", "dx", "dw", "db")):
         assert rel_err(got.numpy(), ref.numpy()) < 2e-5 * max(1.0, (B * H * W / 4096) ** 0.5), name
-    assert all(torch.equal(p, q) for p, q in zip(outs[1], outs[2]))              # bitwise repeatable
+    for p, q, name in zip(outs[1], outs[2], ("y", "dx", "dw", "db")):
+        if name != "dx":                                                         # (dx is PyTorch's transposed convolution: MIOpen may pick an atomic algorithm)
+            assert torch.equal(p, q), name                                        # bitwise repeatable
     with pytest.raises(ValueError):
         train.conv7x7_c4(x[:, :3], w[:, :3], b)
 
