@@ -190,6 +190,11 @@ int nd_conv3x3_wino4_16_splitk_nhwc_f32(const nd_conv3x3* d, float* workspace, i
 int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int cin, int cout);
 /* Tests and A/B tools: pin the form -- 0 by the shape (default), 1 nine taps, 2 Winograd domain on four waves, 3 on eight waves (cout % 64 == 0;
  * else four); anything else only queries.  Returns the previous setting.  Process-wide; ask for the workspace size AFTER setting it. */
+/* The same for an input that is the virtual concatenation cat((x0, x1), channels) -- the up path's skip connections -- without the concatenated
+ * tensor: dw (cout, c0 + c1, 3, 3).  Winograd-domain forms only (H % 4 == 0, W % 16 == 0, c0, c1, cout multiples of 32): ND_E_SHAPE otherwise
+ * (concatenate and call nd_conv3x3_wgrad_nhwc_f32).  Workspace: nd_conv3x3_wgrad_workspace_floats(B, H, W, c0 + c1, cout). */
+int nd_conv3x3_wgrad_cat_nhwc_f32(const float* x0, int ldx0, int c0, const float* x1, int ldx1, int c1, const float* dy, int ldy, float* dw_oihw,
+                                  float* dbias, float* workspace, int B, int H, int W, int cout, void* stream);
 int nd_conv3x3_wgrad_form(int form);
 int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace,
                               int B, int H, int W, int cin, int cout, void* stream);

@@ -126,6 +126,7 @@ SIGNATURES = {
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_pointwise_weights_batch": (i32, [vp, i32, vp]),
     "nd_pack_conv3x3_wino4_weights_batch": (i32, [vp, i32, vp]),
+    "nd_conv3x3_wgrad_cat_nhwc_f32": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_conv3x3_wgrad_form": (i32, [i32]),
     "nd_conv7x7_c4_wgrad_workspace_floats": (i64, [i32, i32, i32, i32]),
     "nd_conv7x7_c4_wgrad_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -288,6 +288,8 @@ constexpr int WW_Y_IT = 4;                                           // float4s 
 
 struct WwArgs {
     const float* x; const float* dy; float* ws; float* wsb;
+    const float* x1;                                                 // second source of a virtual concatenation along cin: channels c0 .. cin - 1 (c0 = cin: none)
+    int ldx1, c0;
     int ldx, ldy, B, H, W, cin, cout;
     int n_co, n_ci, S, gx, gy, n_groups, wide;
 };
@@ -381,14 +383,16 @@ __device__ __forceinline__ void ww_wave(const WwArgs& a, float* sm, const int wa
     // into the scalar offset of the request, the group into the resource's base, so the lane offsets are constants; what lies outside the image is
     // requested out of range (-> zeros): one select for the left edge, one each for the top and the bottom row, a mask test for item 6.
     const int u = (wave & 1) * 64 + lane;                            // 0..127 within the wave pair
-    const int ld = ISV ? a.ldy : a.ldx;
-    const float* const src = ISV ? a.dy : a.x;
+    const bool second = !ISV && ci0 >= a.c0;                         // the workgroup's cin block lies in the second source (blocks never straddle: c0 % 32 == 0)
+    const int ld = ISV ? a.ldy : second ? a.ldx1 : a.ldx;
+    const float* const src = ISV ? a.dy : second ? a.x1 : a.x;
+    const int cs0 = ISV ? co0 : second ? ci0 - a.c0 : ci0;           // first channel of the block within its source
     const int sc = u >> 3, sq = u & 7;
     const int OOB = (int)0x80000000;
-    const int vl = (sc * ld + (ISV ? co0 : ci0) + 4 * sq) * 4;
+    const int vl = (sc * ld + cs0 + 4 * sq) * 4;
     const int vl_left = (!ISV && sc == 0) ? OOB : vl;                // left image edge: halo column 0 is padding
     const int r6 = u >> 4, c6 = 16 + ((u >> 3) & 1);
-    const int v6 = ((r6 * a.W + c6) * ld + ci0 + 4 * sq) * 4;
+    const int v6 = ((r6 * a.W + c6) * ld + cs0 + 4 * sq) * 4;
     const int code6 = (c6 == 17 ? 1 : 0) | (r6 == 0 ? 2 : 0) | (r6 == 5 ? 4 : 0) | (u >= 96 ? 8 : 0);
     const int lds_c = (ISV ? WW_XF : 0) + sc * WW_PS + 4 * sq;       // + row * (16 | 18) * WW_PS
     const int lds_6 = (r6 * WW_HC + c6) * WW_PS + 4 * sq;
@@ -646,13 +650,15 @@ __device__ __forceinline__ void ww8_wave(const WwArgs& a, float* sm, const int w
     // ---- staging (ROLE S: the halo, as the D waves of the four-wave form; ROLE D: the 4 x 16 x 64 dY block, thread = (column, quad), items = rows)
     const int OOB = (int)0x80000000;
     const int u = ROLE == W8_D ? ((wave >> 2) * 2 + (wave & 1)) * 64 + lane : (wave & 1) * 64 + lane;      // 0..255 over the D waves, 0..127 over the S waves
-    const int ld = ROLE == W8_D ? a.ldy : a.ldx;
-    const float* const src = ROLE == W8_D ? a.dy : a.x;
+    const bool second = ROLE != W8_D && ci0 >= a.c0;                 // (see ww_wave)
+    const int ld = ROLE == W8_D ? a.ldy : second ? a.ldx1 : a.ldx;
+    const float* const src = ROLE == W8_D ? a.dy : second ? a.x1 : a.x;
+    const int cs0 = ROLE == W8_D ? co0 : second ? ci0 - a.c0 : ci0;
     const int sc = ROLE == W8_D ? u >> 4 : u >> 3, sq = ROLE == W8_D ? u & 15 : u & 7;
-    const int vl = (sc * ld + (ROLE == W8_D ? co0 : ci0) + 4 * sq) * 4;
+    const int vl = (sc * ld + cs0 + 4 * sq) * 4;
     const int vl_left = (ROLE == W8_S && sc == 0) ? OOB : vl;
     const int r6 = u >> 4, c6 = 16 + ((u >> 3) & 1);
-    const int v6 = ((r6 * a.W + c6) * ld + ci0 + 4 * (u & 7)) * 4;
+    const int v6 = ((r6 * a.W + c6) * ld + cs0 + 4 * (u & 7)) * 4;
     const int code6 = (c6 == 17 ? 1 : 0) | (r6 == 0 ? 2 : 0) | (r6 == 5 ? 4 : 0) | (u >= 96 ? 8 : 0);
     const int st_c = ROLE == W8_D ? W8_XF + sc * W8_PSY + 4 * sq : sc * WW_PS + 4 * sq;      // staged float4s in a raw buffer: + row * (16 PSY | 18 PS)
     const int st_6 = (r6 * WW_HC + c6) * WW_PS + 4 * (u & 7);
@@ -1034,17 +1040,18 @@ extern "C" int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int ci
     return n;
 }
 
-extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace,
-                                         int B, int H, int W, int cin, int cout, void* stream) {
+static int wgrad_run(const float* x, int ldx, int c0, const float* x1, int ldx1, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace,
+                     int B, int H, int W, int cin, int cout, void* stream) {
     ND_REQUIRE(x && dy && dw_oihw && workspace, ND_E_BADARG, "nd_conv3x3_wgrad: null pointer");
     ND_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, ND_E_BADARG, "nd_conv3x3_wgrad: non-positive size");
-    ND_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx >= cin && ldy >= cout && ldx % 4 == 0 && ldy % 4 == 0, ND_E_SHAPE,
+    ND_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx >= c0 && ldy >= cout && ldx % 4 == 0 && ldy % 4 == 0, ND_E_SHAPE,
                "nd_conv3x3_wgrad: cin=%d, cout=%d and the pixel strides must be multiples of 4", cin, cout);
     ND_REQUIRE(nd_aligned16(x) && nd_aligned16(dy), ND_E_ALIGN, "nd_conv3x3_wgrad: x and dy must be 16-byte aligned");
     if (ww_takes(B, H, W, cin, cout) && (long)H * W * ldx * 4 < (1L << 30) && (long)H * W * ldy * 4 < (1L << 30)) {     // F(4x4) Winograd-domain form (a quarter of the MFMAs); 32-bit offsets within a sample
         WwArgs w;
         ww_plan(B, H, W, cin, cout, w);
         w.x = x; w.dy = dy; w.ws = workspace; w.ldx = ldx; w.ldy = ldy;
+        w.x1 = x1; w.ldx1 = ldx1; w.c0 = c0;
         w.wsb = dbias ? workspace + (size_t)w.S * 36 * cout * cin : nullptr;
         static nd_device_once configured_w;
         if (int e = nd_reserve_lds(configured_w, reinterpret_cast<const void*>(wgrad_wino_kernel), WW_LDS, "nd_conv3x3_wgrad (Winograd domain)")) return e;
@@ -1070,6 +1077,7 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
         hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, workspace, w.wsb, dw_oihw, dbias, cin, cout);
         return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (Winograd-domain reduce)");
     }
+    ND_REQUIRE(c0 == cin, ND_E_SHAPE, "nd_conv3x3_wgrad_cat_nhwc_f32: two sources need the Winograd-domain form (H %% 4 == 0, W %% 16 == 0, channel counts %% 32 == 0)");
     WgradArgs a;
     plan(B, H, W, cin, cout, a);
     a.x = x; a.dy = dy; a.ws = workspace; a.ldx = ldx; a.ldy = ldy;
@@ -1092,4 +1100,17 @@ extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* d
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, a.wsb, dw_oihw, dbias, a.S, cin, cout, a.n_co * CB, a.n_ci * CB);
     return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (reduce)");
+}
+
+extern "C" int nd_conv3x3_wgrad_nhwc_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace,
+                                         int B, int H, int W, int cin, int cout, void* stream) {
+    return wgrad_run(x, ldx, cin, nullptr, 0, dy, ldy, dw_oihw, dbias, workspace, B, H, W, cin, cout, stream);
+}
+
+extern "C" int nd_conv3x3_wgrad_cat_nhwc_f32(const float* x0, int ldx0, int c0, const float* x1, int ldx1, int c1, const float* dy, int ldy, float* dw_oihw,
+                                             float* dbias, float* workspace, int B, int H, int W, int cout, void* stream) {
+    ND_REQUIRE(x0 && x1 && c0 > 0 && c1 > 0 && c0 % 32 == 0 && c1 % 32 == 0 && ldx0 >= c0 && ldx1 >= c1 && ldx1 % 4 == 0 && nd_aligned16(x1), ND_E_SHAPE,
+               "nd_conv3x3_wgrad_cat_nhwc_f32: two sources of whole 32-channel blocks (c0=%d, c1=%d)", c0, c1);
+    ND_REQUIRE((long)H * W * ldx1 * 4 < (1L << 30), ND_E_SHAPE, "nd_conv3x3_wgrad_cat_nhwc_f32: second source too large for 32-bit offsets within a sample");
+    return wgrad_run(x0, ldx0, c0, x1, ldx1, dy, ldy, dw_oihw, dbias, workspace, B, H, W, c0 + c1, cout, stream);
 }

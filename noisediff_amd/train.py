@@ -68,7 +68,8 @@ def _stream(device: Optional[torch.device] = None) -> C.c_void_p:
 _SPLIT_K = __import__("os").environ.get("ND_TRAIN_SPLITK", "1") != "0"      # A/B knob (tools/): 0 = never the split-K form of conv3x3_wino4
 
 
-def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], dgrad: bool = False, stats: bool = False):
+def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], dgrad: bool = False, stats: bool = False,
+                  x1: Optional[torch.Tensor] = None):
     """y = conv2d(x, w, bias, padding=1) on the HIP library; x (B, cin, H, W) channels_last, returns (B, cout, H, W) channels_last.
     ``dgrad``: ``w_oihw`` is the FORWARD layer's weight and the operator is its data gradient, conv2d(x, w.flip(2, 3).transpose(0, 1),
     padding=1) -- the pack kernels read the flipped / role-swapped weight in place (nd_pack_conv3x3_*_weight_dgrad).
@@ -76,6 +77,11 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
     pixel counts ``sc`` of the slots, what nd_groupnorm_finalize*_f32 pools."""
     lib = L.load()
     B, cin, H, W = x.shape
+    c0 = cin
+    if x1 is not None:                                                   # the virtual concatenation cat((x, x1), 1): the kernels read both sources (nd_src.p0 / p1)
+        if x1.shape[0] != B or tuple(x1.shape[2:]) != (H, W) or x1.device != x.device or dgrad:
+            raise ValueError(f"conv3x3: second source {tuple(x1.shape)} does not extend {tuple(x.shape)}")
+        cin = c0 + x1.shape[1]
     cout = w_oihw.shape[1 if dgrad else 0]
     if w_oihw.shape[0 if dgrad else 1] != cin:
         raise ValueError(f"conv3x3: x {tuple(x.shape)} does not match weight {tuple(w_oihw.shape)}" + (" (data gradient)" if dgrad else ""))
@@ -92,6 +98,8 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
         wino = H >= 16 and W >= 16 and cin % 8 == 0
         wino4 = (wino and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and cin > 16 and cout <= 2048
                  and (B * H * W + W + 2) * cin * 4 < (1 << 30) - (1 << 16) and B * H * W + W + 2 < (1 << 24))
+        if x1 is not None and not (wino4 and c0 % 16 == 0 and x1.shape[1] % 16 == 0):
+            raise L.HipError(f"conv3x3 over two sources needs the F(4x4) kernel and sources of whole 16-channel chunks ({c0} + {x1.shape[1]} channels, {H}x{W})")
         wino2 = wino and B * H * W < (1 << 24) and src_bytes < (1 << 31)
         if wino4:
             pack, entry = "nd_pack_conv3x3_wino4_weight", "nd_conv3x3_wino4_nhwc_f32"
@@ -108,7 +116,9 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
             L.call(pack + ("_dgrad" if dgrad else ""), w_oihw.data_ptr(), wp.data_ptr(), cin, cout, st)
             wptr = wp.data_ptr()
         d = L.Conv3x3()
-        d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x.data_ptr(), cin, cin, L.PRO_NONE
+        d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x.data_ptr(), c0, c0, L.PRO_NONE
+        if x1 is not None:
+            d.src.p1, d.src.c1, d.src.ld1 = x1.data_ptr(), x1.shape[1], x1.shape[1]
         d.weight, d.out = wptr, out.data_ptr()
         if bias is not None:
             b = bias.detach().to(torch.float32).contiguous()
@@ -190,6 +200,82 @@ def conv3x3_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     if tuple(weight.shape[2:]) != (3, 3) or x.dim() != 4 or x.shape[1] != weight.shape[1]:
         raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)} is not a 3x3 convolution")
     y, st, sc = Conv3x3Function.apply(x, weight, bias, True)
+    return y, (st, sc)
+
+
+def cat_sources_ok(x0: torch.Tensor, x1: torch.Tensor) -> bool:
+    """Can conv3x3_cat / conv1x1_cat take this pair (else the caller concatenates)?  The F(4x4) kernel's geometry and whole 16-channel chunks per source."""
+    B, c0, H, W = x0.shape
+    c1 = x1.shape[1]
+    return (x0.is_cuda and x1.is_cuda and x0.dim() == 4 and tuple(x1.shape[2:]) == (H, W) and x1.shape[0] == B and c0 % 16 == 0 and c1 % 16 == 0
+            and H >= 16 and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048
+            and (B * H * W + W + 2) * (c0 + c1) * 4 < (1 << 30) - (1 << 16) and B * H * W + W + 2 < (1 << 24))
+
+
+class Conv3x3CatFunction(torch.autograd.Function):
+    """conv3x3(torch.cat((x0, x1), 1), weight, bias) without the concatenated tensor: the up path's ``cat((x, skip))`` in front of a ResnetBlock
+    (Diffusion_arch.py:620-630).  Forward: the kernel reads both sources (nd_src.p0 / p1).  Backward: one data gradient of c0 + c1 channels whose channel
+    slices are the two inputs' gradients; the weight gradient per source, joined along cin."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, want_stats=False):
+        a, b = _nhwc(x0), _nhwc(x1)
+        ctx.save_for_backward(a, b, weight)
+        ctx.has_bias = bias is not None
+        if not want_stats:
+            return _conv3x3_nhwc(a, weight, bias, x1=b)
+        y, st, sc = _conv3x3_nhwc(a, weight, bias, stats=True, x1=b)
+        ctx.mark_non_differentiable(st, sc)
+        ctx.set_materialize_grads(False)
+        return y, st, sc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out, *unused):
+        a, b, weight = ctx.saved_tensors
+        if grad_out is None:
+            return None, None, None, None, None
+        lib = L.load()
+        g = _nhwc(grad_out)
+        B, c0, H, W = a.shape
+        c1, cout = b.shape[1], weight.shape[0]
+        gx0 = gx1 = grad_w = grad_b = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            full = _conv3x3_nhwc(g, weight, None, dgrad=True)            # (B, c0 + c1, H, W) channels_last: the slices are views
+            gx0, gx1 = (full[:, :c0] if ctx.needs_input_grad[0] else None), (full[:, c0:] if ctx.needs_input_grad[1] else None)
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[2] and H % 4 == 0 and W % 16 == 0 and c0 % 32 == 0 and c1 % 32 == 0 and cout % 32 == 0 and lib.nd_conv3x3_wgrad_form(-1) != 1:
+            with _on(a.device):                                          # the Winograd-domain forms read a cin block from either source: ONE weight gradient
+                grad_w = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=a.device)
+                grad_b = torch.empty(cout, dtype=torch.float32, device=a.device) if want_b else None
+                ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, c0 + c1, cout)), dtype=torch.float32, device=a.device)
+                L.call("nd_conv3x3_wgrad_cat_nhwc_f32", a.data_ptr(), c0, c0, b.data_ptr(), c1, c1, g.data_ptr(), cout, grad_w.data_ptr(),
+                       grad_b.data_ptr() if want_b else None, ws.data_ptr(), B, H, W, cout, _stream(a.device))
+        elif ctx.needs_input_grad[2]:
+            with _on(a.device):
+                parts = []
+                for i, (src, c) in enumerate(((a, c0), (b, c1))):
+                    dw = torch.empty((cout, c, 3, 3), dtype=torch.float32, device=a.device)
+                    if i == 0 and want_b:
+                        grad_b = torch.empty(cout, dtype=torch.float32, device=a.device)
+                    ws = torch.empty(int(lib.nd_conv3x3_wgrad_workspace_floats(B, H, W, c, cout)), dtype=torch.float32, device=a.device)
+                    L.call("nd_conv3x3_wgrad_nhwc_f32", src.data_ptr(), c, g.data_ptr(), cout, dw.data_ptr(),
+                           grad_b.data_ptr() if (i == 0 and want_b) else None, ws.data_ptr(), B, H, W, c, cout, _stream(a.device))
+                    parts.append(dw)
+                grad_w = torch.cat(parts, dim=1)
+        elif want_b:
+            grad_b = g.sum(dim=(0, 2, 3))
+        return gx0, gx1, grad_w, grad_b, None
+
+
+def conv3x3_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, with_stats: bool = False):
+    """Differentiable F.conv2d(torch.cat((x0, x1), 1), weight, bias, padding=1) that never builds the concatenation (``cat_sources_ok`` says when);
+    ``with_stats``: (y, (st, sc)) as conv3x3_with_stats."""
+    if tuple(weight.shape[2:]) != (3, 3) or x0.shape[1] + x1.shape[1] != weight.shape[1] or not cat_sources_ok(x0, x1):
+        raise ValueError(f"conv3x3_cat: x0 {tuple(x0.shape)} + x1 {tuple(x1.shape)} / weight {tuple(weight.shape)}")
+    if not with_stats:
+        return Conv3x3CatFunction.apply(x0, x1, weight, bias)
+    y, st, sc = Conv3x3CatFunction.apply(x0, x1, weight, bias, True)
     return y, (st, sc)
 
 
@@ -489,12 +575,15 @@ def _tokens(t: torch.Tensor, c: int) -> torch.Tensor:
     return t
 
 
-def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool) -> torch.Tensor:
+def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool, x2b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y[N, cout] = x2[N, cin] @ W^T (+ bias) on nd_pointwise_gemm_nhwc_f32 (pointwise.hip: the sampling path's 1x1 / Linear kernels, exact-fp32
     MFMA), W = ``w`` (cout, cin); ``transposed``: W^T = ``w`` -- the forward weight of the layer whose data gradient dx = dy @ w this is (packed
     in place by nd_pack_pointwise_weight_t)."""
     lib = L.load()
     N, cin = x2.shape
+    c0 = cin
+    if x2b is not None:                                                  # tokens of a second source: the virtual concatenation cat((x2, x2b), -1)
+        cin = c0 + x2b.shape[1]
     cout = w.shape[1] if transposed else w.shape[0]
     st = _stream(x2.device)
     with _on(x2.device):
@@ -510,7 +599,9 @@ def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
                 L.call("nd_pack_pointwise_weight", w32.data_ptr(), wp.data_ptr(), cin, cout, 0, st)
             wptr = wp.data_ptr()
         d = L.Pointwise()
-        d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x2.data_ptr(), cin, cin, L.PRO_NONE
+        d.src.p0, d.src.c0, d.src.ld0, d.src.mode = x2.data_ptr(), c0, c0, L.PRO_NONE
+        if x2b is not None:
+            d.src.p1, d.src.c1, d.src.ld1 = x2b.data_ptr(), x2b.shape[1], x2b.shape[1]
         d.weight, d.out = wptr, y.data_ptr()
         if bias is not None:
             b32 = bias.detach().float().contiguous()
@@ -564,6 +655,58 @@ class LinearFunction(torch.autograd.Function):
                 L.call("nd_linear_wgrad_f32", x2.data_ptr(), cin, g2.data_ptr(), cout, grad_w.data_ptr(),
                        grad_b.data_ptr() if grad_b is not None else None, ws.data_ptr(), N, cin, cout, _stream(x2.device))
         return grad_x, grad_w, grad_b
+
+
+class LinearCatFunction(torch.autograd.Function):
+    """linear(torch.cat((t0, t1), -1), weight, bias) over tokens without the concatenated tensor (the 1x1 ``res_conv`` of the up path's ResnetBlocks on
+    ``cat((x, skip))``): forward with two sources, one data gradient whose channel slices are the inputs' gradients, the weight gradient per source."""
+
+    @staticmethod
+    def forward(ctx, t0, t1, weight, bias):
+        ctx.save_for_backward(t0, t1, weight)
+        ctx.has_bias = bias is not None
+        cout = weight.shape[0]
+        c0, c1 = t0.shape[-1], t1.shape[-1]
+        return _pointwise_gemm(_tokens(t0, c0), weight, bias, False, _tokens(t1, c1)).view(*t0.shape[:-1], cout)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        t0, t1, weight = ctx.saved_tensors
+        lib = L.load()
+        cout, cin = weight.shape
+        c0, c1 = t0.shape[-1], t1.shape[-1]
+        g0 = g1 = grad_w = grad_b = None
+        g2 = _tokens(grad_out, cout)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            full = _pointwise_gemm(g2, weight, None, True).view(*t0.shape[:-1], cin)
+            g0, g1 = (full[..., :c0] if ctx.needs_input_grad[0] else None), (full[..., c0:] if ctx.needs_input_grad[1] else None)
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            with _on(g2.device):
+                parts = []
+                for i, (t, c) in enumerate(((t0, c0), (t1, c1))):
+                    x2 = _tokens(t, c)
+                    N = x2.shape[0]
+                    dw = torch.empty((cout, c), dtype=torch.float32, device=x2.device)
+                    if i == 0 and ctx.has_bias:
+                        grad_b = torch.empty(cout, dtype=torch.float32, device=x2.device)
+                    ws = torch.empty(int(lib.nd_linear_wgrad_workspace_floats(N, c, cout)), dtype=torch.float32, device=x2.device)
+                    L.call("nd_linear_wgrad_f32", x2.data_ptr(), c, g2.data_ptr(), cout, dw.data_ptr(),
+                           grad_b.data_ptr() if (i == 0 and grad_b is not None) else None, ws.data_ptr(), N, c, cout, _stream(x2.device))
+                    parts.append(dw)
+                grad_w = torch.cat(parts, dim=1)
+        return g0, g1, grad_w, grad_b
+
+
+def conv1x1_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable F.conv2d(torch.cat((x0, x1), 1), weight, bias) for 1x1 kernels that never builds the concatenation (channels_last in and out; both
+    channel counts multiples of 4)."""
+    if x0.dim() != 4 or tuple(weight.shape[2:]) != (1, 1) or x0.shape[1] + x1.shape[1] != weight.shape[1] or x0.shape[1] % 4 or x1.shape[1] % 4 \
+            or weight.shape[0] % 4 or not (x0.is_cuda and x1.is_cuda):
+        raise ValueError(f"conv1x1_cat: x0 {tuple(x0.shape)} + x1 {tuple(x1.shape)} / weight {tuple(weight.shape)}")
+    t0, t1 = x0.permute(0, 2, 3, 1), x1.permute(0, 2, 3, 1)
+    y = LinearCatFunction.apply(t0 if t0.is_contiguous() else t0.contiguous(), t1 if t1.is_contiguous() else t1.contiguous(), weight.flatten(1), bias)
+    return y.permute(0, 3, 1, 2)
 
 
 def _linear_ok(cin: int, cout: int) -> bool:

@@ -62,8 +62,18 @@ class _Ops:
             FALLBACKS[(name, op)] = why
             _log.warning("%s: %s stays on PyTorch (%s)", name, op, why)
 
-    def conv(self, name: str, x: torch.Tensor, padding: int = 0) -> torch.Tensor:
+    def conv(self, name: str, x, padding: int = 0) -> torch.Tensor:
+        """``x``: a tensor, or a pair (x0, x1) standing for torch.cat((x0, x1), 1) -- the up path's skip concatenations, which the library's 3x3 and
+        1x1 convolutions read as two sources (train.conv3x3_cat / conv1x1_cat) instead of a concatenated copy."""
         w, b = self.p[name + ".weight"], self.p.get(name + ".bias")
+        if isinstance(x, tuple):
+            from . import train
+            if self.hip and train.cat_sources_ok(*x) and w.shape[0] % 8 == 0:
+                if w.shape[2:] == (3, 3) and padding == 1:
+                    return train.conv3x3_cat(x[0], x[1], w, b)
+                if w.shape[2:] == (1, 1) and padding == 0:
+                    return train.conv1x1_cat(x[0], x[1], w, b)
+            x = torch.cat(x, dim=1)
         if self.hip and x.is_cuda and w.shape[2:] == (3, 3) and padding == 1 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
             from . import train
             return train.conv3x3(x, w, b)
@@ -116,11 +126,19 @@ class _Ops:
         along dim 1: (B, 2C, 1, 1) from the time embedding or (B, 2C, H, W) per-pixel maps."""
         from . import train
         w = self.p[name + ".proj.weight"]
-        fused = (self.hip and x.is_cuda and train._group_norm_ok(w.shape[0], groups)
-                 and (ss is None or ss.numel() == x.shape[0] * 2 * w.shape[0]))   # norm, per-sample modulation, SiLU (and the block's shortcut) as one operator
+        pair = x if isinstance(x, tuple) else None                             # (x0, x1) = torch.cat((x0, x1), 1), read as two sources where the kernels can
+        if pair is not None and not (self.hip and train.cat_sources_ok(*pair) and w.shape[0] % 8 == 0 and train._group_norm_ok(w.shape[0], groups)
+                                     and (ss is None or ss.numel() == pair[0].shape[0] * 2 * w.shape[0])):
+            x, pair = torch.cat(pair, dim=1), None
+        x0 = pair[0] if pair is not None else x
+        fused = (self.hip and x0.is_cuda and train._group_norm_ok(w.shape[0], groups)
+                 and (ss is None or ss.numel() == x0.shape[0] * 2 * w.shape[0]))   # norm, per-sample modulation, SiLU (and the block's shortcut) as one operator
         if fused and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
             # ... fed by the convolution's statistics epilogue, as in the sampling engine: no pass of the norm's own over the conv output for its moments
-            x, cs = train.conv3x3_with_stats(x, w, self.p.get(name + ".proj.bias"))
+            if pair is not None:
+                x, cs = train.conv3x3_cat(pair[0], pair[1], w, self.p.get(name + ".proj.bias"), with_stats=True)
+            else:
+                x, cs = train.conv3x3_with_stats(x, w, self.p.get(name + ".proj.bias"))
             return train.group_norm_silu(x, groups, self.p[name + ".norm.weight"], self.p[name + ".norm.bias"], ss, 1e-5, res=res, conv_stats=cs)
         x = self.conv(name + ".proj", x, 1)
         if fused:
@@ -146,6 +164,8 @@ class _Ops:
                 ss = self.ss[name][:, :, None, None]
             else:
                 ss = self.linear(name + ".mlp.1", emb)[:, :, None, None]
+        if isinstance(x, tuple) and name + ".res_conv.weight" not in self.p:
+            x = torch.cat(x, dim=1)                                            # an identity shortcut needs the tensor itself
         res = self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x
         return self.block(name + ".block2", self.block(name + ".block1", x, groups, ss), groups, res=res)      # block2(...) + res, the add inside block2's fused tail
 
@@ -284,13 +304,13 @@ def _forward(o: _Ops, x: torch.Tensor, time: torch.Tensor, condition, arch: str 
     x = o.resnet("mid_block2", x, t, GROUPS)
     for i in range(4):
         n = f"ups.{i}"
-        x = o.resnet(n + ".0", torch.cat((x, skips.pop()), dim=1), t, GROUPS)
-        x = o.stage_attention(f"up_attns.{i}", kinds[3 - i], o.resnet(n + ".1", torch.cat((x, skips.pop()), dim=1), t, GROUPS))
+        x = o.resnet(n + ".0", (x, skips.pop()), t, GROUPS)                    # (a pair = the concatenation, read as two sources)
+        x = o.stage_attention(f"up_attns.{i}", kinds[3 - i], o.resnet(n + ".1", (x, skips.pop()), t, GROUPS))
         if tr.iso_attn:
             x = o.attn_block(n + ".2", x, iso)
         x = o.conv(f"{n}.{rs}", x, 1) if i == 3 else o.conv(f"{n}.{rs}.1", F.interpolate(x, scale_factor=2, mode="nearest"), 1)
     x = pos_block("pos_block2", x)
-    x = o.resnet("final_res_block", torch.cat((x, stem), dim=1), t, GROUPS)
+    x = o.resnet("final_res_block", (x, stem), t, GROUPS)
     out = o.conv("final_conv", x)
     return out if shot is None else shot + out
 

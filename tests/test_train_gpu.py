@@ -724,3 +724,35 @@ def test_wgrad_reads_channel_slices_of_wider_tensors(shape):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     ref = torch.nn.grad.conv2d_weight(xs.permute(0, 3, 1, 2).double().cpu(), (cout, cin, 3, 3), gs.permute(0, 3, 1, 2).double().cpu(), padding=1)
     assert rel_err(res[0][0].numpy(), ref.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64, 128), (4, 32, 32, 512, 256, 512), (1, 48, 96, 32, 64, 48), (1, 32, 32, 48, 16, 64), (4, 128, 128, 128, 64, 128)])
+def test_convolutions_over_two_sources_equal_the_concatenation(shape):
+    """train.conv3x3_cat / conv1x1_cat (the up path's cat((x, skip)) read as two kernel sources, never materialised): outputs, the GroupNorm statistics
+    epilogue and every gradient equal those of the same operators on torch.cat -- bit for bit, since the kernels walk the same channel chunks in the same
+    order (the deep case runs the split-K form); the 3x3 weight gradient reads its cin blocks from either source (nd_conv3x3_wgrad_cat_nhwc_f32: the same bits
+    too) where both are whole 32-channel blocks."""
+    B, H, W, c0, c1, cout = shape
+    x0, x1 = U("cat.x0", (B, c0, H, W), -1.5, 1.5).to(DEV), U("cat.x1", (B, c1, H, W), -1.5, 1.5).to(DEV)
+    w3 = (U("cat.w3", (cout, c0 + c1, 3, 3)) / (9 * (c0 + c1)) ** 0.5).to(DEV)
+    w1 = (U("cat.w1", (cout, c0 + c1, 1, 1)) / (c0 + c1) ** 0.5).to(DEV)
+    b = U("cat.b", (cout,)).to(DEV)
+    gy = U("cat.gy", (B, cout, H, W)).to(DEV)
+    assert train.cat_sources_ok(x0, x1)
+    for kind, w in (("3x3", w3), ("1x1", w1)):
+        outs = []
+        for two in (False, True):
+            a, c, wa, ba = x0.clone().requires_grad_(), x1.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+            if kind == "3x3":
+                y, (st, sc) = train.conv3x3_cat(a, c, wa, ba, with_stats=True) if two else train.conv3x3_with_stats(torch.cat((a, c), 1), wa, ba)
+            else:
+                y, st = (train.conv1x1_cat(a, c, wa, ba) if two else train.conv1x1(torch.cat((a, c), 1), wa, ba)), None
+            y.backward(gy)
+            outs.append([t.detach().cpu() for t in (y, a.grad, c.grad, wa.grad, ba.grad)] + ([st.cpu()] if st is not None else []))
+        names = ("y", "dx0", "dx1", "dw", "db", "stats")
+        for got, ref, name in zip(outs[1], outs[0], names):
+            if name in ("dw", "db") and (kind == "1x1" or c0 % 32 or c1 % 32):    # weight gradient per source: another split, another summation order
+                assert rel_err(got.numpy(), ref.numpy()) < 2e-5, (kind, name)
+            else:
+                assert torch.equal(got, ref), (kind, name)
+    assert not train.cat_sources_ok(x0[:, :8], x1)                                # half a 16-channel chunk: the caller concatenates
