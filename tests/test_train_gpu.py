@@ -703,11 +703,13 @@ def test_training_with_the_one_launch_adam_follows_torch_adam_step_by_step():
     assert curves[1] == pytest.approx(curves[0], rel=2e-4)
 
 
+@pytest.mark.parametrize("form", [0, 2, 3])
 @pytest.mark.parametrize("shape", [(2, 16, 32, 32, 64), (2, 16, 24, 32, 64)])
-def test_wgrad_reads_channel_slices_of_wider_tensors(shape):
+def test_wgrad_reads_channel_slices_of_wider_tensors(shape, form, wgrad_form):
     """x and dy as channel slices of wider NHWC tensors (pixel strides ldx > cin, ldy > cout: the halves of a concat, a gradient that is a view), both
     forms of the kernel (W = 32: Winograd domain, W = 24: nine taps), against the gradient computed from contiguous copies -- the same bits."""
     lib = L.load()
+    wgrad_form(form)                                                 # the product's choice, four waves, eight waves (cout = 64)
     B, H, W, cin, cout = shape
     xw = U("wgs.x", (B, H, W, cin + 32)).to(DEV)
     gw = U("wgs.g", (B, H, W, cout + 16)).to(DEV)
