@@ -291,7 +291,7 @@ struct WwArgs {
     const float* x1;                                                 // second source of a virtual concatenation along cin: channels c0 .. cin - 1 (c0 = cin: none)
     int ldx1, c0;
     int ldx, ldy, B, H, W, cin, cout;
-    int n_co, n_ci, S, gx, gy, n_groups, wide;
+    int n_co, n_ci, S, gx, gy, n_groups, wide, coP, ciP;
 };
 
 typedef float ww_f2 __attribute__((ext_vector_type(2)));
@@ -389,11 +389,13 @@ __device__ __forceinline__ void ww_wave(const WwArgs& a, float* sm, const int wa
     const int cs0 = ISV ? co0 : second ? ci0 - a.c0 : ci0;           // first channel of the block within its source
     const int sc = u >> 3, sq = u & 7;
     const int OOB = (int)0x80000000;
-    const int vl = (sc * ld + cs0 + 4 * sq) * 4;
+    // channel counts that are multiples of 16 only (d = 48: 48 / 96 / ...): the quads past the tensor's last channel are requested out of range (zeros)
+    const int c_end = ISV ? a.cout : second ? a.cin - a.c0 : a.c0;   // channels of this source
+    const int vl = cs0 + 4 * sq < c_end ? (sc * ld + cs0 + 4 * sq) * 4 : OOB;
     const int vl_left = (!ISV && sc == 0) ? OOB : vl;                // left image edge: halo column 0 is padding
     const int r6 = u >> 4, c6 = 16 + ((u >> 3) & 1);
     const int v6 = ((r6 * a.W + c6) * ld + cs0 + 4 * sq) * 4;
-    const int code6 = (c6 == 17 ? 1 : 0) | (r6 == 0 ? 2 : 0) | (r6 == 5 ? 4 : 0) | (u >= 96 ? 8 : 0);
+    const int code6 = (c6 == 17 ? 1 : 0) | (r6 == 0 ? 2 : 0) | (r6 == 5 ? 4 : 0) | ((u >= 96 || cs0 + 4 * sq >= c_end) ? 8 : 0);
     const int lds_c = (ISV ? WW_XF : 0) + sc * WW_PS + 4 * sq;       // + row * (16 | 18) * WW_PS
     const int lds_6 = (r6 * WW_HC + c6) * WW_PS + 4 * sq;
     const int row_bytes = a.W * ld * 4;
@@ -902,15 +904,16 @@ __global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(float* __restrict__
 
 // dW (OIHW) = G^T M G from the summed positions M[pos][co][ci] (split-0 slot); a thread owns one (co, ci): 36 coalesced reads, 9 results; db from the summed bias row
 __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw,
-                                                                float* __restrict__ db, int cin, int cout) {
+                                                                float* __restrict__ db, int cin, int cout, int coP, int ciP) {
     constexpr float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                                {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-    const size_t plane = (size_t)cout * cin, total = plane + (db ? cout : 0);
+    const size_t plane = (size_t)cout * cin, total = plane + (db ? cout : 0), planeP = (size_t)coP * ciP;     // (the workspace planes are padded to whole blocks)
     for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
         if (j >= plane) { db[j - plane] = wsb[j - plane];  continue; }
+        const size_t jp = (j / cin) * ciP + j % cin;
         float M[36];
 #pragma unroll
-        for (int pos = 0; pos < 36; ++pos) M[pos] = ws[(size_t)pos * plane + j];
+        for (int pos = 0; pos < 36; ++pos) M[pos] = ws[(size_t)pos * planeP + jp];
         float R[3][6];                                               // G^T M: (3 x 6)(6 x 6)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -939,11 +942,11 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __r
 // (tap, cin) forms its tap of G^T M G.  The last workgroups add the bias partials [s][co].  (r5 first form: a sum launch + a transform launch,
 // 14 us of a 128 -> 128 layer's 89.  Same additions in the same order: the same bits as the two launches.)
 __global__ __launch_bounds__(384) void wgrad_wino_finish_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw,
-                                                                float* __restrict__ db, int S, int cin, int cout) {
+                                                                float* __restrict__ db, int S, int cin, int cout, int coP, int ciP) {
     constexpr float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                                {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
     __shared__ float M[36][32];
-    const int tid = threadIdx.x, n_cb = cin / 32, n_main = cout * n_cb;
+    const int tid = threadIdx.x, n_cb = ciP / 32, n_main = cout * n_cb;
     auto sum_splits = [&](const float* p, size_t stride) {
         float sum = p[0];
         int s_ = 1;
@@ -959,15 +962,15 @@ __global__ __launch_bounds__(384) void wgrad_wino_finish_kernel(const float* __r
     };
     if ((int)blockIdx.x >= n_main) {                                 // bias rows
         const int co = ((int)blockIdx.x - n_main) * 384 + tid;
-        if (db && co < cout) db[co] = sum_splits(wsb + co, (size_t)cout);
+        if (db && co < cout) db[co] = sum_splits(wsb + co, (size_t)coP);
         return;
     }
     const int co = blockIdx.x / n_cb, ci0 = (blockIdx.x % n_cb) * 32, cl = tid & 31, pg = tid >> 5;
-    const size_t plane = (size_t)cout * cin;
+    const size_t plane = (size_t)coP * ciP;                          // (padded to whole blocks)
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int pos = 3 * pg + q;
-        M[pos][cl] = sum_splits(ws + (size_t)pos * plane + (size_t)co * cin + ci0 + cl, 36 * plane);
+        M[pos][cl] = sum_splits(ws + (size_t)pos * plane + (size_t)co * ciP + ci0 + cl, 36 * plane);
     }
     __syncthreads();
     if (tid < 288) {
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(384) void wgrad_wino_finish_kernel(const float* __r
             for (int i = 0; i < 6; ++i) rj += G[i][r] * M[i * 6 + jj][cl];
             v += rj * G[jj][c];
         }
-        dw[((size_t)co * cin + ci0 + cl) * 9 + pg] = v;
+        if (ci0 + cl < cin) dw[((size_t)co * cin + ci0 + cl) * 9 + pg] = v;
     }
 }
 
@@ -993,15 +996,16 @@ int& ww_form() {
 }
 
 bool ww_takes(int B, int H, int W, int cin, int cout) {
-    return ww_form() != 1 && H % WW_GH == 0 && W % WW_GW == 0 && cin % WW_CB == 0 && cout % WW_CB == 0 && (long)B * H * W < (1L << 30);
+    return ww_form() != 1 && H % WW_GH == 0 && W % WW_GW == 0 && cin % 16 == 0 && cout % 16 == 0 && (long)B * H * W < (1L << 30);      // (blocks of 32 channels, the last one may be half empty)
 }
 
 void ww_plan(int B, int H, int W, int cin, int cout, WwArgs& a) {
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
     // the eight-wave form ((64 couts x 32 cins) blocks): 20 % fewer cycles per tile group and block, but twice the accumulators per CU -- twice the
     // partial sums to write and add.  It pays where the groups x blocks product is large (measured over the d = 64 layers: profiles/r5_wgrad_wino.txt)
-    a.wide = ww_form() != 2 && cout % W8_CO == 0 && (ww_form() == 3 || (long)B * (H / WW_GH) * (W / WW_GW) * (cin / WW_CB) * (cout / WW_CB) >= 20000);
-    a.n_co = cout / (a.wide ? W8_CO : WW_CB);  a.n_ci = cin / WW_CB;
+    a.wide = ww_form() != 2 && cout % W8_CO == 0 && cin % WW_CB == 0 && (ww_form() == 3 || (long)B * (H / WW_GH) * (W / WW_GW) * (cin / WW_CB) * (cout / WW_CB) >= 20000);
+    a.n_co = a.wide ? cout / W8_CO : nd_cdiv(cout, WW_CB);  a.n_ci = nd_cdiv(cin, WW_CB);
+    a.coP = a.n_co * (a.wide ? W8_CO : WW_CB);  a.ciP = a.n_ci * WW_CB;      // the workspace planes: whole blocks
     a.gx = W / WW_GW;  a.gy = H / WW_GH;
     a.n_groups = B * a.gx * a.gy;
     // The split over the tile groups: fixed by the shape (the summation order never depends on the device).  Workgroups run in rounds of
@@ -1034,7 +1038,7 @@ extern "C" int64_t nd_conv3x3_wgrad_workspace_floats(int B, int H, int W, int ci
     if (ww_takes(B, H, W, cin, cout)) {                                  // the Winograd-domain form: [S][36][co][ci] + [S][co]
         WwArgs w;
         ww_plan(B, H, W, cin, cout, w);
-        const int64_t m = (int64_t)w.S * cout * (36 * (int64_t)cin + 1);
+        const int64_t m = (int64_t)w.S * w.coP * (36 * (int64_t)w.ciP + 1);
         if (m > n) n = m;
     }
     return n;
@@ -1052,7 +1056,7 @@ static int wgrad_run(const float* x, int ldx, int c0, const float* x1, int ldx1,
         ww_plan(B, H, W, cin, cout, w);
         w.x = x; w.dy = dy; w.ws = workspace; w.ldx = ldx; w.ldy = ldy;
         w.x1 = x1; w.ldx1 = ldx1; w.c0 = c0;
-        w.wsb = dbias ? workspace + (size_t)w.S * 36 * cout * cin : nullptr;
+        w.wsb = dbias ? workspace + (size_t)w.S * 36 * w.coP * w.ciP : nullptr;
         static nd_device_once configured_w;
         if (int e = nd_reserve_lds(configured_w, reinterpret_cast<const void*>(wgrad_wino_kernel), WW_LDS, "nd_conv3x3_wgrad (Winograd domain)")) return e;
         hipStream_t st = (hipStream_t)stream;
@@ -1063,18 +1067,18 @@ static int wgrad_run(const float* x, int ldx, int c0, const float* x1, int ldx1,
         } else
         hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)(w.n_co * w.n_ci * w.S)), dim3(256), WW_LDS, st, w);
         if (int e = nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (Winograd domain)")) return e;
-        const int n_main = cout * (cin / 32), n_bias = dbias ? (cout + 383) / 384 : 0;
+        const int n_main = cout * (w.ciP / 32), n_bias = dbias ? (cout + 383) / 384 : 0;
         if (w.S > 1 && n_main >= 512) {
-            hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((unsigned)(n_main + n_bias)), dim3(384), 0, st, workspace, w.wsb, dw_oihw, dbias, w.S, cin, cout);
+            hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((unsigned)(n_main + n_bias)), dim3(384), 0, st, workspace, w.wsb, dw_oihw, dbias, w.S, cin, cout, w.coP, w.ciP);
             return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (Winograd-domain sum + reduce)");
         }
-        const size_t n_w = (size_t)36 * cout * cin;
+        const size_t n_w = (size_t)36 * w.coP * w.ciP;
         if (w.S > 1) {
-            const size_t tot = n_w + (dbias ? cout : 0);
-            hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)), dim3(256), 0, st, workspace, w.wsb, w.S, n_w, cout);
+            const size_t tot = n_w + (dbias ? w.coP : 0);
+            hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)), dim3(256), 0, st, workspace, w.wsb, w.S, n_w, w.coP);
         }
         const size_t total = (size_t)cout * (cin + 1);
-        hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, workspace, w.wsb, dw_oihw, dbias, cin, cout);
+        hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, workspace, w.wsb, dw_oihw, dbias, cin, cout, w.coP, w.ciP);
         return nd_launch_status("nd_conv3x3_wgrad_nhwc_f32 (Winograd-domain reduce)");
     }
     ND_REQUIRE(c0 == cin, ND_E_SHAPE, "nd_conv3x3_wgrad_cat_nhwc_f32: two sources need the Winograd-domain form (H %% 4 == 0, W %% 16 == 0, channel counts %% 32 == 0)");

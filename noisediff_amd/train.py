@@ -244,7 +244,7 @@ class Conv3x3CatFunction(torch.autograd.Function):
             full = _conv3x3_nhwc(g, weight, None, dgrad=True)            # (B, c0 + c1, H, W) channels_last: the slices are views
             gx0, gx1 = (full[:, :c0] if ctx.needs_input_grad[0] else None), (full[:, c0:] if ctx.needs_input_grad[1] else None)
         want_b = ctx.has_bias and ctx.needs_input_grad[3]
-        if ctx.needs_input_grad[2] and H % 4 == 0 and W % 16 == 0 and c0 % 32 == 0 and c1 % 32 == 0 and cout % 32 == 0 and lib.nd_conv3x3_wgrad_form(-1) != 1:
+        if ctx.needs_input_grad[2] and H % 4 == 0 and W % 16 == 0 and c0 % 32 == 0 and c1 % 32 == 0 and cout % 16 == 0 and lib.nd_conv3x3_wgrad_form(-1) != 1:
             with _on(a.device):                                          # the Winograd-domain forms read a cin block from either source: ONE weight gradient
                 grad_w = torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=a.device)
                 grad_b = torch.empty(cout, dtype=torch.float32, device=a.device) if want_b else None

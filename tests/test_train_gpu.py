@@ -59,10 +59,11 @@ def wgrad_form():
 
 @pytest.mark.parametrize("form", sorted(WGRAD_FORMS))
 @pytest.mark.parametrize("shape", [(2, 48, 32, 64, 128), (2, 48, 24, 64, 128), (4, 64, 64, 32, 32), (1, 16, 16, 512, 256), (3, 40, 48, 96, 64), (2, 48, 32, 48, 64),
-                                   (1, 4, 16, 32, 64), (2, 12, 16, 32, 32), (1, 6, 16, 32, 32), (3, 64, 256, 32, 64)])
+                                   (1, 4, 16, 32, 64), (2, 12, 16, 32, 32), (1, 6, 16, 32, 32), (3, 64, 256, 32, 64), (1, 16, 32, 96, 48), (2, 16, 16, 48, 48),
+                                   (2, 8, 32, 80, 112)])
 def test_wgrad_is_bitwise_repeatable_and_matches_a_float64_sum(shape, form, wgrad_form):
     """nd_conv3x3_wgrad_nhwc_f32 in each of its forms -- nine taps (any shape), the Winograd-domain F(4x4) kernel on four waves (H % 4 == 0, W % 16 == 0,
-    channel counts % 32 == 0; down to a single tile group per workgroup, 1 / 2 / 3 groups: the three exits of its pipeline) and on eight waves
+    channel counts % 16 == 0 -- d = 48's 48 / 96 / 80 / 112: half-empty last blocks --; down to a single tile group per workgroup, 1 / 2 / 3 groups: the three exits of its pipeline) and on eight waves
     (cout % 64 == 0 as well) -- against a float64 weight gradient; bitwise repeatable, bias gradient, argument checks.  A form that does not take the
     shape leaves it to the next one, as the product does; the product's own choice (by the shape) is one of them."""
     lib = L.load()

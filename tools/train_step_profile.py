@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One configuration of the training step (GaussianDiffusion.p_losses forward + backward + Adam on the NoiseDiffNet graph with the HIP operators)
 for rocprofv3:  rocprofv3 --kernel-trace --stats -d gpurun_out/train_prof -- python3 tools/train_step_profile.py
-Env: B (4), S (256), STEPS (6), HIP (1: .hip() operators, 0: PyTorch), NET (trainable | dropin: noisediff_amd.NoiseDiffNet under autograd),
+Env: B (4), S (256), DIM (64), STEPS (6), HIP (1: .hip() operators, 0: PyTorch), NET (trainable | dropin: noisediff_amd.NoiseDiffNet under autograd),
 ADAM (hip: noisediff_amd.train.Adam, one launch per step -- the default | torch: torch.optim.Adam's foreach form | fused: PyTorch's single-kernel Adam)."""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,13 +13,14 @@ torch.backends.cudnn.allow_tf32 = False
 torch.backends.cuda.matmul.allow_tf32 = False
 dev = torch.device("cuda", 0)
 B, S, STEPS, HIP = int(os.environ.get("B", 4)), int(os.environ.get("S", 256)), int(os.environ.get("STEPS", 6)), os.environ.get("HIP", "1") != "0"
+DIM = int(os.environ.get("DIM", 64))
 cond = {k: v.to(dev) for k, v in synth.make_condition(B, S, seed=1).items()}
 img = synth.uniform(7, "img", (B, 4, S, S), -1.0, 1.0).to(dev)
 torch.manual_seed(0)
 if os.environ.get("NET", "trainable") == "dropin":
-    net = NoiseDiffNet(SimpleNamespace(dim=64, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False)).to(dev).train()
+    net = NoiseDiffNet(SimpleNamespace(dim=DIM, cond_dim=4, inp_dim=4, self_condition=False, normalize_condition=False)).to(dev).train()
 else:
-    net = TrainableNoiseDiffNet(SimpleNamespace(dim=64)).to(dev).hip(HIP)
+    net = TrainableNoiseDiffNet(SimpleNamespace(dim=DIM)).to(dev).hip(HIP)
 gd = GaussianDiffusion(net, image_size=S, timesteps=1000, beta_schedule="sigmoid2", objective="pred_v").to(dev)
 _adam = os.environ.get("ADAM", "hip")
 if _adam == "hip":
@@ -45,7 +46,7 @@ t0 = time.perf_counter()
 for _ in range(STEPS):
     loss = one()
 torch.cuda.synchronize()
-print(f"B={B} {S}x{S} hip={HIP}: {(time.perf_counter() - t0) / STEPS * 1e3:.1f} ms/step, loss {float(loss):.6f}", flush=True)
+print(f"B={B} {S}x{S} dim={DIM} hip={HIP}: {(time.perf_counter() - t0) / STEPS * 1e3:.1f} ms/step, loss {float(loss):.6f}", flush=True)
 if os.environ.get("PROFILE", "0") != "0":          # where do the ATen copies / adds / sums come from: per operator and input shape
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as prof:
