@@ -489,10 +489,16 @@ typedef struct nd_adam_item {
     int64_t      n;
     float        step_size, bias2_sqrt;
     int32_t      vec4, reserved;
+    float*       step;        /* capturable form only: the parameter's step counter (one float in device memory) */
 } nd_adam_item;
 int nd_adam_chunk_elements(void);
 int nd_adam_step_f32(const nd_adam_item* items_dev, int n_items, const int32_t* chunks_dev, int n_chunks, float beta1, float beta2, float eps,
                      float weight_decay, void* stream);
+/* The same with nothing computed on the host (a training step captured as one graph): item.step points at the parameter's step counter in device
+ * memory (a float, as torch.optim.Adam(capturable=True) keeps it); the call adds one to every counter and derives step_size / bias2_sqrt from it
+ * (item.step_size, item.bias2_sqrt are ignored).  Two launches. */
+int nd_adam_step_capturable_f32(const nd_adam_item* items_dev, int n_items, const int32_t* chunks_dev, int n_chunks, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------ HIP graph helpers */
 int nd_stream_create(void** stream);

@@ -33,7 +33,7 @@ class Src(C.Structure):
 
 class AdamItem(C.Structure):
     _fields_ = [("p", fptr), ("g", fptr), ("m", fptr), ("v", fptr), ("n", C.c_int64), ("step_size", C.c_float), ("bias2_sqrt", C.c_float),
-                ("vec4", C.c_int32), ("reserved", C.c_int32)]
+                ("vec4", C.c_int32), ("reserved", C.c_int32), ("step", fptr)]
 
 
 class PackItem(C.Structure):
@@ -132,6 +132,7 @@ SIGNATURES = {
     "nd_conv7x7_c4_wgrad_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_adam_chunk_elements": (i32, []),
     "nd_adam_step_f32": (i32, [vp, i32, vp, i32, f32, f32, f32, f32, vp]),
+    "nd_adam_step_capturable_f32": (i32, [vp, i32, vp, i32, f32, f32, f32, f32, f32, vp]),
     "nd_groupnorm_finalize_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp]),
     "nd_groupnorm_finalize_train_f32": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, vp]),
     "nd_layernorm_stats_f32": (i32, [vp, i32, vp, vp, i32, i32, i32, f32, vp]),

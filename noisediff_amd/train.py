@@ -961,10 +961,12 @@ class Adam(torch.optim.Adam):
     all parameters of a group in ONE launch of nd_adam_step_f32 (adam.hip) instead of PyTorch's ~10 foreach passes: 1.14 -> 0.3 ms of the d = 64
     network's 28 ms step.  Same constructor, same state (``step`` -- a CPU tensor per parameter --, ``exp_avg``, ``exp_avg_sq``), so state dicts move
     between the two classes (``--resume_optim``); the same update in fp32 up to the rounding of one fused pass.  What the kernel does not do is refused:
-    amsgrad, maximize, capturable (and a step under stream capture), differentiable, sparse gradients, parameters that are not fp32 on a GPU."""
+    amsgrad, maximize, differentiable, sparse gradients, parameters that are not fp32 on a GPU.  ``capturable=True`` (PyTorch's flag): the step counters live on
+    the device and nothing is computed on the host per step (nd_adam_step_capturable_f32) -- the form a training step captured as ONE CUDA graph needs
+    (tools/train_graph_bench.py); run one step before the capture."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kw):
-        for k in ("amsgrad", "maximize", "capturable", "differentiable", "fused"):
+        for k in ("amsgrad", "maximize", "differentiable", "fused"):
             if kw.get(k):
                 raise NotImplementedError(f"noisediff_amd.train.Adam: {k}=True is not built (use torch.optim.Adam)")
         kw.pop("foreach", None)
@@ -977,9 +979,10 @@ class Adam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("noisediff_amd.train.Adam computes its step sizes on the host and uploads a pointer table per step: it cannot be captured "
-                               "into a CUDA graph (torch.optim.Adam(capturable=True) can)")
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if capturing and not all(g.get("capturable") for g in self.param_groups):
+            raise RuntimeError("noisediff_amd.train.Adam computes its step sizes on the host unless built with capturable=True: this step cannot be captured "
+                               "into a CUDA graph")
         lib = L.load()
         per = int(lib.nd_adam_chunk_elements())
         for gi, group in enumerate(self.param_groups):
@@ -994,16 +997,25 @@ class Adam(torch.optim.Adam):
                     raise NotImplementedError("noisediff_amd.train.Adam: parameters must be contiguous")
             beta1, beta2 = group["betas"]
             lr = float(group["lr"])
+            cap = bool(group.get("capturable"))                          # step counters on the device, nothing computed on the host (nd_adam_step_capturable_f32)
             items = (L.AdamItem * len(ps))()
             keep = []
             for i, p in enumerate(ps):
                 st = self.state[p]
                 if len(st) == 0:                                         # torch.optim.Adam._init_group's state
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    if capturing:
+                        raise RuntimeError("noisediff_amd.train.Adam: run a step before the capture (the optimizer state is created on the first step)")
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if cap else torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                t = float(st["step"])
+                if cap:
+                    if not (st["step"].is_cuda and st["step"].dtype == torch.float32):
+                        raise NotImplementedError("noisediff_amd.train.Adam(capturable=True): the step counters must be fp32 tensors on the parameter's device")
+                    t = 1.0
+                    items[i].step = st["step"].data_ptr()
+                else:
+                    st["step"] += 1
+                    t = float(st["step"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous()) or m.device != dev:
@@ -1016,15 +1028,24 @@ class Adam(torch.optim.Adam):
             key = (gi, tuple(p.data_ptr() for p in ps))
             tab = self._nd_tables.get(key)
             if tab is None:                                              # (item, chunk) pairs: fixed while the group's parameters are
+                if capturing:
+                    raise RuntimeError("noisediff_amd.train.Adam: run a step with the same parameters before the capture (the chunk table is built on the first step)")
                 if len(self._nd_tables) > 64:
                     self._nd_tables.clear()
                 pairs = [(i, c) for i, p in enumerate(ps) for c in range((p.numel() + per - 1) // per)]
                 tab = self._nd_tables[key] = (torch.tensor(pairs, dtype=torch.int32).reshape(-1, 2).to(dev), len(pairs))
             # pointers and step sizes of this step (a few KB): pinned + asynchronous, so the host keeps running ahead of the device
-            table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True)
+            host_table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory()
+            table = host_table.to(dev, non_blocking=True)
             with _on(dev):
-                L.call("nd_adam_step_f32", table.data_ptr(), len(ps), tab[0].data_ptr(), tab[1], float(beta1), float(beta2), float(group["eps"]),
-                       float(group["weight_decay"]), _stream(dev))
+                if cap:
+                    L.call("nd_adam_step_capturable_f32", table.data_ptr(), len(ps), tab[0].data_ptr(), tab[1], lr, float(beta1), float(beta2),
+                           float(group["eps"]), float(group["weight_decay"]), _stream(dev))
+                else:
+                    L.call("nd_adam_step_f32", table.data_ptr(), len(ps), tab[0].data_ptr(), tab[1], float(beta1), float(beta2), float(group["eps"]),
+                           float(group["weight_decay"]), _stream(dev))
+            if capturing:                                                # a captured step replays with these tables: they live as long as the optimizer
+                self._nd_captured = getattr(self, "_nd_captured", []) + [(table, host_table, keep)]
             self._nd_keep = (table, keep)                                # alive until the next step (the launch is asynchronous)
             for p in ps:                                                 # the kernel wrote through raw pointers: tell autograd (and the packing caches, which
                 st = self.state[p]                                       # compare version counters) that these tensors changed

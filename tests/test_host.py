@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(L.SamplerState) == 6 * 8 + 2 * 4
     assert C.sizeof(L.ChainStage) == 2 * 8 + 4 * 4
     assert C.sizeof(L.PackItem) == 2 * 8 + 4 * 4
-    assert C.sizeof(L.AdamItem) == 4 * 8 + 8 + 2 * 4 + 2 * 4                    # nd_adam_item
+    assert C.sizeof(L.AdamItem) == 4 * 8 + 8 + 2 * 4 + 2 * 4 + 8                # nd_adam_item
     assert C.sizeof(L.Chain) == C.sizeof(L.Src) + 3 * C.sizeof(L.ChainStage) + 8 + 4 * 4
 
 

@@ -759,3 +759,52 @@ def test_convolutions_over_two_sources_equal_the_concatenation(shape):
             else:
                 assert torch.equal(got, ref), (kind, name)
     assert not train.cat_sources_ok(x0[:, :8], x1)                                # half a 16-channel chunk: the caller concatenates
+
+
+def test_a_training_step_with_the_capturable_adam_replays_as_one_graph():
+    """train.Adam(capturable=True): step counters on the device, nothing computed on the host -- forward + backward + optimizer captured into one
+    torch.cuda.CUDAGraph and replayed; the losses follow torch.optim.Adam run eagerly on a copy of the net (the packing caches' repack launches are part of
+    the graph)."""
+    torch.manual_seed(0)
+    net = nn.Sequential(_Block(32, 64), _Block(64, 64), nn.Conv2d(64, 4, 1)).to(DEV)
+    train.accelerate(net)
+    x = U("capnet.x", (2, 32, 32, 64)).to(DEV)
+    target = U("capnet.t", (2, 4, 32, 64)).to(DEV)
+    ref, cap = copy.deepcopy(net), copy.deepcopy(net)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=2e-3)
+    want = []
+    for _ in range(6):
+        opt_ref.zero_grad(set_to_none=True)
+        loss = F.mse_loss(ref(x), target)
+        loss.backward()
+        opt_ref.step()
+        want.append(float(loss))
+    opt = train.Adam(cap.parameters(), lr=2e-3, capturable=True)
+    got = []
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                                                   # two eager steps on a side stream (state, chunk tables), as torch's recipe asks
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = F.mse_loss(cap(x), target)
+            loss.backward()
+            opt.step()
+            got.append(float(loss))
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        gloss = F.mse_loss(cap(x), target)
+        gloss.backward()
+        opt.step()
+    for _ in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        got.append(float(gloss))
+    assert float(opt.state[next(iter(cap.parameters()))]["step"]) == 6.0          # (the capture itself does not execute)
+    assert got == pytest.approx(want, rel=3e-4)
+    with pytest.raises(RuntimeError):
+        bad = train.Adam(copy.deepcopy(net).parameters(), lr=1e-3)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            bad.step()

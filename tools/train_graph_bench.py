@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Training step of TrainableNoiseDiffNet(...).hip() as ONE captured graph (torch.cuda.CUDAGraph): forward + backward + Adam(capturable=True).
+"""Training step of TrainableNoiseDiffNet(...).hip() as ONE captured graph (torch.cuda.CUDAGraph): forward + backward + Adam(capturable=True) --
+noisediff_amd.train.Adam (one launch + a counter launch; env ADAM=torch: torch.optim.Adam).
 The library's launches are queued on torch's current stream, so they are captured like any ATen kernel; replaying the graph removes the host side of the
 ~300 autograd-function calls of a step (which bounds the small configurations in eager mode)."""
 import os, sys, time
@@ -7,13 +8,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from types import SimpleNamespace
 from noisediff_amd import GaussianDiffusion, TrainableNoiseDiffNet, synth
+from noisediff_amd.train import Adam as HipAdam
 dev = torch.device("cuda", 0)
 for (B, S) in [(4, 256), (8, 128)]:
     cond = {k: v.to(dev) for k, v in synth.make_condition(B, S, seed=1).items()}
     img = synth.uniform(7, "img", (B, 4, S, S), -1.0, 1.0).to(dev)
     net = TrainableNoiseDiffNet(SimpleNamespace(dim=64)).to(dev).hip(True)
     gd = GaussianDiffusion(net, image_size=S, timesteps=1000, beta_schedule="sigmoid2", objective="pred_v").to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=True)
+    opt = (torch.optim.Adam if os.environ.get("ADAM") == "torch" else HipAdam)(net.parameters(), lr=1e-4, capturable=True)
     def one():
         opt.zero_grad(set_to_none=True)
         loss = gd(img, cond)
