@@ -593,28 +593,31 @@ __global__ __launch_bounds__(256) void c7_wgrad_kernel(const C7wArgs a) {
     }
 }
 
-// dw (cout, 4, 7, 7) and db from the partial sums, in workgroup order
+// dw (cout, 4, 7, 7) and db from the partial sums: four lanes share an output, lane q adds workgroups q, q + 4, ... in order, the four meet in lane order
 __global__ __launch_bounds__(256) void c7_wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw, float* __restrict__ db,
                                                               int n_wg, int cout) {
     const int total = cout * 196 + (db ? cout : 0);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const bool bias = i >= cout * 196;
-        const int co = bias ? i - cout * 196 : i / 196, e = bias ? 0 : i - co * 196;                  // e = ci 49 + tap in dw
-        const int ci = e / 49, tap = e - ci * 49;
-        const float* p = bias ? wsb + co : ws + (size_t)co * C7W_N + tap * 4 + ci;
-        const size_t stride = bias ? (size_t)cout : (size_t)cout * C7W_N;
-        float sum = 0.0f;
-        int s = 0;
-        for (; s + 8 <= n_wg; s += 8) {
-            float v[8];
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3;
+    const bool live = i < total;
+    const int ii = live ? i : 0;
+    const bool bias = ii >= cout * 196;
+    const int co = bias ? ii - cout * 196 : ii / 196, e = bias ? 0 : ii - co * 196;                   // e = ci 49 + tap in dw
+    const int ci = e / 49, tap = e - ci * 49;
+    const float* p = bias ? wsb + co : ws + (size_t)co * C7W_N + tap * 4 + ci;
+    const size_t stride = bias ? (size_t)cout : (size_t)cout * C7W_N;
+    float sum = 0.0f;
+    int s = q;
+    for (; s + 28 < n_wg; s += 32) {                                     // eight loads in flight
+        float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(s + q) * stride];
+        for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s + 4 * k) * stride];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sum += v[q];
-        }
-        for (; s < n_wg; ++s) sum += p[(size_t)s * stride];
-        if (bias) db[co] = sum; else dw[i] = sum;
+        for (int k = 0; k < 8; ++k) sum += v[k];
     }
+    for (; s < n_wg; s += 4) sum += p[(size_t)s * stride];
+    sum += __shfl_down(sum, 1, 4) ;                                      // (q, q + 1), then (0 + 1) + (2 + 3)
+    sum += __shfl_down(sum, 2, 4);
+    if (live && q == 0) { if (bias) db[co] = sum; else dw[i] = sum; }
 }
 
 bool c7w_takes(int B, int H, int W, int cout) {
@@ -661,6 +664,6 @@ extern "C" int nd_conv7x7_c4_wgrad_f32(const float* x, const float* dy, int ldy,
     }
     if (e) return e;
     const int total = cout * 196 + (dbias ? cout : 0);
-    hipLaunchKernelGGL(c7_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, a.wsb, dw_oihw, dbias, a.n_wg, cout);
+    hipLaunchKernelGGL(c7_wgrad_reduce_kernel, dim3((unsigned)((4 * total + 255) / 256)), dim3(256), 0, st, workspace, a.wsb, dw_oihw, dbias, a.n_wg, cout);
     return nd_launch_status("nd_conv7x7_c4_wgrad_f32 (reduce)");
 }
