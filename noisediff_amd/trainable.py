@@ -362,13 +362,14 @@ class TrainableNoiseDiffNet(nn.Module):
         if x_self_cond is not None:
             raise ValueError("self-conditioning is not part of this configuration")
         cache = self.__dict__.get("_nd_param_table")                        # (name -> Parameter, [(owner's _parameters, key, Parameter)]): named_parameters() costs 1.5 ms per step
-        if cache is None or not all(d.get(k) is q for d, k, q in cache[1]):     # a replaced Parameter rebuilds it; conversions (.to, .float) keep the objects
+        if cache is None or cache[2] != id(self) or not all(d.get(k) is q for d, k, q in cache[1]):     # a replaced Parameter rebuilds it; conversions (.to, .float) keep the
+            # objects; an nn.DataParallel replica (a shallow copy of this module's __dict__ with its own broadcast tensors) must not inherit the owner's table
             table, checks = {}, []
             for prefix, m in self.named_modules():
                 for k, q in m._parameters.items():
                     if q is not None:
                         table[f"{prefix}.{k}" if prefix else k] = q
                         checks.append((m._parameters, k, q))
-            cache = self.__dict__["_nd_param_table"] = (table, checks)
+            cache = self.__dict__["_nd_param_table"] = (table, checks, id(self))
         table = cache[0]
         return _forward(_Ops(table, self._hip), x, time, condition, arch=self.arch, mid_attn=self.has_mid_attn, stage_attn=self.stage_attn)
