@@ -299,6 +299,18 @@ int nd_pack_pointwise_weight_t(const float* w_t, float* packed, int cin, int cou
  * floats), exactly as nd_pack_pointwise_weight / nd_pack_pointwise_weight_t do. */
 int nd_pack_pointwise_weights_batch(const nd_pack_item* items_dev, int n_items, void* stream);
 
+/* The same operator (same descriptor, prologues, epilogues, errors) with every product on the bf16 matrix cores at the operands' FULL fp32
+ * significand: each fp32 operand is split exactly into three bf16 terms (v = v1 + v2 + v3, round-to-nearest-even remainders), six of the nine
+ * term products are kept (the dropped ones lie below 2^-25 of the product -- under the rounding of an fp32 FMA), accumulation in fp32.  Replaces
+ * the same reference layers as nd_pointwise_gemm_nhwc_f32 where they are wide: FeedForward's Linears and AttnBlock.proj_out at C >= 128
+ * (Diffusion_arch.py:405-443), res_conv of the up path (:156), Attention.to_qkv / to_out (:252-253).  `weight`: nd_pack_pointwise_weight_split
+ * ((cout, cin) row-major -> [cin/16][term 3][cout/32][64 lanes][8 bf16]).  Takes: cin % 32 == 0, cin >= 64, cout % 128 == 0, plain pixel
+ * addressing, LayerNorm with src.rowstats, a concat on a 32-channel boundary (nd_pointwise_gemm_split_takes); anything else: ND_E_SHAPE. */
+int nd_pointwise_gemm_split_nhwc_f32(const nd_pointwise* d, void* stream);
+int nd_pointwise_gemm_split_takes(const nd_pointwise* d);
+int64_t nd_pack_pointwise_weight_split_floats(int cin, int cout);
+int nd_pack_pointwise_weight_split(const float* w, float* packed, int cin, int cout, void* stream);
+
 /* ------------------------------------------------------------------ chained pointwise layers
  * Two or three per-pixel Linear layers in one kernel, the intermediate activations never leaving registers:
  *   Mlp (Diffusion_arch.py:340-356):            out = fc2(act(fc1(x)))
@@ -326,6 +338,13 @@ int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream);
 int nd_pointwise_chain_supported(int cin, int n1, int n2, int n3);   /* n3 = 0: two stages */
 int64_t nd_pack_chain_weight_floats(int cin, int cout, int first_stage);
 int nd_pack_chain_weight(const float* w, float* packed, int cin, int cout, int first_stage, void* stream);
+/* The same chains (same descriptor, widths, prologues, residuals, errors) with the products on the bf16 matrix cores at full fp32 significand
+ * (three-term split, six products, fp32 accumulation: see nd_pointwise_gemm_split_nhwc_f32); the stages' `weight` pointers are
+ * nd_pack_chain_weight_split packings (three bf16 terms per value in the operand order of v_mfma_f32_32x32x16_bf16, K padded to 16 for the first
+ * stage and to 32 for the later ones, N to 32). */
+int nd_pointwise_chain_split_nhwc_f32(const nd_chain* d, void* stream);
+int64_t nd_pack_chain_weight_split_floats(int cin, int cout, int first_stage);
+int nd_pack_chain_weight_split(const float* w, float* packed, int cin, int cout, int first_stage, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm plumbing */
 

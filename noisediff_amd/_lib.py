@@ -121,6 +121,13 @@ SIGNATURES = {
     "nd_pointwise_chain_supported": (i32, [i32, i32, i32, i32]),
     "nd_pack_chain_weight_floats": (i64, [i32, i32, i32]),
     "nd_pack_chain_weight": (i32, [vp, vp, i32, i32, i32, vp]),
+    "nd_pointwise_chain_split_nhwc_f32": (i32, [C.POINTER(Chain), vp]),
+    "nd_pack_chain_weight_split_floats": (i64, [i32, i32, i32]),
+    "nd_pack_chain_weight_split": (i32, [vp, vp, i32, i32, i32, vp]),
+    "nd_pointwise_gemm_split_nhwc_f32": (i32, [C.POINTER(Pointwise), vp]),
+    "nd_pointwise_gemm_split_takes": (i32, [C.POINTER(Pointwise)]),
+    "nd_pack_pointwise_weight_split_floats": (i64, [i32, i32]),
+    "nd_pack_pointwise_weight_split": (i32, [vp, vp, i32, i32, vp]),
     "nd_pack_pointwise_weight_floats": (i64, [i32, i32]),
     "nd_pack_pointwise_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "nd_pack_pointwise_weight_t": (i32, [vp, vp, i32, i32, vp]),

@@ -502,6 +502,201 @@ __global__ __launch_bounds__(256, 1) void pointwise_big_kernel(const PwArgs a) {
 #endif
 }
 
+// ---- SPLIT variant (r6; nd_pointwise_gemm_split_nhwc_f32): the same per-pixel GEMM with every product on the bf16 matrix pipe at the operands' FULL fp32
+// significand.  v = v1 + v2 + v3 exactly (v1 = bf16(v), v2 = bf16(v - v1), round-to-nearest-even; v3 = v - v1 - v2: at most 8 significant bits); six of the nine
+// term products are kept (w1 v1, w1 v2, w2 v1, w2 v2, w1 v3, w3 v1: the dropped ones are below 2^-25 of the product), each one v_mfma_f32_32x32x16_bf16 -- 16
+// channels of a 32 x 32 tile cost 6 x 32 matrix cycles against 8 x 64 on v_mfma_f32_32x32x2_f32, and the bf16 instruction leaves the vector ALU to the split,
+// the prologue and the epilogue (the fp32 one issues on the VALU's own lanes).  The wide 1x1 layers then sit against HBM, so the kernel is built to keep bytes
+// in flight: TWO workgroups per CU (67.6 KB of LDS, 256 registers each), each one software-pipelined over 32-channel chunks.
+//   * activations: 128 rows x 32 channels per chunk, thread = (row, 8-channel segment): two 16-byte loads, the prologue, the split ONCE per element
+//     (11 VALU instructions per value pair), three ds_write_b128 into the chunk's term planes [term 3][row 128][64 bytes + 16 pad] (conflict-free b128 reads);
+//   * weights: split once at pack time (nd_pack_pointwise_weight_split: [K step][term][32-cout tile][lane 64] x 16 bytes, lane (cout l & 31, K group l >> 5) holding
+//     channels 16 ks + 8 (l >> 5) .. + 7), straight from the L2 into a register ring one K step ahead;
+//   * a wave owns 64 pixels x 64 couts: 4 accumulators, 6 + 6 operand reads (16 bytes per lane each) per 24 MFMAs.
+// Epilogue: pw_epilogue, as every other kernel of this file.  Accuracy against fp64: profiles/r6_split_gemm_accuracy.txt.
+typedef __bf16 pw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pw_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int SKC = 32;                                      // channels per chunk: two 16-channel K steps
+constexpr int SROW = SKC * 2 + 16;                           // bytes per row of a term plane
+constexpr int SPLANE = 128 * SROW, SABUF = 3 * SPLANE;       // one term plane, one chunk buffer (30 KB)
+constexpr int SPLIT_LDS = 2 * SABUF > 128 * 132 * 4 ? 2 * SABUF : 128 * 132 * 4;
+
+// (x, y) -> one dword of each of the three bf16 terms (x in the low half)
+__device__ __forceinline__ void pw_split2(float x, float y, unsigned& w1, unsigned& w2, unsigned& w3) {
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x, y}, pw_bf16x2));
+    const float rx = x - __builtin_bit_cast(float, w1 << 16), ry = y - __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{rx, ry}, pw_bf16x2));
+    const float sx = rx - __builtin_bit_cast(float, w2 << 16), sy = ry - __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+    w3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sy), __builtin_bit_cast(unsigned, sx), 0x07060302u);   // the upper halves ARE the third terms
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const PwArgs a) {
+    constexpr int MB = 2, NB = 2, BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) float Ab[];  // two chunk buffers during the K loop, the output tile in the epilogue
+    char* const As = reinterpret_cast<char*>(Ab);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, col = lane & 31;
+
+    int lid = nd_xcd_remap(blockIdx.x, a.total_wg);
+    const int nt = lid % a.n_tiles;  lid /= a.n_tiles;
+    const int mt = lid % a.m_tiles;
+    const int b = lid / a.m_tiles;
+
+    const nd_src& s = a.d.src;
+    const int HW = a.d.HW, Cin = a.d.cin;
+    const int p0 = mt * BM, n0 = nt * BN;
+
+    // operand addresses: activations = A (rows = pixels), weights = B (columns = couts)
+    int a_off[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a_off[mb] = ((wm * MB + mb) * 32 + col) * SROW + half * 16;
+    const int n32 = a.coutP / 32;                              // 32-cout tiles of the packed weight
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d.weight), 0, (int)((long)a.cinP * a.coutP * 6), 0x00020000);
+    const unsigned wvoff = (unsigned)(lane * 16);
+    const int wtile = (n0 + wn * (NB * 32)) / 32;
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+    const int seg = tid & 3, prow = tid >> 2;                  // staging: 8-channel segment, row (two passes of 64 rows)
+    size_t pixoff0[2], pixoff1[2];
+    float rmean[2], rrstd[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const size_t pix = (size_t)b * HW + min(p0 + prow + it * 64, HW - 1);
+        pixoff0[it] = pix * s.ld0;
+        pixoff1[it] = pix * s.ld1;
+        rmean[it] = 0.0f; rrstd[it] = 1.0f;
+        if (MODE == ND_PRO_LAYERNORM) {                       // host: rowstats present
+            rmean[it] = s.rowstats[2 * pix];
+            rrstd[it] = s.rowstats[2 * pix + 1];
+        }
+    }
+
+    pw_u32x4 bq[2][3][NB];                                     // weight ring: K step parity x term x 32-cout tile
+    f32x4 raw[2][2];                                           // the next chunk's activations in flight: pass x half segment
+    f32x4 pA[2], pB[2], pC[2];                                 // per-chunk channel constants of the prologue
+    auto load_b = [&](int slot, int ks) {                      // weight fragments of K step ks (beyond the last one: a harmless reload of it)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bq[slot][t][nb] = __builtin_bit_cast(pw_u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, wvoff, __builtin_amdgcn_readfirstlane((((ks * 3 + t) * n32 + wtile + nb) * 64) * 16), 0));
+    };
+    auto stage_load = [&](int cb) {
+        const int c = cb + seg * 8;                            // < Cin: cin % 32 == 0
+        const bool sec = c >= s.c0;                            // a chunk never straddles the sources (host check)
+        const float* base = sec ? s.p1 : s.p0;
+        const int cc = sec ? c - s.c0 : c;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const float* p = base + (sec ? pixoff1[it] : pixoff0[it]) + cc;
+            raw[it][0] = nd_ld4(p);
+            raw[it][1] = nd_ld4(p + 4);
+        }
+        if (MODE == ND_PRO_LAYERNORM) {
+            const f32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                pA[j] = nd_ld4(s.gamma + c + 4 * j); pB[j] = nd_ld4(s.beta + c + 4 * j);
+                pC[j] = s.vec ? nd_ld4(s.vec + (size_t)b * Cin + c + 4 * j) : zero;
+            }
+        }
+        if (MODE == ND_PRO_AFFINE_SILU) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* m = s.mad + (size_t)b * 3 * Cin + c + 4 * j;
+                pA[j] = nd_ld4(m); pB[j] = nd_ld4(m + Cin); pC[j] = nd_ld4(m + 2 * Cin);
+            }
+        }
+    };
+    auto stage_write = [&](char* dst) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = prow + it * 64;
+            pw_u32x4 t1, t2, t3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = raw[it][j];
+                if (MODE == ND_PRO_LAYERNORM) v = ((v + pC[j]) - rmean[it]) * rrstd[it] * pA[j] + pB[j];
+                else if (MODE == ND_PRO_SILU) v = nd_silu4(v);
+                else if (MODE == ND_PRO_AFFINE_SILU) v = nd_silu4((v - pA[j]) * pB[j] + pC[j]);
+                else if (MODE == ND_PRO_LEAKY) v = nd_leaky4(v);
+                const f32x4 zero = {0, 0, 0, 0};
+                v = (p0 + r < HW) ? v : zero;
+                unsigned u1, u2, u3;
+                pw_split2(v.x, v.y, u1, u2, u3);  t1[2 * j] = u1;  t2[2 * j] = u2;  t3[2 * j] = u3;
+                pw_split2(v.z, v.w, u1, u2, u3);  t1[2 * j + 1] = u1;  t2[2 * j + 1] = u2;  t3[2 * j + 1] = u3;
+            }
+            char* o = dst + r * SROW + seg * 16;
+            *reinterpret_cast<pw_u32x4*>(o) = t1;
+            *reinterpret_cast<pw_u32x4*>(o + SPLANE) = t2;
+            *reinterpret_cast<pw_u32x4*>(o + 2 * SPLANE) = t3;
+        }
+    };
+    auto mfma = [&](pw_u32x4 av, pw_u32x4 bv, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pw_bf16x8, av), __builtin_bit_cast(pw_bf16x8, bv), c, 0, 0, 0);
+    };
+    auto kstep = [&](auto slot_c, const char* src, int k2) {   // one 16-channel K step of the chunk in `src` (k2 = 0, 1) on ring slot `slot_c`
+        constexpr int S = decltype(slot_c)::value;
+        pw_u32x4 av[MB][3];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) av[mb][t] = *reinterpret_cast<const pw_u32x4*>(src + t * SPLANE + a_off[mb] + k2 * 32);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x16 c = acc[mb][nb];
+                c = mfma(av[mb][0], bq[S][0][nb], c);
+                c = mfma(av[mb][1], bq[S][0][nb], c);
+                c = mfma(av[mb][0], bq[S][1][nb], c);
+                c = mfma(av[mb][1], bq[S][1][nb], c);
+                c = mfma(av[mb][2], bq[S][0][nb], c);
+                c = mfma(av[mb][0], bq[S][2][nb], c);
+                acc[mb][nb] = c;
+            }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    const int n_chunks = a.cinP / SKC, last_ks = 2 * n_chunks - 1;
+    stage_load(0);
+    load_b(0, 0);
+    load_b(1, 1);
+    stage_write(As);
+    __syncthreads();
+    // (no branch between a load and the MFMAs it overlaps; sched_barriers keep hipcc from sinking the prefetches to their uses: see pointwise_pipe_kernel)
+    for (int c = 0; c < n_chunks; ++c) {
+        const char* cur = As + (c & 1) * SABUF;
+        char* nxt = As + ((c + 1) & 1) * SABUF;
+        const int cbn = (c + 1 < n_chunks ? c + 1 : c) * SKC;  // behind the last chunk: a harmless re-stage of it
+        stage_load(cbn);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(S0{}, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(0, min(2 * c + 2, last_ks));
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(S1{}, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(1, min(2 * c + 3, last_ks));
+        stage_write(nxt);
+        __syncthreads();                                       // the other buffer is complete, this one has been consumed
+    }
+    pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0);
+}
+
 // NOTE on code shape: every global load below is unconditional (clamped address + select) and the prologue mode is a
 // template parameter.  With data-dependent branches around loads hipcc emits s_waitcnt vmcnt(0) after each one, which
 // turned the staging pass and the residual reads into chains of serialized HBM round trips (measured 2-5x slower).
@@ -801,6 +996,47 @@ void launch(const PwArgs& a, hipStream_t st) {
     }
 }
 
+// (cout, cin) row-major -> three bf16 terms in [K step][term][32-cout tile][lane 64][8]: slot i of lane l = W[32 tile + (l & 31)][16 ks + 8 (l >> 5) + i]
+__global__ void pack_pointwise_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cin, int cout, int cinP, int coutP) {
+    const size_t total = (size_t)cinP * coutP;
+    const int n32 = coutP / 32;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+        const size_t rest = idx >> 9;
+        const int tile = (int)(rest % n32), ks = (int)(rest / n32);
+        const int n = 32 * tile + (l & 31), k = 16 * ks + 8 * (l >> 5) + i;
+        const float v = (n < cout && k < cin) ? w[(size_t)n * cin + k] : 0.0f;
+        const __bf16 t1 = (__bf16)v;
+        const float r1 = v - (float)t1;                       // exact
+        const __bf16 t2 = (__bf16)r1;
+        const float r2 = r1 - (float)t2;                      // exact, at most 8 significant bits: its upper half is the third term
+        unsigned short* o = out + (((size_t)ks * 3 * n32 + tile) * 64 + l) * 8 + i;
+        const size_t term = (size_t)n32 * 512;
+        o[0] = __builtin_bit_cast(unsigned short, t1);
+        o[term] = __builtin_bit_cast(unsigned short, t2);
+        o[2 * term] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+}
+
+int launch_split(const PwArgs& a, hipStream_t st) {
+    const dim3 grid(a.total_wg), block(256);
+#define PWS_LAUNCH(MODE)                                                                                                      \
+    {                                                                                                                         \
+        static nd_device_once configured;                                                                                     \
+        if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(pointwise_split_kernel<MODE>), SPLIT_LDS, "nd_pointwise_split")) return e; \
+        hipLaunchKernelGGL((pointwise_split_kernel<MODE>), grid, block, SPLIT_LDS, st, a);                                    \
+    }
+    switch (a.d.src.mode) {
+        case ND_PRO_LAYERNORM: PWS_LAUNCH(ND_PRO_LAYERNORM) break;
+        case ND_PRO_SILU: PWS_LAUNCH(ND_PRO_SILU) break;
+        case ND_PRO_AFFINE_SILU: PWS_LAUNCH(ND_PRO_AFFINE_SILU) break;
+        case ND_PRO_LEAKY: PWS_LAUNCH(ND_PRO_LEAKY) break;
+        default: PWS_LAUNCH(ND_PRO_NONE)
+    }
+#undef PWS_LAUNCH
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int64_t nd_pack_pointwise_weight_floats(int cin, int cout) {
@@ -852,7 +1088,14 @@ long pw_big_tiles(const nd_pointwise* d) {                                  // 0
     return tiles >= nd_device_cus() ? tiles : 0;
 }
 
-int pw_run(const nd_pointwise* d, void* stream) {
+// layers the SPLIT kernel takes: whole 32-channel chunks (at least two), 128-cout tiles, plain addressing, LayerNorm statistics from the pre-pass
+bool pw_split_takes(const nd_pointwise* d) {
+    const nd_src& s = d->src;
+    return d->cin % SKC == 0 && d->cin >= 2 * SKC && d->cout % 128 == 0 && !s.unshuffle && d->shuffle_c == 0 && (s.mode != ND_PRO_LAYERNORM || s.rowstats) &&
+           (s.c1 == 0 || (s.c0 % SKC == 0 && nd_aligned16(s.p1)));
+}
+
+int pw_run(const nd_pointwise* d, void* stream, bool split = false) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_pointwise: null descriptor");
     const nd_src& s = d->src;
     ND_REQUIRE(s.p0 && d->weight && d->out, ND_E_BADARG, "nd_pointwise: null tensor pointer");
@@ -895,6 +1138,18 @@ int pw_run(const nd_pointwise* d, void* stream) {
 
     PwArgs a;
     a.d = *d;
+    if (split) {
+        ND_REQUIRE(pw_split_takes(d), ND_E_SHAPE, "nd_pointwise_gemm_split: %d -> %d is not a layer of the split kernel (cin %% 32, cin >= 64, cout %% 128, plain "
+                   "addressing, LayerNorm with rowstats, concat on a 32-channel boundary: nd_pointwise_gemm_split_takes)", d->cin, d->cout);
+        a.cinP = d->cin;  a.coutP = d->cout;
+        a.m_tiles = nd_cdiv(d->HW, 128);
+        a.n_tiles = d->cout / 128;
+        const long wgs = (long)d->B * a.m_tiles * a.n_tiles;
+        ND_REQUIRE(wgs < (1L << 31), ND_E_SHAPE, "nd_pointwise_gemm_split: grid too large");
+        a.total_wg = (int)wgs;
+        if (int e = launch_split(a, (hipStream_t)stream)) return e;
+        return nd_launch_status("nd_pointwise_gemm_split_nhwc_f32");
+    }
     a.cinP = nd_round_up(d->cin, 8);
     a.coutP = nd_round_up(d->cout, 64);
     // tiling: 128x128, 128x64, 64x64 -- first with >= 2 workgroups per CU, else the smallest
@@ -946,3 +1201,23 @@ int pw_run(const nd_pointwise* d, void* stream) {
 }  // namespace
 
 extern "C" int nd_pointwise_gemm_nhwc_f32(const nd_pointwise* d, void* stream) { return pw_run(d, stream); }
+
+// The same operator with the products on the bf16 matrix pipe at full fp32 significand (pointwise_split_kernel above); `weight` is an
+// nd_pack_pointwise_weight_split packing.  Same prologues, epilogues and errors; takes the layers nd_pointwise_gemm_split_takes names.
+extern "C" int nd_pointwise_gemm_split_nhwc_f32(const nd_pointwise* d, void* stream) { return pw_run(d, stream, true); }
+
+extern "C" int nd_pointwise_gemm_split_takes(const nd_pointwise* d) { return d && pw_split_takes(d) ? 1 : 0; }
+
+extern "C" int64_t nd_pack_pointwise_weight_split_floats(int cin, int cout) {
+    return (int64_t)nd_round_up(cin, 32) * nd_round_up(cout, 128) * 3 / 2;       // three bf16 terms per value, counted in floats (the arena's unit)
+}
+
+extern "C" int nd_pack_pointwise_weight_split(const float* w, float* packed, int cin, int cout, void* stream) {
+    ND_REQUIRE(w && packed && nd_aligned16(packed), ND_E_BADARG, "nd_pack_pointwise_weight_split: null or unaligned pointer");
+    ND_REQUIRE(cin > 0 && cout > 0, ND_E_BADARG, "nd_pack_pointwise_weight_split: non-positive size");
+    const int cinP = nd_round_up(cin, 32), coutP = nd_round_up(cout, 128);
+    const size_t total = (size_t)cinP * coutP;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_pointwise_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, reinterpret_cast<unsigned short*>(packed), cin, cout, cinP, coutP);
+    return nd_launch_status("nd_pack_pointwise_weight_split");
+}

@@ -17,10 +17,39 @@
 // Weights (packed in operand order by nd_pack_chain_weight), biases and LayerNorm gamma/beta of all stages sit in LDS for
 // the lifetime of the persistent workgroup (80 KB at C = 64): an A fragment is one ds_read_b128 per four MFMAs.  Three or
 // four waves per SIMD (768 / 1024 threads) let one wave's activation VALU run under the others' MFMAs.
+//
+// SPLIT instances (r6; nd_pointwise_chain_split_nhwc_f32): the same chain with every product on the bf16 matrix pipe at the operands' FULL
+// fp32 significand.  x = x1 + x2 + x3 exactly, x1 = bf16(x), x2 = bf16(x - x1) (round-to-nearest-even, v_cvt_pk_bf16_f32), x3 = x - x1 - x2 (both
+// remainders are exact in fp32 and the second has at most 8 significant bits); weights are split once at pack time, activations per 16-channel
+// K step in registers (11 VALU instructions per value pair).  Six of the nine term products are kept -- w1 x1, w1 x2, w2 x1, w2 x2, w1 x3, w3 x1;
+// the dropped ones are below 2^-25 of the product, under the rounding of an fp32 FMA -- each one v_mfma_f32_32x32x16_bf16 (products of bf16 pairs
+// are exact in fp32; accumulation in fp32).  16 channels cost 6 x 32 matrix cycles per 32 x 32 tile against 8 x 64 for v_mfma_f32_32x32x2_f32
+// (2.67x), and -- unlike the fp32 instruction, which issues on the VALU's own lanes -- leave 24 of every 32 cycles of vector issue to the split,
+// LayerNorm and GELU work of the other waves.  Same operand pairing as the fp32 form: slot (K step s, lane half h, i < 8) = channel
+// 16 s + 8 (i >> 2) + 4 h + (i & 3), which is both "registers (2s, 2s+1) of the input row's float4s" and "registers 8 (s & 1) .. + 7 of n-tile
+// s >> 1 of the previous stage's accumulators": the chain still flows register to register.  Weight terms sit in LDS (120 KB at C = 64).
+// Accuracy against fp64: profiles/r6_split_gemm_accuracy.txt (the r5 study of the same split on the F(4x4) kernel: rms error 0.94 of fp32's).
 #include <type_traits>
 #include "nd_common.h"
 
 namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// (x, y) -> one dword of each of the three bf16 terms (x in the low half): x == t1 + t2 + t3 exactly
+__device__ __forceinline__ void chain_split2(float x, float y, unsigned& w1, unsigned& w2, unsigned& w3) {
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x, y}, bf16x2_t));
+    const float rx = x - __builtin_bit_cast(float, w1 << 16), ry = y - __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{rx, ry}, bf16x2_t));
+    const float sx = rx - __builtin_bit_cast(float, w2 << 16), sy = ry - __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+    w3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sy), __builtin_bit_cast(unsigned, sx), 0x07060302u);   // the upper halves ARE the third terms
+}
+
+__device__ __forceinline__ f32x16 chain_mfma_bf16(u32x4_t a, u32x4_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 
 struct ChainArgs {
     nd_chain d;
@@ -48,6 +77,43 @@ __device__ __forceinline__ void chain_gemm(const float (&in)[K / 2], const float
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[nt] = nd_mfma(a4[i], in[4 * jq + i], acc[nt]);
         }
+}
+
+// SPLIT: `w` = the stage's weight terms in LDS, [n-tile][K step][term 3][lane 64] x 16 bytes (eight bf16: the lane's slots of the K step)
+template <int K, int N>
+__device__ __forceinline__ void chain_gemm_split(const float (&in)[K / 2], const char* __restrict__ w, const float* __restrict__ bias,
+                                                 f32x16 (&acc)[N / 32], const int lane) {
+    static_assert(K % 16 == 0, "whole 16-channel K steps");
+    const int half = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = nd_ld4(bias + 32 * nt + 8 * g + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = b4[i];
+        }
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+        u32x4_t x1, x2, x3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned t1, t2, t3;
+            chain_split2(in[8 * s + 2 * j], in[8 * s + 2 * j + 1], t1, t2, t3);
+            x1[j] = t1;  x2[j] = t2;  x3[j] = t3;
+        }
+#pragma unroll
+        for (int nt = 0; nt < N / 32; ++nt) {
+            const u32x4_t* p = reinterpret_cast<const u32x4_t*>(w + (size_t)((nt * (K / 16) + s) * 3) * 1024) + lane;
+            const u32x4_t w1 = p[0], w2 = p[64], w3 = p[128];
+            acc[nt] = chain_mfma_bf16(w1, x1, acc[nt]);
+            acc[nt] = chain_mfma_bf16(w1, x2, acc[nt]);
+            acc[nt] = chain_mfma_bf16(w2, x1, acc[nt]);
+            acc[nt] = chain_mfma_bf16(w2, x2, acc[nt]);
+            acc[nt] = chain_mfma_bf16(w1, x3, acc[nt]);
+            acc[nt] = chain_mfma_bf16(w3, x1, acc[nt]);
+        }
+    }
 }
 
 template <int N>
@@ -101,14 +167,18 @@ __device__ __forceinline__ void chain_store(const f32x16 (&acc)[N / 32], float* 
 // VALU of one wave runs under the MFMAs of the others
 constexpr int chain_threads(int n1) { return n1 >= 128 ? 768 : 1024; }
 
-template <int K0, int N1, int N2, int N3, int MODE>
+// floats of LDS a stage's weights take: fp32 operands, or three bf16 terms (6 bytes per value)
+template <bool SPLIT> constexpr int chain_w_floats(int n, int k) { return SPLIT ? n * k * 3 / 2 : n * k; }
+
+template <int K0, int N1, int N2, int N3, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const ChainArgs a) {
     constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
+    static_assert(!SPLIT || K0 % 16 == 0, "SPLIT: the first stage reads whole 16-channel K steps");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w1 = lds;
-    float* w2 = w1 + N1 * K0;
-    float* w3 = w2 + N2 * N1;
-    float* b1 = w3 + N3 * N2;
+    float* w2 = w1 + chain_w_floats<SPLIT>(N1, K0);
+    float* w3 = w2 + chain_w_floats<SPLIT>(N2, N1);
+    float* b1 = w3 + chain_w_floats<SPLIT>(N3, N2);
     float* b2 = b1 + N1;
     float* b3 = b2 + N2;
     float* gam = b3 + (N3 > 0 ? N3 : 0);
@@ -127,12 +197,12 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
         auto copy_pad = [&](float* dst, const float* src, int n, int npad, float fill) {
             for (int i = tid; i < npad; i += THREADS) dst[i] = (src && i < n) ? src[i] : fill;
         };
-        copy4(w1, a.d.st[0].weight, N1 * K0);
-        copy4(w2, a.d.st[1].weight, N2 * N1);
+        copy4(w1, a.d.st[0].weight, chain_w_floats<SPLIT>(N1, K0));
+        copy4(w2, a.d.st[1].weight, chain_w_floats<SPLIT>(N2, N1));
         copy_pad(b1, a.d.st[0].bias, a.d.st[0].cout, N1, 0.0f);
         copy_pad(b2, a.d.st[1].bias, a.d.st[1].cout, N2, 0.0f);
         if (N3 > 0) {
-            copy4(w3, a.d.st[2].weight, N3 * N2);
+            copy4(w3, a.d.st[2].weight, chain_w_floats<SPLIT>(N3, N2));
             copy_pad(b3, a.d.st[2].bias, a.d.st[2].cout, N3, 0.0f);
         }
         if (MODE == ND_PRO_LAYERNORM) {
@@ -200,7 +270,8 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
 
         // ---- stage 0
         f32x16 H1[N1 / 32];
-        chain_gemm<K0, N1>(in0, w1, b1, H1, lane);
+        if constexpr (SPLIT) chain_gemm_split<K0, N1>(in0, reinterpret_cast<const char*>(w1), b1, H1, lane);
+        else chain_gemm<K0, N1>(in0, w1, b1, H1, lane);
         chain_res<K0, N1>(H1, X, s.vec ? myv : nullptr, a.d.st[0].res, half);
         chain_act<N1>(H1, a.d.st[0].act);
         // ---- stage 1: accumulator register r of n-tile nt is operand 16*nt + r
@@ -210,7 +281,8 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
 #pragma unroll
             for (int r = 0; r < 16; ++r) in1[16 * nt + r] = H1[nt][r];
         f32x16 H2[N2 / 32];
-        chain_gemm<N1, N2>(in1, w2, b2, H2, lane);
+        if constexpr (SPLIT) chain_gemm_split<N1, N2>(in1, reinterpret_cast<const char*>(w2), b2, H2, lane);
+        else chain_gemm<N1, N2>(in1, w2, b2, H2, lane);
         chain_res<K0, N2>(H2, X, s.vec ? myv : nullptr, a.d.st[1].res, half);
         chain_act<N2>(H2, a.d.st[1].act);
         float* row = a.d.out + pix * a.d.ldo;
@@ -221,7 +293,8 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
 #pragma unroll
                 for (int r = 0; r < 16; ++r) in2[16 * nt + r] = H2[nt][r];
             f32x16 H3[(N3 > 0 ? N3 : 32) / 32];
-            chain_gemm<N2, (N3 > 0 ? N3 : 32)>(in2, w3, b3, H3, lane);
+            if constexpr (SPLIT) chain_gemm_split<N2, (N3 > 0 ? N3 : 32)>(in2, reinterpret_cast<const char*>(w3), b3, H3, lane);
+            else chain_gemm<N2, (N3 > 0 ? N3 : 32)>(in2, w3, b3, H3, lane);
             chain_res<K0, (N3 > 0 ? N3 : 32)>(H3, X, s.vec ? myv : nullptr, a.d.st[2].res, half);
             chain_act<(N3 > 0 ? N3 : 32)>(H3, a.d.st[2].act);
             chain_store<(N3 > 0 ? N3 : 32)>(H3, row, cout_last, half);
@@ -242,24 +315,44 @@ __global__ void pack_chain_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+// the same operand order as three bf16 terms: [nt][K step s][term][lane][8], slot i of lane l = W[32*nt + (l & 31)][16*s + 8*(i >> 2) + 4*(l >> 5) + (i & 3)]
+__global__ void pack_chain_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cin, int cout, int KP, int NP) {
+    const int total = KP * NP;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int i = idx & 7, l = (idx >> 3) & 63, rest = idx >> 9;
+        const int s = rest % (KP / 16), nt = rest / (KP / 16);
+        const int n = 32 * nt + (l & 31), k = 16 * s + 8 * (i >> 2) + 4 * (l >> 5) + (i & 3);
+        const float v = (n < cout && k < cin) ? w[(size_t)n * cin + k] : 0.0f;
+        const __bf16 t1 = (__bf16)v;
+        const float r1 = v - (float)t1;                       // exact
+        const __bf16 t2 = (__bf16)r1;
+        const float r2 = r1 - (float)t2;                      // exact, at most 8 significant bits: its upper half is the third term
+        unsigned short* o = out + ((size_t)(nt * (KP / 16) + s) * 3 * 64 + l) * 8 + i;
+        o[0] = __builtin_bit_cast(unsigned short, t1);
+        o[512] = __builtin_bit_cast(unsigned short, t2);
+        o[1024] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+}
+
 static inline int device_cus() { return nd_device_cus(); }
 
-template <int K0, int N1, int N2, int N3, int MODE>
+template <int K0, int N1, int N2, int N3, int MODE, bool SPLIT = false>
 int launch(const ChainArgs& a, hipStream_t st) {
     static nd_device_once configured;
     constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
-    const size_t lds = (size_t)(N1 * K0 + N2 * N1 + N3 * N2 + N1 + N2 + N3 + 2 * K0 + WAVES * K0) * sizeof(float);
-    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE>), lds, "nd_pointwise_chain")) return e;
+    const size_t lds = (size_t)(chain_w_floats<SPLIT>(N1, K0) + chain_w_floats<SPLIT>(N2, N1) + chain_w_floats<SPLIT>(N3, N2) + N1 + N2 + N3 + 2 * K0 + WAVES * K0) * sizeof(float);
+    static_assert((size_t)(chain_w_floats<SPLIT>(N1, K0) + chain_w_floats<SPLIT>(N2, N1) + chain_w_floats<SPLIT>(N3, N2) + N1 + N2 + N3 + 2 * K0 + 16 * K0) * 4 <= 160 * 1024, "LDS");
+    if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE, SPLIT>), lds, "nd_pointwise_chain")) return e;
     const int wgs = nd_cdiv(a.n_tiles, WAVES);
     const int grid = wgs < device_cus() ? wgs : device_cus();
-    hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE>), dim3(grid), dim3(THREADS), lds, st, a);
+    hipLaunchKernelGGL((chain_kernel<K0, N1, N2, N3, MODE, SPLIT>), dim3(grid), dim3(THREADS), lds, st, a);
     return 0;
 }
 
-template <int K0, int N1, int N2, int N3>
+template <int K0, int N1, int N2, int N3, bool SPLIT = false>
 int launch_mode(const ChainArgs& a, hipStream_t st) {
-    if (a.d.src.mode == ND_PRO_LAYERNORM) return launch<K0, N1, N2, N3, ND_PRO_LAYERNORM>(a, st);
-    return launch<K0, N1, N2, N3, ND_PRO_NONE>(a, st);
+    if (a.d.src.mode == ND_PRO_LAYERNORM) return launch<K0, N1, N2, N3, ND_PRO_LAYERNORM, SPLIT>(a, st);
+    return launch<K0, N1, N2, N3, ND_PRO_NONE, SPLIT>(a, st);
 }
 
 }  // namespace
@@ -289,7 +382,21 @@ extern "C" int nd_pointwise_chain_supported(int cin, int n1, int n2, int n3) {
     return 0;
 }
 
-extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) {
+extern "C" int64_t nd_pack_chain_weight_split_floats(int cin, int cout, int first_stage) {
+    return (int64_t)nd_round_up(cin, first_stage ? 16 : 32) * nd_round_up(cout, 32) * 3 / 2;      // three bf16 terms per value, counted in floats (the arena's unit)
+}
+
+extern "C" int nd_pack_chain_weight_split(const float* w, float* packed, int cin, int cout, int first_stage, void* stream) {
+    ND_REQUIRE(w && packed && nd_aligned16(packed), ND_E_BADARG, "nd_pack_chain_weight_split: null or unaligned pointer");
+    ND_REQUIRE(cin > 0 && cout > 0, ND_E_SHAPE, "nd_pack_chain_weight_split: non-positive size");
+    const int KP = nd_round_up(cin, first_stage ? 16 : 32), NP = nd_round_up(cout, 32);
+    const int total = KP * NP;
+    hipLaunchKernelGGL(pack_chain_split_kernel, dim3(nd_cdiv(total, 256) < 1024 ? nd_cdiv(total, 256) : 1024), dim3(256), 0, (hipStream_t)stream,
+                       w, reinterpret_cast<unsigned short*>(packed), cin, cout, KP, NP);
+    return nd_launch_status("nd_pack_chain_weight_split");
+}
+
+static int chain_run(const nd_chain* d, void* stream, bool split) {
     ND_REQUIRE(d, ND_E_BADARG, "nd_pointwise_chain: null descriptor");
     const nd_src& s = d->src;
     ND_REQUIRE(d->n_stages == 2 || d->n_stages == 3, ND_E_BADARG, "nd_pointwise_chain: n_stages=%d (2 or 3)", d->n_stages);
@@ -325,8 +432,27 @@ extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) {
     ND_REQUIRE(tiles < (1L << 31), ND_E_SHAPE, "nd_pointwise_chain: too many pixels");
     a.n_tiles = (int)tiles;
     hipStream_t st = (hipStream_t)stream;
-    const int K0 = nd_round_up(cin, 8), N1 = nd_round_up(d->st[0].cout, 32), N2 = nd_round_up(d->st[1].cout, 32), N3 = n3 ? nd_round_up(n3, 32) : 0;
+    const int K0 = nd_round_up(cin, split ? 16 : 8), N1 = nd_round_up(d->st[0].cout, 32), N2 = nd_round_up(d->st[1].cout, 32), N3 = n3 ? nd_round_up(n3, 32) : 0;
     int rc = ND_E_SHAPE;
+    if (split) {          // the same widths with the first stage's channels in whole 16-channel K steps
+#define ND_CHAIN_SPLIT_CASE(k0, n1, n2, n3) \
+        if (K0 == k0 && N1 == n1 && N2 == n2 && N3 == n3) rc = launch_mode<k0, n1, n2, n3, true>(a, st);
+        ND_CHAIN_SPLIT_CASE(16, 32, 32, 0)
+        ND_CHAIN_SPLIT_CASE(16, 32, 32, 32)
+        ND_CHAIN_SPLIT_CASE(32, 32, 32, 0)
+        ND_CHAIN_SPLIT_CASE(32, 32, 32, 32)
+        ND_CHAIN_SPLIT_CASE(32, 64, 32, 32)
+        ND_CHAIN_SPLIT_CASE(16, 64, 64, 0)
+        ND_CHAIN_SPLIT_CASE(48, 64, 64, 0)
+        ND_CHAIN_SPLIT_CASE(48, 96, 64, 64)
+        ND_CHAIN_SPLIT_CASE(64, 64, 64, 0)
+        ND_CHAIN_SPLIT_CASE(64, 64, 32, 0)
+        ND_CHAIN_SPLIT_CASE(48, 64, 32, 0)
+        ND_CHAIN_SPLIT_CASE(64, 128, 64, 64)
+#undef ND_CHAIN_SPLIT_CASE
+        if (rc) return rc;
+        return nd_launch_status("nd_pointwise_chain_split_nhwc_f32");
+    }
 #define ND_CHAIN_CASE(k0, n1, n2, n3) \
     if (K0 == k0 && N1 == n1 && N2 == n2 && N3 == n3) rc = launch_mode<k0, n1, n2, n3>(a, st);
     ND_CHAIN_CASE(8, 32, 32, 0)
@@ -346,3 +472,9 @@ extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) {
     if (rc) return rc;
     return nd_launch_status("nd_pointwise_chain_nhwc_f32");
 }
+
+extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) { return chain_run(d, stream, false); }
+
+// The same chain with the products on the bf16 matrix pipe at full fp32 significand (three-term split, six products: see the head of this file);
+// the stages' `weight` pointers are nd_pack_chain_weight_split packings.  Same widths, prologues, residuals, activations and errors.
+extern "C" int nd_pointwise_chain_split_nhwc_f32(const nd_chain* d, void* stream) { return chain_run(d, stream, true); }

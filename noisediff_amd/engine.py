@@ -57,6 +57,10 @@ EIGHT_TILES_RULE = True  # layers with <= 8 tiles of the 16 x 32 form per sample
 WINO4_16 = os.environ.get("ND_WINO4_16", "narrow")
 WINO4_16_SPLIT = True    # geometry-only K ranges on the 16 x 16-region form (profiles/r4a_cfg2_cfg3_sampling_split_k_ab.txt; was ND_WINO4_16_SPLIT)
 _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
+# r6: wide 1x1 / Linear layers and the fused per-pixel chains on the bf16 matrix cores at full fp32 significand (three-term split of every operand, six
+# products, fp32 accumulation: pointwise.hip / pwchain.hip, "SPLIT").  Same results within fp32 rounding (error against fp64 at or below the fp32 kernels',
+# profiles/r6_split_gemm_accuracy.txt), 1.5-2x the speed: the fp32 matrix instruction issues on the VALU's own lanes.  ND_SPLIT_GEMM=0: A/B knob (tools/ only).
+SPLIT_GEMM = os.environ.get("ND_SPLIT_GEMM", "1") != "0"
 TIME_TABLE = True        # the time embedding's head looked up per timestep (r3; was ND_TIME_TABLE)
 PROJ_TABLE = True        # ... and the stacked ResnetBlock.mlp projection (r4e; was ND_PROJ_TABLE)
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -81,6 +85,11 @@ def _blocked_map_rows(C_: int) -> torch.Tensor:
     i = torch.arange(2 * C_)
     c, j = i // 32, i % 32
     return torch.where(j < 16, 16 * c + j, C_ + 16 * c + j - 16)
+
+
+def _split_layer(cin: int, cout: int) -> bool:
+    """1x1 / Linear layers whose weights are also packed as three bf16 terms for nd_pointwise_gemm_split_nhwc_f32 (pointwise.hip: pw_split_takes)."""
+    return SPLIT_GEMM and cin % 32 == 0 and cin >= 64 and cout % 128 == 0
 
 
 def _classify(name: str, shape: Sequence[int]) -> str:
@@ -180,6 +189,10 @@ class Engine:
                 if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
                     first = int(p.name.endswith(_CHAIN_FIRST))
                     add(p.name + ".chain", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
+                    if SPLIT_GEMM:
+                        add(p.name + ".chain_s", self.lib.nd_pack_chain_weight_split_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
+                if kind == "pw" and _split_layer(p.shape[1], p.shape[0]):
+                    add(p.name + ".split", self.lib.nd_pack_pointwise_weight_split_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind == "conv7":
                 n = 196 * p.shape[0]
             else:
@@ -256,6 +269,11 @@ class Engine:
                     if p.name + ".chain" in self.slots:
                         L.call("nd_pack_chain_weight", t.data_ptr(), self.p(p.name + ".chain"), p.shape[1], p.shape[0],
                                int(p.name.endswith(_CHAIN_FIRST)), st)
+                    if p.name + ".chain_s" in self.slots:
+                        L.call("nd_pack_chain_weight_split", t.data_ptr(), self.p(p.name + ".chain_s"), p.shape[1], p.shape[0],
+                               int(p.name.endswith(_CHAIN_FIRST)), st)
+                    if p.name + ".split" in self.slots:
+                        L.call("nd_pack_pointwise_weight_split", t.data_ptr(), self.p(p.name + ".split"), p.shape[1], p.shape[0], st)
                 elif kind == "pw_unshuffle":
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], p.shape[1] // 4, st)
                 elif kind == "conv7":
@@ -630,9 +648,12 @@ class Plan:
         if out is None:
             out = self._alloc(self.B, HW, cout)
         d = L.Pointwise()
-        d.src, d.weight, d.out = src, e.p(name + ".weight" + variant), out.data_ptr()
+        d.src, d.out = src, out.data_ptr()
         d.bias = e.p(name + ".bias" + variant) if bias else None
         d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = self.B, HW, W, cin, cout, cout, act
+        # wide layers: the split-product kernel on the bf16 matrix cores (a function of the layer's shape alone, never of the batch)
+        split = not variant and (name + ".weight.split") in e.slots and bool(e.lib.nd_pointwise_gemm_split_takes(C.byref(d)))
+        d.weight = e.p(name + (".weight.split" if split else ".weight" + variant))
         if res0 is not None:
             d.res0, d.ldr0 = res0.data_ptr(), res0.shape[-1]
         if res1 is not None:
@@ -641,7 +662,8 @@ class Plan:
             d.vec = vec.data_ptr()
         if gn_t is not None:
             d.gn_t, d.ldt, d.gn_mad = gn_t.data_ptr(), gn_t.shape[-1], gn_mad.data_ptr()
-        self._add("nd_pointwise_gemm_nhwc_f32", C.byref(d), e.stream, meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout})
+        self._add("nd_pointwise_gemm_split_nhwc_f32" if split else "nd_pointwise_gemm_nhwc_f32", C.byref(d), e.stream,
+                  meta={"layer": name, "B": self.B, "HW": HW, "cin": cin, "cout": cout, "split": int(split)})
         self._keep.append(d)
         return out
 
@@ -701,10 +723,11 @@ class Plan:
         out = self._alloc(self.B, HW, stages[-1][2])
         d = L.Chain()
         d.src, d.out, d.n_stages, d.B, d.HW, d.ldo = src, out.data_ptr(), len(stages), self.B, HW, stages[-1][2]
+        split = all((layer + ".weight.chain_s") in e.slots for layer, *_ in stages)
         for i, (layer, cin, cout, act, res) in enumerate(stages):
-            d.st[i].weight, d.st[i].bias = e.p(layer + ".weight.chain"), e.p(layer + ".bias")
+            d.st[i].weight, d.st[i].bias = e.p(layer + (".weight.chain_s" if split else ".weight.chain")), e.p(layer + ".bias")
             d.st[i].cin, d.st[i].cout, d.st[i].act, d.st[i].res = cin, cout, act, res
-        self._add("nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
+        self._add("nd_pointwise_chain_split_nhwc_f32" if split else "nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
                   meta={"layer": name, "B": self.B, "HW": HW, "cin": stages[0][1], "cout": stages[-1][2],
                         "flop_per_px": 2.0 * sum(c_in * c_out for _, c_in, c_out, _, _ in stages)})
         self._keep.append(d)

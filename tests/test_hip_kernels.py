@@ -246,12 +246,15 @@ CHAIN_CASES = {  # (B, HW, [widths]): Mlp chains (two stages) and AttnBlock tail
 }
 
 
+@pytest.mark.parametrize("form", ["fp32", "split"])
 @pytest.mark.parametrize("case", sorted(CHAIN_CASES))
-def test_pointwise_chain_matches_layer_by_layer(ctx, case):
-    """nd_pointwise_chain_nhwc_f32 == the same Linear layers applied one by one (Mlp :340-356, AttnBlock tail :405-443)."""
+def test_pointwise_chain_matches_layer_by_layer(ctx, case, form):
+    """nd_pointwise_chain_nhwc_f32 / nd_pointwise_chain_split_nhwc_f32 (bf16 x 3 split products, r6) == the same Linear layers applied one by one
+    (Mlp :340-356, AttnBlock tail :405-443), at the same tolerance."""
     import hiputil as hu
     B, HW, widths = CHAIN_CASES[case]
-    pack, entry = "nd_pack_chain_weight", "nd_pointwise_chain_nhwc_f32"
+    pack, entry = (("nd_pack_chain_weight", "nd_pointwise_chain_nhwc_f32") if form == "fp32" else
+                   ("nd_pack_chain_weight_split", "nd_pointwise_chain_split_nhwc_f32"))
     n = len(widths) - 1
     x = U(case + ".x", (B, HW, widths[0]), -1.5, 1.5)
     ws = [U(f"{case}.w{i}", (widths[i + 1], widths[i]), -0.3, 0.3) for i in range(n)]
@@ -260,7 +263,7 @@ def test_pointwise_chain_matches_layer_by_layer(ctx, case):
     d = L.Chain()
     for i in range(n):
         wd = hu.dev(ws[i])
-        wp = hu.full((ctx.lib.nd_pack_chain_weight_floats(widths[i], widths[i + 1], int(i == 0)),))
+        wp = hu.full((getattr(ctx.lib, pack + "_floats")(widths[i], widths[i + 1], int(i == 0)),))
         L.call(pack, wd.data_ptr(), wp.data_ptr(), widths[i], widths[i + 1], int(i == 0), ctx.stream)
         bd = hu.dev(bs[i])
         keep += [wd, wp, bd]
@@ -269,16 +272,15 @@ def test_pointwise_chain_matches_layer_by_layer(ctx, case):
     out = hu.full((B, HW, widths[-1]))
     d.out, d.n_stages, d.B, d.HW, d.ldo = out.data_ptr(), n, B, HW, widths[-1]
     if n == 2:          # Mlp: fc2(GELU(fc1(x))); the 8-wide case is the virtual concat cat[clean_img, x] of shot_mlp1
-        if widths[0] == 8:
-            d.src = hu.src(hu.dev(x[..., :4].contiguous()), hu.dev(x[..., 4:].contiguous()))
-        else:
-            d.src = hu.src(hu.dev(x))
+        s = hu.src(hu.dev(x[..., :4].contiguous()), hu.dev(x[..., 4:].contiguous())) if widths[0] == 8 else hu.src(hu.dev(x))
+        d.src = s
         d.st[0].act = L.ACT_GELU
         ref = F.linear(F.gelu(F.linear(x, ws[0], bs[0])), ws[1], bs[1])
     else:               # AttnBlock tail
         Cc = widths[0]
         vec, g, be = U(case + ".v", (B, Cc)), U(case + ".g", (Cc,), 0.5, 1.5), U(case + ".be", (Cc,))
-        d.src = hu.src(hu.dev(x), None, L.PRO_LAYERNORM, vec=hu.dev(vec), gamma=hu.dev(g), beta=hu.dev(be))
+        s = hu.src(hu.dev(x), None, L.PRO_LAYERNORM, vec=hu.dev(vec), gamma=hu.dev(g), beta=hu.dev(be))
+        d.src = s
         d.st[0].act, d.st[1].res, d.st[2].res = L.ACT_GELU, L.CHAIN_RES_INPUT, L.CHAIN_RES_INPUT_RAW
         x1 = x + vec[:, None]
         h = F.gelu(F.linear(F.layer_norm(x1, (Cc,), g, be, eps=1e-5), ws[0], bs[0]))
@@ -286,10 +288,80 @@ def test_pointwise_chain_matches_layer_by_layer(ctx, case):
     L.call(entry, C.byref(d), ctx.stream)
     ctx.sync()
     assert rel_err(out.cpu(), ref) < TOL
+    keep.append(s)                                      # (the descriptor holds a COPY of the struct: the tensors behind its pointers live in s._refs)
+    first = out.clone()
+    torch.cuda.synchronize()
+    L.call(entry, C.byref(d), ctx.stream)
+    ctx.sync()
+    assert torch.equal(out, first)                      # bitwise repeatable
     # widths this build does not instantiate are refused, not approximated
     d.st[0].cout = d.st[1].cin = 160
     assert getattr(ctx.lib, entry)(C.byref(d), ctx.stream) != 0
     assert b"not instantiated" in ctx.lib.nd_last_error()
+
+
+SPLIT_GEMM_CASES = {  # (B, HW, cin, cout, first concat source, kind): the wide 1x1 layers of the U-Net (Diffusion_arch.py:156,405-443,252-253)
+    "ff1_ln_gelu": (2, 200, 128, 256, 0, "ln"),      # LayerNorm(x + v) -> Linear -> GELU, ragged last pixel tile
+    "ff2_res_vec": (2, 256, 256, 128, 0, "res"),     # Linear + x + v
+    "res_conv_cat": (3, 128, 192, 128, 128, "gn"),   # res_conv over the virtual concat + silu(GN(c2)) tail
+    "qkv_nobias": (1, 1024, 512, 384, 0, "plain"),
+    "two_chunks": (2, 64, 64, 128, 0, "plain"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SPLIT_GEMM_CASES))
+def test_pointwise_split_matches_torch_and_the_fp32_kernel(ctx, case):
+    """nd_pointwise_gemm_split_nhwc_f32 (r6: three bf16 terms per fp32 operand, six products on v_mfma_f32_32x32x16_bf16, fp32 accumulation): the same
+    prologues / epilogues as nd_pointwise_gemm_nhwc_f32, the same tolerance against torch, error against fp64 no worse than 1.5x the fp32 kernel's."""
+    import hiputil as hu
+    B, HW, cin, cout, c0, kind = SPLIT_GEMM_CASES[case]
+    x = U(case + ".x", (B, HW, cin), -1.5, 1.5)
+    w, b = U(case + ".w", (cout, cin), -0.2, 0.2), U(case + ".b", (cout,))
+    wp = hu.pack_pw(ctx, w)
+    wd, ws = hu.dev(w), hu.full((ctx.lib.nd_pack_pointwise_weight_split_floats(cin, cout),))
+    L.call("nd_pack_pointwise_weight_split", wd.data_ptr(), ws.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    kw, bias = {}, hu.dev(b)
+    x64, w64, b64 = x.double(), w.double(), b.double()
+    if kind == "ln":
+        vec, g, be = U(case + ".v", (B, cin)), U(case + ".g", (cin,), 0.5, 1.5), U(case + ".be", (cin,))
+        xd, vd = hu.dev(x), hu.dev(vec)
+        rs = hu.full((B, HW, 2))
+        L.call("nd_layernorm_stats_f32", xd.data_ptr(), cin, vd.data_ptr(), rs.data_ptr(), B, HW, cin, 1e-5, ctx.stream)
+        ctx.sync()
+        s = hu.src(xd, None, L.PRO_LAYERNORM, vec=vd, gamma=hu.dev(g), beta=hu.dev(be), rowstats=rs)
+        kw["act"] = L.ACT_GELU
+        ref = F.gelu(F.linear(F.layer_norm(x64 + vec.double()[:, None], (cin,), g.double(), be.double(), eps=1e-5), w64, b64))
+    elif kind == "res":
+        r0, vec = U(case + ".r0", (B, HW, cout)), U(case + ".v", (B, cout))
+        s = hu.src(hu.dev(x))
+        kw.update(res0=hu.dev(r0), vec=hu.dev(vec))
+        ref = F.linear(x64, w64, b64) + r0.double() + vec.double()[:, None]
+    elif kind == "gn":
+        t, mad = U(case + ".t", (B, HW, cout), -2, 2), U(case + ".mad", (B, 3, cout), 0.5, 1.5)
+        s = hu.src(hu.dev(x[..., :c0].contiguous()), hu.dev(x[..., c0:].contiguous()))
+        kw.update(gn_t=hu.dev(t), gn_mad=hu.dev(mad))
+        m64 = mad.double()
+        ref = F.linear(x64, w64, b64) + F.silu((t.double() - m64[:, None, 0]) * m64[:, None, 1] + m64[:, None, 2])
+    else:
+        s = hu.src(hu.dev(x))
+        if case == "qkv_nobias":
+            bias, b64 = None, None
+        ref = F.linear(x64, w64, b64)
+    d = L.Pointwise()
+    d.src, d.cin, d.cout = s, cin, cout
+    assert ctx.lib.nd_pointwise_gemm_split_takes(C.byref(d)) == 1
+    o32 = hu.pointwise(ctx, s, wp, bias, B, HW, int(HW ** 0.5), cin, cout, **kw)
+    osp = hu.pointwise(ctx, s, ws, bias, B, HW, int(HW ** 0.5), cin, cout, entry="nd_pointwise_gemm_split_nhwc_f32", **kw)
+    assert rel_err(osp.cpu(), ref.float()) < TOL
+    e32, esp = (o32.cpu().double() - ref).abs().max().item(), (osp.cpu().double() - ref).abs().max().item()
+    assert esp <= 1.5 * e32 + 1e-7, (esp, e32)
+    again = hu.pointwise(ctx, s, ws, bias, B, HW, int(HW ** 0.5), cin, cout, entry="nd_pointwise_gemm_split_nhwc_f32", **kw)
+    assert torch.equal(osp, again)                      # bitwise repeatable
+    # shapes outside the kernel's set are refused by the split entry, not approximated
+    d2 = L.Pointwise()
+    d2.src, d2.cin, d2.cout = s, cin, 64
+    assert ctx.lib.nd_pointwise_gemm_split_takes(C.byref(d2)) == 0
 
 
 def test_pointwise_prologues(ctx):

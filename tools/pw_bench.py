@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""nd_pointwise_gemm_nhwc_f32 on the bench workload's wide 1x1 layers: correctness against torch and us / TF per layer.
+"""nd_pointwise_gemm_nhwc_f32 and nd_pointwise_gemm_split_nhwc_f32 (bf16 x 3 split products) on the bench workload's wide 1x1 layers: error against fp64 and us / TF per layer.
 ND_PW_BIG=0 (pipelined 64-pixel tiles) / 1 (large tiles, one wave per SIMD) / 2 (large tiles, 128 couts only): run once per value.
 Errors are against an fp64 product, relative to the output's largest magnitude."""
 import os, sys, ctypes as C
@@ -18,7 +18,15 @@ LAYERS = [(1024, 768, 512, 512, 0, 0), (1024, 512, 1024, 0, 1, 0), (1024, 1024, 
           (4096, 384, 256, 256, 0, 0), (4096, 256, 512, 0, 1, 0), (4096, 512, 256, 0, 0, 1), (4096, 256, 256, 0, 0, 1),
           (16384, 192, 128, 128, 0, 0), (16384, 128, 256, 0, 1, 0), (16384, 256, 128, 0, 0, 1), (16384, 128, 128, 0, 0, 1),
           (65536, 128, 128, 0, 0, 0)]
-tot = {"fp32": 0.0}
+tot = {"fp32": 0.0, "split": 0.0}
+rms_ratio = []
+
+
+def pack_split(w):
+    cout, cin = w.shape
+    wd, out = hu.dev(w), torch.empty(ctx.lib.nd_pack_pointwise_weight_split_floats(cin, cout), device=hu.DEV)
+    L.call("nd_pack_pointwise_weight_split", wd.data_ptr(), out.data_ptr(), cin, cout, ctx.stream); ctx.sync()
+    return out
 for (HW, cin, cout, c0, ln, res) in LAYERS:
     g = torch.Generator().manual_seed(HW + cin)
     x = torch.randn(B, HW, cin, generator=g); w = torch.randn(cout, cin, generator=g) / cin ** 0.5; b = torch.randn(cout, generator=g)
@@ -42,12 +50,13 @@ for (HW, cin, cout, c0, ln, res) in LAYERS:
     d = L.Pointwise(); d.src, d.weight, d.bias, d.out = s, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
     d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = B, HW, int(HW ** 0.5), cin, cout, cout, (L.ACT_GELU if ln else 0)
     if res: d.res0, d.ldr0 = rd.data_ptr(), cout
-    cells = []
-    for form, entry, wt in (("fp32", "nd_pointwise_gemm_nhwc_f32", wp),):
+    cells, rms = [], {}
+    for form, entry, wt in (("fp32", "nd_pointwise_gemm_nhwc_f32", wp), ("split", "nd_pointwise_gemm_split_nhwc_f32", pack_split(w))):
         d.weight = wt.data_ptr()
         out.zero_(); torch.cuda.synchronize()        # (zero_ runs on torch's stream, the kernel on ctx.stream)
         L.call(entry, C.byref(d), ctx.stream); ctx.sync()
         err = float((out.double() - ref).abs().max() / ref.abs().max())
+        rms[form] = float(((out.double() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
         e0, e1 = C.c_void_p(), C.c_void_p(); L.call("nd_event_create", C.byref(e0)); L.call("nd_event_create", C.byref(e1))
         reps = 10
         L.call("nd_event_record", e0, ctx.stream)
@@ -60,6 +69,8 @@ for (HW, cin, cout, c0, ln, res) in LAYERS:
             L.call(entry, C.byref(d), ctx.stream); ctx.sync()
             same = same and torch.equal(out, first)
         err2 = float((out.double() - ref).abs().max() / ref.abs().max())
-        cells.append(f"{form} {us:8.1f} us {2.0 * B * HW * cin * cout / us / 1e6:6.1f} TF rel err {max(err, err2):.1e}{'' if same else ' NOT REPEATABLE'}")
+        cells.append(f"{form} {us:8.1f} us {2.0 * B * HW * cin * cout / us / 1e6:6.1f} TF max err {max(err, err2):.1e} rms {rms[form]:.1e}{'' if same else ' NOT REPEATABLE'}")
+    rms_ratio.append(rms["split"] / rms["fp32"])
     print(f"{cin:5d} -> {cout:5d} @{HW:6d}px {'cat ' if c0 else 'LN+GELU ' if ln else 'res ' if res else ''}: " + " | ".join(cells), flush=True)
 print("total us:", {k: round(v, 1) for k, v in tot.items()}, f"(ND_PW_BIG={os.environ.get('ND_PW_BIG', '1')})")
+print(f"rms error of the split form / rms error of the fp32 form, against fp64: mean {sum(rms_ratio) / len(rms_ratio):.2f}, worst {max(rms_ratio):.2f}")
