@@ -672,11 +672,17 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const PwArgs a)
     using S1 = std::integral_constant<int, 1>;
 
     const int n_chunks = a.cinP / SKC, last_ks = 2 * n_chunks - 1;
+#ifdef PWS_STAMP                 // diagnostic (tools/pw_clock.py FORM=split): phase stamps of a workgroup, written over the first 32 bytes of its output tile
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     stage_load(0);
     load_b(0, 0);
     load_b(1, 1);
     stage_write(As);
     __syncthreads();
+#ifdef PWS_STAMP
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     // (no branch between a load and the MFMAs it overlaps; sched_barriers keep hipcc from sinking the prefetches to their uses: see pointwise_pipe_kernel)
     for (int c = 0; c < n_chunks; ++c) {
         const char* cur = As + (c & 1) * SABUF;
@@ -694,7 +700,19 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const PwArgs a)
         stage_write(nxt);
         __syncthreads();                                       // the other buffer is complete, this one has been consumed
     }
+#ifdef PWS_STAMP
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+    unsigned long long ph[4];
+    pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0, ph);
+    if (tid == 0) {                                           // (row 0, columns 0-7 of the tile are this thread's own stores: program order)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.d.out + ((size_t)b * HW + p0) * a.d.ldo + n0);
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        o[0] = st1 - st0;  o[1] = st2 - st1;  o[2] = st3 - st2;
+        o[3] = (ph[1] - ph[0]) | ((ph[2] - ph[1]) << 16) | ((ph[3] - ph[2]) << 32) | ((st3 - ph[3]) << 48);    // 16 bits each: barrier, acc -> LDS, barrier, rows -> global
+    }
+#else
     pw_epilogue<MB, NB, 8>(a, acc, Ab, b, p0, n0);
+#endif
 }
 
 // NOTE on code shape: every global load below is unconditional (clamped address + select) and the prologue mode is a

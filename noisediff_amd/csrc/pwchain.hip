@@ -79,41 +79,58 @@ __device__ __forceinline__ void chain_gemm(const float (&in)[K / 2], const float
         }
 }
 
-// SPLIT: `w` = the stage's weight terms in LDS, [n-tile][K step][term 3][lane 64] x 16 bytes (eight bf16: the lane's slots of the K step)
+// SPLIT: `w` = the stage's weight terms in LDS, [n-tile][K step][term 3][lane 64] x 16 bytes (eight bf16: the lane's slots of the K step).
+// One software-pipelined stream per stage: the three weight reads of group (s, nt) + 1 are issued BEFORE the six MFMAs of group (s, nt) -- left to itself
+// hipcc puts every ds_read_b128 right in front of its first use, one exposed LDS round trip per pair of MFMAs (profiles/r6a_chain_wave_states.txt: half the
+// wave time parked) -- and the split of K step s + 1 (44 VALU instructions) sits in the same scheduling region as the MFMAs of K step s.
 template <int K, int N>
 __device__ __forceinline__ void chain_gemm_split(const float (&in)[K / 2], const char* __restrict__ w, const float* __restrict__ bias,
                                                  f32x16 (&acc)[N / 32], const int lane) {
     static_assert(K % 16 == 0, "whole 16-channel K steps");
+    constexpr int S = K / 16, NT = N / 32;
     const int half = lane >> 5;
+    const u32x4_t* const wl = reinterpret_cast<const u32x4_t*>(w) + lane;
+    u32x4_t wq[2][3], xs[2][3];
+    auto load_w = [&](int slot, int s_, int nt_) {
+        const u32x4_t* p = wl + ((nt_ * S + s_) * 3) * 64;
+        wq[slot][0] = p[0];  wq[slot][1] = p[64];  wq[slot][2] = p[128];
+    };
+    auto split = [&](int slot, int s_) {
 #pragma unroll
-    for (int nt = 0; nt < N / 32; ++nt)
+        for (int j = 0; j < 4; ++j) {
+            unsigned t1, t2, t3;
+            chain_split2(in[8 * s_ + 2 * j], in[8 * s_ + 2 * j + 1], t1, t2, t3);
+            xs[slot][0][j] = t1;  xs[slot][1][j] = t2;  xs[slot][2][j] = t3;
+        }
+    };
+    load_w(0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 b4 = nd_ld4(bias + 32 * nt + 8 * g + 4 * half);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = b4[i];
         }
+    split(0, 0);
 #pragma unroll
-    for (int s = 0; s < K / 16; ++s) {
-        u32x4_t x1, x2, x3;
+    for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned t1, t2, t3;
-            chain_split2(in[8 * s + 2 * j], in[8 * s + 2 * j + 1], t1, t2, t3);
-            x1[j] = t1;  x2[j] = t2;  x3[j] = t3;
-        }
-#pragma unroll
-        for (int nt = 0; nt < N / 32; ++nt) {
-            const u32x4_t* p = reinterpret_cast<const u32x4_t*>(w + (size_t)((nt * (K / 16) + s) * 3) * 1024) + lane;
-            const u32x4_t w1 = p[0], w2 = p[64], w3 = p[128];
+        for (int nt = 0; nt < NT; ++nt) {
+            const int g = s * NT + nt;
+            if (g + 1 < S * NT) load_w((g + 1) & 1, nt + 1 < NT ? s : s + 1, nt + 1 < NT ? nt + 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nt == 0 && s + 1 < S) split((s + 1) & 1, s + 1);
+            const u32x4_t w1 = wq[g & 1][0], w2 = wq[g & 1][1], w3 = wq[g & 1][2];
+            const u32x4_t x1 = xs[s & 1][0], x2 = xs[s & 1][1], x3 = xs[s & 1][2];
             acc[nt] = chain_mfma_bf16(w1, x1, acc[nt]);
             acc[nt] = chain_mfma_bf16(w1, x2, acc[nt]);
             acc[nt] = chain_mfma_bf16(w2, x1, acc[nt]);
             acc[nt] = chain_mfma_bf16(w2, x2, acc[nt]);
             acc[nt] = chain_mfma_bf16(w1, x3, acc[nt]);
             acc[nt] = chain_mfma_bf16(w3, x1, acc[nt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    }
 }
 
 template <int N>
@@ -148,6 +165,19 @@ __device__ __forceinline__ void chain_res(f32x16 (&acc)[N / 32], const f32x4 (&x
         }
 }
 
+// SPLIT: the same stores through a buffer resource, a lane beyond cout writing out of range (dropped) instead of branching around the store
+template <int N>
+__device__ __forceinline__ void chain_store_buf(const f32x16 (&acc)[N / 32], __amdgpu_buffer_rsrc_t rso, const unsigned row_bytes, const int cout, const int half) {
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = 32 * nt + 8 * g + 4 * half;
+            const f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rso, n0 < cout ? row_bytes + n0 * 4u : 0xFFFFFFF0u, 0, 0);
+        }
+}
+
 template <int N>
 __device__ __forceinline__ void chain_store(const f32x16 (&acc)[N / 32], float* row, const int cout, const int half) {
 #pragma unroll
@@ -165,14 +195,25 @@ __device__ __forceinline__ void chain_store(const f32x16 (&acc)[N / 32], float* 
 // K0: stage-0 input channels rounded up to 8; N1, N2, N3: stage widths rounded up to 32 (N3 = 0: two stages)
 // waves per workgroup: as many as the register budget of the widest stage allows (3 or 4 per SIMD) -- the activation
 // VALU of one wave runs under the MFMAs of the others
-constexpr int chain_threads(int n1) { return n1 >= 128 ? 768 : 1024; }
+// SPLIT: two or three waves per SIMD -- the next tile's rows are prefetched into registers (the bf16 products leave a tile too short to hide a cold HBM
+// round trip behind the other waves), and nothing may spill: a scratch reload parks the wave like any other memory wait
+constexpr int chain_threads(int n1, bool split = false, int k0 = 0) { return split ? (n1 >= 128 || k0 >= 48 ? 512 : 768) : (n1 >= 128 ? 768 : 1024); }
+
+#ifdef CHAIN_STAMP               // diagnostic build (tools/chain_clock.py): per-wave phase sums in shader cycles
+__device__ unsigned long long chain_dbg[4096 * 16 * 10];
+#define CH_T0() (stamp_t = __builtin_amdgcn_s_memtime())
+#define CH_ACC(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp[i] += now_ - stamp_t; stamp_t = now_; }
+#else
+#define CH_T0()
+#define CH_ACC(i)
+#endif
 
 // floats of LDS a stage's weights take: fp32 operands, or three bf16 terms (6 bytes per value)
 template <bool SPLIT> constexpr int chain_w_floats(int n, int k) { return SPLIT ? n * k * 3 / 2 : n * k; }
 
 template <int K0, int N1, int N2, int N3, int MODE, bool SPLIT = false>
-__global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const ChainArgs a) {
-    constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
+__global__ __launch_bounds__(chain_threads(N1, SPLIT, K0), 1) void chain_kernel(const ChainArgs a) {
+    constexpr int THREADS = chain_threads(N1, SPLIT, K0), WAVES = THREADS / 64;
     static_assert(!SPLIT || K0 % 16 == 0, "SPLIT: the first stage reads whole 16-channel K steps");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w1 = lds;
@@ -219,7 +260,37 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
     int b_cur = -1;
     const int cout_last = a.d.st[N3 > 0 ? 2 : 1].cout;
 
+    // SPLIT: every global access of the tile loop is UNCONDITIONAL -- buffer loads / stores whose lane offset is out of range where the lane has nothing to
+    // read or write (a channel quad of the other source or of the padding: the load returns 0, the store is dropped).  With lane-dependent branches around
+    // them hipcc cannot count the operations in flight at the joins and falls back to s_waitcnt vmcnt(0): the wait for this tile's rows (requested one tile
+    // ago) would also wait for the prefetch just issued and for the previous tile's stores.  Two sources only where the first stage is one K step (cin <= 16).
+    constexpr bool TWO = SPLIT && K0 == 16;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p0), 0, (int)((unsigned)a.d.B * a.d.HW * s.ld0 * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p1 ? s.p1 : s.p0), 0,
+                                                                          s.p1 ? (int)((unsigned)a.d.B * a.d.HW * s.ld1 * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(a.d.out, 0, (int)((unsigned)a.d.B * a.d.HW * a.d.ldo * 4u), 0x00020000);
+    f32x4 Xn[SPLIT ? K0 / 8 : 1], Xm[TWO ? K0 / 8 : 1];     // SPLIT: the next tile's rows, in flight over this tile's stages
+    auto prefetch_rows = [&](int t_) {
+        const unsigned pix_ = (unsigned)t_ * 32u + (unsigned)(lane & 31);
+#pragma unroll
+        for (int q = 0; q < K0 / 8; ++q) {
+            const int c = 8 * q + 4 * half;
+            Xn[SPLIT ? q : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, c < s.c0 ? (pix_ * (unsigned)s.ld0 + c) * 4u : OOB, 0, 0));
+            if constexpr (TWO)
+                Xm[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, (c >= s.c0 && c < cin) ? (pix_ * (unsigned)s.ld1 + (c - s.c0)) * 4u : OOB, 0, 0));
+        }
+    };
+    if constexpr (SPLIT) {
+        if (t_begin < t_end) prefetch_rows(t_begin);
+    }
+
+#ifdef CHAIN_STAMP
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = 0;
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = t_begin; t < t_end; ++t) {
+        CH_T0();
         const int b = t / a.tiles_per_sample;             // wave-uniform
         const size_t pix = (size_t)t * 32 + (lane & 31);
         if (s.vec && b != b_cur) {                         // stash vec[b] for this wave
@@ -228,14 +299,27 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
         }
         // ---- this pixel's input row, channels 8q + 4*half .. +3 (two sources = virtual concat)
         f32x4 X[K0 / 8];
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int q = 0; q < K0 / 8; ++q) {
-            const int c = 8 * q + 4 * half;
-            const f32x4 zero = {0, 0, 0, 0};
-            X[q] = zero;
-            if (c < s.c0) X[q] = nd_ld4(s.p0 + pix * s.ld0 + c);
-            else if (c < cin) X[q] = nd_ld4(s.p1 + pix * s.ld1 + (c - s.c0));
-            if (s.vec) X[q] += nd_ld4(myv + c);
+            for (int q = 0; q < K0 / 8; ++q) {
+                X[q] = Xn[q];
+                if constexpr (TWO) X[q] += Xm[q];
+            }
+            prefetch_rows(t + 1 < t_end ? t + 1 : t);      // (behind the last tile: a harmless reload of it)
+            if (s.vec) {
+#pragma unroll
+                for (int q = 0; q < K0 / 8; ++q) X[q] += nd_ld4(myv + 8 * q + 4 * half);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < K0 / 8; ++q) {
+                const int c = 8 * q + 4 * half;
+                const f32x4 zero = {0, 0, 0, 0};
+                X[q] = zero;
+                if (c < s.c0) X[q] = nd_ld4(s.p0 + pix * s.ld0 + c);
+                else if (c < cin) X[q] = nd_ld4(s.p1 + pix * s.ld1 + (c - s.c0));
+                if (s.vec) X[q] += nd_ld4(myv + c);
+            }
         }
         // ---- prologue -> operands of stage 0
         float in0[K0 / 2];
@@ -268,12 +352,15 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
                 for (int i = 0; i < 4; ++i) in0[4 * q + i] = X[q][i];
         }
 
+        CH_ACC(0);                                         // rows + vector + prologue
         // ---- stage 0
         f32x16 H1[N1 / 32];
         if constexpr (SPLIT) chain_gemm_split<K0, N1>(in0, reinterpret_cast<const char*>(w1), b1, H1, lane);
         else chain_gemm<K0, N1>(in0, w1, b1, H1, lane);
+        CH_ACC(1);
         chain_res<K0, N1>(H1, X, s.vec ? myv : nullptr, a.d.st[0].res, half);
         chain_act<N1>(H1, a.d.st[0].act);
+        CH_ACC(2);
         // ---- stage 1: accumulator register r of n-tile nt is operand 16*nt + r
         float in1[N1 / 2];
 #pragma unroll
@@ -283,8 +370,10 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
         f32x16 H2[N2 / 32];
         if constexpr (SPLIT) chain_gemm_split<N1, N2>(in1, reinterpret_cast<const char*>(w2), b2, H2, lane);
         else chain_gemm<N1, N2>(in1, w2, b2, H2, lane);
+        CH_ACC(3);
         chain_res<K0, N2>(H2, X, s.vec ? myv : nullptr, a.d.st[1].res, half);
         chain_act<N2>(H2, a.d.st[1].act);
+        CH_ACC(4);
         float* row = a.d.out + pix * a.d.ldo;
         if (N3 > 0) {
             float in2[N2 / 2];
@@ -295,13 +384,26 @@ __global__ __launch_bounds__(chain_threads(N1), 1) void chain_kernel(const Chain
             f32x16 H3[(N3 > 0 ? N3 : 32) / 32];
             if constexpr (SPLIT) chain_gemm_split<N2, (N3 > 0 ? N3 : 32)>(in2, reinterpret_cast<const char*>(w3), b3, H3, lane);
             else chain_gemm<N2, (N3 > 0 ? N3 : 32)>(in2, w3, b3, H3, lane);
+            CH_ACC(5);
             chain_res<K0, (N3 > 0 ? N3 : 32)>(H3, X, s.vec ? myv : nullptr, a.d.st[2].res, half);
             chain_act<(N3 > 0 ? N3 : 32)>(H3, a.d.st[2].act);
-            chain_store<(N3 > 0 ? N3 : 32)>(H3, row, cout_last, half);
+            if constexpr (SPLIT) chain_store_buf<(N3 > 0 ? N3 : 32)>(H3, rso, (unsigned)pix * (unsigned)a.d.ldo * 4u, cout_last, half);
+            else chain_store<(N3 > 0 ? N3 : 32)>(H3, row, cout_last, half);
         } else {
-            chain_store<N2>(H2, row, cout_last, half);
+            if constexpr (SPLIT) chain_store_buf<N2>(H2, rso, (unsigned)pix * (unsigned)a.d.ldo * 4u, cout_last, half);
+            else chain_store<N2>(H2, row, cout_last, half);
         }
+        CH_ACC(6);
     }
+#ifdef CHAIN_STAMP
+    if (lane == 0 && wid < 4096 * 16) {
+        unsigned long long* o = chain_dbg + (size_t)wid * 10;
+        for (int i = 0; i < 7; ++i) o[i] = stamp[i];
+        o[7] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        o[8] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        o[9] = (unsigned long long)(t_end - t_begin);
+    }
+#endif
 }
 
 // (cout, cin) row-major -> operand order [nt][jq][lane][4]: element i of lane l = W[32*nt + (l & 31)][8*jq + i + 4*(l >> 5)]
@@ -339,7 +441,7 @@ static inline int device_cus() { return nd_device_cus(); }
 template <int K0, int N1, int N2, int N3, int MODE, bool SPLIT = false>
 int launch(const ChainArgs& a, hipStream_t st) {
     static nd_device_once configured;
-    constexpr int THREADS = chain_threads(N1), WAVES = THREADS / 64;
+    constexpr int THREADS = chain_threads(N1, SPLIT, K0), WAVES = THREADS / 64;
     const size_t lds = (size_t)(chain_w_floats<SPLIT>(N1, K0) + chain_w_floats<SPLIT>(N2, N1) + chain_w_floats<SPLIT>(N3, N2) + N1 + N2 + N3 + 2 * K0 + WAVES * K0) * sizeof(float);
     static_assert((size_t)(chain_w_floats<SPLIT>(N1, K0) + chain_w_floats<SPLIT>(N2, N1) + chain_w_floats<SPLIT>(N3, N2) + N1 + N2 + N3 + 2 * K0 + 16 * K0) * 4 <= 160 * 1024, "LDS");
     if (int e = nd_reserve_lds(configured, reinterpret_cast<const void*>(chain_kernel<K0, N1, N2, N3, MODE, SPLIT>), lds, "nd_pointwise_chain")) return e;
@@ -435,6 +537,9 @@ static int chain_run(const nd_chain* d, void* stream, bool split) {
     const int K0 = nd_round_up(cin, split ? 16 : 8), N1 = nd_round_up(d->st[0].cout, 32), N2 = nd_round_up(d->st[1].cout, 32), N3 = n3 ? nd_round_up(n3, 32) : 0;
     int rc = ND_E_SHAPE;
     if (split) {          // the same widths with the first stage's channels in whole 16-channel K steps
+        ND_REQUIRE(s.c1 == 0 || K0 == 16, ND_E_SHAPE, "nd_pointwise_chain_split: two sources only with cin <= 16 (got %d + %d)", s.c0, s.c1);
+        ND_REQUIRE((long)d->B * d->HW * s.ld0 * 4 < (1L << 32) - 65536 && (long)d->B * d->HW * (s.c1 ? s.ld1 : 0) * 4 < (1L << 32) - 65536 &&
+                   (long)d->B * d->HW * d->ldo * 4 < (1L << 32) - 65536, ND_E_SHAPE, "nd_pointwise_chain_split: a tensor of 4 GiB or more");
 #define ND_CHAIN_SPLIT_CASE(k0, n1, n2, n3) \
         if (K0 == k0 && N1 == n1 && N2 == n2 && N3 == n3) rc = launch_mode<k0, n1, n2, n3, true>(a, st);
         ND_CHAIN_SPLIT_CASE(16, 32, 32, 0)
@@ -472,6 +577,12 @@ static int chain_run(const nd_chain* d, void* stream, bool split) {
     if (rc) return rc;
     return nd_launch_status("nd_pointwise_chain_nhwc_f32");
 }
+
+#ifdef CHAIN_STAMP
+extern "C" int nd_chain_debug_read(unsigned long long* host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(chain_dbg), (size_t)n_words * 8);
+}
+#endif
 
 extern "C" int nd_pointwise_chain_nhwc_f32(const nd_chain* d, void* stream) { return chain_run(d, stream, false); }
 
