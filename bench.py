@@ -64,15 +64,27 @@ def parse():
     ap.add_argument("--broadcast", choices=["weights", "plan-slices", "arena"], default="weights",
                     help="what the one collective carries: the raw fp32 weights (every rank packs its arena), the packed slices the plan reads, the whole packed arena")
     ap.add_argument("--soak-s", type=float, default=3.0, help="seconds of untimed step replays before the W warm-up steps")
+    ap.add_argument("--no-full-sample", action="store_true", help="skip the one complete sample() call timed behind the K-step leg (N = 1 only)")
     ap.add_argument("--no-alt", action="store_true", help="accepted and ignored (r4 timed a second product form here; there is one form since r5)")
     return ap.parse_args()
 
 
-def _latest_profile(kind):
-    """profiles/r<round><letter>_<kind>.json of the newest build that has one (written by tools/pmc_*.py on the GPU box)."""
+def _pmc_profile(kind):
+    """(path, stale): the profiles/r*_<kind>.json (written by tools/pmc_*.py on the GPU box) that was measured on THIS tree's kernel sources -- the files carry
+    the git blob ids of conv3x3_wino4.hip / pointwise.hip / pwchain.hip / norm.hip at the time of the PMC pass -- or, when no summary matches, the last one by
+    name, marked stale (the figures cited on the line must be tied to the build that is benchmarked)."""
     import glob
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from source_blobs import source_blobs
+    mine = source_blobs(REPO)
     files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{kind}.json")))
-    return files[-1] if files else ""
+    for f in reversed(files):
+        try:
+            if json.load(open(f)).get("source_blobs") == mine:
+                return f, False
+        except (OSError, ValueError):
+            continue
+    return (files[-1], True) if files else ("", True)
 
 
 def conv_flops(m):
@@ -354,14 +366,14 @@ def roofline(a, loop, plan, L, per_step):
     wf = WINO_FACTOR.get(tid[0], 1.0)
     headline = (a.dim, a.size, a.batch) == (64, 256, 16)
     traffic = tsrc = busy_pmc = bsrc = None
-    tfile = _latest_profile("traffic")                               # PMC passes cannot run inside this process
+    tfile, tstale = _pmc_profile("traffic")                          # PMC passes cannot run inside this process
     if os.path.exists(tfile) and headline:
         tk = json.load(open(tfile))["kernels"].get(kname(tid))
         if tk:
             traffic = tk["hbm_bytes_per_launch"]
             tsrc = (f"builder box, profiles/{os.path.basename(tfile)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same "
                     "workload) -- NOT measured in this run")
-    bfile = _latest_profile("mfma_busy")                             # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), own PMC pass
+    bfile, bstale = _pmc_profile("mfma_busy")                        # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), own PMC pass
     if os.path.exists(bfile) and headline:
         bk = json.load(open(bfile))["kernels"].get(kname(tid))
         if bk:
@@ -378,8 +390,9 @@ def roofline(a, loop, plan, L, per_step):
         "frac": ach / wf / PEAK_FP32_MFMA_TFLOPS, "algorithmic_frac": ach / PEAK_FP32_MFMA_TFLOPS,
         "frac_definition": "executed MFMA FLOP/s (= achieved / winograd_multiply_reduction) / peak; algorithmic_frac = achieved / peak "
                            "may exceed 1 for Winograd kernels",
-        "traffic": traffic, "traffic_measured_on": tsrc,
-        "matrix_pipe_busy_pmc": busy_pmc, "matrix_pipe_busy_measured_on": bsrc,
+        "traffic": traffic, "traffic_measured_on": tsrc, "traffic_stale": None if traffic is None else tstale,
+        "matrix_pipe_busy_pmc": busy_pmc, "matrix_pipe_busy_measured_on": bsrc, "matrix_pipe_busy_stale": None if busy_pmc is None else bstale,
+        "stale_definition": "true = the PMC summary was measured on kernel sources (git blob ids in the profiles/*.json) that differ from this tree's",
         "avg_launch_ms": d["ms"] / d["launches"], "launches_per_step": d["launches"] // n_inst,
         "algorithmic_flop_per_launch": d["flop"] / d["launches"],
         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
@@ -569,6 +582,9 @@ def main():
         "metric": f"sampled RAW patches/sec ({S}x{S}x4, {sampler})", "value": value, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "arithmetic": "fp32 storage and accumulation everywhere; 3x3 convolutions, the 7x7 stem and attention on the exact-fp32 matrix instruction; wide 1x1 / Linear "
+                      "layers and the fused per-pixel chains on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (six products, "
+                      "full 24-bit significand: error against fp64 at or below the fp32 kernels', profiles/r6_split_gemm_accuracy.txt)",
         "config": {"workload": f"NoiseDiffNet dim={a.dim}{' + mid Attention' if a.mid_attn else ''}, {S}x{S}x4 patches, " +
                                sampler + " (sigmoid2, pred_v), "
                                f"{B} patches per GPU; a step = " +
@@ -578,6 +594,18 @@ def main():
                    "global_batch": world * B, "launch": "eager" if a.eager else "hipGraph replay",
                    "noise": "device Philox4x32-10", "untimed_soak_steps": soak_steps},
     }
+    if rank == 0 and world == 1 and not a.full and not a.eager and not a.no_full_sample:
+        # the metric itself, once: ONE complete sample() call (x_T, every reverse step, the final clamp and the NCHW read-back) on the same condition; the
+        # K-step figure above extrapolates a step x n_sample_steps, this is the driver-visible check of that extrapolation
+        kw = dict(batch_size=B, condition={k: v.to(dev) for k, v in cond.items()})
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        gd.sample(seed=3, **kw)
+        plan.e.sync()
+        torch.cuda.synchronize(dev)
+        secs = time.perf_counter() - t0
+        out["full_sample"] = {"seconds": secs, "patches_per_s": B / secs, "steps": n_sample_steps, "ratio_to_value": (B / secs) / value,
+                              "note": "one complete GaussianDiffusion.sample() call, wall clock on the host"}
     if bcast:
         out["multi_gpu"] = bcast
     if rank == 0 and not a.no_roofline:
@@ -590,6 +618,11 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    fs = out.get("full_sample")
+    if fs and fs["ratio_to_value"] < 0.98:
+        print(f"bench.py: the complete sample() call ran at {fs['patches_per_s']:.4f} patches/s, more than 2 % below the extrapolated value {value:.4f}",
+              file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,6 @@ from torch import nn
 
 from . import _lib as L
 
-_SAMPLER_SWITCH = threading.RLock()          # p_sample_loop / ddim_sample switch the wrapper's sampler for one call (GaussianDiffusion._as_sampler)
 
 BUFFER_NAMES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
                 "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
@@ -114,6 +113,9 @@ class GaussianDiffusion(nn.Module):
         # rank shard bookkeeping for the device noise stream (see shard.py): global index of sample 0
         self.sample_offset = 0
         self._loop_cache: Dict[tuple, "_Loop"] = {}
+        # p_sample_loop / ddim_sample switch THIS wrapper's sampler for one call (_as_sampler): a lock per instance, so that wrappers on other devices or
+        # in other threads never wait for each other
+        self._sampler_switch = threading.RLock()
 
     # ------------------------------------------------------------------ reference-compatible helpers
     def normalize(self, img):
@@ -166,6 +168,7 @@ class GaussianDiffusion(nn.Module):
 
     # ------------------------------------------------------------------ sampling
     _MAX_LOOPS = 4       # captured step graphs kept per wrapper (one per (plan, sampler settings))
+    _SHARD_BLOCK = 8     # one process, several devices: steps queued per device and turn (see sample())
 
     def _loop_for(self, plan) -> "_Loop":
         key = (id(plan), self.is_ddim_sampling, self.objective, self.sampling_timesteps, float(self.ddim_sampling_eta))
@@ -211,7 +214,7 @@ class GaussianDiffusion(nn.Module):
         # ---- nn.DataParallel(net, device_ids=[...]) with several devices: the reference's --gpu_ids entry (models/modules.py:73-83).
         # The reference replicates the weights and scatters / gathers the batch on EVERY step (:332); here the batch rows are split
         # once, every device gets its own engine (arena copied device to device from the first), plan and captured step graph, and
-        # the host thread queues each device's whole chain of graph replays: no per-step traffic between the devices.  Row i of the batch draws the
+        # the host thread queues each device's graph replays round-robin, a block of steps at a time: no per-step traffic between the devices.  Row i of the batch draws the
         # same Philox noise (keyed by its global index) and runs the same kernels whatever the number of devices.
         from .shard import shard_bounds
         shards = []
@@ -228,10 +231,15 @@ class GaussianDiffusion(nn.Module):
         out_dev = self.device
         gather = lambda: torch.cat([p.read_nchw(p.x).to(out_dev) for _, p in shards], dim=0)
         if not return_all_timesteps:
-            # every shard's whole chain is queued on its own device's stream at once (graph launches do not block the host): the devices then run
-            # their n_steps replays side by side without waiting for this thread between steps
-            for loop, _p in shards:
-                loop.advance(n_steps)
+            # the shards advance round-robin in blocks of _SHARD_BLOCK steps: every device's stream always holds a few queued graph replays (no waiting
+            # for this thread between steps), and a hipGraphLaunch that blocks on a full queue delays the other devices by at most one block -- queueing
+            # one device's whole chain first (r5) leaves the others idle for as long as that queue stays full.  The bits do not depend on the block.
+            done = 0
+            while done < n_steps:
+                n = min(self._SHARD_BLOCK, n_steps - done)
+                for loop, _p in shards:
+                    loop.advance(n)
+                done += n
             return self.unnormalize(gather())
         frames = [gather()]
         for _ in range(n_steps):
@@ -253,7 +261,12 @@ class GaussianDiffusion(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_loop_cache"] = {}
+        state.pop("_sampler_switch", None)          # (a lock is neither copied nor pickled: __setstate__ makes a new one)
         return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._sampler_switch = threading.RLock()
 
     def release_graphs(self) -> None:
         """Destroy every captured step graph of this wrapper (they are rebuilt on demand)."""
@@ -323,7 +336,7 @@ class GaussianDiffusion(nn.Module):
     @contextlib.contextmanager
     def _as_sampler(self, ddim: bool):
         """Run sample() as the named sampler whatever the wrapper was configured with (p_sample_loop / ddim_sample are public in the reference)."""
-        with _SAMPLER_SWITCH:                       # (the attribute is read by sample() and its loops: another thread sampling on this wrapper waits here)
+        with self._sampler_switch:                  # (the attribute is read by sample() and its loops: another thread sampling on THIS wrapper waits here)
             saved = self.is_ddim_sampling
             self.is_ddim_sampling = ddim
             try:

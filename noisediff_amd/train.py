@@ -91,7 +91,8 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
     if cin % 4 or cout % 4:
         raise L.HipError(f"conv3x3 on the HIP library needs channel counts that are multiples of 4 (cin={cin}, cout={cout})")
     st = _stream(x.device)
-    cached = _PackCache.cacheable(w_oihw)             # a parameter: the packing lives until the optimizer changes it, all stale ones repacked in one launch
+    wbase = _PackCache._base(w_oihw) if _PackCache.cacheable(w_oihw) else None     # a parameter: the packing lives until the optimizer changes it, all stale ones repacked in one launch
+    cached = wbase is not None
     w_oihw = w_oihw.detach().to(torch.float32).contiguous()
     with _on(x.device):
         out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
@@ -111,7 +112,7 @@ def _conv3x3_nhwc(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Te
             if cin % 8:
                 raise L.HipError(f"conv3x3 on the HIP library needs cin % 8 == 0 (cin={cin})")
         if wino4 and cached:
-            wptr = _pack_cache(x.device).get(w_oihw, cin, cout, dgrad, st, kind="w4")
+            wptr = _pack_cache(x.device).get(w_oihw, cin, cout, dgrad, st, kind="w4", base=wbase)
         else:
             wp = torch.empty(int(getattr(lib, pack + "_floats")(cin, cout)), dtype=torch.float32, device=x.device)
             L.call(pack + ("_dgrad" if dgrad else ""), w_oihw.data_ptr(), wp.data_ptr(), cin, cout, st)
@@ -490,62 +491,104 @@ _PW_GEMM = __import__("os").environ.get("ND_TRAIN_PW", "1") != "0"
 class _PackCache:
     """Packed operands of one device's weights: the Linear / 1x1 weights (kind "pw": nd_pack_pointwise_weight, ``flag`` = the transposed data-gradient
     packing) and the 3x3 weights on the F(4x4) kernels (kind "w4": nd_pack_conv3x3_wino4_weight, ``flag`` = the data-gradient form).  An entry belongs
-    to a parameter (or a view of one: ``weight.flatten(1)`` of a 1x1 convolution): key (kind, data_ptr, shape, flag), valid while the tensor's
+    to an ``nn.Parameter`` (or a view of one: ``weight.flatten(1)`` of a 1x1 convolution): key (kind, data_ptr, shape, flag), valid while the parameter's
     version counter stands.  The first stale entry of a kind that a step meets repacks EVERY stale entry of that kind in one launch over a descriptor
-    table kept in device memory.  Weights that are not parameters (the per-step torch.cat of the stacked time projections, nn.DataParallel's
-    broadcast copies) are packed per call and never cached."""
+    table kept in device memory.  Anything that is not a parameter (the per-step torch.cat of the stacked time projections, nn.DataParallel's
+    broadcast copies, a padded temporary under no_grad) is packed per call and never cached.
+
+    What the version counter does NOT see -- call ``train.invalidate_packs()`` after any of these, before the next eager forward:
+      * writes through ``.data`` (``p.data.copy_ / lerp_ / normal_``: ema_pytorch's update of its shadow model, SID_arch's re-initialisation);
+      * replays of a captured whole-step graph: the optimizer inside it moves the parameters without bumping a version.  Entries that were packed
+        while a stream was capturing are flagged ``volatile`` and repacked on EVERY eager use from then on, so the sequence replay / eager forward /
+        replay never computes with a packing from before the last update even without the call.
+    Parameters are held by weak reference: a deleted model's packings are dropped the next time the cache is used."""
     _FLOATS = {"pw": "nd_pack_pointwise_weight_floats", "w4": "nd_pack_conv3x3_wino4_weight_floats"}
     _BATCH = {"pw": "nd_pack_pointwise_weights_batch", "w4": "nd_pack_conv3x3_wino4_weights_batch"}
+    # entry fields
+    _REF, _BUF, _VER, _CIN, _COUT, _FLAG, _VOLATILE = range(7)
 
     def __init__(self, device: torch.device):
         self.device = device
-        self.entries: Dict[tuple, list] = {}        # key -> [weight tensor (kept alive), packed buffer, version packed, cin, cout, flag]
+        self.entries: Dict[tuple, list] = {}        # key -> [weakref to the base parameter, packed buffer, version packed, cin, cout, flag, volatile]
         self.tables: Dict[str, Optional[torch.Tensor]] = {"pw": None, "w4": None}     # device copies of the nd_pack_item records, in the order of `order`
         self.order: Dict[str, list] = {"pw": [], "w4": []}
 
     @staticmethod
-    def cacheable(w: torch.Tensor) -> bool:
-        return (w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
-                and (w.is_leaf or (w._is_view() and w._base is not None and w._base.is_leaf)))
+    def _base(w: torch.Tensor):
+        """The nn.Parameter behind ``w``: itself, or the root of a view of it (``p.detach()``, ``p.flatten(1)``, ``p.detach().flatten(1)``); else None."""
+        if isinstance(w, torch.nn.Parameter):
+            return w
+        b = w._base if w._is_view() else None
+        return b if isinstance(b, torch.nn.Parameter) else None
 
-    def get(self, w: torch.Tensor, cin: int, cout: int, flag: bool, st, kind: str = "pw") -> int:
+    @staticmethod
+    def cacheable(w: torch.Tensor) -> bool:
+        return w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda and _PackCache._base(w) is not None
+
+    def _drop(self, key: tuple) -> None:
+        self.entries.pop(key, None)
+        kind = key[0]
+        if key in self.order[kind]:
+            self.order[kind].remove(key)
+        self.tables[kind] = None
+
+    def invalidate(self) -> None:
+        for e in self.entries.values():
+            e[self._VER] = -1
+
+    def get(self, w: torch.Tensor, cin: int, cout: int, flag: bool, st, kind: str = "pw", base=None) -> int:
+        """Device pointer of the packing of ``w`` (``base``: the parameter behind it where the caller has already detached ``w``)."""
+        import weakref
         lib = L.load()
         key = (kind, w.data_ptr(), tuple(w.shape), flag)
+        base = base if base is not None else self._base(w)
+        if base is None:
+            raise L.HipError("_PackCache.get: not a parameter (check cacheable() first)")
         e = self.entries.get(key)
+        if e is not None and e[self._REF]() is not base:     # the parameter that owned this address is gone (or replaced): the entry goes with it
+            self._drop(key)
+            e = None
         if e is None:
-            if len(self.entries) >= 4096:            # (a model is a few hundred weights: anything beyond is a leak of temporaries -- start over)
+            if len(self.entries) >= 4096:            # (a model is a few hundred weights: anything beyond is a leak -- start over)
                 self.entries.clear(); self.order = {"pw": [], "w4": []}; self.tables = {"pw": None, "w4": None}
             buf = torch.empty(int(getattr(lib, self._FLOATS[kind])(cin, cout)), dtype=torch.float32, device=self.device)
-            e = self.entries[key] = [w, buf, -1, cin, cout, flag]
+            e = self.entries[key] = [weakref.ref(base), buf, -1, cin, cout, flag, False]
             self.order[kind].append(key)
             self.tables[kind] = None
-        if e[2] != w._version:
-            e[0] = w                                 # (the same storage and version counter; keeps the newest tensor object alive)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if e[self._VER] != base._version or (e[self._VOLATILE] and not capturing):
+            if e[self._VOLATILE] and not capturing:
+                e[self._VER] = -1                    # packed inside a captured graph: replays may have moved the weight since, unseen by the version counter
             self._repack_stale(kind, st)
-        return e[1].data_ptr()
+        return e[self._BUF].data_ptr()
 
-    def _pack_one(self, kind: str, w, buf, cin, cout, flag, st) -> None:
+    def _pack_one(self, kind: str, key, e, st) -> None:
+        ptr, buf, cin, cout, flag = key[1], e[self._BUF], e[self._CIN], e[self._COUT], e[self._FLAG]
         if kind == "pw":
-            L.call("nd_pack_pointwise_weight_t" if flag else "nd_pack_pointwise_weight", w.data_ptr(), buf.data_ptr(), cin, cout, *(() if flag else (0,)), st)
+            L.call("nd_pack_pointwise_weight_t" if flag else "nd_pack_pointwise_weight", ptr, buf.data_ptr(), cin, cout, *(() if flag else (0,)), st)
         else:
-            L.call("nd_pack_conv3x3_wino4_weight" + ("_dgrad" if flag else ""), w.data_ptr(), buf.data_ptr(), cin, cout, st)
+            L.call("nd_pack_conv3x3_wino4_weight" + ("_dgrad" if flag else ""), ptr, buf.data_ptr(), cin, cout, st)
 
     def _repack_stale(self, kind: str, st) -> None:
+        for k in [k for k in self.order[kind] if self.entries[k][self._REF]() is None]:      # parameters that have been freed since
+            self._drop(k)
         order = self.order[kind]
-        stale = [k for k in order if self.entries[k][2] != self.entries[k][0]._version]
-        if (self.tables[kind] is None or len(stale) != len(order)) and torch.cuda.is_current_stream_capturing():
+        live = {k: self.entries[k][self._REF]() for k in order}
+        stale = [k for k in order if self.entries[k][self._VER] != live[k]._version]
+        capturing = torch.cuda.is_current_stream_capturing()
+        if (self.tables[kind] is None or len(stale) != len(order)) and capturing:
             # a new descriptor table would need a host-to-device copy, which a capturing stream refuses: one capturable launch per stale weight instead
             for k in stale:
-                w, buf, _, cin, cout, flag = self.entries[k]
-                self._pack_one(kind, w, buf, cin, cout, flag, st)
-                self.entries[k][2] = w._version
+                e = self.entries[k]
+                self._pack_one(kind, k, e, st)
+                e[self._VER], e[self._VOLATILE] = live[k]._version, True
             return
         if self.tables[kind] is None or len(stale) != len(order):
             # first use, or only part of the table is stale (a partially frozen model): a table of the stale entries only
             items = (L.PackItem * len(stale))()
             for i, k in enumerate(stale):
-                w, buf, _, cin, cout, flag = self.entries[k]
-                items[i].w, items[i].packed, items[i].cin, items[i].cout, items[i].transposed = w.data_ptr(), buf.data_ptr(), cin, cout, int(flag)
+                e = self.entries[k]
+                items[i].w, items[i].packed, items[i].cin, items[i].cout, items[i].transposed = k[1], e[self._BUF].data_ptr(), e[self._CIN], e[self._COUT], int(e[self._FLAG])
             host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
             table = host.to(self.device)                     # (synchronous copy of a few KB)
             if len(stale) == len(order):
@@ -556,7 +599,9 @@ class _PackCache:
         self._last_table = getattr(self, "_last_table", {})
         self._last_table[kind] = table                       # alive until the next repack (the launch is asynchronous)
         for k in stale:
-            self.entries[k][2] = self.entries[k][0]._version
+            self.entries[k][self._VER] = live[k]._version
+            if capturing:
+                self.entries[k][self._VOLATILE] = True
 
 
 _PACK_CACHES: Dict[int, _PackCache] = {}
@@ -567,6 +612,15 @@ def _pack_cache(device: torch.device) -> _PackCache:
     if cache is None:
         cache = _PACK_CACHES[device.index] = _PackCache(device)
     return cache
+
+
+def invalidate_packs(device: Optional[torch.device] = None) -> None:
+    """Mark every cached weight packing (of one device, or of all) stale: the next forward repacks them in one launch per kind.  Needed after writes the
+    parameters' version counters do not see -- ``p.data.copy_ / lerp_ / normal_`` (ema_pytorch's shadow-model update, SID_arch's initialisation) -- and after
+    replays of a captured whole-step graph (see _PackCache)."""
+    for idx, cache in _PACK_CACHES.items():
+        if device is None or device.index == idx:
+            cache.invalidate()
 
 
 def _tokens(t: torch.Tensor, c: int) -> torch.Tensor:
@@ -974,6 +1028,16 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, **{k: v for k, v in kw.items() if k != "fused"})
         self._nd_tables: Dict[tuple, tuple] = {}     # (group index, parameter data_ptrs) -> (chunk table on the device, number of chunks)
 
+    def check_captured_lr(self) -> None:
+        """Call before replaying a captured training step: a captured ``capturable=True`` step carries the learning rate it was captured with (a launch
+        argument).  Raises if a scheduler or the caller has changed ``group['lr']`` since -- re-capture the step then."""
+        cap = getattr(self, "_nd_captured_lr", {})
+        for group in self.param_groups:
+            lr0 = cap.get(id(group))
+            if lr0 is not None and float(group["lr"]) != lr0:
+                raise RuntimeError(f"noisediff_amd.train.Adam: the captured step was recorded with lr={lr0:g}, the group now has lr={float(group['lr']):g}: "
+                                   "a replay would ignore the change; capture the step again")
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -989,17 +1053,27 @@ class Adam(torch.optim.Adam):
         per = int(lib.nd_adam_chunk_elements())
         item_t = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("step_size", "<f4"), ("bias2_sqrt", "<f4"), ("vec4", "<i4"),
                            ("reserved", "<i4"), ("step", "<u8")])                    # nd_adam_item (L.AdamItem)
+        # ---- what does not change from step to step is checked and laid out once per set of parameters (the host side of a step is ~1 ms this way, 4.4
+        #      per parameter); EVERY group's table is validated before ANY group is launched (a rebuild in the middle used to re-run the whole
+        #      step and move the groups already updated twice)
+        work = []
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             dev = ps[0].device
-            beta1, beta2 = group["betas"]
-            lr = float(group["lr"])
             cap = bool(group.get("capturable"))                          # step counters on the device, nothing computed on the host (nd_adam_step_capturable_f32)
-            # ---- what does not change from step to step: checked and laid out once per set of parameters (the host side of a step is ~1 ms this way, 4.4 per-parameter)
             key = (gi, cap, tuple(p.data_ptr() for p in ps))
             ent = self._nd_tables.get(key)
+            if ent is not None:
+                # load_state_dict (or anything else) replaced the state tensors: lay the table out again (compared by object, not by id() of a dict that
+                # may have been freed and its id reused)
+                _, _, _, ms0, vs0, steps0 = ent
+                for p, m0, v0, t0 in zip(ps, ms0, vs0, steps0):
+                    st = self.state[p]
+                    if st.get("exp_avg") is not m0 or st.get("exp_avg_sq") is not v0 or st.get("step") is not t0:
+                        ent = None
+                        break
             if ent is None:
                 if capturing:
                     raise RuntimeError("noisediff_amd.train.Adam: run a step with the same parameters before the capture (state and tables are built on the first step)")
@@ -1030,12 +1104,18 @@ class Adam(torch.optim.Adam):
                     items["step"] = [t.data_ptr() for t in steps]
                 pairs = [(i, c) for i, p in enumerate(ps) for c in range((p.numel() + per - 1) // per)]
                 chunks = torch.tensor(pairs, dtype=torch.int32).reshape(-1, 2).to(dev)
-                uniform = cap or len({float(t) for t in steps}) == 1         # every parameter at the same step count (it stays so: all are advanced together)
-                ent = self._nd_tables[key] = (items, chunks, len(pairs), ms, vs, steps, [id(self.state[p]) for p in ps], uniform)
-            items, chunks, n_chunks, ms, vs, steps, state_ids, uniform = ent
-            if any(id(self.state[p]) != i for p, i in zip(ps, state_ids)):              # load_state_dict replaced the state: lay it out again
-                del self._nd_tables[key]
-                return self.step()
+                ent = self._nd_tables[key] = (items, chunks, len(pairs), ms, vs, steps)
+            work.append((group, ps, dev, cap, ent))
+        for group, ps, dev, cap, ent in work:
+            beta1, beta2 = group["betas"]
+            lr = float(group["lr"])
+            if cap:
+                # the learning rate is a launch argument: a captured step replays with the value it was captured with (the reference's CosineAnnealingLR
+                # and its hand-written group['lr'] = ..., trainer_diffusion.py:95,104-105, do not reach a replayed graph) -- refuse a silent mismatch
+                if capturing:
+                    self._nd_captured_lr = getattr(self, "_nd_captured_lr", {})
+                    self._nd_captured_lr[id(group)] = lr
+            items, chunks, n_chunks, ms, vs, steps = ent
             # ---- this step: gradient pointers, step sizes
             gs = [p.grad for p in ps]
             if not all(g.is_contiguous() and g.dtype == torch.float32 and not g.is_sparse for g in gs):
@@ -1047,7 +1127,9 @@ class Adam(torch.optim.Adam):
             items["vec4"] = ((items["p"] | items["g"] | items["m"] | items["v"]) & 15) == 0
             if not cap:
                 torch._foreach_add_(steps, 1.0)                          # (CPU scalars: one C++ loop)
-                ts = np.full(len(ps), float(steps[0])) if uniform else np.array([float(t) for t in steps], dtype=np.float64)
+                # every parameter's OWN step count (a cheap loop over CPU scalars): parameters that were stepped under another set -- grad None on some
+                # steps -- carry different counts, and each gets its own bias correction
+                ts = np.array([float(t) for t in steps], dtype=np.float64)
                 items["step_size"] = lr / (1.0 - beta1 ** ts)
                 items["bias2_sqrt"] = np.sqrt(1.0 - beta2 ** ts)
             # pointers and step sizes of this step (a few KB): pinned + asynchronous, so the host keeps running ahead of the device

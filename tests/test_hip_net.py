@@ -827,3 +827,31 @@ def test_n_rank_hip_sampler_equals_single_rank(mode, world, total):
     assert rel_err(got, one) < 1e-5
     ref = O.sample(state_dict(dim), cond, image_size=H, batch_size=total, timesteps=T, x_T=x_T, noise=lambda i, s: steps[i])
     assert rel_err(got, ref.numpy()) < SAMPLE_TOL / 10
+
+
+def test_bench_self_launcher_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` as the driver starts it: a fresh child process that spawns the two rank processes itself (both on cuda:0 here, gloo
+    rendezvous on 127.0.0.1), one weight broadcast, zero per-step collectives, one JSON line from rank 0; and a job size that contradicts WORLD_SIZE is
+    refused with exit code 2 instead of being reported as something it is not (reference entry: models/modules.py:73-83)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--soak-s", "0",
+           "--no-cpu", "--no-roofline", "--size", "64", "--batch", "2", "--timesteps", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = line["multi_gpu"]
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["scaling"] == "weak"
+    assert mg["ranks_in_broadcast"] == 2 and mg["arena_checksum_equal_on_all_ranks"] is True and mg["per_step_collectives"] == 0
+    assert len(mg["ms_per_step_by_rank_wall"]) == 2 and len(mg["ms_per_step_by_rank_gpu_events"]) == 2
+    assert "bench.py started the ranks itself" in mg["launcher"]
+    bad = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "3", "--one-device", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--soak-s", "0", "--no-cpu", "--no-roofline"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode == 2 and "WORLD_SIZE=2" in bad.stderr

@@ -808,3 +808,80 @@ def test_a_training_step_with_the_capturable_adam_replays_as_one_graph():
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2):
             bad.step()
+
+
+def test_packing_cache_sees_data_writes_after_invalidate_and_drops_dead_models():
+    """the packing caches compare version counters, which ``p.data.copy_`` (ema_pytorch's shadow update, SID_arch's re-initialisation) does not
+    bump.  Documented contract: train.invalidate_packs() after such writes.  Also: only nn.Parameters (and views of them) are cached, and a deleted
+    model's entries go away (weak references), so the cache does not pin GPU memory."""
+    import gc
+    torch.manual_seed(0)
+    net = nn.Sequential(_Block(32, 64), nn.Conv2d(64, 64, 1)).to(DEV)
+    train.accelerate(net)
+    x = U("pc.x", (2, 32, 32, 32)).to(DEV)
+    with torch.no_grad():
+        y0 = net(x).clone()
+        for p in net.parameters():
+            p.data.mul_(0.5)                               # no version bump
+        stale = net(x).clone()                             # documented hazard: still the old packings (where a packing is cached at all)
+        train.invalidate_packs()
+        y1 = net(x).clone()
+    ref = copy.deepcopy(net).to(DEV)
+    with torch.no_grad():
+        want = ref(x)                                      # fresh module, fresh packings: the halved weights
+    assert torch.allclose(y1, want, rtol=1e-5, atol=1e-6)
+    assert not torch.allclose(y0, y1, rtol=1e-3, atol=1e-4)
+    del stale
+    cache = train._pack_cache(DEV)
+    n_live = len(cache.entries)
+    assert n_live > 0 and all(isinstance(e[cache._REF](), nn.Parameter) for e in cache.entries.values())
+    # a non-parameter leaf is never cached
+    w = torch.randn(64, 64, device=DEV)
+    assert not train._PackCache.cacheable(w) and train._PackCache.cacheable(net[1].weight.flatten(1))
+    del net, ref, want
+    gc.collect()
+    m2 = nn.Sequential(_Block(32, 64)).to(DEV)
+    train.accelerate(m2)
+    with torch.no_grad():
+        m2(x)
+    assert all(e[cache._REF]() is not None for k, e in cache.entries.items() if k[0] == "w4")       # the dead model's 3x3 entries were dropped on this use
+
+
+def test_adam_keeps_per_parameter_step_counts_and_updates_each_group_once():
+    """ADVICE r5: (a) parameters stepped under different sets of gradients carry different step counts, and each must get its own bias correction;
+    (b) a table rebuild (replaced optimizer state) must not re-run groups that were already updated in the same call; (c) the closure's loss is returned."""
+    torch.manual_seed(0)
+    pa, pb = [nn.Parameter(torch.randn(64, 32, device=DEV)) for _ in range(2)]
+    qa, qb = [nn.Parameter(p.detach().clone()) for p in (pa, pb)]
+    ours = train.Adam([{"params": [pa]}, {"params": [pb]}], lr=1e-2)
+    theirs = torch.optim.Adam([{"params": [qa]}, {"params": [qb]}], lr=1e-2)
+    g = [torch.randn(64, 32, device=DEV) for _ in range(6)]
+    for i in range(6):
+        for opt, (a, b) in ((ours, (pa, pb)), (theirs, (qa, qb))):
+            a.grad = g[i].clone()
+            b.grad = g[i].clone() * 0.5 if i % 2 == 0 else None          # the second group sits out every other step
+            opt.step()
+    assert torch.allclose(pa, qa, rtol=2e-5, atol=2e-6) and torch.allclose(pb, qb, rtol=2e-5, atol=2e-6)
+    assert float(ours.state[pb]["step"]) == 3.0 and float(ours.state[pa]["step"]) == 6.0
+    # same group, parameters with DIFFERENT counts: one group holding both, the second parameter joins late
+    pc, pd = [nn.Parameter(torch.randn(32, 32, device=DEV)) for _ in range(2)]
+    qc, qd = [nn.Parameter(p.detach().clone()) for p in (pc, pd)]
+    ours2, theirs2 = train.Adam([pc, pd], lr=1e-2), torch.optim.Adam([qc, qd], lr=1e-2)
+    for i in range(5):
+        for opt, (c, d) in ((ours2, (pc, pd)), (theirs2, (qc, qd))):
+            c.grad = g[i][:32].clone()
+            d.grad = g[i][32:].clone() if i >= 2 else None
+            opt.step()
+    assert torch.allclose(pc, qc, rtol=2e-5, atol=2e-6) and torch.allclose(pd, qd, rtol=2e-5, atol=2e-6)
+    # (b) + (c): replace the state between steps (load_state_dict), then one step with a closure
+    sd = copy.deepcopy(ours.state_dict())
+    ours.load_state_dict(sd)
+    theirs.load_state_dict(copy.deepcopy(theirs.state_dict()))
+    for opt, (a, b) in ((ours, (pa, pb)), (theirs, (qa, qb))):
+        a.grad, b.grad = g[0].clone(), g[1].clone()
+    before = float(ours.state[pa]["step"])
+    out = ours.step(lambda: torch.tensor(3.5))
+    theirs.step()
+    assert float(out) == 3.5
+    assert float(ours.state[pa]["step"]) == before + 1.0                 # once, not twice
+    assert torch.allclose(pa, qa, rtol=2e-5, atol=2e-6) and torch.allclose(pb, qb, rtol=2e-5, atol=2e-6)

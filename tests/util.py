@@ -43,14 +43,15 @@ def elem_excess(a, b, rtol=ELEM_RTOL):
     return float(np.max(np.abs(a - b) - rtol * np.abs(b)))
 
 
-def close(a, b, tol, atol=ELEM_ATOL, rtol=ELEM_RTOL):
+def close(a, b, tol, atol=ELEM_ATOL, rtol=ELEM_RTOL, log_only=False):
     """Both parity criteria of DESIGN section 6: rel_err(a, b) < tol (max |a - b| / max(1, max |b|)) AND zero elements outside |a - b| <= atol + rtol * |b|.
-    Set ND_TEST_ELEM_LOG=<file> to log the measured figures of every call."""
+    Set ND_TEST_ELEM_LOG=<file> to log the measured figures of every call.  ``log_only=True`` (an explicit argument of the caller, never the environment:
+    ADVICE r5) records the element-wise figure without asserting it -- for the tools that measure the floors."""
     import os
     r, x = rel_err(a, b), elem_excess(a, b, rtol)
     if os.environ.get("ND_TEST_ELEM_LOG"):
         with open(os.environ["ND_TEST_ELEM_LOG"], "a") as f:
             f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?')}: rel_err {r:.3e} (tol {tol:g}), element-wise floor needed {x:.3e} (atol {atol:g})\n")
     assert r < tol, f"rel_err {r:.3e} >= {tol:g}"
-    assert x <= atol or os.environ.get("ND_TEST_ELEM_LOG_ONLY"), f"element-wise: |a - b| exceeds {rtol:g} * |b| by {x:.3e} > atol {atol:g}"
+    assert x <= atol or log_only, f"element-wise: |a - b| exceeds {rtol:g} * |b| by {x:.3e} > atol {atol:g}"
     return True

@@ -32,4 +32,9 @@ for f in sorted(glob.glob("gpurun_out/first_node_n[0-9]*.jsonl"), key=lambda s: 
     mg = j.get("multi_gpu") or {}
     print(f"n={n}: {j['value']:.4f} {j['unit']}  per GPU {j['value'] / n:.4f}  efficiency vs n=1 {j['value'] / n / base:.3f}  "
           f"broadcast {mg.get('broadcast_and_pack_ms')} ms / {mg.get('broadcast_bytes')} B  checksum equal {mg.get('arena_checksum_equal_on_all_ranks')}")
+    # a slow RANK shows in its own GPU-event time, a slow BARRIER only in the wall clock of every rank
+    if mg.get("ms_per_step_by_rank_gpu_events"):
+        gpu, wall = mg["ms_per_step_by_rank_gpu_events"], mg["ms_per_step_by_rank_wall"]
+        print("      ms/step by rank, GPU events: " + " ".join(f"{v:.2f}" for v in gpu) + f"   (spread {max(gpu) - min(gpu):.2f})")
+        print("      ms/step by rank, wall clock: " + " ".join(f"{v:.2f}" for v in wall) + f"   (max wall - max GPU = {max(wall) - max(gpu):.2f}: barrier / launch side)")
 PY

@@ -4,13 +4,15 @@
 usage: tools/pmc_mfma.py <pmc_dir> <out.json> "<command that was profiled>"
 matrix-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (n_SIMD * GRBM_GUI_ACTIVE / 8): the SQ counter is summed over every
 SIMD of the chip (256 CUs x 4), GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md, DVFS note)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_blobs import source_blobs
 
 f = glob.glob(f"{sys.argv[1]}/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"command": sys.argv[3], "n_simd": 1024, "kernels": {}}
+out = {"command": sys.argv[3], "source_blobs": source_blobs(), "n_simd": 1024, "kernels": {}}
 for k, c in sorted(agg.items()):
     name = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
     if name.startswith(("at::", "__amd")) or "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:

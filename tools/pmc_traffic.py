@@ -4,7 +4,9 @@
 usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> "<command that was profiled>"
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and on gfx950 FETCH_SIZE
 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_blobs import source_blobs
 
 def avg(dirname, counter):
     f = glob.glob(f"{dirname}/*/*counter_collection.csv")[0]
@@ -15,7 +17,7 @@ def avg(dirname, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
-out = {"command": sys.argv[4], "units": "KiB per launch (rocprofv3 raw); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
+out = {"command": sys.argv[4], "source_blobs": source_blobs(), "units": "KiB per launch (rocprofv3 raw); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
 for k in sorted(fetch):
     name = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
     if name.startswith(("at::", "__amd")):
