@@ -1,4 +1,4 @@
-"""Diagnostic: effective shader clock and cycle split of conv3x3_wino4 (needs a -DW4_STAMP side build, ND_LIB)."""
+"""Diagnostic: effective shader clock and cycle split of conv3x3_wino4 (needs a -DW4_STAMP side build, ND_LIB).  W4_MODE=aff: the GroupNorm-affine + SiLU prologue."""
 import os, sys, ctypes as C
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -22,14 +22,19 @@ for (B, H, W, cin, cout) in SHAPES:
     dbg = torch.zeros(16 * 1024, dtype=torch.int64, device=hu.DEV)
     st = torch.zeros(B * ctx.lib.nd_conv3x3_wino4_stat_slots(H, W) * cout * 2, device=hu.DEV)
     torch.cuda.synchronize()
-    d = L.Conv3x3(); d.src, d.weight, d.out = hu.src(x), wp.data_ptr(), out.data_ptr()
+    if os.environ.get("W4_MODE") == "aff":
+        mad = torch.randn(B, 3, cin, device=hu.DEV); mad[:, 1] = mad[:, 1].abs() + 0.5
+        src = hu.src(x, None, L.PRO_AFFINE_SILU, mad=mad)
+    else:
+        src = hu.src(x)
+    d = L.Conv3x3(); d.src, d.weight, d.out = src, wp.data_ptr(), out.data_ptr()
     d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
     d.slot_count = dbg.data_ptr(); d.stats = st.data_ptr()
     for _ in range(3):
         L.call(ENTRY, C.byref(d), ctx.stream); ctx.sync()
     v = dbg.cpu().view(1024, 16).double()
     v = v[v[:, 2] > 0]                                  # workgroups that had work (small problems start fewer than 256)
-    print(f"{v.shape[0]} workgroups;", end=" ")
+    print(f"{os.environ.get('W4_MODE', 'plain')}: {v.shape[0]} workgroups;", end=" ")
     cyc, real, chunks, epi, xf, second, first, last, third, wait, pro, top, stile = (v[:, i] for i in range(13))
     n_chunks = (cin + 15) // 16
     mhz = cyc / (real / 100.0)
