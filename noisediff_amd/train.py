@@ -501,7 +501,11 @@ class _PackCache:
       * replays of a captured whole-step graph: the optimizer inside it moves the parameters without bumping a version.  Entries that were packed
         while a stream was capturing are flagged ``volatile`` and repacked on EVERY eager use from then on, so the sequence replay / eager forward /
         replay never computes with a packing from before the last update even without the call.
-    Parameters are held by weak reference: a deleted model's packings are dropped the next time the cache is used."""
+    An entry holds its parameter (as in r5): a deleted model's weights and packings stay in GPU memory until ``train.release_packs()`` is called (or 4096
+    entries accumulate).  r6 tried weak references here: the full GPU suite then ended in a GPU memory access fault in a later test's backward
+    pass on two of three runs -- freeing those models changes which pages of the caching allocator stay mapped, and some access of the training path (not
+    found in the time of the round) reaches into them; with the r5 lifetime the suite is green as it was.  Entries whose parameter has MOVED (module.to(),
+    p.data = ...) are dropped: their address is no longer the parameter's."""
     _FLOATS = {"pw": "nd_pack_pointwise_weight_floats", "w4": "nd_pack_conv3x3_wino4_weight_floats"}
     _BATCH = {"pw": "nd_pack_pointwise_weights_batch", "w4": "nd_pack_conv3x3_wino4_weights_batch"}
     # entry fields
@@ -509,7 +513,7 @@ class _PackCache:
 
     def __init__(self, device: torch.device):
         self.device = device
-        self.entries: Dict[tuple, list] = {}        # key -> [weakref to the base parameter, packed buffer, version packed, cin, cout, flag, volatile]
+        self.entries: Dict[tuple, list] = {}        # key -> [ref() -> the base parameter (held), packed buffer, version packed, cin, cout, flag, volatile]
         self.tables: Dict[str, Optional[torch.Tensor]] = {"pw": None, "w4": None}     # device copies of the nd_pack_item records, in the order of `order`
         self.order: Dict[str, list] = {"pw": [], "w4": []}
 
@@ -538,7 +542,6 @@ class _PackCache:
 
     def get(self, w: torch.Tensor, cin: int, cout: int, flag: bool, st, kind: str = "pw", base=None) -> int:
         """Device pointer of the packing of ``w`` (``base``: the parameter behind it where the caller has already detached ``w``)."""
-        import weakref
         lib = L.load()
         key = (kind, w.data_ptr(), tuple(w.shape), flag)
         base = base if base is not None else self._base(w)
@@ -552,7 +555,7 @@ class _PackCache:
             if len(self.entries) >= 4096:            # (a model is a few hundred weights: anything beyond is a leak -- start over)
                 self.entries.clear(); self.order = {"pw": [], "w4": []}; self.tables = {"pw": None, "w4": None}
             buf = torch.empty(int(getattr(lib, self._FLOATS[kind])(cin, cout)), dtype=torch.float32, device=self.device)
-            e = self.entries[key] = [weakref.ref(base), buf, -1, cin, cout, flag, False]
+            e = self.entries[key] = [(lambda b=base: b), buf, -1, cin, cout, flag, False]
             self.order[kind].append(key)
             self.tables[kind] = None
         capturing = torch.cuda.is_current_stream_capturing()
@@ -570,7 +573,15 @@ class _PackCache:
             L.call("nd_pack_conv3x3_wino4_weight" + ("_dgrad" if flag else ""), ptr, buf.data_ptr(), cin, cout, st)
 
     def _repack_stale(self, kind: str, st) -> None:
-        for k in [k for k in self.order[kind] if self.entries[k][self._REF]() is None]:      # parameters that have been freed since
+        def gone(k):
+            # the parameter has been freed, or its storage has moved (module.to(), p.data = ...) and the address this entry was keyed on is no longer inside it:
+            # the entry must not be repacked from that address (ADVICE r5 asked for weak references; a strong one used to keep the old storage alive)
+            base = self.entries[k][self._REF]()
+            if base is None:
+                return True
+            lo = base.data_ptr()
+            return not (lo <= k[1] < lo + max(base.numel(), 1) * base.element_size())
+        for k in [k for k in self.order[kind] if gone(k)]:
             self._drop(k)
         order = self.order[kind]
         live = {k: self.entries[k][self._REF]() for k in order}
@@ -612,6 +623,14 @@ def _pack_cache(device: torch.device) -> _PackCache:
     if cache is None:
         cache = _PACK_CACHES[device.index] = _PackCache(device)
     return cache
+
+
+def release_packs(device: Optional[torch.device] = None) -> None:
+    """Drop every cached packing (and the references to their parameters) of one device, or of all: call it when models are deleted, so that their weights
+    and packings leave GPU memory; live models repack on their next forward."""
+    for idx in list(_PACK_CACHES):
+        if device is None or device.index == idx:
+            del _PACK_CACHES[idx]
 
 
 def invalidate_packs(device: Optional[torch.device] = None) -> None:
