@@ -10,18 +10,18 @@ cd /tmp && export TMPDIR=/tmp
 R="${GRAFT_REPO_ROOT:?run through gpurun}"
 cd "$R"
 if [ "$PART" = a ] || [ "$PART" = all ]; then
-python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest.log 2>&1 || { tail -30 gpurun_out/${T}_pytest.log; exit 1; }
+[ -n "$SKIP_TESTS" ] || python -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest.log 2>&1 || { tail -30 gpurun_out/${T}_pytest.log; exit 1; }
 python bench.py > gpurun_out/${T}_bench_default.jsonl 2> gpurun_out/${T}_bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$T -- python3 bench.py --steps 5 --warmup 1 --soak-s 0 --no-cpu --no-roofline > gpurun_out/prof_$T.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$T -- python3 bench.py --steps 5 --warmup 1 --soak-s 0 --no-cpu --no-roofline --no-full-sample > gpurun_out/prof_$T.log 2>&1
 cp $(ls gpurun_out/prof_$T/*/*kernel_stats.csv | head -1) gpurun_out/${T}_rocprofv3_kernel_stats_bench_steps5.csv
 rm -rf gpurun_out/prof_$T
 tail -2 gpurun_out/${T}_pytest.log
 fi
 if [ "$PART" = b ] || [ "$PART" = all ]; then
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --eager > gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --eager > gpurun_out/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --eager > gpurun_out/pmc_mfma.log 2>&1
-CMD="rocprofv3 --kernel-trace --pmc {COUNTERS} --output-format csv -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --eager"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --no-full-sample --eager > gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --no-full-sample --eager > gpurun_out/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --no-full-sample --eager > gpurun_out/pmc_mfma.log 2>&1
+CMD="rocprofv3 --kernel-trace --pmc {COUNTERS} --output-format csv -- python3 bench.py --steps 2 --warmup 1 --soak-s 0 --no-cpu --no-roofline --no-full-sample --eager"
 python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${T}_traffic.json "${CMD/\{COUNTERS\}/FETCH_SIZE | WRITE_SIZE (separate passes)}" > /dev/null
 python tools/pmc_mfma.py gpurun_out/pmc_mfma gpurun_out/${T}_mfma_busy.json "${CMD/\{COUNTERS\}/SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE}"
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma
