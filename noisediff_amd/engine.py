@@ -60,7 +60,9 @@ _ALIGN = 64   # floats; keeps every arena slice 256-byte aligned
 # r6: wide 1x1 / Linear layers and the fused per-pixel chains on the bf16 matrix cores at full fp32 significand (three-term split of every operand, six
 # products, fp32 accumulation: pointwise.hip / pwchain.hip, "SPLIT").  Same results within fp32 rounding (error against fp64 at or below the fp32 kernels',
 # profiles/r6_split_gemm_accuracy.txt), 1.5-2x the speed: the fp32 matrix instruction issues on the VALU's own lanes.  ND_SPLIT_GEMM=0: A/B knob (tools/ only).
-SPLIT_GEMM = os.environ.get("ND_SPLIT_GEMM", "1") != "0"
+_SPLIT = os.environ.get("ND_SPLIT_GEMM", "1")                 # "1" both kinds, "chain" / "pw" one of them, "0" neither (A/B, tools/ only)
+SPLIT_GEMM = _SPLIT != "0"
+SPLIT_CHAIN, SPLIT_PW = _SPLIT in ("1", "chain"), _SPLIT in ("1", "pw")
 TIME_TABLE = True        # the time embedding's head looked up per timestep (r3; was ND_TIME_TABLE)
 PROJ_TABLE = True        # ... and the stacked ResnetBlock.mlp projection (r4e; was ND_PROJ_TABLE)
 TIME_TABLE_ROWS = 1000                                      # timesteps the table covers (the reference's --timesteps; larger t: computed)
@@ -89,7 +91,7 @@ def _blocked_map_rows(C_: int) -> torch.Tensor:
 
 def _split_layer(cin: int, cout: int) -> bool:
     """1x1 / Linear layers whose weights are also packed as three bf16 terms for nd_pointwise_gemm_split_nhwc_f32 (pointwise.hip: pw_split_takes)."""
-    return SPLIT_GEMM and cin % 32 == 0 and cin >= 64 and cout % 128 == 0
+    return SPLIT_PW and cin % 32 == 0 and cin >= 64 and cout % 128 == 0
 
 
 def _classify(name: str, shape: Sequence[int]) -> str:
@@ -189,7 +191,7 @@ class Engine:
                 if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
                     first = int(p.name.endswith(_CHAIN_FIRST))
                     add(p.name + ".chain", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
-                    if SPLIT_GEMM:
+                    if SPLIT_CHAIN:
                         add(p.name + ".chain_s", self.lib.nd_pack_chain_weight_split_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
                 if kind == "pw" and _split_layer(p.shape[1], p.shape[0]):
                     add(p.name + ".split", self.lib.nd_pack_pointwise_weight_split_floats(p.shape[1], p.shape[0]), "derived", p.shape)
