@@ -89,6 +89,9 @@ def _blocked_map_rows(C_: int) -> torch.Tensor:
     return torch.where(j < 16, 16 * c + j, C_ + 16 * c + j - 16)
 
 
+_CHAIN_SPLIT_LIMIT = (1 << 32) - (1 << 17)    # bytes of one tensor a launch of nd_pointwise_chain_split_nhwc_f32 addresses (32-bit buffer offsets)
+
+
 def _split_layer(cin: int, cout: int) -> bool:
     """1x1 / Linear layers whose weights are also packed as three bf16 terms for nd_pointwise_gemm_split_nhwc_f32 (pointwise.hip: pw_split_takes)."""
     return SPLIT_PW and cin % 32 == 0 and cin >= 64 and cout % 128 == 0
@@ -723,16 +726,34 @@ class Plan:
         """Fused per-pixel Linear chain; stages = [(layer, cin, cout, act, res)]."""
         e = self.e
         out = self._alloc(self.B, HW, stages[-1][2])
-        d = L.Chain()
-        d.src, d.out, d.n_stages, d.B, d.HW, d.ldo = src, out.data_ptr(), len(stages), self.B, HW, stages[-1][2]
-        split = all((layer + ".weight.chain_s") in e.slots for layer, *_ in stages)
-        for i, (layer, cin, cout, act, res) in enumerate(stages):
-            d.st[i].weight, d.st[i].bias = e.p(layer + (".weight.chain_s" if split else ".weight.chain")), e.p(layer + ".bias")
-            d.st[i].cin, d.st[i].cout, d.st[i].act, d.st[i].res = cin, cout, act, res
-        self._add("nd_pointwise_chain_split_nhwc_f32" if split else "nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
-                  meta={"layer": name, "B": self.B, "HW": HW, "cin": stages[0][1], "cout": stages[-1][2],
-                        "flop_per_px": 2.0 * sum(c_in * c_out for _, c_in, c_out, _, _ in stages)})
-        self._keep.append(d)
+        # the split-product form (a function of the widths alone); two sources only where the first stage is one K step (pwchain.hip)
+        split = all((layer + ".weight.chain_s") in e.slots for layer, *_ in stages) and (src.c1 == 0 or stages[0][1] <= 16)
+        ldo = stages[-1][2]
+        # the split kernel addresses its tensors through 32-bit buffer offsets (below 4 GiB): a larger batch runs as equal pieces of whole samples -- same kernel,
+        # same arithmetic per pixel, so a sample's bits do not depend on the batch (as Plan._conv_rows does for the convolutions)
+        rows = self.B
+        if split:
+            per = 4 * HW * max(src.ld0, src.ld1, ldo)
+            rows = max(1, min(self.B, _CHAIN_SPLIT_LIMIT // per))
+            rows = -(-self.B // -(-self.B // rows))
+        for b0 in range(0, self.B, rows):
+            nb = min(rows, self.B - b0)
+            d = L.Chain()
+            sp = L.Src.from_buffer_copy(src)
+            if b0:
+                sp.p0 = src.p0 + 4 * b0 * HW * src.ld0
+                if src.p1:
+                    sp.p1 = src.p1 + 4 * b0 * HW * src.ld1
+                if src.vec:
+                    sp.vec = src.vec + 4 * b0 * (src.c0 + src.c1)
+            d.src, d.out, d.n_stages, d.B, d.HW, d.ldo = sp, out.data_ptr() + 4 * b0 * HW * ldo, len(stages), nb, HW, ldo
+            for i, (layer, cin, cout, act, res) in enumerate(stages):
+                d.st[i].weight, d.st[i].bias = e.p(layer + (".weight.chain_s" if split else ".weight.chain")), e.p(layer + ".bias")
+                d.st[i].cin, d.st[i].cout, d.st[i].act, d.st[i].res = cin, cout, act, res
+            self._add("nd_pointwise_chain_split_nhwc_f32" if split else "nd_pointwise_chain_nhwc_f32", C.byref(d), e.stream,
+                      meta={"layer": name, "B": nb, "HW": HW, "cin": stages[0][1], "cout": stages[-1][2], "split": int(split),
+                            "flop_per_px": 2.0 * sum(c_in * c_out for _, c_in, c_out, _, _ in stages)})
+            self._keep.append(d)
         return out
 
     def _chain_ok(self, HW: int, widths) -> bool:

@@ -855,3 +855,24 @@ def test_bench_self_launcher_two_ranks_on_one_device():
                           "--soak-s", "0", "--no-cpu", "--no-roofline"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
                          timeout=300)
     assert bad.returncode == 2 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_split_chains_of_a_batch_cut_into_pieces_equal_the_whole_batch_bit_for_bit(monkeypatch):
+    """nd_pointwise_chain_split_nhwc_f32 addresses its tensors through 32-bit offsets; Plan.chain runs a batch beyond that as equal pieces of whole samples
+    (B >= 256 at 256 x 256, d = 64).  Forced here with a small limit: the forward of a batch of 5 in pieces of 2 + 2 + 1 equals the one-launch forward bit for bit."""
+    from noisediff_amd import engine as E
+    dim, H, B = 16, 32, 5
+    sd = state_dict(dim)
+    cond = to_dev(synth.make_condition(B, H, seed=1))
+    x = synth.make_noise(3, "piece.x", B, 4, H).to(DEV)
+    t = torch.tensor([3, 500, 999, 0, 77], dtype=torch.long, device=DEV)
+    outs = []
+    for limit in (E._CHAIN_SPLIT_LIMIT, 2 * 4 * H * H * dim):           # the second: two samples of a dim-channel tensor per launch
+        monkeypatch.setattr(E, "_CHAIN_SPLIT_LIMIT", limit)
+        net = make_net(dim)
+        plan = net.hip_engine(DEV).plan(B, H, H)
+        n_chain = sum(1 for op in plan.step_ops if op[2] == "nd_pointwise_chain_split_nhwc_f32")
+        plan.set_condition(cond)
+        outs.append((plan.forward(x, t).clone(), n_chain))
+    assert outs[1][1] > outs[0][1] > 0                                   # more launches, same layers
+    assert torch.equal(outs[0][0], outs[1][0])
