@@ -423,6 +423,13 @@ int64_t nd_conv7x7_c4_wgrad_workspace_floats(int B, int H, int W, int cout);
 int nd_conv7x7_c4_wgrad_f32(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, float* workspace, int B, int H, int W, int cout,
                             void* stream);
 int nd_pack_conv7x7_weight(const float* oihw, float* packed, int cout, void* stream);
+/* The same stem (same arguments, shapes, errors) with the products on the bf16 matrix cores at the operands' full fp32 significand: three bf16 terms per
+ * fp32 value, six of nine term products, fp32 accumulation (see nd_pointwise_gemm_split_nhwc_f32).  `wsplit`: nd_pack_conv7x7_weight_split
+ * ((cout, 4, 7, 7) OIHW -> [cout/32][13 K steps][term 3][64 lanes][8 bf16], nd_pack_conv7x7_weight_split_floats(cout) floats). */
+int nd_conv7x7_c4_split_f32(const float* x, const float* wsplit, const float* bias, float* out, int ldo,
+                            int B, int H, int W, int cout, void* stream);
+int64_t nd_pack_conv7x7_weight_split_floats(int cout);
+int nd_pack_conv7x7_weight_split(const float* oihw, float* packed, int cout, void* stream);
 /* LearnedSinusoidalPosEmb (:331-337): position NCHW (B,2,H,W) -> NHWC (B,H,W,3*hid):
  * w = conv1x1(position); cat(w, sin(2 pi w), cos(2 pi w)). */
 int nd_pos_enc_f32(const float* position_nchw, const float* w /*[hid][2]*/, const float* bias,

@@ -154,6 +154,9 @@ SIGNATURES = {
     "nd_embedding_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "nd_conv7x7_c4_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "nd_pack_conv7x7_weight": (i32, [vp, vp, i32, vp]),
+    "nd_conv7x7_c4_split_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "nd_pack_conv7x7_weight_split_floats": (i64, [i32]),
+    "nd_pack_conv7x7_weight_split": (i32, [vp, vp, i32, vp]),
     "nd_pos_enc_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "nd_maxpool2x2_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "nd_nchw_to_nhwc_pad_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

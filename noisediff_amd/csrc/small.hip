@@ -205,6 +205,131 @@ __global__ __launch_bounds__(512, 1) void conv7x7_kernel(const float* __restrict
     }
 }
 
+// ---- the same stem on the bf16 matrix cores at full fp32 significand (r6: the split-product form of pointwise.hip / pwchain.hip).  K = 49 taps x 4 channels in
+// 13 K steps of 16 (4 taps x 4 channels; taps 49-51 carry zero weights): slot i of lane (column, half h) in K step s = tap 4 s + 2 h + (i >> 2), channel i & 3.
+// The weights of a wave's 32 couts sit in registers as three bf16 terms (13 x 3 x 4 = 156 registers, two waves per SIMD); the halo tile is split ONCE per element when
+// it is staged into LDS term planes [term][pixel][4 x bf16]; a lane's operand of a K step is two 8-byte reads per term.  13 x 6 MFMAs of 32 cycles per 32-pixel row and
+// 32 couts against 98 of 64.
+typedef __bf16 c7_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 c7_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned c7_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned c7_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int C7_KS = 13;
+
+__device__ __forceinline__ void c7_split2(float x, float y, unsigned& w1, unsigned& w2, unsigned& w3) {
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x, y}, c7_bf16x2));
+    const float rx = x - __builtin_bit_cast(float, w1 << 16), ry = y - __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{rx, ry}, c7_bf16x2));
+    const float sx = rx - __builtin_bit_cast(float, w2 << 16), sy = ry - __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+    w3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sy), __builtin_bit_cast(unsigned, sx), 0x07060302u);
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void conv7x7_split_kernel(const float* __restrict__ x, const c7_u32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int ldo, int B, int H, int W, int cout) {
+    constexpr int NPX = C7_HH * C7_HW;
+    __shared__ __attribute__((aligned(16))) c7_u32x2 tile[3][NPX];                 // term planes: a pixel's four channels as bf16 = 8 bytes
+    constexpr int RG = 8 / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int nt = wave % NT, rg = wave / NT;
+    // ---- this wave's weight terms: [cout tile][K step][term][lane] x 16 bytes
+    c7_u32x4 wq[C7_KS][3];
+#pragma unroll
+    for (int s = 0; s < C7_KS; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) wq[s][t] = wp[((nt * C7_KS + s) * 3 + t) * 64 + lane];
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n0 = nt * 32 + 8 * g + 4 * half;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[g][i] = n0 + i < cout ? bias[n0 + i] : 0.0f;
+    }
+    // tile offsets (pixels) of this lane's two taps of every K step: tap 4 s + 2 half + j (the zero-weight padding taps read tap 48's pixel)
+    int toff[C7_KS][2];
+#pragma unroll
+    for (int s = 0; s < C7_KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tp = min(4 * s + 2 * half + j, 48);
+            toff[s][j] = (tp / 7) * C7_HW + tp % 7;
+        }
+    const int tiles_x = (W + C7_TW - 1) / C7_TW, tiles_y = (H + C7_TH - 1) / C7_TH;
+    const int n_tiles = B * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int ty0 = ty * C7_TH, tx0 = tx * C7_TW;
+        __syncthreads();                                   // previous tile consumed
+        for (int i = tid; i < NPX; i += 512) {
+            const int hy = i / C7_HW, hx = i - hy * C7_HW;
+            const int y = ty0 + hy - 3, xx = tx0 + hx - 3;
+            f32x4 v = {0, 0, 0, 0};
+            if (y >= 0 && y < H && xx >= 0 && xx < W) v = nd_ld4(x + ((size_t)(b * H + y) * W + xx) * 4);
+            unsigned a1, a2, a3, b1, b2, b3;
+            c7_split2(v.x, v.y, a1, a2, a3);
+            c7_split2(v.z, v.w, b1, b2, b3);
+            tile[0][i] = c7_u32x2{a1, b1};
+            tile[1][i] = c7_u32x2{a2, b2};
+            tile[2][i] = c7_u32x2{a3, b3};
+        }
+        __syncthreads();
+        for (int ly = rg; ly < C7_TH; ly += RG) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * g + i] = bias4[g][i];
+            const int p = ly * C7_HW + col;
+#pragma unroll
+            for (int s = 0; s < C7_KS; ++s) {
+                c7_u32x4 xv[3];
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) {
+                    const c7_u32x2 lo = tile[tm][p + toff[s][0]], hi = tile[tm][p + toff[s][1]];
+                    xv[tm] = c7_u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+#define C7_MFMA(wt, xt) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c7_bf16x8, wq[s][wt]), __builtin_bit_cast(c7_bf16x8, xv[xt]), acc, 0, 0, 0)
+                C7_MFMA(0, 0);  C7_MFMA(0, 1);  C7_MFMA(1, 0);  C7_MFMA(1, 1);  C7_MFMA(0, 2);  C7_MFMA(2, 0);
+#undef C7_MFMA
+            }
+            const int y = ty0 + ly, xx = tx0 + col;
+            if (y < H && xx < W) {
+                float* o = out + ((size_t)(b * H + y) * W + xx) * ldo;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n0 = nt * 32 + 8 * g + 4 * half;
+                    if (n0 + 4 <= cout) {
+                        nd_st4(o + n0, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]});
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (n0 + i < cout) o[n0 + i] = acc[4 * g + i];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// OIHW (cout, 4, 7, 7) -> [cout tile 32][K step 13][term 3][lane 64][8 bf16]: slot i of lane l = W[32 tile + (l & 31)][channel i & 3][tap 4 s + 2 (l >> 5) + (i >> 2)]
+__global__ void pack_conv7x7_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout, int ntiles) {
+    const int total = ntiles * C7_KS * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int i = idx & 7, l = (idx >> 3) & 63, rest = idx >> 9;
+        const int s = rest % C7_KS, tile = rest / C7_KS;
+        const int n = 32 * tile + (l & 31), tap = 4 * s + 2 * (l >> 5) + (i >> 2), c = i & 3;
+        const float v = (n < cout && tap < 49) ? w[((size_t)n * 4 + c) * 49 + tap] : 0.0f;
+        const __bf16 t1 = (__bf16)v;
+        const float r1 = v - (float)t1;
+        const __bf16 t2 = (__bf16)r1;
+        const float r2 = r1 - (float)t2;
+        unsigned short* o = out + ((size_t)((tile * C7_KS + s) * 3) * 64 + l) * 8 + i;
+        o[0] = __builtin_bit_cast(unsigned short, t1);
+        o[512] = __builtin_bit_cast(unsigned short, t2);
+        o[1024] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+}
+
 __global__ void pack_conv7x7_kernel(const float* __restrict__ w, float* __restrict__ out, int cout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [49*4][cout]
     if (i >= 196 * cout) return;
@@ -485,6 +610,39 @@ extern "C" int nd_conv7x7_c4_f32(const float* x, const float* wpacked, const flo
     else ND_C7_LAUNCH(8);
 #undef ND_C7_LAUNCH
     return nd_launch_status("nd_conv7x7_c4_f32");
+}
+
+extern "C" int64_t nd_pack_conv7x7_weight_split_floats(int cout) { return (int64_t)nd_cdiv(cout, 32) * C7_KS * 3 * 64 * 4; }
+
+extern "C" int nd_pack_conv7x7_weight_split(const float* oihw, float* packed, int cout, void* stream) {
+    ND_REQUIRE(oihw && packed && cout > 0 && nd_aligned16(packed), ND_E_BADARG, "nd_pack_conv7x7_weight_split: bad argument");
+    const int ntiles = nd_cdiv(cout, 32);
+    hipLaunchKernelGGL(pack_conv7x7_split_kernel, dim3(nd_cdiv(ntiles * C7_KS * 512, 256)), dim3(256), 0, (hipStream_t)stream, oihw,
+                       reinterpret_cast<unsigned short*>(packed), cout, ntiles);
+    return nd_launch_status("nd_pack_conv7x7_weight_split");
+}
+
+// nd_conv7x7_c4_f32 with the products on the bf16 matrix cores at full fp32 significand (three-term split, six products, fp32 accumulation);
+// `wsplit` from nd_pack_conv7x7_weight_split.  Same shapes and errors.
+extern "C" int nd_conv7x7_c4_split_f32(const float* x, const float* wsplit, const float* bias, float* out, int ldo, int B, int H, int W,
+                                       int cout, void* stream) {
+    ND_REQUIRE(x && wsplit && bias && out, ND_E_BADARG, "nd_conv7x7_c4_split: null pointer");
+    ND_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && ldo >= cout, ND_E_SHAPE, "nd_conv7x7_c4_split: bad shape");
+    ND_REQUIRE(nd_aligned16(x) && nd_aligned16(wsplit), ND_E_ALIGN, "nd_conv7x7_c4_split: x and the weights must be 16-byte aligned");
+    ND_REQUIRE(cout <= 256 && ldo % 4 == 0 && nd_aligned16(out), ND_E_SHAPE, "nd_conv7x7_c4_split: cout <= 256, ldo %% 4 == 0, out 16-byte aligned");
+    const long tiles = (long)B * nd_cdiv(H, C7_TH) * nd_cdiv(W, C7_TW);
+    ND_REQUIRE(tiles < (1L << 31), ND_E_SHAPE, "nd_conv7x7_c4_split: grid too large");
+    const int cus = nd_device_cus();
+    const dim3 grid((unsigned)(tiles < cus ? tiles : cus)), block(512);
+    const int ntiles = nd_cdiv(cout, 32);
+    const c7_u32x4* wq = reinterpret_cast<const c7_u32x4*>(wsplit);
+#define ND_C7S_LAUNCH(NT) hipLaunchKernelGGL(conv7x7_split_kernel<NT>, grid, block, 0, (hipStream_t)stream, x, wq, bias, out, ldo, B, H, W, cout)
+    if (ntiles <= 1) ND_C7S_LAUNCH(1);
+    else if (ntiles <= 2) ND_C7S_LAUNCH(2);
+    else if (ntiles <= 4) ND_C7S_LAUNCH(4);
+    else ND_C7S_LAUNCH(8);
+#undef ND_C7S_LAUNCH
+    return nd_launch_status("nd_conv7x7_c4_split_f32");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------

@@ -200,6 +200,8 @@ class Engine:
                     add(p.name + ".split", self.lib.nd_pack_pointwise_weight_split_floats(p.shape[1], p.shape[0]), "derived", p.shape)
             elif kind == "conv7":
                 n = 196 * p.shape[0]
+                if SPLIT_PW and p.name == "init_conv.weight":      # the per-step stem on the split-product kernel (cond_init_conv runs once per condition)
+                    add(p.name + ".split", self.lib.nd_pack_conv7x7_weight_split_floats(p.shape[0]), "derived", p.shape)
             else:
                 n = math.prod(p.shape)
             add(p.name, n, kind, p.shape)
@@ -283,6 +285,8 @@ class Engine:
                     L.call("nd_pack_pointwise_weight", t.data_ptr(), dst, p.shape[1], p.shape[0], p.shape[1] // 4, st)
                 elif kind == "conv7":
                     L.call("nd_pack_conv7x7_weight", t.data_ptr(), dst, p.shape[0], st)
+                    if p.name + ".split" in self.slots:
+                        L.call("nd_pack_conv7x7_weight_split", t.data_ptr(), self.p(p.name + ".split"), p.shape[0], st)
             L.call("nd_stream_sync", st)
             tw = torch.cat([self.view(r + ".mlp.1.weight") for r in self.resnet_names])
             tb = torch.cat([self.view(r + ".mlp.1.bias") for r in self.resnet_names])
@@ -865,8 +869,9 @@ class Plan:
             self._release(r_shot, s, s2, s3)
         # ---- trunk
         x0 = self._alloc(B, H, W, d)
-        self._add("nd_conv7x7_c4_f32", self.x.data_ptr(), e.p("init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d,
-                  B, H, W, d, e.stream)
+        stem_split = "init_conv.weight.split" in e.slots
+        self._add("nd_conv7x7_c4_split_f32" if stem_split else "nd_conv7x7_c4_f32", self.x.data_ptr(),
+                  e.p("init_conv.weight.split" if stem_split else "init_conv.weight"), e.p("init_conv.bias"), x0.data_ptr(), d, B, H, W, d, e.stream)
         self._tap("init_conv", x0)
         xin = x0
         if tr.cond_branch:          # x = cond_concat_conv(cat[init_conv(x), clean_emb])   others_arch.py:495-498

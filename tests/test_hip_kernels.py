@@ -586,7 +586,22 @@ def test_conv7x7(ctx, shape):
     L.call("nd_pack_conv7x7_weight", wd.data_ptr(), wp.data_ptr(), cout, ctx.stream)
     L.call("nd_conv7x7_c4_f32", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, B, H, W, cout, ctx.stream)
     ctx.sync()
-    assert rel_err(hu.nchw(out), F.conv2d(x, w, b, padding=3)) < TOL
+    ref = F.conv2d(x, w, b, padding=3)
+    assert rel_err(hu.nchw(out), ref) < TOL
+    # the split-product form (r6): three bf16 terms per operand on v_mfma_f32_32x32x16_bf16, same tolerance, no worse than 1.5 x the fp32 kernel against fp64
+    ws, out2 = hu.full((ctx.lib.nd_pack_conv7x7_weight_split_floats(cout),)), hu.full((B, H, W, cout))
+    L.call("nd_pack_conv7x7_weight_split", wd.data_ptr(), ws.data_ptr(), cout, ctx.stream)
+    L.call("nd_conv7x7_c4_split_f32", xd.data_ptr(), ws.data_ptr(), bd.data_ptr(), out2.data_ptr(), cout, B, H, W, cout, ctx.stream)
+    ctx.sync()
+    assert rel_err(hu.nchw(out2), ref) < TOL
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=3)
+    e32, esp = (hu.nchw(out).double() - ref64).abs().max().item(), (hu.nchw(out2).double() - ref64).abs().max().item()
+    assert esp <= 1.5 * e32 + 1e-7, (esp, e32)
+    first = out2.clone()
+    torch.cuda.synchronize()
+    L.call("nd_conv7x7_c4_split_f32", xd.data_ptr(), ws.data_ptr(), bd.data_ptr(), out2.data_ptr(), cout, B, H, W, cout, ctx.stream)
+    ctx.sync()
+    assert torch.equal(out2, first)
 
 
 @pytest.mark.parametrize("N", [64, 1024, 200])
