@@ -582,8 +582,8 @@ def main():
         "metric": f"sampled RAW patches/sec ({S}x{S}x4, {sampler})", "value": value, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 storage and accumulation everywhere; 3x3 convolutions, the 7x7 stem and attention on the exact-fp32 matrix instruction; wide 1x1 / Linear "
-                      "layers and the fused per-pixel chains on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (six products, "
+        "arithmetic": "fp32 storage and accumulation everywhere; 3x3 convolutions and attention on the exact-fp32 matrix instruction; wide 1x1 / Linear "
+                      "layers, the 7x7 stem and the fused per-pixel chains on the bf16 matrix cores with every fp32 operand split exactly into three bf16 terms (six products, "
                       "full 24-bit significand: error against fp64 at or below the fp32 kernels', profiles/r6_split_gemm_accuracy.txt)",
         "config": {"workload": f"NoiseDiffNet dim={a.dim}{' + mid Attention' if a.mid_attn else ''}, {S}x{S}x4 patches, " +
                                sampler + " (sigmoid2, pred_v), "
