@@ -649,10 +649,11 @@ def _tokens(t: torch.Tensor, c: int) -> torch.Tensor:
     return t
 
 
-def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool, x2b: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y[N, cout] = x2[N, cin] @ W^T (+ bias) on nd_pointwise_gemm_nhwc_f32 (pointwise.hip: the sampling path's 1x1 / Linear kernels, exact-fp32
+def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool, x2b: Optional[torch.Tensor] = None,
+                    res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[N, cout] = x2[N, cin] @ W^T (+ bias) (+ res[N, cout]) on nd_pointwise_gemm_nhwc_f32 (pointwise.hip: the sampling path's 1x1 / Linear kernels, exact-fp32
     MFMA), W = ``w`` (cout, cin); ``transposed``: W^T = ``w`` -- the forward weight of the layer whose data gradient dx = dy @ w this is (packed
-    in place by nd_pack_pointwise_weight_t)."""
+    in place by nd_pack_pointwise_weight_t).  ``res``: a residual added in the kernel's epilogue (the sampling engine's res0)."""
     lib = L.load()
     N, cin = x2.shape
     c0 = cin
@@ -680,6 +681,8 @@ def _pointwise_gemm(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
         if bias is not None:
             b32 = bias.detach().float().contiguous()
             d.bias = b32.data_ptr()
+        if res is not None:
+            d.res0, d.ldr0 = res.data_ptr(), cout
         d.B, d.HW, d.W, d.cin, d.cout, d.ldo, d.act = 1, N, 1, cin, cout, cout, L.ACT_NONE
         L.call("nd_pointwise_gemm_nhwc_f32", C.byref(d), st)
     return y
@@ -696,13 +699,17 @@ class LinearFunction(torch.autograd.Function):
     come from nd_linear_wgrad_f32 (linear_wgrad.hip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, res=None):
+        """``res`` (optional, the shape of the output): y = x @ W^T + b + res with the addition in the GEMM's epilogue (the residual connections around the
+        AttnBlock's feed-forward and ``proj_out``, Diffusion_arch.py:440-443); its gradient is the output's."""
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         cout, cin = weight.shape
         if x.is_cuda and _pw_takes(x.numel() // cin, cin, cout):
-            return _pointwise_gemm(_tokens(x, cin), weight, bias, False).view(*x.shape[:-1], cout)
-        return torch.nn.functional.linear(x, weight, bias)
+            r2 = _tokens(res, cout) if res is not None else None
+            return _pointwise_gemm(_tokens(x, cin), weight, bias, False, res=r2).view(*x.shape[:-1], cout)
+        y = torch.nn.functional.linear(x, weight, bias)
+        return y if res is None else y + res
 
     @staticmethod
     @once_differentiable
@@ -728,7 +735,7 @@ class LinearFunction(torch.autograd.Function):
                 ws = torch.empty(int(lib.nd_linear_wgrad_workspace_floats(N, cin, cout)), dtype=torch.float32, device=x2.device)
                 L.call("nd_linear_wgrad_f32", x2.data_ptr(), cin, g2.data_ptr(), cout, grad_w.data_ptr(),
                        grad_b.data_ptr() if grad_b is not None else None, ws.data_ptr(), N, cin, cout, _stream(x2.device))
-        return grad_x, grad_w, grad_b
+        return grad_x, grad_w, grad_b, (grad_out if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
 
 
 class LinearCatFunction(torch.autograd.Function):
@@ -787,19 +794,24 @@ def _linear_ok(cin: int, cout: int) -> bool:
     return cin % 4 == 0 and cout % 4 == 0
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Differentiable F.linear(x, weight, bias) with the weight / bias gradient on the HIP library (channel counts multiples of 4)."""
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable F.linear(x, weight, bias) (+ res, added in the GEMM's epilogue) with the weight / bias gradient on the HIP library (channel counts multiples of 4)."""
     if weight.dim() != 2 or x.shape[-1] != weight.shape[1] or not _linear_ok(weight.shape[1], weight.shape[0]):
         raise ValueError(f"linear: x {tuple(x.shape)} / weight {tuple(weight.shape)}: needs a 2-D weight with channel counts that are multiples of 4")
-    return LinearFunction.apply(x, weight, bias)
+    if res is None:
+        return LinearFunction.apply(x, weight, bias)
+    if tuple(res.shape) != tuple(x.shape[:-1]) + (weight.shape[0],):
+        raise ValueError(f"linear: residual {tuple(res.shape)} is not the output's shape {tuple(x.shape[:-1]) + (weight.shape[0],)}")
+    return LinearFunction.apply(x, weight, bias, res)
 
 
-def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Differentiable F.conv2d(x, weight, bias) for 1x1 kernels as a Linear over the pixels (NHWC tokens; channels_last in and out)."""
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable F.conv2d(x, weight, bias) (+ res, NCHW-shaped like the output) for 1x1 kernels as a Linear over the pixels (NHWC tokens; channels_last in and out)."""
     if x.dim() != 4 or tuple(weight.shape[2:]) != (1, 1) or x.shape[1] != weight.shape[1]:
         raise ValueError(f"conv1x1: x {tuple(x.shape)} / weight {tuple(weight.shape)} is not a 1x1 convolution")
     t = x.permute(0, 2, 3, 1)                                              # a view; contiguous when x is channels_last
-    y = linear(t if t.is_contiguous() else t.contiguous(), weight.flatten(1), bias)
+    r = res.permute(0, 2, 3, 1) if res is not None else None
+    y = linear(t if t.is_contiguous() else t.contiguous(), weight.flatten(1), bias, r)
     return y.permute(0, 3, 1, 2)                                           # NCHW-shaped, channels_last in memory
 
 

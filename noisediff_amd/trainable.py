@@ -30,6 +30,21 @@ _log = logging.getLogger(__name__)
 FALLBACKS: Dict[Tuple[str, str], str] = {}      # (layer, operator) -> why it runs on PyTorch although the network is .hip() (filled on first use, logged once each)
 
 
+class _ZeroGrads(torch.autograd.Function):
+    """``y`` unchanged; the parameters after it receive exactly-zero gradients -- what autograd gives parameters whose only path to the loss runs through a
+    softmax over ONE key (CrossAttention's to_q / to_k and the LayerNorm that feeds only them, one-token ISO context: SURVEY fact 4).  Written as
+    ``y + (sum(p) + ...) * 0`` this costs four reductions and a dozen scalar kernels per AttnBlock and step, forward and backward; here it costs the zero fills."""
+
+    @staticmethod
+    def forward(ctx, y, *params):
+        ctx.save_for_backward(*params)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return (grad_out,) + tuple(torch.zeros_like(q) if need else None for q, need in zip(ctx.saved_tensors, ctx.needs_input_grad[1:]))
+
+
 class _Ops:
     """Layer primitives over the parameter table; 3x3 convolutions and GroupNorms go to the HIP library when asked to and able to."""
 
@@ -62,10 +77,17 @@ class _Ops:
             FALLBACKS[(name, op)] = why
             _log.warning("%s: %s stays on PyTorch (%s)", name, op, why)
 
-    def conv(self, name: str, x, padding: int = 0) -> torch.Tensor:
+    def conv(self, name: str, x, padding: int = 0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``x``: a tensor, or a pair (x0, x1) standing for torch.cat((x0, x1), 1) -- the up path's skip concatenations, which the library's 3x3 and
-        1x1 convolutions read as two sources (train.conv3x3_cat / conv1x1_cat) instead of a concatenated copy."""
+        1x1 convolutions read as two sources (train.conv3x3_cat / conv1x1_cat) instead of a concatenated copy.  ``res``: conv(x) + res, the addition in the
+        epilogue of the library's 1x1 kernel where that runs."""
         w, b = self.p[name + ".weight"], self.p.get(name + ".bias")
+        if res is not None:
+            if (self.hip and not isinstance(x, tuple) and x.is_cuda and w.shape[2:] == (1, 1) and padding == 0 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0
+                    and res.shape[1] == w.shape[0]):
+                from . import train
+                return train.conv1x1(x, w, b, res=res)
+            return self.conv(name, x, padding) + res
         if isinstance(x, tuple):
             from . import train
             if self.hip and train.cat_sources_ok(*x) and w.shape[0] % 8 == 0:
@@ -93,14 +115,16 @@ class _Ops:
             self._left_library(name, f"conv{w.shape[2]}x{w.shape[3]}", f"{w.shape[1]} -> {w.shape[0]} channels: the library's differentiable convolutions are 3x3 (channels % 8), 1x1 (cout % 4) and the 7x7 stem of a 4-channel image")
         return F.conv2d(x, w, b, padding=padding)
 
-    def linear(self, name: str, x: torch.Tensor) -> torch.Tensor:
+    def linear(self, name: str, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``res``: linear(x) + res, the addition in the GEMM's epilogue on the library."""
         w, b = self.p[name + ".weight"], self.p.get(name + ".bias")
         if self.hip and x.is_cuda and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
             from . import train
-            return train.linear(x, w, b)
+            return train.linear(x, w, b, res)
         if x.is_cuda:
             self._left_library(name, "linear", f"{w.shape[1]} -> {w.shape[0]}: channel counts must be multiples of 4")
-        return F.linear(x, w, b)
+        y = F.linear(x, w, b)
+        return y if res is None else y + res
 
     def group_norm(self, name: str, x: torch.Tensor, groups: int) -> torch.Tensor:
         w, b = self.p[name + ".weight"], self.p[name + ".bias"]
@@ -181,8 +205,7 @@ class _Ops:
         b, n, _ = x.shape
         if ctx.shape[1] == 1:
             out = self.linear(name + ".to_out.0", self.linear(name + ".to_v", ctx))              # (b, 1, C): broadcasts over the n tokens
-            dead = (self.p[name + ".to_q.weight"].sum() + self.p[name + ".to_k.weight"].sum()) * 0.0   # zero gradients, as autograd gives them there
-            return out + dead
+            return _ZeroGrads.apply(out, self.p[name + ".to_q.weight"], self.p[name + ".to_k.weight"])   # zero gradients, as autograd gives them there
         q, k, v = self.linear(name + ".to_q", x), self.linear(name + ".to_k", ctx), self.linear(name + ".to_v", ctx)
         d = q.shape[-1] // HEADS
         heads = lambda t: t.reshape(b, t.shape[1], HEADS, d).transpose(1, 2)               # b h n d
@@ -196,8 +219,7 @@ class _Ops:
         b, c, h, w = x.shape
         t = x.flatten(2).transpose(1, 2)
         if ctx.shape[1] == 1:                                                # norm1 feeds only the (dead) queries: skipped, its gradient is zero
-            dead = (self.p[name + ".norm1.weight"].sum() + self.p[name + ".norm1.bias"].sum()) * 0.0
-            vec = self.cross_attention(name + ".attn", t, ctx) + dead                  # (b, 1, C): the same vector for every token
+            vec = _ZeroGrads.apply(self.cross_attention(name + ".attn", t, ctx), self.p[name + ".norm1.weight"], self.p[name + ".norm1.bias"])   # (b, 1, C): the same vector for every token
             if self.hip and t.is_cuda:
                 from . import train
                 t = train.broadcast_add(t, vec)                                     # its gradient: a token sum on the library (fixed order)
@@ -205,8 +227,8 @@ class _Ops:
                 t = vec + t
         else:
             t = self.cross_attention(name + ".attn", self.layer_norm(name + ".norm1", t), ctx) + t
-        t = self.linear(name + ".ff.net.2", F.gelu(self.linear(name + ".ff.net.0.0", self.layer_norm(name + ".norm2", t)))) + t
-        return self.conv(name + ".proj_out", t.transpose(1, 2).reshape(b, c, h, w)) + x
+        t = self.linear(name + ".ff.net.2", F.gelu(self.linear(name + ".ff.net.0.0", self.layer_norm(name + ".norm2", t))), res=t)
+        return self.conv(name + ".proj_out", t.transpose(1, 2).reshape(b, c, h, w), res=x)
 
 
     # ---- the attention modules the reference defines next to the network (Diffusion_arch.py:84-90,198-266): BASELINE config 4's mid-block Attention and

@@ -4,7 +4,7 @@ noisediff_amd.train.Adam (one launch + a counter launch; env ADAM=torch: torch.o
 The library's launches are queued on torch's current stream, so they are captured like any ATen kernel; replaying the graph removes the host side of the
 ~300 autograd-function calls of a step (which bounds the small configurations in eager mode)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("ND_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # ND_PKG_ROOT: another copy of the package (A/B against a saved state)
 import torch
 from types import SimpleNamespace
 from noisediff_amd import GaussianDiffusion, TrainableNoiseDiffNet, synth

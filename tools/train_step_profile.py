@@ -5,7 +5,7 @@ Env: B (4), S (256), DIM (64), STEPS (6), HIP (1: .hip() operators, 0: PyTorch),
 ADAM (hip: noisediff_amd.train.Adam, one launch per step -- the default | torch: torch.optim.Adam's foreach form | fused: PyTorch's single-kernel Adam)."""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, REPO)
+sys.path.insert(0, os.environ.get("ND_PKG_ROOT") or REPO)      # ND_PKG_ROOT: another copy of the package (A/B against a saved state)
 from types import SimpleNamespace
 import torch
 from noisediff_amd import GaussianDiffusion, NoiseDiffNet, TrainableNoiseDiffNet, synth
