@@ -790,6 +790,78 @@ def conv1x1_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: 
     return y.permute(0, 3, 1, 2)
 
 
+class ShortcutCatFunction(torch.autograd.Function):
+    """ResnetBlock.res_conv on ``cat((t0, t1), -1)`` (tokens) AND the hand-over of the two inputs to the block's first convolution: returns (t0, t1, r =
+    linear(cat(t0, t1), weight, bias)).  The block reads the returned aliases, so the convolution's data gradient arrives HERE instead of being added to the
+    shortcut's by autograd (one elementwise pass over a block input per source: 18 of a step's additions, 6 of them full resolution): the shortcut's own data
+    gradient dr @ W takes it as the residual of its GEMM epilogue.  Diffusion_arch.py:163-170 (h + res_conv(x)) on the up path's concatenations (:620-630)."""
+
+    @staticmethod
+    def forward(ctx, t0, t1, weight, bias):
+        ctx.save_for_backward(t0, t1, weight)
+        ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)
+        cout = weight.shape[0]
+        c0, c1 = t0.shape[-1], t1.shape[-1]
+        r = _pointwise_gemm(_tokens(t0, c0), weight, bias, False, _tokens(t1, c1)).view(*t0.shape[:-1], cout)
+        return t0.view_as(t0), t1.view_as(t1), r
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d0, d1, dr):
+        t0, t1, weight = ctx.saved_tensors
+        cout, cin = weight.shape
+        c0, c1 = t0.shape[-1], t1.shape[-1]
+        if dr is None:
+            return d0, d1, None, None
+        g2 = _tokens(dr, cout)
+        g0 = g1 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # the convolution's gradients are the two channel slices of ONE (tokens, c0 + c1) tensor (Conv3x3CatFunction.backward): the residual of the epilogue
+            want, acc = [], 1                                            # strides of a contiguous (..., cin) tensor: what both slices must sit in
+            for n in (cin,) + tuple(reversed(t0.shape[:-1])):
+                want.insert(0, acc)
+                acc *= n
+            joined = (d0 is not None and d1 is not None and d0.dtype == torch.float32 and d1.dtype == torch.float32 and d0.shape == t0.shape and d1.shape == t1.shape
+                      and list(d0.stride()) == want and list(d1.stride()) == want and d0.data_ptr() + 4 * c0 == d1.data_ptr() and d0.data_ptr() % 16 == 0)
+            if joined:
+                res = torch.as_strided(d0, (g2.shape[0], cin), (cin, 1))
+                full = _pointwise_gemm(g2, weight, None, True, res=res).view(*t0.shape[:-1], cin)
+                g0, g1 = full[..., :c0], full[..., c0:]
+            else:
+                full = _pointwise_gemm(g2, weight, None, True).view(*t0.shape[:-1], cin)
+                g0 = full[..., :c0] if d0 is None else full[..., :c0] + d0
+                g1 = full[..., c0:] if d1 is None else full[..., c0:] + d1
+        grad_w = grad_b = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            lib = L.load()
+            with _on(g2.device):
+                parts = []
+                for i, (t, c) in enumerate(((t0, c0), (t1, c1))):
+                    x2 = _tokens(t, c)
+                    N = x2.shape[0]
+                    dw = torch.empty((cout, c), dtype=torch.float32, device=x2.device)
+                    if i == 0 and ctx.has_bias:
+                        grad_b = torch.empty(cout, dtype=torch.float32, device=x2.device)
+                    ws = torch.empty(int(lib.nd_linear_wgrad_workspace_floats(N, c, cout)), dtype=torch.float32, device=x2.device)
+                    L.call("nd_linear_wgrad_f32", x2.data_ptr(), c, g2.data_ptr(), cout, dw.data_ptr(),
+                           grad_b.data_ptr() if (i == 0 and grad_b is not None) else None, ws.data_ptr(), N, c, cout, _stream(x2.device))
+                    parts.append(dw)
+                grad_w = torch.cat(parts, dim=1)
+        return g0, g1, grad_w, grad_b
+
+
+def conv1x1_shortcut_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """(x0', x1', F.conv2d(torch.cat((x0, x1), 1), weight, bias)) for a ResnetBlock whose shortcut is a 1x1 convolution of a concatenation: x0' / x1' are the inputs
+    again, to be read by the block's first convolution, whose data gradient then joins the shortcut's inside one GEMM (ShortcutCatFunction)."""
+    if x0.dim() != 4 or tuple(weight.shape[2:]) != (1, 1) or x0.shape[1] + x1.shape[1] != weight.shape[1] or x0.shape[1] % 4 or x1.shape[1] % 4 \
+            or weight.shape[0] % 4 or not (x0.is_cuda and x1.is_cuda):
+        raise ValueError(f"conv1x1_shortcut_cat: x0 {tuple(x0.shape)} + x1 {tuple(x1.shape)} / weight {tuple(weight.shape)}")
+    t0, t1 = x0.permute(0, 2, 3, 1), x1.permute(0, 2, 3, 1)
+    a0, a1, r = ShortcutCatFunction.apply(t0 if t0.is_contiguous() else t0.contiguous(), t1 if t1.is_contiguous() else t1.contiguous(), weight.flatten(1), bias)
+    return a0.permute(0, 3, 1, 2), a1.permute(0, 3, 1, 2), r.permute(0, 3, 1, 2)
+
+
 def _linear_ok(cin: int, cout: int) -> bool:
     return cin % 4 == 0 and cout % 4 == 0
 

@@ -190,6 +190,13 @@ class _Ops:
                 ss = self.linear(name + ".mlp.1", emb)[:, :, None, None]
         if isinstance(x, tuple) and name + ".res_conv.weight" not in self.p:
             x = torch.cat(x, dim=1)                                            # an identity shortcut needs the tensor itself
+        if isinstance(x, tuple) and self.hip:
+            from . import train
+            w = self.p[name + ".res_conv.weight"]
+            if train.cat_sources_ok(*x) and w.shape[0] % 8 == 0:               # (what conv() asks before it reads the pair as two sources)
+                # the shortcut hands the pair on to block1: that convolution's data gradient then joins the shortcut's in one GEMM instead of two additions
+                x0, x1, res = train.conv1x1_shortcut_cat(x[0], x[1], w, self.p.get(name + ".res_conv.bias"))
+                return self.block(name + ".block2", self.block(name + ".block1", (x0, x1), groups, ss), groups, res=res)
         res = self.conv(name + ".res_conv", x) if name + ".res_conv.weight" in self.p else x
         return self.block(name + ".block2", self.block(name + ".block1", x, groups, ss), groups, res=res)      # block2(...) + res, the add inside block2's fused tail
 

@@ -761,6 +761,36 @@ def test_convolutions_over_two_sources_equal_the_concatenation(shape):
     assert not train.cat_sources_ok(x0[:, :8], x1)                                # half a 16-channel chunk: the caller concatenates
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64, 64), (4, 32, 32, 512, 256, 512), (1, 48, 96, 32, 64, 48)])
+@pytest.mark.parametrize("joined", [True, False])
+def test_shortcut_of_a_concatenation_takes_the_block_convolutions_gradient_in_its_epilogue(shape, joined):
+    """train.conv1x1_shortcut_cat: (x0, x1, res_conv(cat(x0, x1))) with the inputs handed on to the block's first convolution -- its data gradient (the two channel
+    slices of ONE tensor out of conv3x3_cat: ``joined``) is the residual of the shortcut's own data-gradient GEMM instead of two autograd additions; any other
+    consumer of the hand-over (``not joined``: the gradients arrive as separate tensors) takes the additions.  Every gradient against the unfused operators."""
+    B, H, W, c0, c1, cout = shape
+    x0, x1 = U("sc.x0", (B, c0, H, W), -1.5, 1.5).to(DEV), U("sc.x1", (B, c1, H, W), -1.5, 1.5).to(DEV)
+    x0, x1 = x0.contiguous(memory_format=torch.channels_last), x1.contiguous(memory_format=torch.channels_last)
+    w3 = (U("sc.w3", (cout, c0 + c1, 3, 3)) / (9 * (c0 + c1)) ** 0.5).to(DEV)
+    w1 = (U("sc.w1", (cout, c0 + c1, 1, 1)) / (c0 + c1) ** 0.5).to(DEV)
+    b = U("sc.b", (cout,)).to(DEV)
+    gh, gr = U("sc.gh", (B, cout, H, W)).to(DEV), U("sc.gr", (B, cout, H, W)).to(DEV)
+    outs = []
+    for fused in (False, True):
+        a, c, w3a, w1a, ba = (t.clone().requires_grad_() for t in (x0, x1, w3, w1, b))
+        if fused:
+            a2, c2, r = train.conv1x1_shortcut_cat(a, c, w1a, ba)
+        else:
+            a2, c2, r = a, c, train.conv1x1_cat(a, c, w1a, ba)
+        h = train.conv3x3_cat(a2, c2, w3a, None) if joined else train.conv3x3(a2 * 1.5, w3a[:, :c0].contiguous(), None) + (c2 * c2).sum() * 1e-3
+        torch.autograd.backward((h, r), (gh, gr))
+        outs.append([t.detach().cpu() for t in (h, r, a.grad, c.grad, w3a.grad, w1a.grad, ba.grad)])
+    for got, ref, name in zip(outs[1], outs[0], ("h", "r", "dx0", "dx1", "dw3", "dw1", "db")):
+        if name in ("h", "r", "dw3", "dw1", "db"):
+            assert torch.equal(got, ref), name                 # the same launches on the same operands
+        else:
+            assert rel_err(got.numpy(), ref.numpy()) < 2e-6, name          # (a + b in the epilogue against b + a by autograd: fp32 addition commutes, fma contraction may differ)
+
+
 def test_a_training_step_with_the_capturable_adam_replays_as_one_graph():
     """train.Adam(capturable=True): step counters on the device, nothing computed on the host -- forward + backward + optimizer captured into one
     torch.cuda.CUDAGraph and replayed; the losses follow torch.optim.Adam run eagerly on a copy of the net (the packing caches' repack launches are part of
