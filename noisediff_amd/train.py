@@ -205,10 +205,13 @@ def conv3x3_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     return y, (st, sc)
 
 
-def cat_sources_ok(x0: torch.Tensor, x1: torch.Tensor) -> bool:
-    """Can conv3x3_cat / conv1x1_cat take this pair (else the caller concatenates)?  The F(4x4) kernel's geometry and whole 16-channel chunks per source."""
+def cat_sources_ok(x0: torch.Tensor, x1: torch.Tensor, cout: Optional[int] = None) -> bool:
+    """Can conv3x3_cat / conv1x1_cat take this pair (else the caller concatenates)?  The F(4x4) kernel's geometry and whole 16-channel chunks per source;
+    ``cout`` (when given): a multiple of 8 within the kernel's bias table (2048)."""
     B, c0, H, W = x0.shape
     c1 = x1.shape[1]
+    if cout is not None and (cout % 8 or cout > 2048):
+        return False
     return (x0.is_cuda and x1.is_cuda and x0.dim() == 4 and tuple(x1.shape[2:]) == (H, W) and x1.shape[0] == B and c0 % 16 == 0 and c1 % 16 == 0
             and H >= 16 and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048
             and (B * H * W + W + 2) * (c0 + c1) * 4 < (1 << 30) - (1 << 16) and B * H * W + W + 2 < (1 << 24))
@@ -273,7 +276,7 @@ class Conv3x3CatFunction(torch.autograd.Function):
 def conv3x3_cat(x0: torch.Tensor, x1: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, with_stats: bool = False):
     """Differentiable F.conv2d(torch.cat((x0, x1), 1), weight, bias, padding=1) that never builds the concatenation (``cat_sources_ok`` says when);
     ``with_stats``: (y, (st, sc)) as conv3x3_with_stats."""
-    if tuple(weight.shape[2:]) != (3, 3) or x0.shape[1] + x1.shape[1] != weight.shape[1] or not cat_sources_ok(x0, x1):
+    if tuple(weight.shape[2:]) != (3, 3) or x0.shape[1] + x1.shape[1] != weight.shape[1] or not cat_sources_ok(x0, x1, weight.shape[0]):
         raise ValueError(f"conv3x3_cat: x0 {tuple(x0.shape)} + x1 {tuple(x1.shape)} / weight {tuple(weight.shape)}")
     if not with_stats:
         return Conv3x3CatFunction.apply(x0, x1, weight, bias)

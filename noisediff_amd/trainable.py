@@ -90,7 +90,7 @@ class _Ops:
             return self.conv(name, x, padding) + res
         if isinstance(x, tuple):
             from . import train
-            if self.hip and train.cat_sources_ok(*x) and w.shape[0] % 8 == 0:
+            if self.hip and train.cat_sources_ok(*x, w.shape[0]):
                 if w.shape[2:] == (3, 3) and padding == 1:
                     return train.conv3x3_cat(x[0], x[1], w, b)
                 if w.shape[2:] == (1, 1) and padding == 0:
@@ -151,7 +151,7 @@ class _Ops:
         from . import train
         w = self.p[name + ".proj.weight"]
         pair = x if isinstance(x, tuple) else None                             # (x0, x1) = torch.cat((x0, x1), 1), read as two sources where the kernels can
-        if pair is not None and not (self.hip and train.cat_sources_ok(*pair) and w.shape[0] % 8 == 0 and train._group_norm_ok(w.shape[0], groups)
+        if pair is not None and not (self.hip and train.cat_sources_ok(*pair, w.shape[0]) and train._group_norm_ok(w.shape[0], groups)
                                      and (ss is None or ss.numel() == pair[0].shape[0] * 2 * w.shape[0])):
             x, pair = torch.cat(pair, dim=1), None
         x0 = pair[0] if pair is not None else x
@@ -193,7 +193,7 @@ class _Ops:
         if isinstance(x, tuple) and self.hip:
             from . import train
             w = self.p[name + ".res_conv.weight"]
-            if train.cat_sources_ok(*x) and w.shape[0] % 8 == 0:               # (what conv() asks before it reads the pair as two sources)
+            if train.cat_sources_ok(*x, w.shape[0]):               # (what conv() asks before it reads the pair as two sources)
                 # the shortcut hands the pair on to block1: that convolution's data gradient then joins the shortcut's in one GEMM instead of two additions
                 x0, x1, res = train.conv1x1_shortcut_cat(x[0], x[1], w, self.p.get(name + ".res_conv.bias"))
                 return self.block(name + ".block2", self.block(name + ".block1", (x0, x1), groups, ss), groups, res=res)
