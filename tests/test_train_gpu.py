@@ -476,6 +476,36 @@ def test_linear_weight_and_bias_gradient_match_a_float64_sum(case):
     assert torch.equal(wa.grad.cpu(), outs[0][2])
 
 
+def test_linear_and_conv1x1_with_the_residual_in_the_gemm_epilogue():
+    """train.linear(x, w, b, res) / train.conv1x1(x, w, b, res=): y = x W^T + b + res with the addition in the GEMM's epilogue (the AttnBlock's feed-forward and
+    proj_out residuals, Diffusion_arch.py:440-443): output and every gradient -- the residual's is the output's -- against F.linear / F.conv2d + res; the residual
+    must have the output's shape."""
+    x, w, b = U("lres.x", (2, 1536, 128)).to(DEV), (U("lres.w", (64, 128)) / 128 ** 0.5).to(DEV), U("lres.b", (64,)).to(DEV)
+    r, gy = U("lres.r", (2, 1536, 64)).to(DEV), U("lres.gy", (2, 1536, 64)).to(DEV)
+    outs = []
+    for fused in (False, True):
+        xa, wa, ba, ra = (t.clone().requires_grad_() for t in (x, w, b, r))
+        y = train.linear(xa, wa, ba, ra) if fused else F.linear(xa, wa, ba) + ra
+        y.backward(gy)
+        outs.append([t.detach().cpu() for t in (y, xa.grad, wa.grad, ba.grad, ra.grad)])
+    for got, ref, name in zip(outs[1], outs[0], ("y", "dx", "dw", "db", "dres")):
+        assert rel_err(got.numpy(), ref.numpy()) < 2e-5, name
+    assert torch.equal(outs[1][4], gy.cpu())
+    with pytest.raises(ValueError, match="residual"):
+        train.linear(x, w, b, r[:, :8])
+    xc = U("cres.x", (2, 128, 32, 48)).to(DEV).contiguous(memory_format=torch.channels_last)
+    wc = (U("cres.w", (64, 128, 1, 1)) / 128 ** 0.5).to(DEV)
+    rc, gc = (U(n, (2, 64, 32, 48)).to(DEV).contiguous(memory_format=torch.channels_last) for n in ("cres.r", "cres.g"))
+    outs = []
+    for fused in (False, True):
+        xa, wa, ba, ra = (t.clone().requires_grad_() for t in (xc, wc, b, rc))
+        y = train.conv1x1(xa, wa, ba, res=ra) if fused else F.conv2d(xa, wa, ba) + ra
+        y.backward(gc)
+        outs.append([t.detach().cpu() for t in (y, xa.grad, wa.grad, ba.grad, ra.grad)])
+    for got, ref, name in zip(outs[1], outs[0], ("y", "dx", "dw", "db", "dres")):
+        assert rel_err(got.numpy(), ref.numpy()) < 2e-5, name
+
+
 def test_conv1x1_and_accelerated_linears():
     torch.manual_seed(2)
     ref = nn.Sequential(nn.Conv2d(32, 64, 1), nn.SiLU(), nn.Conv2d(64, 64, 3, padding=1), nn.GroupNorm(8, 64), nn.Conv2d(64, 8, 1)).to(DEV)
