@@ -52,8 +52,12 @@ enum nd_prologue {
     ND_PRO_SILU        = 4,  /* silu(x): ResnetBlock2.mlp[0], Diffusion_arch.py:177         */
     ND_PRO_LEAKY       = 5,  /* LeakyReLU(0.2)(x): LSID's nn.LeakyReLU after every conv,
                                 models/archs/SID_arch.py:58,108-168 (applied by the consumer)   */
-    ND_PRO_LEAKY_SECOND = 6  /* LeakyReLU(0.2) on the p1 channels of a virtual concat only:
+    ND_PRO_LEAKY_SECOND = 6, /* LeakyReLU(0.2) on the p1 channels of a virtual concat only:
                                 torch.cat((up(x), conv_k)), SID_arch.py:135,142,150,158          */
+    ND_PRO_AFFINE_GENMAP_SILU = 7  /* ND_PRO_AFFINE_MAP_SILU with the maps FORMED IN THE KERNEL (r6; nd_conv3x3_wino4_nhwc_f32 only): scale | shift =
+                                ResnetBlock2.mlp[1] (a 1x1 convolution 8 -> 2C, Diffusion_arch.py:177,188) of the ACTIVATED position embedding.  `map` =
+                                silu(pos_emb) [B][H][W][8] (32 bytes per pixel instead of 8 C), `gamma` = mlp[1].weight [2C][8] (rows 0..C-1 scale,
+                                C..2C-1 shift), `beta` = mlp[1].bias [2C].  One source, C a multiple of 16.                                             */
 };
 
 typedef struct nd_src {

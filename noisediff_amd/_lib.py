@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libnoisediff_hip.so")
 
 # enum nd_prologue / nd_act
-PRO_NONE, PRO_AFFINE_SILU, PRO_AFFINE_MAP_SILU, PRO_LAYERNORM, PRO_SILU, PRO_LEAKY, PRO_LEAKY_SECOND = 0, 1, 2, 3, 4, 5, 6
+PRO_NONE, PRO_AFFINE_SILU, PRO_AFFINE_MAP_SILU, PRO_LAYERNORM, PRO_SILU, PRO_LEAKY, PRO_LEAKY_SECOND, PRO_AFFINE_GENMAP_SILU = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 OBJECTIVES = {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}
 

@@ -91,6 +91,9 @@ struct W4Geo {
 #ifndef W4_UR_MAP
 #define W4_UR_MAP 6          // ... of the map variant (20 more staging registers per in-flight halo item): no spill in any fp32 instance; 9 measures the same
 #endif
+#ifndef W4_UR_GEN
+#define W4_UR_GEN 9          // ... of the variant that forms the maps in the kernel (the maps live in registers only between their MFMAs and the clump)
+#endif
 #ifndef W4_UR_EPI
 #define W4_UR_EPI 6          // ... across a tile's epilogue (its output transform needs the registers): the ring runs down in the
 #endif                       // last stage of a tile and is refilled in one burst at the start of the next tile's first stage
@@ -207,10 +210,12 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     constexpr int NT = Geo::NT, TGW = Geo::TGW;
     constexpr int RAW_FLOATS = Geo::RAW_FLOATS, BIAS_OFF_BYTES = Geo::BIAS_OFF_BYTES, ACC_AGPR = Geo::ACC_AGPR, REG_W = Geo::REG_W, HALO_W = Geo::HALO_W;
     constexpr bool MAP = MODE == ND_PRO_AFFINE_MAP_SILU;                  // + per-pixel scale / shift maps (ResnetBlock2)
-    constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAP;               // GroupNorm-affine + SiLU applied while the halo is written to LDS
+    constexpr bool GEN = MODE == ND_PRO_AFFINE_GENMAP_SILU;               // ... the maps formed here, per chunk, from silu(pos_emb) (8 channels) on the matrix pipe: see gen_maps
+    constexpr bool MAPX = MAP || GEN;
+    constexpr bool AFF = MODE == ND_PRO_AFFINE_SILU || MAPX;              // GroupNorm-affine + SiLU applied while the halo is written to LDS
     constexpr bool LEAKY = MODE == ND_PRO_LEAKY || MODE == ND_PRO_LEAKY_SECOND;      // LSID: LeakyReLU(0.2) of the producer, applied by the consumer
-    constexpr int UR = TGW == 1 ? (AFF ? W4_UR1_AFF : W4_UR1) : MAP ? W4_UR_MAP : AFF ? W4_UR_AFF : W4_UR, UR_EPI = TGW == 1 ? W4_UR1_EPI : W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
-    static_assert(TGW == 2 || !MAP, "the map prologue (20 more staging registers per halo item in flight) stays on the 512-register form");
+    constexpr int UR = TGW == 1 ? (AFF ? W4_UR1_AFF : W4_UR1) : MAP ? W4_UR_MAP : GEN ? W4_UR_GEN : AFF ? W4_UR_AFF : W4_UR, UR_EPI = TGW == 1 ? W4_UR1_EPI : W4_UR_EPI;      // weight ring depth in the K loop / across the epilogue
+    static_assert(TGW == 2 || !MAPX, "the map prologues (20 more staging registers per halo item in flight) stay on the 512-register form");
     extern __shared__ __attribute__((aligned(16))) float lds_[];        // the LDS map above (dynamic shared memory starts at LDS address 0)
     float* const Vd = lds_ + RAW_FLOATS;                                // [tg NTG][VD_FLOATS]: the V images
 
@@ -289,14 +294,18 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     };
     const __amdgpu_buffer_rsrc_t rsrc0 = src_rsrc(s.p0, s.ld0);
     const __amdgpu_buffer_rsrc_t rsrc1 = s.p1 ? src_rsrc(s.p1, s.ld1) : rsrc0;
-    const __amdgpu_buffer_rsrc_t rsrcm = MAP ? src_rsrc(s.map, 2 * Ctot) : rsrc0;
+    const __amdgpu_buffer_rsrc_t rsrcm = MAP ? src_rsrc(s.map, 2 * Ctot) : GEN ? src_rsrc(s.map, 8) : rsrc0;      // GEN: silu(pos_emb), 8 floats per pixel
     const int map_shift = s.map_blocked ? 64 : Ctot * 4;                 // bytes from a channel's scale to its shift (blocked layout: [chunk][scale 16 | shift 16])
     float* const vd_tg = Vd + tg * VD_FLOATS;                            // the V image this wave's transform lanes write
     char* const rawbuf = reinterpret_cast<char*>(lds_);                  // [18][40] records of 64 bytes
     lds_u32_ptr const ptab = (lds_u32_ptr)(Vd + NTG * VD_FLOATS) + tid;  // [RAW_IT][256] source pixel of this thread's items
     auto cperm = [](int c) { return ((c >> 2) & 3) | ((c & 3) << 2) | (c & 48); };
     auto swz = [](int r, int c) { return (2 * ((r >> 2) & 3)) ^ (4 * ((c >> 3) & 1)); };       // slot swizzle of a pixel's 8 channel pairs (even: quads stay 16 contiguous bytes)
-    const int sq = tid & 3;                                              // channel quad of this thread's items
+    // A wave's staging instruction covers 16 pixels x 4 channel quads = 64 contiguous bytes per pixel: lane = (pixel l >> 2, quad l & 3).  GEN: lane = (pixel l & 15,
+    // quad l >> 4) -- the same items in the lane layout of a 16 x 16 MFMA result (column l & 15, rows 4 (l >> 4) .. + 3), so that the maps formed on the matrix pipe
+    // land in the registers of the lane that stages the item (same cache lines per instruction; measured: the plain instance does not care, profiles/r6_w4_map_traffic_probe.txt)
+    auto pixl_of = [](int t) { return GEN ? 16 * (t >> 6) + (t & 15) : t >> 2; };
+    const int sq = GEN ? (tid >> 4) & 3 : tid & 3;                       // channel quad of this thread's items
     // per-thread constants live in LDS tables (thread-private columns), not in registers: [10] LDS address of staged item k,
     // [12] raw-image address of the transform lane's patch column b for patch rows 0-3 / 4-5 (the slot swizzle changes where the
     // patch crosses a multiple-of-4 row): entry (a, b) is at ttab[(a >> 2) * 6 + b] + a * RAW_ROWP * 64
@@ -305,7 +314,7 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     lds_u16_ptr const ttab = dtab + RAW_IT * NT;
     float* const bias_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_) + BIAS_OFF_BYTES);
     auto item_rc = [&](int k, int tid_) {                                // item k of this thread: pixel relative to the region | halo row << 16 | column << 24
-        const int pix = (tid_ >> 2) + (NT / 4) * k, r = pix / HALO_W, c = pix - HALO_W * r;
+        const int pix = pixl_of(tid_) + (NT / 4) * k, r = pix / HALO_W, c = pix - HALO_W * r;
         // pixel of halo entry (r, c) relative to the region's base pixel (one source row above, one pixel left of the halo origin):
         // nearest-x2 upsample addressing halves the coordinates -- (16 ty - 1 + r) >> 1 = 8 ty - 1 + ((r + 1) >> 1)
         const int dy = up ? (r + 1) >> 1 : r, dx = up ? (c + 1) >> 1 : c;
@@ -313,7 +322,7 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     };
 #pragma unroll
     for (int k = 0; k < RAW_IT; ++k) {
-        const int pix = (tid >> 2) + (NT / 4) * k, r = pix / HALO_W, c = pix - HALO_W * r;
+        const int pix = pixl_of(tid) + (NT / 4) * k, r = pix / HALO_W, c = pix - HALO_W * r;
         // (the per-item values are tables, not registers: kept in registers they get spilled, and a scratch reload in the K loop
         //  drains the weight ring; any per-item VALU arithmetic in the stage loops costs an MFMA <-> VALU switch)
         dtab[k * NT] = (unsigned short)((r * RAW_ROWP + cperm(c)) * 64 + (((2 * sq) ^ swz(r, c)) * 8));     // byte address in LDS (items beyond pixel 611 are never written)
@@ -367,7 +376,12 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     };
     // the chunk being staged: source, channel base, affine constants of the transform lane
     f32x4 raw[RAW_IT];                                                   // the halo in flight: loaded during a chunk's stage 0, written to LDS during its stage 1
-    f32x4 msc[MAP ? RAW_IT : 1], msh[MAP ? RAW_IT : 1];                  // MAP: the items' scale / shift map values
+    constexpr int GEN_H = RAW_IT / 2;                                    // GEN: the maps of half the items at a time (registers)
+    f32x4 msc[MAP ? RAW_IT : GEN ? GEN_H : 1], msh[MAP ? RAW_IT : GEN ? GEN_H : 1];     // MAP: the items' scale / shift map values (GEN: between gen_maps and the clump)
+    float ev0[GEN ? RAW_IT : 1], ev1[GEN ? RAW_IT : 1];                  // GEN: silu(pos_emb)[pixel][sq], [sq + 4] of the items: the B operand (k = l >> 4, pixel = l & 15)
+    float gw_sc0 = 0, gw_sc1 = 0, gw_sh0 = 0, gw_sh1 = 0;                // GEN: mlp[1].weight[channel cb + (l & 15)][sq], [sq + 4], scale and shift rows: the A operand
+    f32x4 gb_sc = {0, 0, 0, 0}, gb_sh = {0, 0, 0, 0};                    // GEN: mlp[1].bias of this lane's quad: the C operand of the first MFMA
+    int i_eoff = 0;
     bool i_second = false;                                               // wave-uniform: the chunk comes from the second concat source
     __amdgpu_buffer_rsrc_t i_rs = rsrc0;
     int i_soff = 0, i_mapoff = 0;
@@ -380,6 +394,12 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
         i_ld4 = (unsigned)(sec ? s.ld1 : s.ld0) * 4u;
         i_soff = (int)((sec ? cb_ - s.c0 : cb_) * 4u + spx_ * i_ld4);
         i_bias = cb_ + 4 * sq < Cin ? 16u * sq : OOB;                    // invalid channel quad: every item out of range
+        if (GEN) {                                                       // (host: one source, whole chunks)
+            i_eoff = (int)(spx_ * 32u);
+            const float* wr = s.gamma + (size_t)(cb_ + (lane & 15)) * 8 + sq;
+            gw_sc0 = wr[0];  gw_sc1 = wr[4];  gw_sh0 = wr[(size_t)Ctot * 8];  gw_sh1 = wr[(size_t)Ctot * 8 + 4];
+            gb_sc = nd_ld4(s.beta + cb_ + 4 * sq);  gb_sh = nd_ld4(s.beta + Ctot + cb_ + 4 * sq);
+        }
         if (AFF) {                                                       // this thread's channel quad: cb + 4 sq .. + 3
             const int c = cb_ + 4 * sq;
             const float* m = s.mad + (size_t)sb_ * 3 * Ctot + (c < Cin ? c : 0);
@@ -388,7 +408,7 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
             tD4 = D - M * A;                                             // (v - M) * A + D = v * A + (D - M * A)
         }
     };
-    auto stage_issue_one = [&](int k, unsigned px) {                     // px = ptab[k * NT], read by the caller one step ahead
+    auto stage_issue_one = [&](int k, unsigned px, auto tile_first_c) {  // px = ptab[k * NT], read by the caller one step ahead; tile_first_c: the staged chunk is its tile's first
 #if !(W4_ABLATE & 1)
         // ONE VALU instruction per item (no branch, no masking: every per-item instruction in a stage loop costs an MFMA <-> VALU
         // switch): pixel x stride + this lane's channel-quad offset, the latter out of range for a quad beyond cin.  The table entry
@@ -396,6 +416,12 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
         // the last MFMA of one position pair and the first of the next, twenty times per chunk.
         const unsigned voff = __umul24(px, i_ld4) + i_bias;
         raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i_rs, voff, i_soff, 0));
+        if (GEN && decltype(tile_first_c)::value) {                      // 8 bytes of the pixel's 32 per lane (the four quads of a pixel read all of them), ONCE PER TILE: the
+            // items' pixels are the same in every chunk of a tile, and 32 bytes per pixel and chunk next to the chunk's own 64 cost 48 us of 350 (r6_w4_map_traffic_probe.txt)
+            const unsigned eo = __umul24(px, 32u) + 4u * sq;
+            ev0[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcm, eo, i_eoff, 0));
+            ev1[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcm, eo, i_eoff + 16, 0));
+        }
         if (MAP) {                                                       // the maps have the conv's resolution (host: no upsample with MAP): [pixel][scale C | shift C]
             const unsigned mo = __umul24(px, (unsigned)(2 * Ctot * 4)) + i_bias;
             msc[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcm, mo, i_mapoff, 0));
@@ -405,14 +431,29 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
         raw[k] = f32x4{(float)k, 1.0f, 0.5f, 0.25f};
 #endif
     };
+    // GEN: scale | shift of the staged chunk's ten items on the matrix pipe: D[16 channels][16 pixels] = W[16][8] E[8][16] + bias, two K steps of v_mfma_f32_16x16x4_f32
+    // each -- lane (pixel l & 15, quad l >> 4) receives rows 4 (l >> 4) .. + 3 of column l & 15: its own item's four channels.  40 MFMAs per chunk and wave (+ 14 %)
+    // instead of 2 x 16 bytes of map per item from HBM (537 MB per launch: 80 us of 361, profiles/r6_w4_map_traffic_probe.txt).  No operand is written by a vector
+    // instruction (loads only); dependent MFMAs are ten apart; the results are read by the clump behind W4_MFMA_DRAIN.
+    auto gen_maps = [&](int k0) {                                        // items k0 .. k0 + GEN_H - 1
+#pragma unroll
+        for (int k = 0; k < GEN_H; ++k) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(msc[GEN ? k : 0]) : "v"(gw_sc0), "v"(ev0[GEN ? k0 + k : 0]), "v"(gb_sc));
+#pragma unroll
+        for (int k = 0; k < GEN_H; ++k) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(msh[GEN ? k : 0]) : "v"(gw_sh0), "v"(ev0[GEN ? k0 + k : 0]), "v"(gb_sh));
+#pragma unroll
+        for (int k = 0; k < GEN_H; ++k) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(msc[GEN ? k : 0]) : "v"(gw_sc1), "v"(ev1[GEN ? k0 + k : 0]));
+#pragma unroll
+        for (int k = 0; k < GEN_H; ++k) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(msh[GEN ? k : 0]) : "v"(gw_sh1), "v"(ev1[GEN ? k0 + k : 0]));
+        W4_MFMA_DRAIN();
+    };
     auto stage_commit_one = [&](int k, unsigned daddr, unsigned pxk) {   // daddr = dtab[k * NT], pxk = ptab[k * NT] (AFF only): read ahead by the caller
-        if (k == RAW_IT - 1 && (tid >> 2) + (NT / 4) * k >= 18 * HALO_W) return;   // the last round covers 36 (NTG == 1: 4) pixels only
+        if (k == RAW_IT - 1 && pixl_of(tid) + (NT / 4) * k >= 18 * HALO_W) return;   // the last round covers 36 (NTG == 1: 4) pixels only
         f32x4 v = raw[k];
         if (AFF) {
             // GroupNorm-affine + SiLU on the raw halo (each pixel once: 40 values per thread and chunk); silu(x) = x / (1 + 2^(-x log2 e)).
             // The zero padding is applied after the activation (silu(affine(0)) != 0): items outside the image carry PX_MARK
             f32x4 x = v * tA4 + tD4;
-            if (MAP) x = x * (msc[k] + 1.0f) + msh[k];                   // ResnetBlock2: x * (scale + 1) + shift per pixel (Diffusion_arch.py:188-192)
+            if (MAPX) x = x * (msc[MAP ? k : GEN ? k % GEN_H : 0] + 1.0f) + msh[MAP ? k : GEN ? k % GEN_H : 0];                   // ResnetBlock2: x * (scale + 1) + shift per pixel (Diffusion_arch.py:188-192)
             const f32x4 t = x * -1.44269504088896340736f;
             f32x4 e;
             e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y); e.z = __builtin_amdgcn_exp2f(t.z); e.w = __builtin_amdgcn_exp2f(t.w);
@@ -624,14 +665,17 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
     stage_tile(b, ty, rx);
     stage_issue_begin(SPLIT ? sp * n_chunks * KC4 : 0);
 #pragma unroll
-    for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k, ptab[k * NT]);
+    for (int k = 0; k < RAW_IT; ++k) stage_issue_one(k, ptab[k * NT], std::true_type{});
     {
         const int wb = wblock(SPLIT ? 2 * sp * n_chunks : 0, nt * 4 + (wave & 3));
 #pragma unroll
         for (int q = 0; q < UR_EPI; ++q) load_u(q, q, wb);
     }
 #pragma unroll
-    for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, dtab[k * NT], AFF ? ptab[k * NT] : 0u);
+    for (int k = 0; k < RAW_IT; ++k) {
+        if (GEN && k % GEN_H == 0) gen_maps(k);
+        stage_commit_one(k, dtab[k * NT], AFF ? ptab[k * NT] : 0u);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (TGW == 2) {
@@ -683,12 +727,12 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
             // (unconditional: behind the very last item this is a harmless re-stage of the tile's first chunk -- a conditional load /
             // store pair would keep the staging registers alive everywhere)
             unsigned tab1 = 0;                                            // the table entry of position pair pp's item, read ahead of its MFMAs
-            constexpr bool PRE_P = AFF && !MAP;                           // (the map variant has no registers to spare: it reads ptab inside the clump)
+            constexpr bool PRE_P = AFF && !MAPX;                           // (the map variant has no registers to spare: it reads ptab inside the clump)
             unsigned tabd[(AFF || LEAKY) ? RAW_IT : 1], tabp[PRE_P ? RAW_IT : 1];   // AFF / LEAKY: the clump's ten items
             auto issue_pre = [&](int pp) { if (pp < RAW_IT) tab1 = ptab[pp * NT]; };
             auto issue = [&](int pp) {
                 if (pp == 0) stage_issue_begin(last ? ch0n * KC4 : (ch0 + ch + 1) * KC4);
-                if (pp < RAW_IT) stage_issue_one(pp, tab1);
+                if (pp < RAW_IT) stage_issue_one(pp, tab1, last_c);      // (a tile's last chunk stages the next tile's first)
             };
             auto commit_pre = [&](int pp) {
                 if (AFF || LEAKY) {
@@ -707,7 +751,10 @@ __global__ __launch_bounds__((64 * NW), (W4Geo<NTG, NW>::WG_PER_CU)) void wino4_
                 if (AFF || LEAKY) {     // the activation is VALU work: one clump (every MFMA <-> VALU switch costs ~18 cycles)
                     if (pp == W4_COMMIT_AT) {
 #pragma unroll
-                        for (int k = 0; k < RAW_IT; ++k) stage_commit_one(k, tabd[(AFF || LEAKY) ? k : 0], PRE_P ? tabp[PRE_P ? k : 0] : MAP ? ptab[k * NT] : 0u);
+                        for (int k = 0; k < RAW_IT; ++k) {
+                            if (GEN && k % GEN_H == 0) gen_maps(k);
+                            stage_commit_one(k, tabd[(AFF || LEAKY) ? k : 0], PRE_P ? tabp[PRE_P ? k : 0] : MAPX ? ptab[k * NT] : 0u);
+                        }
                     }
                 } else if (pp < RAW_IT) stage_commit_one(pp, tab1, 0u);
                 if constexpr (TGW == 2) {
@@ -1083,7 +1130,7 @@ template <int MODE, int NTG = 2, int NW = 4>
 int launch4(const Wino4Args& a, hipStream_t st) {
     static const long stream_min = (getenv("ND_W4_STREAM_MB") ? atol(getenv("ND_W4_STREAM_MB")) : 48) << 20;     // A/B knob (tools/ only)
     static const int stream_kinds = getenv("ND_W4_STREAM_KINDS") ? atoi(getenv("ND_W4_STREAM_KINDS")) : 7;           // A/B knob (tools/ only)
-    const int kind = (MODE == ND_PRO_AFFINE_SILU || MODE == ND_PRO_AFFINE_MAP_SILU) ? 2 : a.d.stats ? 1 : 4;   // block2 / block1 / resampling convs
+    const int kind = (MODE == ND_PRO_AFFINE_SILU || MODE == ND_PRO_AFFINE_MAP_SILU || MODE == ND_PRO_AFFINE_GENMAP_SILU) ? 2 : a.d.stats ? 1 : 4;   // block2 / block1 / resampling convs
     const long out_bytes = (long)a.d.B * a.d.H * a.d.W * a.d.ldo * 4;
     return (out_bytes >= stream_min && (stream_kinds & kind)) ? launch4s<MODE, true, NTG, NW>(a, st) : launch4s<MODE, false, NTG, NW>(a, st);
 }
@@ -1137,9 +1184,13 @@ static int w4_prepare(const nd_conv3x3* d, Wino4Args& a, int ntg = 2) {
     ND_REQUIRE(nd_aligned16(s.p0) && nd_aligned16(s.p1) && nd_aligned16(d->weight) && nd_aligned16(s.mad) && nd_aligned16(d->out) &&
                nd_aligned16(d->bias), ND_E_ALIGN, "nd_conv3x3_wino4: pointers must be 16-byte aligned");
     ND_REQUIRE(d->ldo >= d->cout && d->ldo % 4 == 0, ND_E_SHAPE, "nd_conv3x3_wino4: ldo must be >= cout and a multiple of 4");
-    const bool aff = s.mode == ND_PRO_AFFINE_SILU || s.mode == ND_PRO_AFFINE_MAP_SILU;
+    const bool aff = s.mode == ND_PRO_AFFINE_SILU || s.mode == ND_PRO_AFFINE_MAP_SILU || s.mode == ND_PRO_AFFINE_GENMAP_SILU;
     ND_REQUIRE(s.mode == ND_PRO_NONE || aff || s.mode == ND_PRO_LEAKY || s.mode == ND_PRO_LEAKY_SECOND, ND_E_BADARG,
                "nd_conv3x3_wino4: unsupported prologue %d", s.mode);
+    ND_REQUIRE(s.mode != ND_PRO_AFFINE_GENMAP_SILU || (ntg == 2 && s.map && s.gamma && s.beta && !s.upsample && !s.map_blocked && s.c1 == 0 && s.c0 % KC4 == 0 &&
+                                                     nd_aligned16(s.map) && nd_aligned16(s.gamma) && nd_aligned16(s.beta)), ND_E_BADARG,
+               "nd_conv3x3_wino4: the in-kernel map prologue needs silu(pos_emb) (map), mlp[1].weight (gamma) and mlp[1].bias (beta), 16-byte aligned, one source of whole "
+               "16-channel chunks, no upsample addressing, the 16 x 32-region form");
     ND_REQUIRE(!aff || s.mad, ND_E_BADARG, "nd_conv3x3_wino4: affine prologue needs mad");
     ND_REQUIRE(s.mode != ND_PRO_AFFINE_MAP_SILU || (s.map && !s.upsample && nd_aligned16(s.map)), ND_E_BADARG,
                "nd_conv3x3_wino4: the map prologue needs a 16-byte aligned map and no upsample addressing");
@@ -1228,6 +1279,7 @@ extern "C" int nd_conv3x3_wino4_nhwc_f32(const nd_conv3x3* d, void* stream) {
     switch (s.mode) {
         case ND_PRO_AFFINE_SILU: rc = launch4<ND_PRO_AFFINE_SILU>(a, st); break;
         case ND_PRO_AFFINE_MAP_SILU: rc = launch4<ND_PRO_AFFINE_MAP_SILU>(a, st); break;
+        case ND_PRO_AFFINE_GENMAP_SILU: rc = launch4<ND_PRO_AFFINE_GENMAP_SILU>(a, st); break;
         case ND_PRO_LEAKY: rc = launch4<ND_PRO_LEAKY>(a, st); break;
         case ND_PRO_LEAKY_SECOND: rc = launch4<ND_PRO_LEAKY_SECOND>(a, st); break;
         default: rc = launch4<ND_PRO_NONE>(a, st); break;

@@ -43,6 +43,9 @@ _CHAIN_FIRST = (".ff.net.0.0.weight", ".fc1.weight")     # Linear layers that ca
 _CHAIN_LATER = (".ff.net.2.weight", ".proj_out.weight", ".fc2.weight")
 WINO2 = os.environ.get("ND_WINO2", "1") != "0"           # A-B knob: 0 = the two-waves-per-SIMD Winograd kernel (conv3x3_wino.hip)
 MAP_BLOCKED = True       # ResnetBlock2 scale / shift maps in the 16-channel-blocked layout the F(4x4) kernel reads (was ND_MAP_BLOCKED)
+# r6: ... or not stored at all -- the F(4x4) kernel forms them per chunk from silu(pos_emb) (8 channels) on the matrix pipe (ND_PRO_AFFINE_GENMAP_SILU): 2 x 33 MB per
+# launch instead of 2 x 268, -50 us per launch, no map tensors (1 GB at 16 patches of 256 x 256).  ND_GENMAP=0: A/B knob (tools/ only): the stored maps.
+GENMAP = os.environ.get("ND_GENMAP", "1") != "0"
 COND_STEP = True         # time embedding / time_mlp / projections in one launch where it fits the LDS (was ND_COND_STEP)
 WINO4 = os.environ.get("ND_WINO4", "1") != "0"           # A-B knob: 0 = never the F(4x4,3x3) kernel (conv3x3_wino4.hip)
 # Low-latency mode for SMALL batches (opt-in: ND_SPLIT_K=1 or engine.SPLIT_K = True before the plans are recorded): plain-source F(4x4) layers whose
@@ -191,6 +194,8 @@ class Engine:
                     # the 16-channel-blocked layout the F(4x4,3x3) kernel reads one 128-byte line at a time (nd_src.map_blocked)
                     add(p.name + ".blk16", n, "derived", p.shape)
                     add(p.name[:-len("weight")] + "bias.blk16", p.shape[0], "derived", (p.shape[0],))
+                    if GENMAP and p.shape[1] == POS_DIM == 8 and p.shape[0] % 32 == 0:
+                        add(p.name + ".gen", p.shape[0] * p.shape[1], "derived", p.shape)      # the weight as it is, [2C][8]: the kernel's A operand
                 if kind == "pw" and p.name.endswith(_CHAIN_FIRST + _CHAIN_LATER):
                     first = int(p.name.endswith(_CHAIN_FIRST))
                     add(p.name + ".chain", self.lib.nd_pack_chain_weight_floats(p.shape[1], p.shape[0], first), "derived", p.shape)
@@ -273,6 +278,8 @@ class Engine:
                         L.call("nd_pack_pointwise_weight", tp.data_ptr(), self.p(p.name + ".blk16"), p.shape[1], p.shape[0], 0, st)
                         bname = p.name[:-len("weight")] + "bias"
                         self.view(bname + ".blk16").copy_(sd[bname].detach().to(device=self.device, dtype=torch.float32)[perm])
+                    if p.name + ".gen" in self.slots:
+                        self.view(p.name + ".gen").copy_(t.reshape(-1))
                     if p.name + ".chain" in self.slots:
                         L.call("nd_pack_chain_weight", t.data_ptr(), self.p(p.name + ".chain"), p.shape[1], p.shape[0],
                                int(p.name.endswith(_CHAIN_FIRST)), st)
@@ -459,10 +466,19 @@ class Plan:
             self.model_out = f(B, H, W, eng.inp_dim)
             self.nchw_tmp = f(B, eng.inp_dim, H, W)
             self.pos_emb = f(B, H, W, POS_DIM)
-            self.posmap1 = f(B, H, W, 2 * d)
-            self.posmap2 = f(B, H, W, 2 * d)
-            # the maps' consumers are pos_block{1,2}.block2.proj (d -> d, map prologue): blocked layout when those run on conv3x3_wino4
-            self.posmap_blocked = (MAP_BLOCKED and "pos_block1.mlp.1.weight.blk16" in eng.slots and
+            # the maps' consumers are pos_block{1,2}.block2.proj (d -> d, map prologue): formed inside conv3x3_wino4's 16 x 32-region form where that takes the layer
+            # (a function of the sample's geometry alone), else stored -- in the blocked layout when the layer runs on conv3x3_wino4 at all
+            self.posgen = (GENMAP and eng.traits.position and all(b + ".mlp.1.weight.gen" in eng.slots for b in ("pos_block1", "pos_block2")) and d % 16 == 0 and
+                           self._wino4_kind("pos_block1.block2.proj", L.PRO_AFFINE_GENMAP_SILU, False, d, 0, d, 0, d, d, H, W,
+                                            self._conv_rows(H, W, 0, d, 0, d, d, L.PRO_AFFINE_GENMAP_SILU)) == "wino4")
+            self.posmap1 = self.posmap2 = None
+            if self.posgen:
+                self.pos_e = f(B, H, W, POS_DIM)             # silu(pos_emb): what ResnetBlock2.mlp = Sequential(SiLU, Conv2d) applies its 1x1 to (Diffusion_arch.py:177)
+                self.pos_e_mad = torch.tensor([0.0, 1.0, 0.0], device=self.dev).repeat_interleave(POS_DIM).repeat(B).view(B, 3, POS_DIM).contiguous()
+            else:
+                self.posmap1 = f(B, H, W, 2 * d)
+                self.posmap2 = f(B, H, W, 2 * d)
+            self.posmap_blocked = (not self.posgen and MAP_BLOCKED and "pos_block1.mlp.1.weight.blk16" in eng.slots and
                                    self._wino4_takes("pos_block1.block2.proj", L.PRO_AFFINE_MAP_SILU, False, d, 0, d, 0, d, d, H, W))
             self.iso_emb = f(B, ISO_DIM)
             self.attn_names = [p.name[:-len(".attn.to_v.weight")] for p in eng.spec if p.name.endswith(".attn.to_v.weight")]
@@ -557,6 +573,8 @@ class Plan:
                  and rows * H * W * 4 * max(src.ld0, src.ld1, 2 * cin if src.mode == L.PRO_AFFINE_MAP_SILU else 0) < (1 << 31))
         w4kind = self._wino4_kind(name, src.mode, bool(src.upsample), src.c0, src.c1, src.ld0, src.ld1, cin, cout, H, W, rows) if wino else ""
         wino4 = bool(w4kind)
+        if src.mode == L.PRO_AFFINE_GENMAP_SILU and w4kind != "wino4":
+            raise L.HipError(f"{name}: maps formed in the kernel need conv3x3_wino4's 16 x 32-region form (Plan.posgen decides by the same rule)")
         if wino and not wino4 and (name + ".weight.wino4") in e.slots and src.mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU) and not _few_items(H, W, cout):
             _log.warning("%s (%d -> %d at %d x %d, batch %d): not on the F(4x4) kernel", name, cin, cout, H, W, self.B)
         st = sc = None
@@ -592,7 +610,7 @@ class Plan:
                 if src.mad:
                     s.mad = src.mad + 4 * b0 * 3 * ctot
                 if src.map:
-                    s.map = src.map + 4 * b0 * H * W * 2 * ctot
+                    s.map = src.map + 4 * b0 * H * W * (POS_DIM if src.mode == L.PRO_AFFINE_GENMAP_SILU else 2 * ctot)
             d.src, d.weight, d.bias, d.out = s, weight, e.p(name + ".bias"), out.data_ptr() + 4 * b0 * H * W * cout
             d.B, d.H, d.W, d.cin, d.cout, d.ldo = nb, H, W, cin, cout, cout
             if stats:
@@ -644,8 +662,9 @@ class Plan:
         src_px = rows * (H >> up) * (W >> up) + (W >> up) + 2            # the kernel's buffer resource starts one row + one pixel in front of the tensor
         src_bytes = src_px * 4 * max(ld0, ld1)
         return (WINOGRAD and WINO4 and H >= 16 and W >= 16 and cout <= 2048 and (name + ".weight.wino4") in self.e.slots
-                and mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU)
+                and mode in (L.PRO_NONE, L.PRO_AFFINE_SILU, L.PRO_AFFINE_MAP_SILU, L.PRO_AFFINE_GENMAP_SILU)
                 and not (mode == L.PRO_AFFINE_MAP_SILU and (up or (rows * H + 2) * W * 8 * cin >= (1 << 30) - (1 << 16)))
+                and not (mode == L.PRO_AFFINE_GENMAP_SILU and (up or c1 or cin % 16))
                 and W >= 32 and (W % 32 == 0 or W >= 96) and W <= 2048 and (c1 == 0 or (c0 % 16 == 0 and not up))
                 and src_bytes < (1 << 30) - (1 << 16) and src_px < (1 << 24)
                 and (not up or (H % 2 == 0 and W % 2 == 0)))
@@ -707,8 +726,12 @@ class Plan:
                       meta={"layer": name + ".block1.act", "stream_bytes": 4.0 * self.B * HW * cout * 2})
             src2 = self._src(a1)
         else:
-            mode = L.PRO_AFFINE_MAP_SILU if posmap is not None else L.PRO_AFFINE_SILU
-            src2 = self._src(c1, None, mode, mad=mad1, **({"map": posmap, "map_blocked": int(self.posmap_blocked)} if posmap is not None else {}))
+            if posmap is not None and self.posgen:           # scale | shift formed in the kernel from silu(pos_emb) and this block's mlp[1]
+                src2 = self._src(c1, None, L.PRO_AFFINE_GENMAP_SILU, mad=mad1, map=self.pos_e, gamma=self.e.p(name + ".mlp.1.weight.gen"),
+                                 beta=self.e.p(name + ".mlp.1.bias"))
+            else:
+                mode = L.PRO_AFFINE_MAP_SILU if posmap is not None else L.PRO_AFFINE_SILU
+                src2 = self._src(c1, None, mode, mad=mad1, **({"map": posmap, "map_blocked": int(self.posmap_blocked)} if posmap is not None else {}))
         c2, st2, sc2, n2 = self.conv3(name + ".block2.proj", src2, cout, cout, H, W, stats=True)
         if a1 is not None:
             self._release(a1)
@@ -810,7 +833,10 @@ class Plan:
                       pe.data_ptr(), B, H, W, POS_DIM, st)
             h = self.pw("pos_mlp.fc1", self._src(pe), 3 * POS_DIM, 2 * POS_DIM, H * W, W, act=L.ACT_GELU)
             self.pw("pos_mlp.fc2", self._src(h), 2 * POS_DIM, POS_DIM, H * W, W, out=self.pos_emb)
-            for blk, dst in (("pos_block1", self.posmap1), ("pos_block2", self.posmap2)):
+            if self.posgen:                                  # the maps are formed by their consumers: only the activation is shared work
+                self._add("nd_affine_silu_add_f32", self.pos_emb.data_ptr(), POS_DIM, self.pos_e_mad.data_ptr(), None, POS_DIM, None, POS_DIM,
+                          self.pos_e.data_ptr(), POS_DIM, B, H * W, POS_DIM, st, meta={"layer": "pos_emb.silu", "stream_bytes": 8.0 * B * H * W * POS_DIM})
+            for blk, dst in (() if self.posgen else (("pos_block1", self.posmap1), ("pos_block2", self.posmap2))):
                 self.pw(blk + ".mlp.1", self._src(self.pos_emb, None, L.PRO_SILU), POS_DIM, 2 * e.dim, H * W, W, out=dst,
                         variant=".blk16" if self.posmap_blocked else "")
             self._release(pe, h)
@@ -877,7 +903,7 @@ class Plan:
         if tr.cond_branch:          # x = cond_concat_conv(cat[init_conv(x), clean_emb])   others_arch.py:495-498
             xin, *_ = self.conv3("cond_concat_conv", self._src(x0, self.clean_emb), 2 * d, d, H, W, stats=False)
             self._tap("cond_concat", xin)
-        pm1, pm2 = (self.posmap1, self.posmap2) if tr.position else (None, None)   # else plain ResnetBlocks without time
+        pm1, pm2 = ((self.pos_e, self.pos_e) if self.posgen else (self.posmap1, self.posmap2)) if tr.position else (None, None)   # else plain ResnetBlocks without time
         x = self._tap("pos_block1", self.resnet("pos_block1", xin, None, d, H, W, POS_GROUPS, posmap=pm1))
         if xin is not x0:
             self._release(xin)

@@ -819,6 +819,20 @@ def test_conv3x3_winograd_f4x4_matches_direct_semantics(ctx, case):
             d.src, d.weight, d.bias, d.out = smb, wp.data_ptr(), bd.data_ptr(), out.data_ptr()
             d.B, d.H, d.W, d.cin, d.cout, d.ldo = B, H, W, cin, cout, cout
             assert getattr(ctx.lib, other)(C.byref(d), ctx.stream) != 0
+    # ND_PRO_AFFINE_GENMAP_SILU: the same modulation with the maps formed in the kernel -- scale | shift = mlp[1] (1x1, 8 -> 2 cin) of the activated position
+    # embedding (Diffusion_arch.py:177,188) on the matrix pipe, from 32 bytes per pixel
+    pe = U(case + ".pe", (B, 8, H, W), -2.0, 2.0)
+    gw, gb = U(case + ".gw", (2 * cin, 8), -0.4, 0.4), U(case + ".gb", (2 * cin,), -0.3, 0.3)
+    gen = hu.src(hu.nhwc(x), None, L.PRO_AFFINE_GENMAP_SILU, mad=hu.dev(torch.stack((M, A, D), 1)), map=hu.nhwc(pe), gamma=hu.dev(gw), beta=hu.dev(gb))
+    if cin % 16 == 0:
+        ss = F.conv2d(pe.double(), gw.double()[:, :, None, None], gb.double()).float()
+        actg = F.silu(((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None]) * (ss[:, :cin] + 1) + ss[:, cin:])
+        out, st, sc_, slots = run(gen)
+        assert rel_err(hu.nchw(out), F.conv2d(actg, w, b, padding=1)) < 5e-5
+        _check_gn(ctx, case + ".gen", F.conv2d(actg, w, b, padding=1), st, sc_, slots, B, cout, 5e-5)
+    else:
+        with pytest.raises(L.HipError, match="in-kernel map prologue"):
+            run(gen, stats=False)
     out, *_ = run(hu.src(hu.nhwc(x), None, L.PRO_LEAKY), stats=False)
     assert rel_err(hu.nchw(out), F.conv2d(F.leaky_relu(x, 0.2), w, b, padding=1)) < 5e-5
     if c0:
@@ -828,6 +842,33 @@ def test_conv3x3_winograd_f4x4_matches_direct_semantics(ctx, case):
         xs = x[:, :, : H // 2, : W // 2].contiguous()
         out, *_ = run(hu.src(hu.nhwc(xs), upsample=1), stats=False)
         assert rel_err(hu.nchw(out), F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)) < 5e-5
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 256, 64, 64), (3, 80, 112, 32, 48), (2, 64, 96, 128, 64)])
+def test_conv3x3_winograd_f4x4_maps_formed_in_the_kernel_equal_the_maps_read(ctx, shape):
+    """ND_PRO_AFFINE_GENMAP_SILU against ND_PRO_AFFINE_MAP_SILU on the maps torch computes from the same operands (mlp[1] of the activated position embedding) and
+    against torch's convolution: several tiles per workgroup (the position embedding is loaded once per TILE and kept across its chunks), two to eight chunks,
+    border regions, a cout mask.  The two prologues differ in the summation order of the eight map terms only."""
+    import hiputil as hu
+    B, H, W, cin, cout = shape
+    x = U("gen.x", (B, cin, H, W), -1.5, 1.5)
+    w, b = U("gen.w", (cout, cin, 3, 3), -0.2, 0.2), U("gen.b", (cout,))
+    M, A, D = U("gen.M", (B, cin)), U("gen.A", (B, cin), 0.5, 1.5), U("gen.D", (B, cin))
+    pe = U("gen.pe", (B, 8, H, W), -2.0, 2.0)
+    gw, gb = U("gen.gw", (2 * cin, 8), -0.4, 0.4), U("gen.gb", (2 * cin,), -0.3, 0.3)
+    ss = F.conv2d(pe, gw[:, :, None, None], gb)
+    wd, bd = hu.dev(w), hu.dev(b)
+    wp = hu.full((ctx.lib.nd_pack_conv3x3_wino4_weight_floats(cin, cout),))
+    L.call("nd_pack_conv3x3_wino4_weight", wd.data_ptr(), wp.data_ptr(), cin, cout, ctx.stream)
+    ctx.sync()
+    mad = hu.dev(torch.stack((M, A, D), 1))
+    got, st, sc, slots = _run_wino4(ctx, hu.src(hu.nhwc(x), None, L.PRO_AFFINE_GENMAP_SILU, mad=mad, map=hu.nhwc(pe), gamma=hu.dev(gw), beta=hu.dev(gb)), wp, bd, B, H, W, cin, cout)
+    read, *_ = _run_wino4(ctx, hu.src(hu.nhwc(x), None, L.PRO_AFFINE_MAP_SILU, mad=mad, map=hu.nhwc(ss)), wp, bd, B, H, W, cin, cout)
+    act = F.silu(((x - M[:, :, None, None]) * A[:, :, None, None] + D[:, :, None, None]) * (ss[:, :cin] + 1) + ss[:, cin:])
+    ref = F.conv2d(act, w, b, padding=1)
+    assert rel_err(hu.nchw(got), ref) < 5e-5
+    assert rel_err(hu.nchw(got), hu.nchw(read)) < 1e-5
+    _check_gn(ctx, "gen", ref, st, sc, slots, B, cout, 5e-5)
 
 
 def test_conv3x3_winograd_f4x4_channel_slice_of_a_wider_tensor(ctx):

@@ -1,4 +1,4 @@
-"""Diagnostic: effective shader clock and cycle split of conv3x3_wino4 (needs a -DW4_STAMP side build, ND_LIB).  W4_MODE=aff: the GroupNorm-affine + SiLU prologue."""
+"""Diagnostic: effective shader clock and cycle split of conv3x3_wino4 (needs a -DW4_STAMP side build, ND_LIB).  W4_MODE=aff: the GroupNorm-affine + SiLU prologue; map / gen: + the per-pixel maps, read or formed in the kernel."""
 import os, sys, ctypes as C
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -25,6 +25,13 @@ for (B, H, W, cin, cout) in SHAPES:
     if os.environ.get("W4_MODE") == "aff":
         mad = torch.randn(B, 3, cin, device=hu.DEV); mad[:, 1] = mad[:, 1].abs() + 0.5
         src = hu.src(x, None, L.PRO_AFFINE_SILU, mad=mad)
+    elif os.environ.get("W4_MODE") in ("map", "gen"):           # ResnetBlock2's per-pixel scale / shift: maps read (blocked layout) or formed in the kernel
+        mad = torch.randn(B, 3, cin, device=hu.DEV); mad[:, 1] = mad[:, 1].abs() + 0.5
+        if os.environ["W4_MODE"] == "map":
+            src = hu.src(x, None, L.PRO_AFFINE_MAP_SILU, mad=mad, map=torch.randn(B, H, W, 2 * cin, device=hu.DEV) * 0.1, map_blocked=1)
+        else:
+            src = hu.src(x, None, L.PRO_AFFINE_GENMAP_SILU, mad=mad, map=torch.randn(B, H, W, 8, device=hu.DEV), gamma=torch.randn(2 * cin, 8, device=hu.DEV) * 0.1,
+                         beta=torch.randn(2 * cin, device=hu.DEV) * 0.1)
     else:
         src = hu.src(x)
     d = L.Conv3x3(); d.src, d.weight, d.out = src, wp.data_ptr(), out.data_ptr()
