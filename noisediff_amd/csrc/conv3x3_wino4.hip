@@ -92,7 +92,8 @@ struct W4Geo {
 #define W4_UR_MAP 6          // ... of the map variant (20 more staging registers per in-flight halo item): no spill in any fp32 instance; 9 measures the same
 #endif
 #ifndef W4_UR_GEN
-#define W4_UR_GEN 9          // ... of the variant that forms the maps in the kernel (the maps live in registers only between their MFMAs and the clump)
+#define W4_UR_GEN 6          // ... of the variant that forms the maps in the kernel (246 registers; 9: 256 and +9 us per launch, 12 spills; reading the pixel table ahead of the clump as the
+                             // plain affine instance does: no gain)
 #endif
 #ifndef W4_UR_EPI
 #define W4_UR_EPI 6          // ... across a tile's epilogue (its output transform needs the registers): the ring runs down in the
